@@ -1,0 +1,63 @@
+/* oracle/oracle.h — TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement (plain C99) of the reference's RFC1951 hot path
+ * (mirage/decompress v1.6.0, lib/de.ml + lib/zl.ml).  Each function cites the
+ * reference file:line it follows.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may link or call this library; the product path
+ * (decompress_amd/, libmdeflate.so) never does.
+ *
+ * Parity pinning: inflate is pinned by the reference's own known-answer vectors
+ * (tests/golden/inflate_ns.json, inflate_stream.json, transcribed from
+ * test/test_ns.ml and test/test.ml) and by libz on valid streams.  Deflate is
+ * pinned only by the reference's 4 encoder KATs + 2 tree KATs
+ * (tests/golden/deflate_kat.json): beyond those, deflate parity is UNPINNED
+ * (no OCaml toolchain in the build image, the reference cannot be run).
+ */
+#ifndef ORACLE_H
+#define ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Status codes: 1:1 with De.Inf.Ns.error (lib/de.ml:1548-1566) and
+ * Zl.Inf.Ns.error (lib/zl.ml:383).  Same numbering as include/mdeflate.h. */
+enum {
+  ORC_OK = 0,
+  ORC_UNEXPECTED_END_OF_INPUT = 1,
+  ORC_UNEXPECTED_END_OF_OUTPUT = 2,
+  ORC_INVALID_KIND_OF_BLOCK = 3,
+  ORC_INVALID_DICTIONARY = 4,
+  ORC_INVALID_COMPLEMENT_OF_LENGTH = 5,
+  ORC_INVALID_DISTANCE = 6,
+  ORC_INVALID_DISTANCE_CODE = 7,
+  ORC_INVALID_HEADER = 8,
+  ORC_INVALID_CHECKSUM = 9
+};
+
+/* Checkseum.Adler32 (external dep, RFC1950 §8.2); call sites lib/de.ml:453-455 */
+uint32_t orc_adler32(uint32_t adler, const uint8_t *buf, size_t len);
+/* Checkseum.Crc32 (RFC1952 §8); call sites lib/gz.ml:428 */
+uint32_t orc_crc32(uint32_t crc, const uint8_t *buf, size_t len);
+
+/* De.Inf.Ns.inflate  (lib/de.ml:1807-1822) */
+int orc_de_inf_ns_inflate(const uint8_t *src, size_t src_len, uint8_t *dst,
+                          size_t dst_cap, size_t *consumed, size_t *written);
+/* Zl.Inf.Ns.inflate  (lib/zl.ml:400-417) */
+int orc_zl_inf_ns_inflate(const uint8_t *src, size_t src_len, uint8_t *dst,
+                          size_t dst_cap, size_t *consumed, size_t *written);
+
+/* De.Inf.huffman (lib/de.ml:523-638).  kind: 0 CODES, 1 LENS, 2 DISTS.
+ * tbl must hold 852 (LENS), 592 (DISTS) or 128 (CODES) entries.
+ * Returns 0, or -1 for Invalid_huffman.  root/maxl outputs as in the OCaml triple. */
+int orc_inf_huffman(int kind, const uint8_t *lens, int codes, uint32_t *tbl,
+                    int *size, int *root, int *maxl);
+
+const char *orc_status_string(int status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,283 @@
+#!/usr/bin/env python3
+"""Transcribe the reference's own known-answer vectors into JSON fixtures.
+
+Run HERE (the build container, where /root/reference exists):
+
+    python tests/golden/gen_golden.py
+
+It parses the OCaml test sources *as data* (string literals and the expected
+result expressions of each Alcotest case) and writes
+
+    tests/golden/inflate_ns.json      <- test/test_ns.ml  (De.Inf.Ns.inflate cases)
+    tests/golden/inflate_stream.json  <- test/test.ml     (De.Inf streaming cases)
+    tests/golden/zlib_frames.json     <- test/test.ml     (Zl.Inf cases)
+
+Only inputs and expected outputs are kept (hex); no reference source text is
+stored.  /root/reference never travels to the GPU box: tests read the JSON.
+"""
+import json
+import os
+import re
+import sys
+
+REF = "/root/reference/test"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+# ---------------------------------------------------------------- OCaml lexing
+def parse_ocaml_string(s, i):
+    """s[i] == '"'.  Returns (bytes, index after closing quote)."""
+    assert s[i] == '"'
+    i += 1
+    out = bytearray()
+    while True:
+        c = s[i]
+        if c == '"':
+            return bytes(out), i + 1
+        if c != "\\":
+            out.append(ord(c))  # test sources are ASCII
+            i += 1
+            continue
+        n = s[i + 1]
+        if n in '\\"\' ':
+            out.append(ord(n))
+            i += 2
+        elif n == "n":
+            out.append(10); i += 2
+        elif n == "t":
+            out.append(9); i += 2
+        elif n == "b":
+            out.append(8); i += 2
+        elif n == "r":
+            out.append(13); i += 2
+        elif n == "x":
+            out.append(int(s[i + 2:i + 4], 16)); i += 4
+        elif n == "o":
+            out.append(int(s[i + 2:i + 5], 8)); i += 5
+        elif n.isdigit():
+            out.append(int(s[i + 1:i + 4])); i += 4
+        elif n == "\n":  # line continuation: skip newline + leading blanks
+            i += 2
+            while s[i] in " \t":
+                i += 1
+        else:
+            raise ValueError("bad escape %r at %d" % (s[i:i + 6], i))
+
+
+def skip_ws_comments(s, i):
+    while i < len(s):
+        if s[i] in " \t\r\n":
+            i += 1
+        elif s.startswith("(*", i):
+            depth, i = 1, i + 2
+            while depth:
+                if s.startswith("(*", i):
+                    depth += 1; i += 2
+                elif s.startswith("*)", i):
+                    depth -= 1; i += 2
+                elif s[i] == '"':
+                    _, i = parse_ocaml_string(s, i)
+                else:
+                    i += 1
+        else:
+            break
+    return i
+
+
+def parse_string_expr(s, i):
+    """Evaluate a small OCaml string expression starting at s[i]:
+    literal | [lit; lit; ...] | String.make N 'c' | String.concat "" <expr>
+    | identifier bound earlier by `let id =` | a ^ b.
+    Returns (bytes, end) or (None, i)."""
+    v, j = parse_string_atom(s, i)
+    while v is not None:
+        k = skip_ws_comments(s, j)
+        if s[k:k + 1] == "^":
+            w, k2 = parse_string_atom(s, k + 1)
+            if w is None:
+                return None, i
+            v, j = v + w, k2
+        else:
+            break
+    return v, j
+
+
+def parse_string_atom(s, i):
+    i = skip_ws_comments(s, i)
+    if s[i] == "(":
+        v, j = parse_string_expr(s, i + 1)
+        if v is None:
+            return None, i
+        j = skip_ws_comments(s, j)
+        return (v, j + 1) if s[j] == ")" else (None, i)
+    if s[i] == '"':
+        return parse_ocaml_string(s, i)
+    if s[i] == "[":
+        i += 1
+        parts = []
+        while True:
+            i = skip_ws_comments(s, i)
+            if s[i] == "]":
+                return b"".join(parts), i + 1
+            if s[i] == ";":
+                i += 1
+                continue
+            if s[i] != '"':
+                return None, i
+            v, i = parse_ocaml_string(s, i)
+            parts.append(v)
+    m = re.compile(r"String\.make\s+\(?([0-9a-fA-Fx+ ]+?)\)?\s+'((?:\\x[0-9a-fA-F]{2})|(?:\\[0-9]{3})|.)'").match(s, i)
+    if m:
+        n = eval(m.group(1))
+        c = m.group(2)
+        if c.startswith("\\x"):
+            b = int(c[2:], 16)
+        elif c.startswith("\\"):
+            b = int(c[1:])
+        else:
+            b = ord(c)
+        return bytes([b]) * n, m.end()
+    m = re.compile(r'String\.concat\s+""\s+').match(s, i)
+    if m:
+        return parse_string_atom(s, m.end())
+    m = re.compile(r"[a-z_][a-z0-9_']*").match(s, i)
+    if m and m.group(0) not in ("let", "in", "fun", "match"):
+        binds = [b for b in re.finditer(r"let %s =" % re.escape(m.group(0)), s[:i])]
+        for b in reversed(binds):
+            if s[b.end():i].strip() == "" or "bigstring_of_string" in s[b.end():b.end() + 24]:
+                continue  # the binding being evaluated
+            v, _ = parse_string_expr(s, b.end())
+            if v is not None:
+                return v, m.end()
+    return None, i
+
+
+def split_cases(text):
+    """Yield (ocaml_name, title, body) for each top-level `let name () = ... Alcotest.test_case "title"`."""
+    tops = [m.start() for m in re.finditer(r"^let ", text, re.M)] + [len(text)]
+    for m in re.finditer(r"^let (\w+) \(\) =", text, re.M):
+        end = min(t for t in tops if t > m.start())
+        body = text[m.start():end]
+        t = re.search(r"Alcotest\.test_case \"([^\"]*)\"", body)
+        if t:
+            yield m.group(1), t.group(1), body
+
+
+ERR_CODES = {
+    "Unexpected_end_of_input": 1, "Unexpected_end_of_output": 2,
+    "Invalid_kind_of_block": 3, "Invalid_dictionary": 4,
+    "Invalid_complement_of_length": 5, "Invalid_distance": 6,
+    "Invalid_distance_code": 7,
+}
+ERR_STRINGS = {
+    "Unexpected end of input": 1, "Invalid kind of block": 3,
+    "Invalid dictionary": 4, "Invalid complement of length": 5,
+    "Invalid distance": 6, "Invalid distance code": 7,
+}
+
+
+# ------------------------------------------------------------- test_ns.ml
+def gen_ns():
+    text = open(os.path.join(REF, "test_ns.ml")).read()
+    cases = []
+    for name, title, body in split_cases(text):
+        m = re.search(r"bigstring_of_string\s", body)
+        if not m:
+            continue
+        src, _ = parse_string_expr(body, m.end())
+        if src is None:
+            continue  # src produced by the encoder: covered by deflate KATs
+        case = {"name": name, "title": title, "src": src.hex(), "ref": "test/test_ns.ml:%d" % (text[:text.index(body)].count("\n") + 1)}
+        md = re.search(r"let dst = bigstring_create (\d+)", body)
+        case["dst_cap"] = int(md.group(1)) if md else 65536
+        me = re.search(r"\(Error `(\w+)\)", body)
+        if me:
+            case["status"] = ERR_CODES[me.group(1)]
+            case["error"] = me.group(1)
+        else:
+            mo = re.search(r"\(Ok\s*\(\s*(.*?),\s*(.*?)\)\)", body, re.S)
+            if not mo:
+                continue
+            a, b = mo.group(1).strip(), mo.group(2).strip()
+            exp = None
+            mx = re.search(r"let expected =", body)
+            if mx:
+                exp, _ = parse_string_expr(body, mx.end())
+            a = a.replace("De.bigstring_length src", str(len(src)))
+            consumed = eval(a)
+            if b == "String.length expected":
+                written = len(exp)
+            else:
+                written = int(b)
+            case["status"] = 0
+            case["consumed"] = consumed
+            case["written"] = written
+            if exp is not None:
+                assert len(exp) == written, name
+                case["dst"] = exp.hex()
+        cases.append(case)
+    return cases
+
+
+# ------------------------------------------------------------- test.ml
+def gen_stream_and_zlib():
+    text = open(os.path.join(REF, "test.ml")).read()
+    stream, zl = [], []
+    for name, title, body in split_cases(text):
+        line = text[:text.index(body)].count("\n") + 1
+        m = re.search(r"Inf\.decoder\s*\(`String\s", body)
+        mz = re.search(r"Zl\.Inf\.decoder\s*\(`String\s", body)
+        if mz:
+            src, _ = parse_string_expr(body, mz.end())
+            if src is None:
+                mi = re.search(r"let inputs =", body)
+                if mi:
+                    src, _ = parse_string_expr(body, mi.end())
+            if src is None:
+                continue
+            # the case asserts the decoder reaches `End (header ok, Adler-32 trailer ok)
+            zl.append({"name": name, "title": title, "src": src.hex(), "status": 0, "ref": "test/test.ml:%d" % line})
+            continue
+        if not m or "Gz." in body or "Zl." in body or "Lzo" in body:
+            continue
+        src, _ = parse_string_expr(body, m.end())
+        if src is None:
+            continue
+        case = {"name": name, "title": title, "src": src.hex(), "ref": "test/test.ml:%d" % line}
+        me = re.search(r"`Malformed \"([^\"]+)\"", body)
+        if me:
+            case["status"] = ERR_STRINGS[me.group(1)]
+            case["error"] = me.group(1)
+            stream.append(case)
+            continue
+        # expected output: either `(check string) "title" <expr> res` after unroll_inflate,
+        # or `"title" <expr>\n (Bstr.sub_string o ...)`
+        exp = None
+        mu = re.search(r"Alcotest\.\(check string\)\s*\"[^\"]*\"\s*", body)
+        if mu:
+            exp, j = parse_string_expr(body, mu.end())
+        if exp is None:
+            mx = re.search(r"let expected =", body)
+            if mx:
+                exp, _ = parse_string_expr(body, mx.end())
+        if exp is None:
+            continue
+        case["status"] = 0
+        case["dst"] = exp.hex()
+        stream.append(case)
+    return stream, zl
+
+
+def main():
+    if not os.path.isdir(REF):
+        sys.exit("reference tree not present; fixtures are already committed")
+    ns = gen_ns()
+    stream, zl = gen_stream_and_zlib()
+    for fn, data in (("inflate_ns.json", ns), ("inflate_stream.json", stream), ("zlib_frames.json", zl)):
+        with open(os.path.join(OUT, fn), "w") as f:
+            json.dump(data, f, indent=1)
+        print(fn, len(data), "cases")
+
+
+if __name__ == "__main__":
+    main()
