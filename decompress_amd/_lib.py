@@ -1,0 +1,55 @@
+"""ctypes binding of libmdeflate.so (the C ABI of include/mdeflate.h).
+
+There is no fallback: if the HIP library is missing this module raises, and
+every compute call goes through the .so.
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "libmdeflate.so")
+
+c_sz = ctypes.c_size_t
+c_u8p = ctypes.c_void_p
+c_vp = ctypes.c_void_p
+
+# every symbol include/mdeflate.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("md_version", ctypes.c_int, []),
+    ("md_status_string", ctypes.c_char_p, [ctypes.c_int]),
+    ("md_last_error_string", ctypes.c_char_p, [c_vp]),
+    ("md_device_count", ctypes.c_int, []),
+    ("md_create", c_vp, [ctypes.c_int, c_vp]),
+    ("md_destroy", None, [c_vp]),
+    ("md_synchronize", ctypes.c_int, [c_vp]),
+    ("md_timing_begin", ctypes.c_int, [c_vp]),
+    ("md_timing_end", ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_float)]),
+    ("md_inflate_batch_device", ctypes.c_int,
+     [c_vp, ctypes.c_int, c_sz] + [c_vp] * 10),
+    ("md_inflate_batch_host", ctypes.c_int,
+     [c_vp, ctypes.c_int, c_sz, c_vp, c_sz, c_vp, c_vp, c_vp, c_sz, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    ("md_de_inf_ns_inflate", ctypes.c_int,
+     [c_vp, c_vp, c_sz, c_vp, c_sz, ctypes.POINTER(c_sz), ctypes.POINTER(c_sz)]),
+    ("md_zl_inf_ns_inflate", ctypes.c_int,
+     [c_vp, c_vp, c_sz, c_vp, c_sz, ctypes.POINTER(c_sz), ctypes.POINTER(c_sz)]),
+]
+# exported but not part of the public header (tuning knobs)
+EXTRA = [("md_set_option", ctypes.c_int, [c_vp, ctypes.c_char_p, ctypes.c_int])]
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO):
+            raise RuntimeError(
+                "decompress_amd: %s is missing — build it with "
+                "`python -m decompress_amd.build` (there is no CPU fallback)" % SO)
+        lib = ctypes.CDLL(SO)
+        for name, res, args in SYMBOLS + EXTRA:
+            fn = getattr(lib, name)  # AttributeError = ABI drift: fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib

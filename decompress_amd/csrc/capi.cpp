@@ -1,0 +1,265 @@
+// capi.cpp — host side of the C ABI declared in include/mdeflate.h.
+// Plain HIP runtime calls; no torch types anywhere in this library.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "mdeflate.h"
+
+extern "C" int md_launch_inflate(int ring_log2, int format, uint32_t n, const uint8_t *in,
+                                 const uint64_t *in_off, const uint64_t *in_len, uint8_t *out,
+                                 const uint64_t *out_off, const uint64_t *out_cap,
+                                 uint64_t *out_len, uint64_t *consumed, int32_t *status,
+                                 uint32_t *checksum, hipStream_t stream);
+
+struct md_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int ring_log2 = 13;
+  std::string err;
+};
+
+namespace {
+thread_local std::string g_err;
+
+int fail(md_ctx *ctx, int code, const char *what, hipError_t e = hipSuccess) {
+  std::string m = what;
+  if (e != hipSuccess) {
+    m += ": ";
+    m += hipGetErrorString(e);
+  }
+  if (ctx) ctx->err = m;
+  g_err = m;
+  return code;
+}
+
+#define HIP_TRY(ctx, expr)                                   \
+  do {                                                       \
+    hipError_t e_ = (expr);                                  \
+    if (e_ != hipSuccess) return fail(ctx, MD_E_HIP, #expr, e_); \
+  } while (0)
+
+bool is_gfx950(int dev) {
+  hipDeviceProp_t p;
+  if (hipGetDeviceProperties(&p, dev) != hipSuccess) return false;
+  return strncmp(p.gcnArchName, "gfx950", 6) == 0;
+}
+}  // namespace
+
+extern "C" {
+
+int md_version(void) { return MD_VERSION; }
+
+const char *md_status_string(int s) {
+  switch (s) {
+  case MD_OK: return "Ok";
+  case MD_UNEXPECTED_END_OF_INPUT: return "Unexpected end of input";
+  case MD_UNEXPECTED_END_OF_OUTPUT: return "Unexpected end of output";
+  case MD_INVALID_KIND_OF_BLOCK: return "Invalid kind of block";
+  case MD_INVALID_DICTIONARY: return "Invalid dictionary";
+  case MD_INVALID_COMPLEMENT_OF_LENGTH: return "Invalid complement of length";
+  case MD_INVALID_DISTANCE: return "Invalid distance";
+  case MD_INVALID_DISTANCE_CODE: return "Invalid distance code";
+  case MD_INVALID_HEADER: return "Invalid Zlib header";
+  case MD_INVALID_CHECKSUM: return "Invalid checksum";
+  case MD_E_INVALID_ARGUMENT: return "Invalid argument";
+  case MD_E_NO_DEVICE: return "No gfx950 device";
+  case MD_E_HIP: return "HIP runtime error";
+  case MD_E_OUT_OF_MEMORY: return "Out of device memory";
+  default: return "Unknown status";
+  }
+}
+
+const char *md_last_error_string(const md_ctx *ctx) {
+  return ctx ? ctx->err.c_str() : g_err.c_str();
+}
+
+int md_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  int ok = 0;
+  for (int d = 0; d < n; d++)
+    if (is_gfx950(d)) ok++;
+  return ok;
+}
+
+md_ctx *md_create(int device, void *hip_stream) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) {
+    fail(nullptr, MD_E_NO_DEVICE, "md_create: no such HIP device");
+    return nullptr;
+  }
+  if (!is_gfx950(device)) {
+    fail(nullptr, MD_E_NO_DEVICE, "md_create: device is not gfx950 (kernels are built for MI355X only)");
+    return nullptr;
+  }
+  md_ctx *ctx = new md_ctx();
+  ctx->device = device;
+  if (hipSetDevice(device) != hipSuccess) {
+    delete ctx;
+    fail(nullptr, MD_E_HIP, "hipSetDevice");
+    return nullptr;
+  }
+  if (hip_stream) {
+    ctx->stream = (hipStream_t)hip_stream;
+  } else {
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+      delete ctx;
+      fail(nullptr, MD_E_HIP, "hipStreamCreate");
+      return nullptr;
+    }
+    ctx->own_stream = true;
+  }
+  hipEventCreate(&ctx->ev0);
+  hipEventCreate(&ctx->ev1);
+  if (const char *e = getenv("MD_RING_LOG2")) {
+    int v = atoi(e);
+    if (v >= 12 && v <= 15) ctx->ring_log2 = v;
+  }
+  return ctx;
+}
+
+void md_destroy(md_ctx *ctx) {
+  if (!ctx) return;
+  hipSetDevice(ctx->device);
+  if (ctx->ev0) hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) hipEventDestroy(ctx->ev1);
+  if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+int md_synchronize(md_ctx *ctx) {
+  if (!ctx) return MD_E_INVALID_ARGUMENT;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return MD_OK;
+}
+
+int md_timing_begin(md_ctx *ctx) {
+  if (!ctx) return MD_E_INVALID_ARGUMENT;
+  HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  return MD_OK;
+}
+
+int md_timing_end(md_ctx *ctx, float *ms) {
+  if (!ctx || !ms) return MD_E_INVALID_ARGUMENT;
+  HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
+  HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+  return MD_OK;
+}
+
+int md_set_option(md_ctx *ctx, const char *key, int value) {
+  if (!ctx || !key) return MD_E_INVALID_ARGUMENT;
+  if (!strcmp(key, "ring_log2")) {
+    if (value < 12 || value > 15) return fail(ctx, MD_E_INVALID_ARGUMENT, "ring_log2 must be 12..15");
+    ctx->ring_log2 = value;
+    return MD_OK;
+  }
+  return fail(ctx, MD_E_INVALID_ARGUMENT, "unknown option");
+}
+
+int md_inflate_batch_device(md_ctx *ctx, int format, size_t n, const uint8_t *d_in,
+                            const uint64_t *d_in_off, const uint64_t *d_in_len, uint8_t *d_out,
+                            const uint64_t *d_out_off, const uint64_t *d_out_cap,
+                            uint64_t *d_out_len, uint64_t *d_consumed, int32_t *d_status,
+                            uint32_t *d_checksum) {
+  if (!ctx) return MD_E_INVALID_ARGUMENT;
+  if (format != MD_FORMAT_DEFLATE && format != MD_FORMAT_ZLIB)
+    return fail(ctx, MD_E_INVALID_ARGUMENT, "unknown format");
+  if (n == 0) return MD_OK;
+  if (n > 0x7fffffffull) return fail(ctx, MD_E_INVALID_ARGUMENT, "too many streams in one batch");
+  if (!d_in_off || !d_in_len || !d_out_off || !d_out_cap || !d_out_len || !d_consumed || !d_status)
+    return fail(ctx, MD_E_INVALID_ARGUMENT, "null descriptor array");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = md_launch_inflate(ctx->ring_log2, format, (uint32_t)n, d_in, d_in_off, d_in_len, d_out,
+                             d_out_off, d_out_cap, d_out_len, d_consumed, d_status, d_checksum,
+                             ctx->stream);
+  if (rc != 0) return fail(ctx, MD_E_HIP, "inflate kernel launch", (hipError_t)rc);
+  return MD_OK;
+}
+
+namespace {
+struct DevBuf {
+  void *p = nullptr;
+  ~DevBuf() {
+    if (p) hipFree(p);
+  }
+  hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
+};
+}  // namespace
+
+int md_inflate_batch_host(md_ctx *ctx, int format, size_t n, const uint8_t *h_in, size_t in_bytes,
+                          const uint64_t *in_off, const uint64_t *in_len, uint8_t *h_out,
+                          size_t out_bytes, const uint64_t *out_off, const uint64_t *out_cap,
+                          uint64_t *out_len, uint64_t *consumed, int32_t *status,
+                          uint32_t *checksum) {
+  if (!ctx) return MD_E_INVALID_ARGUMENT;
+  if (n == 0) return MD_OK;
+  if (!in_off || !in_len || !out_off || !out_cap || !out_len || !consumed || !status)
+    return fail(ctx, MD_E_INVALID_ARGUMENT, "null descriptor array");
+  for (size_t i = 0; i < n; i++) {
+    if (in_off[i] > in_bytes || in_len[i] > in_bytes - in_off[i])
+      return fail(ctx, MD_E_INVALID_ARGUMENT, "input range out of bounds");  // invalid_bounds, lib/de.ml:146
+    if (out_off[i] > out_bytes || out_cap[i] > out_bytes - out_off[i])
+      return fail(ctx, MD_E_INVALID_ARGUMENT, "output range out of bounds");
+  }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  DevBuf din, dout, ddesc;
+  const size_t desc_words = 6 * n;  // in_off in_len out_off out_cap out_len consumed
+  if (din.alloc(in_bytes + 8) != hipSuccess || dout.alloc(out_bytes) != hipSuccess ||
+      ddesc.alloc(desc_words * 8 + n * 8) != hipSuccess)
+    return fail(ctx, MD_E_OUT_OF_MEMORY, "hipMalloc");
+  uint64_t *d64 = (uint64_t *)ddesc.p;
+  int32_t *dstatus = (int32_t *)(d64 + desc_words);
+  uint32_t *dsum = (uint32_t *)(dstatus + n);
+  hipStream_t st = ctx->stream;
+  HIP_TRY(ctx, hipMemcpyAsync(din.p, h_in, in_bytes, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(d64 + 0 * n, in_off, n * 8, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(d64 + 1 * n, in_len, n * 8, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(d64 + 2 * n, out_off, n * 8, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(d64 + 3 * n, out_cap, n * 8, hipMemcpyHostToDevice, st));
+  int rc = md_inflate_batch_device(ctx, format, n, (const uint8_t *)din.p, d64, d64 + n,
+                                   (uint8_t *)dout.p, d64 + 2 * n, d64 + 3 * n, d64 + 4 * n,
+                                   d64 + 5 * n, dstatus, dsum);
+  if (rc != MD_OK) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(h_out, dout.p, out_bytes, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipMemcpyAsync(out_len, d64 + 4 * n, n * 8, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipMemcpyAsync(consumed, d64 + 5 * n, n * 8, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipMemcpyAsync(status, dstatus, n * 4, hipMemcpyDeviceToHost, st));
+  if (checksum) HIP_TRY(ctx, hipMemcpyAsync(checksum, dsum, n * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  return MD_OK;
+}
+
+static int inflate_one(md_ctx *ctx, int format, const uint8_t *src, size_t src_len, uint8_t *dst,
+                       size_t dst_cap, size_t *consumed, size_t *written) {
+  if (!ctx || !consumed || !written || (!src && src_len) || (!dst && dst_cap))
+    return MD_E_INVALID_ARGUMENT;
+  uint64_t in_off = 0, in_len = src_len, out_off = 0, out_cap = dst_cap, out_len = 0, used = 0;
+  int32_t status = 0;
+  int rc = md_inflate_batch_host(ctx, format, 1, src, src_len, &in_off, &in_len, dst, dst_cap,
+                                 &out_off, &out_cap, &out_len, &used, &status, nullptr);
+  if (rc != MD_OK) return rc;
+  *consumed = (size_t)used;
+  *written = (size_t)out_len;
+  return status;
+}
+
+int md_de_inf_ns_inflate(md_ctx *ctx, const uint8_t *src, size_t src_len, uint8_t *dst,
+                         size_t dst_cap, size_t *consumed, size_t *written) {
+  return inflate_one(ctx, MD_FORMAT_DEFLATE, src, src_len, dst, dst_cap, consumed, written);
+}
+
+int md_zl_inf_ns_inflate(md_ctx *ctx, const uint8_t *src, size_t src_len, uint8_t *dst,
+                         size_t dst_cap, size_t *consumed, size_t *written) {
+  return inflate_one(ctx, MD_FORMAT_ZLIB, src, src_len, dst, dst_cap, consumed, written);
+}
+
+}  // extern "C"

@@ -1,0 +1,125 @@
+"""Batch engine: device buffers in, device buffers out (torch is only the
+allocator / stream provider here; the work is done by libmdeflate.so)."""
+import ctypes
+
+from . import _lib
+
+FORMAT_DEFLATE = 0
+FORMAT_ZLIB = 1
+
+# variant names of De.Inf.Ns.error (lib/de.ml:1548-1555) + Zl.Inf.Ns.error (lib/zl.ml:383)
+STATUS_NAMES = {
+    0: "Ok", 1: "Unexpected_end_of_input", 2: "Unexpected_end_of_output",
+    3: "Invalid_kind_of_block", 4: "Invalid_dictionary",
+    5: "Invalid_complement_of_length", 6: "Invalid_distance",
+    7: "Invalid_distance_code", 8: "Invalid_header", 9: "Invalid_checksum",
+}
+
+
+class Error(RuntimeError):
+    """Call-level failure (the reference raises Invalid_argument / Failure)."""
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+class Engine:
+    """One engine per GPU (wraps md_ctx).  Kernels are enqueued on torch's
+    current stream of `device` unless own_stream=True."""
+
+    def __init__(self, device=0, own_stream=False):
+        import torch
+
+        self.torch = torch
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise Error("decompress_amd needs a HIP device (no CPU fallback)")
+        self.device = torch.device("cuda", device)
+        stream = None if own_stream else torch.cuda.current_stream(self.device).cuda_stream
+        self.ctx = self.lib.md_create(device, ctypes.c_void_p(stream) if stream else None)
+        if not self.ctx:
+            raise Error(self.lib.md_last_error_string(None).decode())
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.md_destroy(self.ctx)
+            self.ctx = None
+
+    __del__ = close
+
+    def _check(self, rc):
+        if rc != 0:
+            raise Error("%s: %s" % (self.lib.md_status_string(rc).decode(),
+                                    self.lib.md_last_error_string(self.ctx).decode()))
+
+    def set_option(self, key, value):
+        self._check(self.lib.md_set_option(self.ctx, key.encode(), int(value)))
+
+    def synchronize(self):
+        self._check(self.lib.md_synchronize(self.ctx))
+
+    def timing_begin(self):
+        self._check(self.lib.md_timing_begin(self.ctx))
+
+    def timing_end(self):
+        ms = ctypes.c_float()
+        self._check(self.lib.md_timing_end(self.ctx, ctypes.byref(ms)))
+        return ms.value
+
+    # ------------------------------------------------------------------ inflate
+    def inflate_batch(self, fmt, d_in, in_off, in_len, d_out, out_off, out_cap, results=None):
+        """All arguments are CUDA tensors: d_in/d_out uint8, descriptors int64.
+        Returns (out_len, consumed, status, checksum) CUDA tensors (async)."""
+        torch = self.torch
+        n = in_off.numel()
+        if results is None:
+            results = (torch.empty(n, dtype=torch.int64, device=self.device),
+                       torch.empty(n, dtype=torch.int64, device=self.device),
+                       torch.empty(n, dtype=torch.int32, device=self.device),
+                       torch.empty(n, dtype=torch.int32, device=self.device))
+        out_len, consumed, status, checksum = results
+        self._check(self.lib.md_inflate_batch_device(
+            self.ctx, fmt, n, _ptr(d_in), _ptr(in_off), _ptr(in_len), _ptr(d_out), _ptr(out_off),
+            _ptr(out_cap), _ptr(out_len), _ptr(consumed), _ptr(status), _ptr(checksum)))
+        return results
+
+    def inflate_many(self, streams, caps, fmt=FORMAT_DEFLATE):
+        """Convenience for tests: list of bytes -> list of (status, consumed, bytes, adler)."""
+        import numpy as np
+
+        torch = self.torch
+        n = len(streams)
+        if n == 0:
+            return []
+        in_len = np.array([len(s) for s in streams], dtype=np.int64)
+        in_off = np.zeros(n, dtype=np.int64)
+        np.cumsum(((in_len + 15) // 16 * 16)[:-1], out=in_off[1:])
+        cap = np.array(caps, dtype=np.int64)
+        out_off = np.zeros(n, dtype=np.int64)
+        np.cumsum(((cap + 255) // 256 * 256)[:-1], out=out_off[1:])
+        blob = np.zeros(int(in_off[-1] + in_len[-1]) + 16, dtype=np.uint8)
+        for s, o in zip(streams, in_off):
+            blob[o:o + len(s)] = np.frombuffer(bytes(s), dtype=np.uint8)
+        dev = self.device
+        d_in = torch.from_numpy(blob).to(dev)
+        d_out = torch.zeros(int(out_off[-1] + cap[-1]) + 16, dtype=torch.uint8, device=dev)
+        t = lambda a: torch.from_numpy(a).to(dev)
+        out_len, consumed, status, checksum = self.inflate_batch(
+            fmt, d_in, t(in_off), t(in_len), d_out, t(out_off), t(cap))
+        torch.cuda.synchronize(dev)
+        out = d_out.cpu().numpy()
+        out_len, consumed, status = out_len.cpu().numpy(), consumed.cpu().numpy(), status.cpu().numpy()
+        checksum = checksum.cpu().numpy().view(np.uint32)
+        return [(int(status[i]), int(consumed[i]),
+                 out[out_off[i]:out_off[i] + out_len[i]].tobytes(), int(checksum[i]))
+                for i in range(n)]
+
+
+_default = {}
+
+
+def default_engine(device=0):
+    if device not in _default:
+        _default[device] = Engine(device)
+    return _default[device]

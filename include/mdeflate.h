@@ -1,0 +1,129 @@
+/* mdeflate.h — C ABI of the MI355X-native many-stream DEFLATE engine.
+ *
+ * This is the drop-in boundary for the hot path of mirage/decompress
+ * (lib/de.ml, lib/zl.ml).  The reference has no FFI for this path (its old
+ * ctypes reverse binding was removed in v1.5.3, CHANGES.md:21-26), so the
+ * boundary is the OCaml module signature; each entry point below names the
+ * signature it stands behind.  An OCaml stub layer keeps
+ * `De.Inf.Ns.inflate`, `Zl.Inf.Ns.inflate`, `De.Higher.*`, `Zl.Higher.*`
+ * unchanged on top of these calls.
+ *
+ * Conventions:
+ *  - caller owns every buffer; the engine never allocates caller-visible memory;
+ *  - errors are integer status codes, 1:1 with the reference's variants,
+ *    never exceptions / aborts;
+ *  - a context (md_ctx) is single-owner, distinct contexts are independent
+ *    and thread-safe with respect to each other (one context per GPU);
+ *  - all sizes/offsets are bytes; descriptor arrays are structure-of-arrays.
+ *  - there is NO CPU fallback: every compute entry point runs HIP kernels and
+ *    returns MD_E_NO_DEVICE when no gfx950 device is usable.
+ */
+#ifndef MDEFLATE_H
+#define MDEFLATE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MD_VERSION 0x000100 /* 0.1.0 */
+
+/* Per-stream status: De.Inf.Ns.error (lib/de.ml:1548-1566, lib/de.mli:150-157)
+ * + Zl.Inf.Ns.error (lib/zl.ml:383).  Strings: md_status_string(). */
+enum {
+  MD_OK = 0,
+  MD_UNEXPECTED_END_OF_INPUT = 1,
+  MD_UNEXPECTED_END_OF_OUTPUT = 2,
+  MD_INVALID_KIND_OF_BLOCK = 3,
+  MD_INVALID_DICTIONARY = 4,
+  MD_INVALID_COMPLEMENT_OF_LENGTH = 5,
+  MD_INVALID_DISTANCE = 6,
+  MD_INVALID_DISTANCE_CODE = 7,
+  MD_INVALID_HEADER = 8,   /* Zl: "Invalid Zlib header", lib/zl.ml:183 */
+  MD_INVALID_CHECKSUM = 9  /* Zl: "Invalid checksum", lib/zl.ml:179-181 */
+};
+
+/* Call-level errors (negative): misuse raises Invalid_argument in the
+ * reference (lib/de.ml:146-147); here the call returns one of these. */
+enum {
+  MD_E_INVALID_ARGUMENT = -1,
+  MD_E_NO_DEVICE = -2,
+  MD_E_HIP = -3,
+  MD_E_OUT_OF_MEMORY = -4
+};
+
+/* Container formats */
+enum {
+  MD_FORMAT_DEFLATE = 0, /* raw RFC1951: De.Inf.Ns.inflate, lib/de.ml:1807-1822 */
+  MD_FORMAT_ZLIB = 1     /* RFC1950: Zl.Inf.Ns.inflate, lib/zl.ml:400-417 */
+};
+
+typedef struct md_ctx md_ctx;
+
+int md_version(void);
+/* human strings of lib/de.ml:1557-1567 ("Unexpected end of input", ...) */
+const char *md_status_string(int status);
+/* last call-level error text of this context (HIP error string etc.) */
+const char *md_last_error_string(const md_ctx *ctx);
+
+/* Number of usable gfx950 devices (0 when none / no driver). */
+int md_device_count(void);
+
+/* One context per GPU.  `hip_stream` may be NULL (the context creates its own
+ * non-blocking stream) or an existing hipStream_t to enqueue on (e.g. the
+ * caller's current stream).  Replaces nothing in the reference: state objects
+ * there are the window/queue bigarrays the caller allocates (lib/de.mli:93-106);
+ * here they are per-wavefront LDS rings owned by the kernels. */
+md_ctx *md_create(int device, void *hip_stream);
+void md_destroy(md_ctx *ctx);
+int md_synchronize(md_ctx *ctx);
+
+/* Timing of the dominant kernel with HIP events recorded on the context's
+ * stream: begin/end bracket any number of batch calls; end returns elapsed
+ * milliseconds (synchronises). */
+int md_timing_begin(md_ctx *ctx);
+int md_timing_end(md_ctx *ctx, float *ms);
+
+/* Batched inflate of n independent streams, everything resident in HBM.
+ *   stream i reads  d_in [in_off[i],  in_off[i]  + in_len[i])
+ *            writes d_out[out_off[i], out_off[i] + out_cap[i])
+ * Results per stream (device arrays, may not be NULL unless noted):
+ *   out_len[i]   bytes written          (the `o` of Ok (i, o))
+ *   consumed[i]  input bytes consumed   (the `i` of Ok (i, o); 0 on error)
+ *   status[i]    MD_OK or the error variant
+ *   checksum[i]  Adler-32 of the output (may be NULL)
+ * Semantics per stream = De.Inf.Ns.inflate (lib/de.ml:1807-1822) for
+ * MD_FORMAT_DEFLATE, Zl.Inf.Ns.inflate (lib/zl.ml:400-417) for MD_FORMAT_ZLIB.
+ * Asynchronous on the context's stream.  Returns MD_OK or a call-level error. */
+int md_inflate_batch_device(md_ctx *ctx, int format, size_t n,
+                            const uint8_t *d_in, const uint64_t *d_in_off,
+                            const uint64_t *d_in_len, uint8_t *d_out,
+                            const uint64_t *d_out_off, const uint64_t *d_out_cap,
+                            uint64_t *d_out_len, uint64_t *d_consumed,
+                            int32_t *d_status, uint32_t *d_checksum);
+
+/* Same with HOST pointers: copies inputs H2D, runs the kernels, copies results
+ * D2H and synchronises.  h_in/h_out are the packed buffers the offsets index. */
+int md_inflate_batch_host(md_ctx *ctx, int format, size_t n, const uint8_t *h_in,
+                          size_t in_bytes, const uint64_t *in_off,
+                          const uint64_t *in_len, uint8_t *h_out, size_t out_bytes,
+                          const uint64_t *out_off, const uint64_t *out_cap,
+                          uint64_t *out_len, uint64_t *consumed, int32_t *status,
+                          uint32_t *checksum);
+
+/* Single-stream mirrors of the reference's whole-buffer entry points (host
+ * pointers, batch of one):
+ *   De.Inf.Ns.inflate : bigstring -> bigstring -> (int * int, error) result
+ *   (lib/de.mli:146-173)  and  Zl.Inf.Ns.inflate (lib/zl.mli, lib/zl.ml:400). */
+int md_de_inf_ns_inflate(md_ctx *ctx, const uint8_t *src, size_t src_len,
+                         uint8_t *dst, size_t dst_cap, size_t *consumed,
+                         size_t *written);
+int md_zl_inf_ns_inflate(md_ctx *ctx, const uint8_t *src, size_t src_len,
+                         uint8_t *dst, size_t dst_cap, size_t *consumed,
+                         size_t *written);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

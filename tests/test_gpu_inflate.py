@@ -1,0 +1,180 @@
+"""Parity of the HIP inflate path (through the C ABI) with the CPU oracle and
+the reference's golden vectors.  Needs an MI355X: `pytest -m gpu`."""
+import ctypes
+import random
+import zlib
+
+import numpy as np
+import pytest
+
+from tests.conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+NS = load_golden("inflate_ns.json")
+STREAM = load_golden("inflate_stream.json")
+ZL = load_golden("zlib_frames.json")
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import decompress_amd
+    return decompress_amd.Engine(0)
+
+
+@pytest.fixture(scope="module", params=[12, 13, 15])
+def eng_ring(request, eng):
+    eng.set_option("ring_log2", request.param)
+    yield eng
+    eng.set_option("ring_log2", 13)
+
+
+def test_golden_ns(eng_ring):
+    """test/test_ns.ml vectors: status, (consumed, written) and bytes."""
+    res = eng_ring.inflate_many([bytes.fromhex(c["src"]) for c in NS], [c["dst_cap"] for c in NS])
+    for c, (st, used, out, _) in zip(NS, res):
+        assert st == c["status"], (c["name"], st)
+        if st == 0:
+            assert used == c["consumed"], c["name"]
+            assert len(out) == c["written"], c["name"]
+            if "dst" in c:
+                assert out == bytes.fromhex(c["dst"]), c["name"]
+
+
+def test_golden_stream(eng):
+    res = eng.inflate_many([bytes.fromhex(c["src"]) for c in STREAM], [65536] * len(STREAM))
+    for c, (st, _, out, _) in zip(STREAM, res):
+        assert st == c["status"], c["name"]
+        if st == 0:
+            assert out == bytes.fromhex(c["dst"]), c["name"]
+
+
+def test_golden_zlib(eng):
+    import decompress_amd
+    for c in ZL:
+        src = bytes.fromhex(c["src"])
+        st, used, out, adler = eng.inflate_many([src], [65536], decompress_amd.FORMAT_ZLIB)[0]
+        assert (st, used) == (0, len(src))
+        assert out == zlib.decompress(src)
+        assert adler == zlib.adler32(out)
+
+
+def _mk(rng, n, kind):
+    if kind == "text":
+        words = [bytes(rng.randrange(97, 123) for _ in range(rng.randrange(1, 9))) for _ in range(300)]
+        out = bytearray()
+        while len(out) < n:
+            out += rng.choice(words) + b" "
+        return bytes(out[:n])
+    if kind == "rand":
+        return bytes(rng.getrandbits(8) for _ in range(n))
+    if kind == "runs":
+        out = bytearray()
+        while len(out) < n:
+            out += bytes([rng.randrange(256)]) * rng.randrange(1, 700)
+        return bytes(out[:n])
+    if kind == "far":  # long-distance matches: repeat 20-30 KiB apart
+        base = bytes(rng.getrandbits(8) for _ in range(30000))
+        out = bytearray()
+        while len(out) < n:
+            out += base[: rng.randrange(20000, 30000)]
+        return bytes(out[:n])
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("kind", ["text", "rand", "runs", "far"])
+def test_vs_oracle_raw(eng_ring, oracle, kind):
+    rng = random.Random(hash(kind) & 0xffff)
+    srcs, caps, plains = [], [], []
+    for n in (0, 1, 2, 63, 64, 65, 1023, 1024, 1025, 4095, 4097, 40000, 70001, 300000):
+        data = _mk(rng, n, kind)
+        for level, strat in ((1, 0), (6, 0), (9, 0), (6, zlib.Z_FIXED), (6, zlib.Z_HUFFMAN_ONLY), (0, 0)):
+            co = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strat)
+            srcs.append(co.compress(data) + co.flush())
+            caps.append(n + rng.randrange(0, 3))
+            plains.append(data)
+    res = eng_ring.inflate_many(srcs, caps)
+    for src, cap, plain, (st, used, out, adler) in zip(srcs, caps, plains, res):
+        ost, oused, oout = oracle.de_inflate(src, cap)
+        assert (st, used) == (ost, oused)
+        assert out == oout == plain
+        assert adler == zlib.adler32(plain)
+
+
+def test_vs_oracle_zlib_batch(eng, oracle):
+    import decompress_amd
+    from decompress_amd import workloads
+    streams = workloads.c2_streams(24, nbytes=256 * 1024, workers=0)
+    res = eng.inflate_many(streams, [256 * 1024] * len(streams), decompress_amd.FORMAT_ZLIB)
+    for z, (st, used, out, adler) in zip(streams, res):
+        assert (st, used) == (0, len(z))
+        assert out == zlib.decompress(z)
+        assert adler == zlib.adler32(out)
+
+
+def test_errors_match_oracle(eng, oracle):
+    """Truncations, bit flips, short outputs: same status / same bytes as the oracle."""
+    import decompress_amd
+    rng = random.Random(99)
+    data = _mk(rng, 20000, "text")
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    raw = co.compress(data) + co.flush()
+    srcs, caps = [], []
+    for cut in list(range(0, 40)) + list(range(40, len(raw), 97)):
+        srcs.append(raw[:cut]); caps.append(30000)
+    for k in range(200):
+        b = bytearray(raw)
+        i = rng.randrange(len(b))
+        b[i] ^= 1 << rng.randrange(8)
+        srcs.append(bytes(b)); caps.append(30000)
+    for cap in (0, 1, 100, 19999, 20000):
+        srcs.append(raw); caps.append(cap)
+    res = eng.inflate_many(srcs, caps)
+    for src, cap, (st, used, out, _) in zip(srcs, caps, res):
+        ost, oused, oout = oracle.de_inflate(src, cap)
+        assert st == ost, (len(src), cap, st, ost)
+        assert used == oused
+        assert out == oout
+    z = zlib.compress(data)
+    bad = [z[:-1] + bytes([z[-1] ^ 1]), b"\x79\x9c" + z[2:], b"\x78", z[:5], z]
+    res = eng.inflate_many(bad, [len(data)] * len(bad), decompress_amd.FORMAT_ZLIB)
+    for src, (st, used, out, _) in zip(bad, res):
+        ost, oused, oout = oracle.zl_inflate(src, len(data))
+        assert (st, used) == (ost, oused)
+
+
+def test_stored_config1(eng, oracle):
+    """BASELINE config 1: 64 KiB of stored blocks (65535 + 1)."""
+    from decompress_amd import workloads
+    payload = np.random.default_rng(1).integers(0, 256, 65536, dtype=np.uint8).tobytes()
+    s = workloads.stored_stream(payload)
+    assert len(s) == 65546
+    st, used, out, _ = eng.inflate_many([s], [65536])[0]
+    assert (st, used, out) == (0, len(s), payload)
+    assert oracle.de_inflate(s, 65536) == (0, len(s), payload)
+
+
+def test_c_abi_single_stream(eng):
+    """md_de_inf_ns_inflate / md_zl_inf_ns_inflate with host pointers."""
+    from decompress_amd import _lib
+    lib = _lib.load()
+    ctx = lib.md_create(0, None)
+    assert ctx
+    data = b"De.Inf.Ns.inflate " * 500
+    z = zlib.compress(data, 6)
+    dst = ctypes.create_string_buffer(len(data))
+    used, written = ctypes.c_size_t(), ctypes.c_size_t()
+    rc = lib.md_zl_inf_ns_inflate(ctx, z, len(z), dst, len(data), ctypes.byref(used), ctypes.byref(written))
+    assert (rc, used.value, written.value) == (0, len(z), len(data))
+    assert dst.raw == data
+    rc = lib.md_de_inf_ns_inflate(ctx, z[2:-4], len(z) - 6, dst, 10, ctypes.byref(used), ctypes.byref(written))
+    assert rc == 2  # Unexpected_end_of_output
+    lib.md_destroy(ctx)
+
+
+def test_python_mirror(eng):
+    from decompress_amd import de, zl
+    assert de.Inf.Ns.inflate(b"\x01\x04\x00\xfb\xff\xde\xad\xbe\xef", 65536) == ("Ok", (9, 4), b"\xde\xad\xbe\xef")
+    assert de.Inf.Ns.inflate(b"\x06", 65536) == ("Error", "Invalid_kind_of_block")
+    z = zlib.compress(b"abc" * 100)
+    assert zl.Inf.Ns.inflate(z, 300) == ("Ok", (len(z), 300), b"abc" * 100)
