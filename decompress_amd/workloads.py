@@ -17,29 +17,49 @@ _VOCAB = 16384
 _ZIPF = 1.11  # zlib-6 ratio ~0.38, like English text (book2: 0.34-0.42)
 
 
-def _vocab(rng):
-    lens = rng.integers(2, 11, size=_VOCAB)
-    letters = np.frombuffer(b"etaoinshrdlcumwfgypbvkjxqz", dtype=np.uint8)
-    p = 1.0 / np.arange(1, 27)
-    p /= p.sum()
-    return [bytes(rng.choice(letters, size=int(l), p=p)) for l in lens]
+_SEPS = np.frombuffer(b". , \n   ", dtype=np.uint8).reshape(4, 2)  # ". " ", " "\n" " "
+_SEP_LEN = np.array([2, 2, 1, 1])
+_vocab_cache = None
+
+
+def _vocab():
+    """(chars[V,12] uint8, length[V]) — fixed vocabulary of 2..10-letter words."""
+    global _vocab_cache
+    if _vocab_cache is None:
+        rng = np.random.default_rng(1234)
+        lens = rng.integers(2, 11, size=_VOCAB)
+        letters = np.frombuffer(b"etaoinshrdlcumwfgypbvkjxqz", dtype=np.uint8)
+        p = 1.0 / np.arange(1, 27)
+        p /= p.sum()
+        chars = rng.choice(letters, size=(_VOCAB, 12), p=p)
+        _vocab_cache = (chars, lens)
+    return _vocab_cache
 
 
 def text(seed, nbytes):
-    """Deterministic pseudo-English of exactly nbytes bytes."""
+    """Deterministic pseudo-English of exactly nbytes bytes (vectorised)."""
     rng = np.random.default_rng(seed)
-    vocab = _vocab(np.random.default_rng(1234))
-    ranks = rng.zipf(_ZIPF, size=nbytes // 3 + 64)
-    ranks = (ranks - 1) % _VOCAB
-    punct = rng.integers(0, 23, size=ranks.size)
-    parts = []
-    for r, q in zip(ranks.tolist(), punct.tolist()):
-        parts.append(vocab[r])
-        parts.append(b". " if q == 0 else b", " if q == 1 else b"\n" if q == 2 else b" ")
-    out = b"".join(parts)
-    while len(out) < nbytes:
-        out += out
-    return out[:nbytes]
+    chars, wlen = _vocab()
+    nw = nbytes // 3 + 64
+    ranks = (rng.zipf(_ZIPF, size=nw) - 1) % _VOCAB
+    q = rng.integers(0, 23, size=nw)
+    sep = np.where(q == 0, 0, np.where(q == 1, 1, np.where(q == 2, 2, 3)))
+    wl = wlen[ranks]
+    tl = wl + _SEP_LEN[sep]
+    start = np.zeros(nw, dtype=np.int64)
+    np.cumsum(tl[:-1], out=start[1:])
+    total = int(start[-1] + tl[-1])
+    out = np.empty(total, dtype=np.uint8)
+    tok = np.repeat(np.arange(nw), tl)          # token index of every output byte
+    k = np.arange(total) - start[tok]           # byte index inside the token
+    inword = k < wl[tok]
+    out[inword] = chars[ranks[tok[inword]], k[inword]]
+    ns = ~inword
+    out[ns] = _SEPS[sep[tok[ns]], k[ns] - wl[tok[ns]]]
+    b = out.tobytes()
+    while len(b) < nbytes:
+        b += b
+    return b[:nbytes]
 
 
 def ascii_uniform(seed, nbytes):
