@@ -43,9 +43,12 @@ def parse():
     ap.add_argument("--unique", type=int, default=0, help="distinct streams to generate (0 = all)")
     ap.add_argument("--level", type=int, default=6)
     ap.add_argument("--ring-log2", type=int, default=0)
+    ap.add_argument("--kernel", type=int, default=0, help="1 = serial per wave, 2 = lane-parallel (default)")
+    ap.add_argument("--variant", type=int, default=-1, help="v2 geometry")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--profile", action="store_true", help="print the in-kernel phase profile of stream 0 (stderr)")
     return ap.parse_args()
 
 
@@ -98,6 +101,10 @@ def main():
     eng = decompress_amd.Engine(local_rank)
     if args.ring_log2:
         eng.set_option("ring_log2", args.ring_log2)
+    if args.kernel:
+        eng.set_option("kernel", args.kernel)
+    if args.variant >= 0:
+        eng.set_option("variant", args.variant)
 
     n = args.streams
     nbytes = args.stream_kib * 1024
@@ -132,6 +139,15 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    if args.profile and rank == 0:
+        eng.set_option("profile", 1)
+        step()
+        prof = eng.get_profile()
+        eng.set_option("profile", 0)
+        cyc = sum(v for k, v in prof.items() if k.startswith("cyc_"))
+        print("profile(stream 0): total %.2f Mcycles" % (cyc / 1e6), file=sys.stderr)
+        for k, v in prof.items():
+            print("  %-12s %12d %s" % (k, v, ("%5.1f%%" % (100.0 * v / cyc)) if k.startswith("cyc_") else ""), file=sys.stderr)
     eng.timing_begin()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -190,13 +206,13 @@ def main():
                             "Zl.Inf.Ns semantics, one stream per wavefront" % (n, args.stream_kib, args.level),
                 "streams_per_gpu": n, "stream_bytes": nbytes, "unique_streams": unique,
                 "compressed_ratio": round(comp_bytes / (n * nbytes), 4),
-                "ring_log2": args.ring_log2 or 13, "gen_seconds": round(t_gen, 1),
+                "kernel": args.kernel or 2, "variant": max(args.variant, 0), "gen_seconds": round(t_gen, 1),
                 "result_digest": digest,
             },
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                "kernel": "inflate_kernel", "kernel_ms": round(kernel_ms, 4),
+                "kernel": "inflate_v2_kernel" if (args.kernel or 2) == 2 else "inflate_kernel", "kernel_ms": round(kernel_ms, 4),
                 "algorithmic_bytes_per_launch": algo_bytes,
             },
         }

@@ -34,7 +34,8 @@ SYMBOLS = [
      [c_vp, c_vp, c_sz, c_vp, c_sz, ctypes.POINTER(c_sz), ctypes.POINTER(c_sz)]),
 ]
 # exported but not part of the public header (tuning knobs)
-EXTRA = [("md_set_option", ctypes.c_int, [c_vp, ctypes.c_char_p, ctypes.c_int])]
+EXTRA = [("md_set_option", ctypes.c_int, [c_vp, ctypes.c_char_p, ctypes.c_int]),
+         ("md_get_profile", ctypes.c_int, [c_vp, c_vp])]
 
 _lib = None
 

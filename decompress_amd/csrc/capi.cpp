@@ -17,12 +17,21 @@ extern "C" int md_launch_inflate(int ring_log2, int format, uint32_t n, const ui
                                  uint64_t *out_len, uint64_t *consumed, int32_t *status,
                                  uint32_t *checksum, hipStream_t stream);
 
+extern "C" int md_launch_inflate_v2(int variant, int format, uint32_t n, const uint8_t *in,
+                                    const uint64_t *in_off, const uint64_t *in_len, uint8_t *out,
+                                    const uint64_t *out_off, const uint64_t *out_cap,
+                                    uint64_t *out_len, uint64_t *consumed, int32_t *status,
+                                    uint32_t *checksum, uint64_t *dbg, hipStream_t stream);
+
 struct md_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int ring_log2 = 13;
+  int kernel = 2;   // 1 = serial-per-wave (inflate_kernel.hip), 2 = lane-parallel (inflate_v2.hip)
+  int variant = 0;  // v2 geometry
+  uint64_t *dbg = nullptr;  // device buffer of the optional in-kernel profile (32 x u64)
   std::string err;
 };
 
@@ -123,6 +132,14 @@ md_ctx *md_create(int device, void *hip_stream) {
     int v = atoi(e);
     if (v >= 12 && v <= 15) ctx->ring_log2 = v;
   }
+  if (const char *e = getenv("MD_KERNEL")) {
+    int v = atoi(e);
+    if (v == 1 || v == 2) ctx->kernel = v;
+  }
+  if (const char *e = getenv("MD_VARIANT")) {
+    int v = atoi(e);
+    if (v >= 0 && v <= 2) ctx->variant = v;
+  }
   return ctx;
 }
 
@@ -162,7 +179,35 @@ int md_set_option(md_ctx *ctx, const char *key, int value) {
     ctx->ring_log2 = value;
     return MD_OK;
   }
+  if (!strcmp(key, "kernel")) {
+    if (value != 1 && value != 2) return fail(ctx, MD_E_INVALID_ARGUMENT, "kernel must be 1 or 2");
+    ctx->kernel = value;
+    return MD_OK;
+  }
+  if (!strcmp(key, "profile")) {  // in-kernel phase profile of stream 0 (debug builds of the kernel)
+    if (value && !ctx->dbg) {
+      if (hipMalloc((void **)&ctx->dbg, 32 * 8) != hipSuccess) return fail(ctx, MD_E_OUT_OF_MEMORY, "hipMalloc");
+      if (hipMemset(ctx->dbg, 0, 32 * 8) != hipSuccess) return fail(ctx, MD_E_HIP, "hipMemset");
+    } else if (!value && ctx->dbg) {
+      hipFree(ctx->dbg);
+      ctx->dbg = nullptr;
+    }
+    return MD_OK;
+  }
+  if (!strcmp(key, "variant")) {
+    if (value < 0 || value > 2) return fail(ctx, MD_E_INVALID_ARGUMENT, "variant must be 0..2");
+    ctx->variant = value;
+    return MD_OK;
+  }
   return fail(ctx, MD_E_INVALID_ARGUMENT, "unknown option");
+}
+
+// copies the 32 profile words of the last v2 launch to host (after synchronising)
+int md_get_profile(md_ctx *ctx, uint64_t *out32) {
+  if (!ctx || !out32 || !ctx->dbg) return MD_E_INVALID_ARGUMENT;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, hipMemcpy(out32, ctx->dbg, 32 * 8, hipMemcpyDeviceToHost));
+  return MD_OK;
 }
 
 int md_inflate_batch_device(md_ctx *ctx, int format, size_t n, const uint8_t *d_in,
@@ -178,9 +223,15 @@ int md_inflate_batch_device(md_ctx *ctx, int format, size_t n, const uint8_t *d_
   if (!d_in_off || !d_in_len || !d_out_off || !d_out_cap || !d_out_len || !d_consumed || !d_status)
     return fail(ctx, MD_E_INVALID_ARGUMENT, "null descriptor array");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  int rc = md_launch_inflate(ctx->ring_log2, format, (uint32_t)n, d_in, d_in_off, d_in_len, d_out,
-                             d_out_off, d_out_cap, d_out_len, d_consumed, d_status, d_checksum,
-                             ctx->stream);
+  int rc;
+  if (ctx->kernel == 2)
+    rc = md_launch_inflate_v2(ctx->variant, format, (uint32_t)n, d_in, d_in_off, d_in_len, d_out,
+                              d_out_off, d_out_cap, d_out_len, d_consumed, d_status, d_checksum,
+                              ctx->dbg, ctx->stream);
+  else
+    rc = md_launch_inflate(ctx->ring_log2, format, (uint32_t)n, d_in, d_in_off, d_in_len, d_out,
+                           d_out_off, d_out_cap, d_out_len, d_consumed, d_status, d_checksum,
+                           ctx->stream);
   if (rc != 0) return fail(ctx, MD_E_HIP, "inflate kernel launch", (hipError_t)rc);
   return MD_OK;
 }

@@ -56,6 +56,16 @@ class Engine:
     def set_option(self, key, value):
         self._check(self.lib.md_set_option(self.ctx, key.encode(), int(value)))
 
+    PROFILE_FIELDS = ["cyc_ensure", "cyc_decode1", "cyc_decode2", "cyc_emit_a", "cyc_far", "cyc_near",
+                      "cyc_flush", "cyc_header", "rounds", "passes", "lanes", "tokens", "far", "near",
+                      "near_iters"]
+
+    def get_profile(self):
+        """In-kernel phase profile of stream 0 (enable with set_option('profile', 1))."""
+        buf = (ctypes.c_uint64 * 32)()
+        self._check(self.lib.md_get_profile(self.ctx, buf))
+        return dict(zip(self.PROFILE_FIELDS, list(buf)))
+
     def synchronize(self):
         self._check(self.lib.md_synchronize(self.ctx))
 

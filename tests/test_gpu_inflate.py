@@ -22,10 +22,19 @@ def eng():
     return decompress_amd.Engine(0)
 
 
-@pytest.fixture(scope="module", params=[12, 13, 15])
+# every kernel geometry must be bit-exact: (kernel, option, value)
+GEOMETRIES = [(2, "variant", 0), (2, "variant", 1), (2, "variant", 2),
+              (1, "ring_log2", 12), (1, "ring_log2", 13), (1, "ring_log2", 15)]
+
+
+@pytest.fixture(scope="module", params=GEOMETRIES, ids=lambda g: "k%d-%s%d" % g)
 def eng_ring(request, eng):
-    eng.set_option("ring_log2", request.param)
+    k, opt, val = request.param
+    eng.set_option("kernel", k)
+    eng.set_option(opt, val)
     yield eng
+    eng.set_option("kernel", 2)
+    eng.set_option("variant", 0)
     eng.set_option("ring_log2", 13)
 
 
@@ -41,7 +50,8 @@ def test_golden_ns(eng_ring):
                 assert out == bytes.fromhex(c["dst"]), c["name"]
 
 
-def test_golden_stream(eng):
+def test_golden_stream(eng_ring):
+    eng = eng_ring
     res = eng.inflate_many([bytes.fromhex(c["src"]) for c in STREAM], [65536] * len(STREAM))
     for c, (st, _, out, _) in zip(STREAM, res):
         assert st == c["status"], c["name"]
@@ -112,7 +122,8 @@ def test_vs_oracle_zlib_batch(eng, oracle):
         assert adler == zlib.adler32(out)
 
 
-def test_errors_match_oracle(eng, oracle):
+def test_errors_match_oracle(eng_ring, oracle):
+    eng = eng_ring
     """Truncations, bit flips, short outputs: same status / same bytes as the oracle."""
     import decompress_amd
     rng = random.Random(99)
@@ -143,7 +154,8 @@ def test_errors_match_oracle(eng, oracle):
         assert (st, used) == (ost, oused)
 
 
-def test_stored_config1(eng, oracle):
+def test_stored_config1(eng_ring, oracle):
+    eng = eng_ring
     """BASELINE config 1: 64 KiB of stored blocks (65535 + 1)."""
     from decompress_amd import workloads
     payload = np.random.default_rng(1).integers(0, 256, 65536, dtype=np.uint8).tobytes()
