@@ -61,7 +61,7 @@ struct Scratch {
 // LUT construction: De.Inf.huffman (lib/de.ml:523-638) with 16-bit entries.
 // Runs wave-uniform; lane 0 performs the LDS stores.  Returns false for
 // Invalid_huffman.  `lens` are the code lengths of `codes` symbols.
-__device__ bool build_lut(int kind, const uint8_t *lens, uint32_t codes, Scratch *s, Lut *out,
+__device__ __noinline__ bool build_lut(int kind, const uint8_t *lens, uint32_t codes, Scratch *s, Lut *out,
                           uint32_t lane) {
   uint16_t *tbl = kind == K_LENS ? s->lit : kind == K_DISTS ? s->dist : s->codes;
   uint16_t *cnt = s->cnt, *offs = s->offs, *work = s->work;
