@@ -1,0 +1,790 @@
+// inflate_v4.hip — lane-parallel batched RFC1951 inflate for gfx950 (MI355X).
+//
+// One independent stream per wavefront (one 64-lane workgroup per stream, ~15 KiB
+// of LDS, so 10 streams are resident per CU).  Inside the wavefront the 64 lanes
+// decode 64 consecutive S-bit zones of the compressed block at once:
+//
+//   A1   lane i decodes tokens from bit bp + i*S up to bp + (i+1)*S.  Only lane 0
+//        starts on a token boundary; the others are speculative.
+//   A2   every lane compares its start with its left neighbour's end and re-decodes
+//        from there until the chain start_i == end_{i-1} holds.  Huffman streams
+//        re-synchronise (p ~ 0.9 inside a 256-bit zone), so two more passes settle
+//        almost every lane; the consistent prefix of lanes is accepted.  A chain
+//        of token boundaries that starts on a known boundary IS the serial decode
+//        of the reference loop (`inflate`, lib/de.ml:1667-1712).
+//   B    a wave prefix-sum of the lanes' output sizes gives every token its output
+//        position.  Literals are stored straight to their final place in HBM;
+//        matches copy 8 bytes at a time: sources older than the round are final,
+//        sources inside the round are resolved lane-parallel with exact dependency
+//        tracking (one wave-wide wait for the stores per resolution step).
+//   C    the finished round is re-read 16 bytes per lane (L2 hits) and folded into
+//        the Adler-32 (WInf.update / tail, lib/de.ml:453-455, 499-505).
+//
+// The window is the output buffer itself (De.Inf.Ns semantics, lib/de.ml:1534):
+// no copy of it is kept on chip; the L2 (4 MiB per XCD) serves the re-reads.
+// Error behaviour keeps the oracle's order: the first failing token in stream
+// order decides the status and everything before it is written.
+// Block headers, LUT construction (lib/de.ml:523-638, 1733-1793), stored blocks
+// (lib/de.ml:1613-1627) and the zlib frame (lib/zl.ml:400-417) run wave-uniform
+// between rounds.
+#include "inflate_common.hpp"
+
+namespace md {
+namespace v4 {
+
+#define MD_LDS __attribute__((address_space(3)))
+typedef MD_LDS uint32_t lds_u32;
+typedef MD_LDS uint16_t lds_u16;
+typedef MD_LDS uint8_t lds_u8;
+typedef uint64_t u64_u __attribute__((aligned(1)));
+typedef uint32_t u32_u __attribute__((aligned(1)));
+typedef uint16_t u16_u __attribute__((aligned(1)));
+
+constexpr uint32_t kDistBase = 852;  // Scratch::dist follows Scratch::lit
+constexpr uint32_t kStopEob = 100;   // per-lane stop reasons; values < 100 are MD_* status codes
+
+// match record: gap[31:24] | len-3[23:16] | near[15] | dist-1[14:0]
+constexpr uint32_t kNear = 0x8000u;
+
+enum { P_ENSURE = 0, P_DECODE1, P_DECODE2, P_EMIT_A, P_FAR, P_NEAR, P_ADLER, P_HEADER, P_COUNT };
+enum { C_ROUNDS = 0, C_PASSES, C_LANES, C_TOKENS, C_SLOTS, C_NEAR_IT, C_COUNT };
+template <bool ON>
+struct Prof {
+  uint64_t t0;
+  uint64_t acc[P_COUNT];
+  uint32_t cnt[C_COUNT];
+  __device__ __forceinline__ void init() {
+    for (int i = 0; i < P_COUNT; i++) acc[i] = 0;
+    for (int i = 0; i < C_COUNT; i++) cnt[i] = 0;
+    t0 = clock64();
+  }
+  __device__ __forceinline__ void tick(int i) {
+    uint64_t t = clock64();
+    acc[i] += t - t0;
+    t0 = t;
+  }
+  __device__ __forceinline__ void count(int i, uint32_t n = 1) { cnt[i] += n; }
+};
+template <>
+struct Prof<false> {
+  __device__ __forceinline__ void init() {}
+  __device__ __forceinline__ void tick(int) {}
+  __device__ __forceinline__ void count(int, uint32_t = 1) {}
+};
+
+template <int S_, int LMAX_, int MMAX_, int KMAX_, int INB_, int PASSES_>
+struct Cfg {
+  static constexpr uint32_t S = S_;        // bits per lane zone
+  static constexpr uint32_t LMAX = LMAX_;  // literals per lane per round
+  static constexpr uint32_t MMAX = MMAX_;  // matches per lane per round
+  static constexpr uint32_t KMAX = KMAX_;  // decode slots per pass
+  static constexpr uint32_t PASSES = PASSES_;  // A2 passes after A1
+  static constexpr uint32_t IN_BYTES = INB_;   // compressed-input ring
+  static constexpr uint32_t IN_WORDS = INB_ / 4;
+  static constexpr uint32_t CHUNK = INB_ >= 4096 ? 1024 : 512;  // refill granularity
+  static constexpr uint32_t CHUNK_LANE = CHUNK / 64;
+  static constexpr uint32_t NEED = 8 * S_ + 32 > 640 ? 8 * S_ + 32 : 640;  // bytes a round / header may touch
+  static_assert(LMAX_ + MMAX_ <= 64, "token type mask is one 64-bit register");
+  static_assert(NEED + CHUNK <= IN_BYTES, "input ring too small");
+  static_assert(CHUNK_LANE == 8 || CHUNK_LANE == 16, "refill is 8 or 16 bytes per lane");
+};
+
+template <class C>
+struct Smem {
+  uint32_t inring[C::IN_WORDS + 4];  // +1 mirror word (ring[IN_WORDS] == ring[0]), padded
+  Scratch sc;                        // packed 16-bit LUTs (lit[852] | dist[592]) + construction scratch
+  uint32_t mrec[C::MMAX * kWave];    // match tokens, [m][lane]
+  uint8_t lits[C::LMAX * kWave];     // literal tokens, [i][lane]
+};
+
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t lane) {
+  uint32_t x = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    uint32_t t = __shfl_up(x, o);
+    if (lane >= (uint32_t)o) x += t;
+  }
+  return x - v;
+}
+__device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) {
+  return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(l));
+}
+
+// L1-bypassing (nt) accesses to the output buffer: it is written and re-read by
+// different lanes of this wavefront, and the same 128-B line can be cached by the
+// CU's L1 before a later store completes it.
+__device__ __forceinline__ uint64_t out_ld64(const uint8_t *p) {
+  return __builtin_nontemporal_load(reinterpret_cast<const u64_u *>(p));
+}
+__device__ __forceinline__ uint32_t out_ld8(const uint8_t *p) { return __builtin_nontemporal_load(p); }
+// n (1..8) bytes at g[x ..) without touching g[cap ..)
+__device__ __forceinline__ uint64_t out_ld_guard(const uint8_t *g, uint32_t x, uint32_t n, uint32_t cap) {
+  if (x + 8 <= cap) return out_ld64(g + x);
+  uint64_t v = 0;
+  for (uint32_t j = 0; j < n && j < 8; j++) v |= (uint64_t)out_ld8(g + x + j) << (8 * j);
+  return v;
+}
+// store the low n (1..8) bytes of v
+__device__ __forceinline__ void out_st(uint8_t *p, uint64_t v, uint32_t n) {
+  if (n >= 8) {
+    *reinterpret_cast<u64_u *>(p) = v;
+    return;
+  }
+  if (n & 4) {
+    *reinterpret_cast<u32_u *>(p) = (uint32_t)v;
+    p += 4;
+    v >>= 32;
+  }
+  if (n & 2) {
+    *reinterpret_cast<u16_u *>(p) = (uint16_t)v;
+    p += 2;
+    v >>= 16;
+  }
+  if (n & 1) *p = (uint8_t)v;
+}
+// LZ77 copy of ml bytes to g[q ..) from d bytes back.  Every source byte is read
+// from [q-d, q) — final and visible — never from bytes this copy writes itself.
+// Loads of up to 32 bytes are in flight together.
+__device__ __forceinline__ void copy_match(uint8_t *g, uint32_t q, uint32_t ml, uint32_t d, uint32_t cap) {
+  const uint32_t src = q - d;
+  if (d >= 8) {
+    for (uint32_t o = 0; o < ml; o += d) {  // periodic: dst[o + j] = orig[j], j < d
+      const uint32_t n = ml - o < d ? ml - o : d;
+      for (uint32_t j = 0; j < n; j += 32) {
+        const uint32_t m = n - j;
+        uint64_t v[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) v[u] = m > 8 * u ? out_ld_guard(g, src + j + 8 * u, m - 8 * u, cap) : 0;
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++)
+          if (m > 8 * u) out_st(g + q + o + j + 8 * u, v[u], m - 8 * u);
+      }
+    }
+  } else {
+    // period d < 8: replicate the last d bytes into a 64-bit pattern
+    uint64_t v = out_ld_guard(g, src, d, cap);
+    const uint32_t sh = 8 * d;
+    v &= (1ull << sh) - 1;
+    v |= v << sh;
+    if (2 * sh < 64) v |= v << (2 * sh);
+    if (4 * sh < 64) v |= v << (4 * sh);
+    const uint32_t adv = d * (8 / d);  // largest multiple of the period that fits 8 bytes
+    uint32_t j = 0;
+    for (; j + 8 <= ml; j += adv) out_st(g + q + j, v, 8);
+    if (j < ml) out_st(g + q + j, v, ml - j);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Compressed input: an LDS ring addressed by absolute bit position.
+template <class C>
+struct Input {
+  const uint8_t *p;
+  uint32_t nbytes;
+  uint32_t lane;
+  lds_u32 *ring;
+  uint32_t in_hi;  // stream bytes [.., in_hi) are in the ring (multiple of CHUNK)
+
+  __device__ __forceinline__ void load_chunk() {
+    constexpr uint32_t N = C::CHUNK_LANE;
+    uint32_t off = in_hi + lane * N;
+    uint32_t w[4] = {0, 0, 0, 0};
+    if (off + N <= nbytes) {
+      __builtin_memcpy(w, p + off, N);
+    } else if (off < nbytes) {
+      for (uint32_t k = 0; k < N && off + k < nbytes; k++) w[k >> 2] |= (uint32_t)p[off + k] << (8 * (k & 3));
+    }
+    uint32_t r = (off & (C::IN_BYTES - 1)) >> 2;
+    ring[r] = w[0];
+    ring[r + 1] = w[1];
+    if (N == 16) {
+      ring[r + 2] = w[2];
+      ring[r + 3] = w[3];
+    }
+    if (r == 0) ring[C::IN_WORDS] = w[0];  // mirror of word 0 for the wrap-around peek
+    in_hi += C::CHUNK;
+  }
+  __device__ __forceinline__ void reset(uint32_t byte_pos) { in_hi = byte_pos & ~(C::CHUNK - 1); }
+  __device__ __forceinline__ void ensure(uint32_t byte_pos) {
+    while (in_hi < byte_pos + C::NEED) load_chunk();
+  }
+  // 32 bits of the stream starting at absolute bit position bp (zero beyond the end)
+  __device__ __forceinline__ uint32_t peek(uint32_t bp) const {
+    uint32_t w = (bp >> 5) & (C::IN_WORDS - 1);
+    uint32_t lo = ring[w], hi = ring[w + 1];
+    return __builtin_amdgcn_alignbit(hi, lo, bp & 31);
+  }
+};
+
+// wave-uniform bit cursor over the ring (block headers)
+template <class C>
+struct UReader {
+  const Input<C> *in;
+  uint32_t bp;
+  uint32_t total;  // total real bits of the stream
+  __device__ __forceinline__ int64_t avail() const { return (int64_t)total - (int64_t)bp; }
+  __device__ __forceinline__ uint32_t peek(uint32_t n) const { return uni(in->peek(bp)) & ((1u << n) - 1); }
+  __device__ __forceinline__ void drop(uint32_t n) { bp += n; }
+};
+
+struct LaneState {
+  uint32_t start, end, nlit, nmat, nb, stop;
+  uint64_t tmask;  // bit t set = token t is a match
+};
+
+// One speculative decode pass of this lane's zone [start, limit).
+template <class C, class PF>
+__device__ __forceinline__ void decode_pass(const Input<C> &in, const lds_u16 *lut, lds_u32 *mrec,
+                                            lds_u8 *lits, uint32_t lane, uint32_t total_bits,
+                                            uint32_t lmask, uint32_t lroot, uint32_t dmask,
+                                            uint32_t droot, bool go, uint32_t limit, LaneState &ls,
+                                            PF &pf) {
+  uint32_t p = ls.start, ptok = ls.start, nlit = 0, nmat = 0, nb = 0, stop = 0;
+  uint64_t tmask = 0;
+  // table cursor: first level (shift 0) of the lit/len LUT
+  uint32_t isdist = 0, shift = 0, tbase = 0, tmsk = lmask, mlen = 0;
+  bool run = go;
+  for (uint32_t slot = 0; slot < C::KMAX; ++slot) {
+    if (run && !isdist && shift == 0 &&
+        (p >= limit || nlit == C::LMAX || nmat == C::MMAX))
+      run = false;  // token boundary: zone finished or token budget exhausted
+    if (!__any(run)) break;
+    pf.count(C_SLOTS);
+    if (run) {
+      const uint32_t w = in.peek(p);
+      const uint32_t e = lut[tbase + ((w >> shift) & tmsk)];
+      if (e & kLink) {
+        shift = isdist ? droot : lroot;
+        tbase = (isdist ? kDistBase : 0u) + (e & 1023);
+        tmsk = (1u << ((e >> 10) & 15)) - 1;
+      } else {
+        const uint32_t len = (e >> 9) & 15, sym = e & 511;
+        // RFC1951 symbol -> (base, extra bits), lib/de.ml:293-325 (+3 / +1 folded in)
+        uint32_t xb, base;
+        if (isdist) {
+          const uint32_t dv = sym & 31;
+          xb = (dv >= 4 && dv < 30) ? (dv - 2) >> 1 : 0;
+          base = dv < 4 ? dv + 1 : dv < 30 ? ((2 + (dv & 1)) << xb) + 1 : 0;
+        } else {
+          const uint32_t l = (sym - 257) & 31;
+          xb = (sym > 256 && l >= 8 && l < 28) ? (l - 4) >> 2 : 0;
+          base = (l < 8 ? l : l < 28 ? (4 + (l & 3)) << xb : l == 28 ? 255 : 0) + 3;
+        }
+        const uint32_t val = base + __builtin_amdgcn_ubfe(w >> len, 0, xb);
+        const uint32_t pn = p + len + xb;
+        if (isdist && e == kBad) stop = MD_INVALID_DISTANCE_CODE;  // D2: before the EOI check, like the oracle
+        else if (pn > total_bits) stop = MD_UNEXPECTED_END_OF_INPUT;
+        else if (isdist) {
+          if (val == 0) stop = MD_INVALID_DISTANCE_CODE;
+          else {
+            mrec[nmat * kWave + lane] = ((mlen - 3) << 16) | (val - 1);
+            tmask |= 1ull << (nlit + nmat);
+            nmat++;
+            nb += mlen;
+            ptok = pn;
+          }
+          isdist = 0;
+        } else if (sym < 256) {
+          lits[nlit * kWave + lane] = (uint8_t)sym;
+          nlit++;
+          nb++;
+          ptok = pn;
+        } else if (sym == 256) {
+          ptok = pn;
+          stop = kStopEob;
+        } else {
+          mlen = val;
+          isdist = 1;
+        }
+        p = pn;
+        shift = 0;
+        tbase = isdist ? kDistBase : 0u;
+        tmsk = isdist ? dmask : lmask;
+        if (stop) run = false;
+      }
+    }
+  }
+  if (go) {
+    ls.end = ptok;
+    ls.nlit = nlit;
+    ls.nmat = nmat;
+    ls.nb = nb;
+    ls.stop = stop;
+    ls.tmask = tmask;
+  }
+}
+
+// ---------------------------------------------------------------------------
+struct Sink {
+  uint8_t *g;
+  uint32_t cap;
+  uint32_t pos;  // bytes produced
+  uint32_t lane;
+  uint32_t a, b;
+  bool want_adler;
+
+  __device__ __forceinline__ void adler_fold(uint32_t s1, uint32_t s2, uint32_t n) {
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    b = (b + n * a + s2) % 65521u;
+    a = (a + s1) % 65521u;
+  }
+  // fold g[pos, pos+total) (already written, visible) into the Adler-32 and advance pos
+  __device__ __forceinline__ void account(uint32_t total) {
+    const uint32_t endp = pos + total;
+    if (want_adler) {
+      for (uint32_t ps = pos; ps < endp; ps += 1024) {
+        const uint32_t b0 = ps + 1024 < endp ? ps + 1024 : endp;
+        const uint32_t cpos = ps + lane * 16;
+        uint32_t s1 = 0, s2 = 0;
+        if (cpos < b0) {
+          const uint32_t n = b0 - cpos < 16 ? b0 - cpos : 16;
+          const uint64_t v0 = out_ld_guard(g, cpos, n, cap);
+          const uint64_t v1 = n > 8 ? out_ld_guard(g, cpos + 8, n - 8, cap) : 0;
+#pragma unroll
+          for (uint32_t k = 0; k < 16; k++) {
+            uint32_t d = (uint32_t)((k < 8 ? v0 >> (8 * k) : v1 >> (8 * (k - 8))) & 0xff);
+            if (k >= n) d = 0;
+            s1 += d;
+            s2 += (b0 - (cpos + k)) * d;
+          }
+        }
+        adler_fold(s1, s2, b0 - ps);
+      }
+    }
+    pos = endp;
+  }
+};
+
+// ---------------------------------------------------------------------------
+// Phase B of a round: place the accepted tokens.  Returns MD_OK or the status of
+// the first failing token (stream order); *emitted = bytes produced.
+template <class C, class PF>
+__device__ __forceinline__ int emit_round(lds_u32 *mrec, const lds_u8 *lits, Sink &sk, uint32_t lane,
+                                          uint32_t nvalid, const LaneState &ls, uint32_t *nvalid_out,
+                                          uint32_t *emitted, PF &pf) {
+  const uint32_t R0 = sk.pos, cap = sk.cap;
+  uint8_t *g = sk.g;
+  const bool mine = lane < nvalid;
+  const uint32_t mynb = mine ? ls.nb : 0;
+  const uint32_t off = wave_excl_scan(mynb, lane);
+  const uint32_t q0 = R0 + off;
+  const uint32_t ntok = mine ? ls.nlit + ls.nmat : 0;
+
+  // (a) literals straight to their final place; matches become records (gap of
+  //     literals in front, near/far flag); position-dependent checks in stream order
+  uint32_t q = q0, li = 0, nm = 0, gap = 0, fail = 0, good = 0;  // good = bytes before the failing token
+  for (uint32_t t = 0; t < C::LMAX + C::MMAX; t++) {
+    if (!__any(t < ntok && !fail)) break;
+    if (t < ntok && !fail) {
+      if (!((ls.tmask >> t) & 1)) {
+        if (q >= cap) fail = MD_UNEXPECTED_END_OF_OUTPUT;
+        else {
+          g[q] = lits[li * kWave + lane];
+          li++;
+          q++;
+          gap++;
+        }
+      } else {
+        const uint32_t tk = mrec[nm * kWave + lane];
+        const uint32_t d = (tk & 0x7fff) + 1, ml = ((tk >> 16) & 0xff) + 3;
+        const uint32_t lim = q < 32768u ? q : 32768u;
+        if (d > lim) fail = MD_INVALID_DISTANCE;
+        else if (ml > cap - q) fail = MD_UNEXPECTED_END_OF_OUTPUT;
+        else {
+          mrec[nm * kWave + lane] = tk | (gap << 24) | ((q - d + ml > R0) ? kNear : 0u);
+          nm++;
+          gap = 0;
+          q += ml;
+        }
+      }
+      if (!fail) good = q - q0;
+    }
+  }
+  // first failing lane (stream order) truncates the round
+  int rc = MD_OK;
+  uint32_t total;
+  {
+    uint64_t fm = __ballot(fail != 0);
+    if (fm) {
+      uint32_t fl = __builtin_ctzll(fm);
+      rc = (int)rdlane(fail, fl);
+      total = rdlane(off, fl) + rdlane(good, fl);
+      if (lane > fl) nm = 0;  // later lanes are void
+      nvalid = fl + 1;
+    } else {
+      total = rdlane(off + mynb, nvalid - 1);  // inclusive sum at the last accepted lane
+    }
+  }
+  pf.tick(P_EMIT_A);
+
+  // (b) far matches: the whole source is older than this round — final, and visible
+  //     once the stores of earlier rounds have been waited for.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  {
+    uint32_t qq = q0;
+    for (uint32_t m = 0; m < C::MMAX; m++) {
+      if (!__any(m < nm)) break;
+      if (m < nm) {
+        const uint32_t tk = mrec[m * kWave + lane];
+        const uint32_t d = (tk & 0x7fff) + 1, ml = ((tk >> 16) & 0xff) + 3;
+        qq += tk >> 24;
+        if (!(tk & kNear)) copy_match(g, qq, ml, d, cap);
+        qq += ml;
+      }
+    }
+  }
+  pf.tick(P_FAR);
+
+  // (c) near matches: the source reaches into this round.  `done` is the position
+  //     of this lane's first unresolved match: everything the lane produces before
+  //     it is final.  A match may run when the first unresolved lane at or after
+  //     the producer of its source is itself, or has progressed beyond the source.
+  //     One match per lane per step; the wave waits for the step's stores so the
+  //     next step can read them (L1 bypassed).
+  {
+    uint32_t m = 0, qq = q0;
+    uint32_t d = 0, ml = 0, qm = 0, ja = 0;
+    bool pending = false;
+    auto advance = [&]() {
+      pending = false;
+      while (m < nm) {
+        const uint32_t tk = mrec[m * kWave + lane];
+        d = (tk & 0x7fff) + 1;
+        ml = ((tk >> 16) & 0xff) + 3;
+        qm = qq + (tk >> 24);
+        m++;
+        qq = qm + ml;
+        if (tk & kNear) {
+          pending = true;
+          break;
+        }
+      }
+    };
+    advance();
+    bool need_ja = pending;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the far copies have landed
+    for (;;) {
+      const uint64_t pm = __ballot(pending);
+      if (!pm) break;
+      pf.count(C_NEAR_IT);
+      if (__any(need_ja)) {
+        // producer of the first source byte: the last lane whose q0 <= src
+        const uint32_t src = (pending && qm - d > R0) ? qm - d : R0;
+        uint32_t lo = 0;
+#pragma unroll
+        for (int step = 32; step > 0; step >>= 1) {
+          const uint32_t cand = lo + step;
+          const uint32_t qc = __shfl(q0, cand & 63);
+          if (cand < 64 && qc <= src) lo = cand;
+        }
+        if (need_ja) ja = lo;
+        need_ja = false;
+      }
+      const uint32_t done = pending ? qm : 0xffffffffu;
+      uint32_t f = lane;
+      if (pending) f = ja + (uint32_t)__builtin_ctzll(pm >> ja);  // bit `lane` is set: pm >> ja != 0
+      const uint32_t df = __shfl(done, f);
+      if (pending && (f >= lane || df >= qm - d + ml)) {
+        copy_match(g, qm, ml, d, cap);
+        advance();
+        need_ja = pending;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this step's stores have landed
+    }
+  }
+  pf.tick(P_NEAR);
+  *nvalid_out = nvalid;
+  *emitted = total;
+  return rc;
+}
+
+// ---------------------------------------------------------------------------
+// All rounds of one Huffman block.  On return *bp_io is the bit after the EOB.
+template <class C, class PF>
+__device__ __forceinline__ int inflate_block(Smem<C> *smg, Input<C> &in, Sink &sk, uint32_t lmask,
+                                             uint32_t lroot, uint32_t dmask, uint32_t droot,
+                                             uint32_t lane, uint32_t total_bits, uint32_t *bp_io,
+                                             PF &pf) {
+  uint32_t bp = *bp_io;
+  const lds_u16 *lut = (const lds_u16 *)smg->sc.lit;  // lit[852] then dist[592], contiguous
+  lds_u32 *mrec = (lds_u32 *)smg->mrec;
+  lds_u8 *lits = (lds_u8 *)smg->lits;
+  for (;;) {
+    in.ensure(bp >> 3);
+    pf.tick(P_ENSURE);
+    pf.count(C_ROUNDS);
+    pf.count(C_PASSES);
+    LaneState ls;
+    ls.start = bp + lane * C::S;
+    const uint32_t limit = bp + (lane + 1) * C::S;
+    decode_pass<C>(in, lut, mrec, lits, lane, total_bits, lmask, lroot, dmask, droot, true, limit, ls, pf);
+    pf.tick(P_DECODE1);
+    // A2: chain the lanes
+    for (uint32_t it = 0; it < C::PASSES; it++) {
+      const uint32_t pe = __shfl_up(ls.end, 1), ps = __shfl_up(ls.stop, 1);
+      const bool redo = lane > 0 && ps == 0 && pe != ls.start;
+      if (!__any(redo)) break;
+      if (redo) ls.start = pe;
+      pf.count(C_PASSES);
+      decode_pass<C>(in, lut, mrec, lits, lane, total_bits, lmask, lroot, dmask, droot, redo, limit, ls, pf);
+    }
+    pf.tick(P_DECODE2);
+    uint32_t nvalid;
+    {
+      const uint32_t pe = __shfl_up(ls.end, 1), ps = __shfl_up(ls.stop, 1);
+      const uint64_t bad = __ballot(lane > 0 && (ps != 0 || pe != ls.start));
+      nvalid = bad ? (uint32_t)__builtin_ctzll(bad) : 64;
+    }
+    uint32_t emitted;
+    int rc = emit_round<C>(mrec, lits, sk, lane, nvalid, ls, &nvalid, &emitted, pf);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the round's stores have landed
+    sk.account(emitted);
+    pf.tick(P_ADLER);
+    pf.count(C_LANES, nvalid);
+    pf.count(C_TOKENS, wave_sum(lane < nvalid ? ls.nlit + ls.nmat : 0));
+    if (rc != MD_OK) return rc;
+    const uint32_t lastl = nvalid - 1;
+    const uint32_t lstop = rdlane(ls.stop, lastl);
+    bp = rdlane(ls.end, lastl);
+    if (lstop == kStopEob) break;
+    if (lstop != 0) return (int)lstop;
+  }
+  *bp_io = bp;
+  return MD_OK;
+}
+
+// Dynamic block header (lib/de.ml:1733-1793), wave-uniform over the LDS ring.
+template <class C>
+__device__ __noinline__ int dynamic_header(UReader<C> &ur, Scratch *s, Lut *lit, Lut *dist, uint32_t lane) {
+  if (ur.avail() < 14) return MD_UNEXPECTED_END_OF_INPUT;
+  uint32_t hlit = ur.peek(5) + 257;
+  ur.drop(5);
+  uint32_t hdist = ur.peek(5) + 1;
+  ur.drop(5);
+  uint32_t hclen = ur.peek(4) + 4;
+  ur.drop(4);
+  if (lane < 19) s->lens[lane] = 0;
+  for (uint32_t i = 0; i < hclen; i++) {
+    if (ur.avail() < 3) return MD_UNEXPECTED_END_OF_INPUT;
+    uint32_t v = ur.peek(3);
+    ur.drop(3);
+    if (lane == 0) s->lens[c_zigzag[i]] = (uint8_t)v;
+  }
+  Lut cl;
+  if (!build_lut(K_CODES, s->lens, 19, s, &cl, lane)) return MD_INVALID_DICTIONARY;
+  const uint32_t max_res = hlit + hdist;
+  uint32_t i = 0, prev = 0;
+  while (i < max_res) {
+    if (ur.avail() < (int64_t)cl.maxl) return MD_UNEXPECTED_END_OF_INPUT;
+    uint32_t e = uni(cl.t[ur.peek(cl.maxl)]);
+    if (e == kBad) return MD_INVALID_DICTIONARY;
+    uint32_t sym = e & 511, len = (e >> 9) & 15;
+    ur.drop(len);
+    if (sym < 16) {
+      if (lane == 0) s->lens[i] = (uint8_t)sym;
+      prev = sym;
+      i++;
+    } else {
+      uint32_t nb = sym == 16 ? 2 : sym == 17 ? 3 : 7;
+      if (sym == 16 && i == 0) return MD_INVALID_DICTIONARY;
+      if (ur.avail() < (int64_t)nb) return MD_UNEXPECTED_END_OF_INPUT;
+      uint32_t copy = ur.peek(nb) + (sym == 18 ? 11 : 3);
+      ur.drop(nb);
+      uint32_t val = sym == 16 ? prev : 0;
+      if (i + copy > max_res) return MD_INVALID_DICTIONARY;
+      for (uint32_t x = lane; x < copy; x += kWave) s->lens[i + x] = (uint8_t)val;
+      prev = val;
+      i += copy;
+    }
+  }
+  if (uni(s->lens[256]) == 0) return MD_INVALID_DICTIONARY;
+  if (!build_lut(K_LENS, s->lens, hlit, s, lit, lane)) return MD_INVALID_DICTIONARY;
+  if (!build_lut(K_DISTS, s->lens + hlit, hdist, s, dist, lane)) return MD_INVALID_DICTIONARY;
+  return MD_OK;
+}
+
+__device__ __noinline__ void fixed_tables(Scratch *s, Lut *lit, Lut *dist, uint32_t lane) {
+  for (uint32_t n = lane; n < 288; n += kWave) s->lens[n] = n < 144 ? 8 : n < 256 ? 9 : n < 280 ? 7 : 8;
+  build_lut(K_LENS, s->lens, 288, s, lit, lane);
+  if (lane < 32) s->dist[lane] = (uint16_t)((5u << 9) | (__brev(lane) >> 27));
+  dist->t = s->dist;
+  dist->mask = 31;
+  dist->root = 5;
+  dist->maxl = 5;
+}
+
+template <class C, bool PROF>
+__global__ __launch_bounds__(kWave) void inflate_v4_kernel(
+    int format, uint32_t n, const uint8_t *__restrict__ in, const uint64_t *__restrict__ in_off,
+    const uint64_t *__restrict__ in_len, uint8_t *out, const uint64_t *__restrict__ out_off,
+    const uint64_t *__restrict__ out_cap, uint64_t *__restrict__ out_len,
+    uint64_t *__restrict__ consumed, int32_t *__restrict__ status, uint32_t *__restrict__ checksum,
+    uint64_t *__restrict__ dbg) {
+  extern __shared__ __align__(16) uint8_t smem_raw[];
+  Smem<C> *smg = reinterpret_cast<Smem<C> *>(smem_raw);
+  Prof<PROF> pf;
+  pf.init();
+  const uint32_t lane = threadIdx.x;
+  const uint32_t sid = blockIdx.x;
+  if (sid >= n) return;
+
+  const uint8_t *src = in + in_off[sid];
+  uint64_t slen64 = in_len[sid], cap64 = out_cap[sid];
+  uint32_t slen = slen64 > 0x1ffffff0ull ? 0x1ffffff0u : (uint32_t)slen64;
+  uint32_t cap = cap64 > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)cap64;
+
+  int rc = MD_OK;
+  uint32_t body_off = 0, body_len = slen;
+  if (format == MD_FORMAT_ZLIB) {  // Zl.Inf.Ns.inflate, lib/zl.ml:400-417
+    if (slen < 2) rc = MD_UNEXPECTED_END_OF_INPUT;
+    else {
+      uint32_t cmf = src[0], flg = src[1];
+      if (((cmf << 8) + flg) % 31 != 0 || (cmf & 0xf) != 8) rc = MD_INVALID_HEADER;
+      else if (slen < 6) rc = MD_UNEXPECTED_END_OF_INPUT;
+      else {
+        body_off = 2;
+        body_len = slen - 6;
+      }
+    }
+  }
+
+  Sink sk;
+  sk.g = out + out_off[sid];
+  sk.cap = cap;
+  sk.pos = 0;
+  sk.lane = lane;
+  sk.a = 1;
+  sk.b = 0;
+  sk.want_adler = (checksum != nullptr) || format == MD_FORMAT_ZLIB;
+
+  Input<C> inp;
+  inp.p = src + body_off;
+  inp.nbytes = body_len;
+  inp.lane = lane;
+  inp.ring = (lds_u32 *)smg->inring;
+  inp.reset(0);
+  const uint32_t total_bits = body_len * 8;
+  uint32_t bp = 0;
+
+  if (rc == MD_OK) {
+    bool last = false;
+    while (!last && rc == MD_OK) {
+      inp.ensure(bp >> 3);
+      UReader<C> ur{&inp, bp, total_bits};
+      if (ur.avail() < 3) {
+        rc = MD_UNEXPECTED_END_OF_INPUT;
+        break;
+      }
+      last = ur.peek(1);
+      ur.drop(1);
+      uint32_t type = ur.peek(2);
+      ur.drop(2);
+      bp = ur.bp;
+      if (type == 0) {
+        // flat, lib/de.ml:1613-1627
+        uint32_t p = (bp + 7) >> 3;
+        if (body_len - p < 4) {
+          rc = MD_UNEXPECTED_END_OF_INPUT;
+          break;
+        }
+        uint32_t hdr = uni(inp.peek(p * 8));
+        uint32_t len = hdr & 0xffff, nlen = hdr >> 16;
+        p += 4;
+        if (nlen != 0xffff - len) rc = MD_INVALID_COMPLEMENT_OF_LENGTH;
+        else if (len > body_len - p) rc = MD_UNEXPECTED_END_OF_INPUT;
+        else if (len > sk.cap - sk.pos) rc = MD_UNEXPECTED_END_OF_OUTPUT;
+        else {
+          const uint8_t *q = inp.p + p;
+          uint8_t *dd = sk.g + sk.pos;
+          for (uint32_t j = lane * 8; j < len; j += kWave * 8) {
+            const uint32_t m = len - j < 8 ? len - j : 8;
+            uint64_t v = 0;
+            if (m == 8) v = *reinterpret_cast<const u64_u *>(q + j);
+            else for (uint32_t k = 0; k < m; k++) v |= (uint64_t)q[j + k] << (8 * k);
+            out_st(dd + j, v, m);
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          sk.account(len);
+          p += len;
+          bp = p * 8;
+          inp.reset(p);
+        }
+      } else if (type == 3) {
+        rc = MD_INVALID_KIND_OF_BLOCK;
+      } else {
+        Lut lit, dist;
+        if (type == 1) fixed_tables(&smg->sc, &lit, &dist, lane);
+        else {
+          rc = dynamic_header<C>(ur, &smg->sc, &lit, &dist, lane);
+          bp = ur.bp;
+        }
+        pf.tick(P_HEADER);
+        if (rc == MD_OK)
+          rc = inflate_block<C>(smg, inp, sk, uni(lit.mask), uni(lit.root), uni(dist.mask), uni(dist.root),
+                                lane, total_bits, &bp, pf);
+      }
+    }
+  }
+  uint32_t used = (bp + 7) >> 3;  // i_pos - (bits lsr 3), lib/de.ml:1805
+  uint32_t adler = (sk.b << 16) | sk.a;
+  if (rc == MD_OK && format == MD_FORMAT_ZLIB) {
+    const uint8_t *t = src + 2 + used;
+    uint32_t want = ((uint32_t)t[0] << 24) | ((uint32_t)t[1] << 16) | ((uint32_t)t[2] << 8) | t[3];
+    if (want != adler) rc = MD_INVALID_CHECKSUM;
+    used += 6;
+  }
+  if (lane == 0) {
+    out_len[sid] = sk.pos;
+    consumed[sid] = rc == MD_OK ? used : 0;
+    status[sid] = rc;
+    if (checksum) checksum[sid] = adler;
+  }
+  if constexpr (PROF) {
+    if (lane == 0 && sid == 0 && dbg) {
+      for (int i = 0; i < P_COUNT; i++) dbg[i] = pf.acc[i];
+      for (int i = 0; i < C_COUNT; i++) dbg[P_COUNT + i] = pf.cnt[i];
+    }
+  }
+}
+
+}  // namespace v4
+}  // namespace md
+
+extern "C" int md_launch_inflate_v2(int variant, int format, uint32_t n, const uint8_t *in,
+                                    const uint64_t *in_off, const uint64_t *in_len, uint8_t *out,
+                                    const uint64_t *out_off, const uint64_t *out_cap,
+                                    uint64_t *out_len, uint64_t *consumed, int32_t *status,
+                                    uint32_t *checksum, uint64_t *dbg, hipStream_t stream) {
+  if (n == 0) return 0;
+  dim3 grid(n), block(md::kWave);
+#define MD_LAUNCH_V4(CFG)                                                                        \
+  do {                                                                                           \
+    if (dbg)                                                                                     \
+      hipLaunchKernelGGL((md::v4::inflate_v4_kernel<CFG, true>), grid, block,                    \
+                         sizeof(md::v4::Smem<CFG>), stream, format, n, in, in_off, in_len, out,  \
+                         out_off, out_cap, out_len, consumed, status, checksum, dbg);            \
+    else                                                                                         \
+      hipLaunchKernelGGL((md::v4::inflate_v4_kernel<CFG, false>), grid, block,                   \
+                         sizeof(md::v4::Smem<CFG>), stream, format, n, in, in_off, in_len, out,  \
+                         out_off, out_cap, out_len, consumed, status, checksum, dbg);            \
+  } while (0)
+  //                      S   LMAX MMAX KMAX IN_BYTES PASSES
+  using A = md::v4::Cfg<256, 40, 20, 72, 4096, 3>;
+  using B = md::v4::Cfg<128, 24, 12, 40, 2048, 3>;
+  using Cc = md::v4::Cfg<384, 44, 20, 96, 8192, 2>;
+  switch (variant) {
+  case 0: MD_LAUNCH_V4(A); break;
+  case 1: MD_LAUNCH_V4(B); break;
+  case 2: MD_LAUNCH_V4(Cc); break;
+  default: return -1;
+  }
+#undef MD_LAUNCH_V4
+  return (int)hipGetLastError();
+}

@@ -56,9 +56,9 @@ class Engine:
     def set_option(self, key, value):
         self._check(self.lib.md_set_option(self.ctx, key.encode(), int(value)))
 
-    PROFILE_FIELDS = ["cyc_ensure", "cyc_decode", "cyc_chain", "cyc_emit_a", "cyc_far", "cyc_near",
-                      "cyc_flush", "cyc_header", "rounds", "slots", "lanes", "tokens", "far", "near",
-                      "near_iters", "slowchain"]
+    PROFILE_FIELDS = ["cyc_ensure", "cyc_decode1", "cyc_decode2", "cyc_emit_a", "cyc_far", "cyc_near",
+                      "cyc_adler", "cyc_header", "rounds", "passes", "lanes", "tokens", "slots",
+                      "near_iters"]
 
     def get_profile(self):
         """In-kernel phase profile of stream 0 (enable with set_option('profile', 1))."""
