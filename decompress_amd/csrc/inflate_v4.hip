@@ -89,13 +89,42 @@ struct Cfg {
   static_assert(CHUNK_LANE == 8 || CHUNK_LANE == 16, "refill is 8 or 16 bytes per lane");
 };
 
+// fat LUT entry: base[15:0] | xbits[19:16] | len[23:20] | type[26:24]
+//   base = literal byte / length base (+3) / distance base (+1) / sub-table offset (LINK)
+enum : uint32_t { T_LIT = 0, T_LEN = 1, T_EOB = 2, T_LINK = 3, T_BAD = 4, T_DIST = 5 };
+
 template <class C>
 struct Smem {
   uint32_t inring[C::IN_WORDS + 4];  // +1 mirror word (ring[IN_WORDS] == ring[0]), padded
-  Scratch sc;                        // packed 16-bit LUTs (lit[852] | dist[592]) + construction scratch
-  uint32_t mrec[C::MMAX * kWave];    // match tokens, [m][lane]
-  uint8_t lits[C::LMAX * kWave];     // literal tokens, [i][lane]
+  uint32_t lut[852 + 592];           // fat lit/len LUT, then fat distance LUT
+  union U {
+    Scratch sc;  // packed 16-bit LUTs + construction scratch: live only while a header is parsed
+    struct T {
+      uint32_t mrec[C::MMAX * kWave];  // match tokens, [m][lane]
+      uint8_t lits[C::LMAX * kWave];   // literal tokens, [i][lane]
+    } t;
+  } u;
 };
+
+// RFC1951 length / distance symbol -> (base, extra bits) (lib/de.ml:293-325; +3 / +1 folded in)
+__device__ __forceinline__ uint32_t fat_lit(uint32_t e) {
+  if (e & kLink) return (T_LINK << 24) | (((e >> 10) & 15) << 16) | (e & 1023);
+  const uint32_t len = (e >> 9) & 15, sym = e & 511;
+  if (sym < 256) return (T_LIT << 24) | (len << 20) | sym;
+  if (sym == 256) return (T_EOB << 24) | (len << 20);
+  const uint32_t l = (sym - 257) & 31;
+  const uint32_t xb = (l >= 8 && l < 28) ? (l - 4) >> 2 : 0;
+  const uint32_t base = (l < 8 ? l : l < 28 ? (4 + (l & 3)) << xb : l == 28 ? 255 : 0) + 3;
+  return (T_LEN << 24) | (len << 20) | (xb << 16) | base;
+}
+__device__ __forceinline__ uint32_t fat_dist(uint32_t e) {
+  if (e == kBad) return T_BAD << 24;
+  if (e & kLink) return (T_LINK << 24) | (((e >> 10) & 15) << 16) | (e & 1023);
+  const uint32_t len = (e >> 9) & 15, dv = e & 31;
+  const uint32_t xb = (dv >= 4 && dv < 30) ? (dv - 2) >> 1 : 0;
+  const uint32_t base = dv < 4 ? dv + 1 : dv < 30 ? ((2 + (dv & 1)) << xb) + 1 : 0;
+  return (T_DIST << 24) | (len << 20) | (xb << 16) | base;
+}
 
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
@@ -238,76 +267,56 @@ struct LaneState {
   uint64_t tmask;  // bit t set = token t is a match
 };
 
-// One speculative decode pass of this lane's zone [start, limit).
+// One speculative decode pass of this lane's zone [start, limit).  The slot body
+// is straight-line: one LUT entry per slot (a 2nd-level entry or the distance
+// code of a match take another slot), all state updates are selects.
 template <class C, class PF>
-__device__ __forceinline__ void decode_pass(const Input<C> &in, const lds_u16 *lut, lds_u32 *mrec,
+__device__ __forceinline__ void decode_pass(const Input<C> &in, const lds_u32 *lut, lds_u32 *mrec,
                                             lds_u8 *lits, uint32_t lane, uint32_t total_bits,
                                             uint32_t lmask, uint32_t lroot, uint32_t dmask,
                                             uint32_t droot, bool go, uint32_t limit, LaneState &ls,
                                             PF &pf) {
   uint32_t p = ls.start, ptok = ls.start, nlit = 0, nmat = 0, nb = 0, stop = 0;
   uint64_t tmask = 0;
-  // table cursor: first level (shift 0) of the lit/len LUT
-  uint32_t isdist = 0, shift = 0, tbase = 0, tmsk = lmask, mlen = 0;
-  bool run = go;
+  // table cursor: (shift, tbase, tmsk) index the next entry; (croot, ctb) describe the table in use
+  uint32_t shift = 0, tbase = 0, tmsk = lmask, croot = lroot, ctb = 0, mlen = 0;
+  bool tokstart = true, run = go;
   for (uint32_t slot = 0; slot < C::KMAX; ++slot) {
-    if (run && !isdist && shift == 0 &&
-        (p >= limit || nlit == C::LMAX || nmat == C::MMAX))
-      run = false;  // token boundary: zone finished or token budget exhausted
+    run = run && !(tokstart && (p >= limit || nlit == C::LMAX || nmat == C::MMAX));
     if (!__any(run)) break;
     pf.count(C_SLOTS);
     if (run) {
       const uint32_t w = in.peek(p);
       const uint32_t e = lut[tbase + ((w >> shift) & tmsk)];
-      if (e & kLink) {
-        shift = isdist ? droot : lroot;
-        tbase = (isdist ? kDistBase : 0u) + (e & 1023);
-        tmsk = (1u << ((e >> 10) & 15)) - 1;
-      } else {
-        const uint32_t len = (e >> 9) & 15, sym = e & 511;
-        // RFC1951 symbol -> (base, extra bits), lib/de.ml:293-325 (+3 / +1 folded in)
-        uint32_t xb, base;
-        if (isdist) {
-          const uint32_t dv = sym & 31;
-          xb = (dv >= 4 && dv < 30) ? (dv - 2) >> 1 : 0;
-          base = dv < 4 ? dv + 1 : dv < 30 ? ((2 + (dv & 1)) << xb) + 1 : 0;
-        } else {
-          const uint32_t l = (sym - 257) & 31;
-          xb = (sym > 256 && l >= 8 && l < 28) ? (l - 4) >> 2 : 0;
-          base = (l < 8 ? l : l < 28 ? (4 + (l & 3)) << xb : l == 28 ? 255 : 0) + 3;
-        }
-        const uint32_t val = base + __builtin_amdgcn_ubfe(w >> len, 0, xb);
-        const uint32_t pn = p + len + xb;
-        if (isdist && e == kBad) stop = MD_INVALID_DISTANCE_CODE;  // D2: before the EOI check, like the oracle
-        else if (pn > total_bits) stop = MD_UNEXPECTED_END_OF_INPUT;
-        else if (isdist) {
-          if (val == 0) stop = MD_INVALID_DISTANCE_CODE;
-          else {
-            mrec[nmat * kWave + lane] = ((mlen - 3) << 16) | (val - 1);
-            tmask |= 1ull << (nlit + nmat);
-            nmat++;
-            nb += mlen;
-            ptok = pn;
-          }
-          isdist = 0;
-        } else if (sym < 256) {
-          lits[nlit * kWave + lane] = (uint8_t)sym;
-          nlit++;
-          nb++;
-          ptok = pn;
-        } else if (sym == 256) {
-          ptok = pn;
-          stop = kStopEob;
-        } else {
-          mlen = val;
-          isdist = 1;
-        }
-        p = pn;
-        shift = 0;
-        tbase = isdist ? kDistBase : 0u;
-        tmsk = isdist ? dmask : lmask;
-        if (stop) run = false;
-      }
+      const uint32_t type = (e >> 24) & 7, len = (e >> 20) & 15, xb = (e >> 16) & 15, base = e & 0xffff;
+      const uint32_t val = base + __builtin_amdgcn_ubfe(w >> len, 0, xb);
+      const uint32_t pn = p + len + xb;
+      const bool is_link = type == T_LINK;
+      // oracle order: empty distance slot (D2), then end of input, then distance code 30/31
+      const uint32_t err = type == T_BAD                 ? (uint32_t)MD_INVALID_DISTANCE_CODE
+                           : (!is_link && pn > total_bits) ? (uint32_t)MD_UNEXPECTED_END_OF_INPUT
+                           : (type == T_DIST && val == 0)  ? (uint32_t)MD_INVALID_DISTANCE_CODE
+                                                           : 0u;
+      const bool ok = !err && !is_link;
+      const bool c_lit = ok && type == T_LIT, c_mat = ok && type == T_DIST;
+      const bool is_len = ok && type == T_LEN, is_eob = ok && type == T_EOB;
+      if (c_lit) lits[nlit * kWave + lane] = (uint8_t)val;
+      if (c_mat) mrec[nmat * kWave + lane] = ((mlen - 3) << 16) | (val - 1);
+      tmask |= (uint64_t)c_mat << (nlit + nmat);
+      nb += c_lit ? 1u : c_mat ? mlen : 0u;
+      nlit += c_lit;
+      nmat += c_mat;
+      ptok = (c_lit || c_mat || is_eob) ? pn : ptok;
+      p = ok ? pn : p;
+      mlen = is_len ? val : mlen;
+      stop = err ? err : is_eob ? kStopEob : 0u;
+      shift = is_link ? croot : 0u;
+      tbase = is_link ? ctb + base : is_len ? kDistBase : 0u;
+      tmsk = is_link ? (1u << xb) - 1 : is_len ? dmask : lmask;
+      croot = is_link ? croot : is_len ? droot : lroot;
+      ctb = is_link ? ctb : is_len ? kDistBase : 0u;
+      tokstart = c_lit || c_mat;
+      run = stop == 0;
     }
   }
   if (go) {
@@ -425,18 +434,45 @@ __device__ __forceinline__ int emit_round(lds_u32 *mrec, const lds_u8 *lits, Sin
   pf.tick(P_EMIT_A);
 
   // (b) far matches: the whole source is older than this round — final, and visible
-  //     once the stores of earlier rounds have been waited for.
+  //     once the stores of earlier rounds have been waited for; never overlapping
+  //     (d >= ml).  The loads of up to 4 short matches per lane are in flight together.
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   {
-    uint32_t qq = q0;
-    for (uint32_t m = 0; m < C::MMAX; m++) {
-      if (!__any(m < nm)) break;
-      if (m < nm) {
-        const uint32_t tk = mrec[m * kWave + lane];
-        const uint32_t d = (tk & 0x7fff) + 1, ml = ((tk >> 16) & 0xff) + 3;
-        qq += tk >> 24;
-        if (!(tk & kNear)) copy_match(g, qq, ml, d, cap);
-        qq += ml;
+    uint32_t qq = q0, m = 0;
+    while (__any(m < nm)) {
+      uint64_t v0[4], v1[4];
+      uint32_t dq[4], dl[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        dl[u] = 0;
+        dq[u] = 0;
+        v0[u] = 0;
+        v1[u] = 0;
+        while (m < nm) {  // advance to this lane's next short far record
+          const uint32_t tk = mrec[m * kWave + lane];
+          const uint32_t d = (tk & 0x7fff) + 1, ml = ((tk >> 16) & 0xff) + 3;
+          qq += tk >> 24;
+          const uint32_t cq = qq;
+          qq += ml;
+          m++;
+          if (tk & kNear) continue;
+          if (ml > 16) {
+            copy_match(g, cq, ml, d, cap);  // long far match: rare
+            continue;
+          }
+          v0[u] = out_ld_guard(g, cq - d, ml, cap);
+          if (ml > 8) v1[u] = out_ld_guard(g, cq - d + 8, ml - 8, cap);
+          dq[u] = cq;
+          dl[u] = ml;
+          break;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        if (dl[u]) {
+          out_st(g + dq[u], v0[u], dl[u]);
+          if (dl[u] > 8) out_st(g + dq[u] + 8, v1[u], dl[u] - 8);
+        }
       }
     }
   }
@@ -513,9 +549,9 @@ __device__ __forceinline__ int inflate_block(Smem<C> *smg, Input<C> &in, Sink &s
                                              uint32_t lane, uint32_t total_bits, uint32_t *bp_io,
                                              PF &pf) {
   uint32_t bp = *bp_io;
-  const lds_u16 *lut = (const lds_u16 *)smg->sc.lit;  // lit[852] then dist[592], contiguous
-  lds_u32 *mrec = (lds_u32 *)smg->mrec;
-  lds_u8 *lits = (lds_u8 *)smg->lits;
+  const lds_u32 *lut = (const lds_u32 *)smg->lut;
+  lds_u32 *mrec = (lds_u32 *)smg->u.t.mrec;
+  lds_u8 *lits = (lds_u8 *)smg->u.t.lits;
   for (;;) {
     in.ensure(bp >> 3);
     pf.tick(P_ENSURE);
@@ -720,10 +756,15 @@ __global__ __launch_bounds__(kWave) void inflate_v4_kernel(
         rc = MD_INVALID_KIND_OF_BLOCK;
       } else {
         Lut lit, dist;
-        if (type == 1) fixed_tables(&smg->sc, &lit, &dist, lane);
+        if (type == 1) fixed_tables(&smg->u.sc, &lit, &dist, lane);
         else {
-          rc = dynamic_header<C>(ur, &smg->sc, &lit, &dist, lane);
+          rc = dynamic_header<C>(ur, &smg->u.sc, &lit, &dist, lane);
           bp = ur.bp;
+        }
+        if (rc == MD_OK) {
+          // fat LUTs (base / extra bits / type per entry) from the packed 16-bit ones
+          for (uint32_t i = lane; i < 852; i += kWave) smg->lut[i] = fat_lit(smg->u.sc.lit[i]);
+          for (uint32_t i = lane; i < 592; i += kWave) smg->lut[kDistBase + i] = fat_dist(smg->u.sc.dist[i]);
         }
         pf.tick(P_HEADER);
         if (rc == MD_OK)
