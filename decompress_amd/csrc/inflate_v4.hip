@@ -13,15 +13,16 @@
 //        of token boundaries that starts on a known boundary IS the serial decode
 //        of the reference loop (`inflate`, lib/de.ml:1667-1712).
 //   B    a wave prefix-sum of the lanes' output sizes gives every token its output
-//        position.  Literals are stored straight to their final place in HBM;
-//        matches copy 8 bytes at a time: sources older than the round are final,
-//        sources inside the round are resolved lane-parallel with exact dependency
-//        tracking (one wave-wide wait for the stores per resolution step).
-//   C    the finished round is re-read 16 bytes per lane (L2 hits) and folded into
-//        the Adler-32 (WInf.update / tail, lib/de.ml:453-455, 499-505).
+//        position.  The round's output is assembled in an LDS staging buffer:
+//        literals first; matches whose source is older than the round read it from
+//        already-flushed output (L2/HBM, 16 bytes per load, 4 matches in flight per
+//        lane); matches into the round itself resolve lane-parallel inside LDS with
+//        exact dependency tracking.
+//   C    the round is flushed with 16-byte coalesced stores and folded into the
+//        Adler-32 in the same pass (WInf.update / tail, lib/de.ml:453-455, 499-505).
 //
 // The window is the output buffer itself (De.Inf.Ns semantics, lib/de.ml:1534):
-// no copy of it is kept on chip; the L2 (4 MiB per XCD) serves the re-reads.
+// only the current round lives on chip; the L2 (4 MiB per XCD) serves the far reads.
 // Error behaviour keeps the oracle's order: the first failing token in stream
 // order decides the status and everything before it is written.
 // Block headers, LUT construction (lib/de.ml:523-638, 1733-1793), stored blocks
@@ -72,13 +73,15 @@ struct Prof<false> {
   __device__ __forceinline__ void count(int, uint32_t = 1) {}
 };
 
-template <int S_, int LMAX_, int MMAX_, int KMAX_, int INB_, int PASSES_>
+template <int S_, int LMAX_, int MMAX_, int KMAX_, int INB_, int PASSES_, int STAGE_>
 struct Cfg {
   static constexpr uint32_t S = S_;        // bits per lane zone
   static constexpr uint32_t LMAX = LMAX_;  // literals per lane per round
   static constexpr uint32_t MMAX = MMAX_;  // matches per lane per round
   static constexpr uint32_t KMAX = KMAX_;  // decode slots per pass
   static constexpr uint32_t PASSES = PASSES_;  // A2 passes after A1
+  static constexpr uint32_t STAGE = STAGE_;    // staging bytes (one round of output)
+  static constexpr uint32_t BMAX = STAGE_ - 288;  // a lane stops once it has produced this many bytes
   static constexpr uint32_t IN_BYTES = INB_;   // compressed-input ring
   static constexpr uint32_t IN_WORDS = INB_ / 4;
   static constexpr uint32_t CHUNK = INB_ >= 4096 ? 1024 : 512;  // refill granularity
@@ -102,6 +105,8 @@ struct Smem {
     struct T {
       uint32_t mrec[C::MMAX * kWave];  // match tokens, [m][lane]
       uint8_t lits[C::LMAX * kWave];   // literal tokens, [i][lane]
+      alignas(16) uint8_t stage[C::STAGE + 16];  // +16: 8-byte copies may read a little past the data
+      uint8_t owner[C::STAGE / 32 + 8];          // producer lane of each 32-byte staging block
     } t;
   } u;
 };
@@ -210,6 +215,47 @@ __device__ __forceinline__ void copy_match(uint8_t *g, uint32_t q, uint32_t ml, 
   }
 }
 
+__device__ __forceinline__ uint64_t lds_ld64(const lds_u8 *p) { return *reinterpret_cast<const MD_LDS u64_u *>(p); }
+__device__ __forceinline__ void lds_st64(lds_u8 *p, uint64_t v) { *reinterpret_cast<MD_LDS u64_u *>(p) = v; }
+// store the low r (< 8) bytes of v
+__device__ __forceinline__ void lds_st_tail(lds_u8 *p, uint64_t v, uint32_t r) {
+  if (r & 4) {
+    *reinterpret_cast<MD_LDS u32_u *>(p) = (uint32_t)v;
+    p += 4;
+    v >>= 32;
+  }
+  if (r & 2) {
+    *reinterpret_cast<MD_LDS u16_u *>(p) = (uint16_t)v;
+    p += 2;
+    v >>= 16;
+  }
+  if (r & 1) *p = (uint8_t)v;
+}
+__device__ __forceinline__ void lds_st(lds_u8 *p, uint64_t v, uint32_t n) {
+  if (n >= 8) lds_st64(p, v);
+  else lds_st_tail(p, v, n);
+}
+// staging -> staging LZ77 copy with forward-byte semantics (overlap allowed)
+__device__ __forceinline__ void copy_near(lds_u8 *dst, const lds_u8 *src, uint32_t ml, uint32_t d) {
+  if (d >= 8) {
+    uint32_t j = 0;
+    for (; j + 8 <= ml; j += 8) lds_st64(dst + j, lds_ld64(src + j));
+    if (j < ml) lds_st_tail(dst + j, lds_ld64(src + j), ml - j);
+  } else {
+    // period d < 8: replicate the last d bytes into a 64-bit pattern
+    uint64_t v = lds_ld64(src);
+    const uint32_t sh = 8 * d;
+    v &= (1ull << sh) - 1;
+    v |= v << sh;
+    if (2 * sh < 64) v |= v << (2 * sh);
+    if (4 * sh < 64) v |= v << (4 * sh);
+    const uint32_t adv = d * (8 / d);  // largest multiple of the period that fits 8 bytes
+    uint32_t j = 0;
+    for (; j + 8 <= ml; j += adv) lds_st64(dst + j, v);
+    if (j < ml) lds_st_tail(dst + j, v, ml - j);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // Compressed input: an LDS ring addressed by absolute bit position.
 template <class C>
@@ -282,7 +328,7 @@ __device__ __forceinline__ void decode_pass(const Input<C> &in, const lds_u32 *l
   uint32_t shift = 0, tbase = 0, tmsk = lmask, croot = lroot, ctb = 0, mlen = 0;
   bool tokstart = true, run = go;
   for (uint32_t slot = 0; slot < C::KMAX; ++slot) {
-    run = run && !(tokstart && (p >= limit || nlit == C::LMAX || nmat == C::MMAX));
+    run = run && !(tokstart && (p >= limit || nlit == C::LMAX || nmat == C::MMAX || nb >= C::BMAX));
     if (!__any(run)) break;
     pf.count(C_SLOTS);
     if (run) {
@@ -331,9 +377,10 @@ __device__ __forceinline__ void decode_pass(const Input<C> &in, const lds_u32 *l
 
 // ---------------------------------------------------------------------------
 struct Sink {
+  lds_u8 *stage;
   uint8_t *g;
   uint32_t cap;
-  uint32_t pos;  // bytes produced
+  uint32_t pos;  // bytes produced and flushed
   uint32_t lane;
   uint32_t a, b;
   bool want_adler;
@@ -344,50 +391,84 @@ struct Sink {
     b = (b + n * a + s2) % 65521u;
     a = (a + s1) % 65521u;
   }
-  // fold g[pos, pos+total) (already written, visible) into the Adler-32 and advance pos
-  __device__ __forceinline__ void account(uint32_t total) {
+  // staging index of output position x is x - (pos & ~15)
+  __device__ __forceinline__ uint32_t sbase() const { return pos & ~15u; }
+
+  // write stage[...] for positions [pos, pos+total) to HBM, fold Adler-32, advance pos
+  __device__ __forceinline__ void flush(uint32_t total) {
+    const uint32_t rb = sbase();
     const uint32_t endp = pos + total;
-    if (want_adler) {
-      for (uint32_t ps = pos; ps < endp; ps += 1024) {
-        const uint32_t b0 = ps + 1024 < endp ? ps + 1024 : endp;
-        const uint32_t cpos = ps + lane * 16;
-        uint32_t s1 = 0, s2 = 0;
-        if (cpos < b0) {
-          const uint32_t n = b0 - cpos < 16 ? b0 - cpos : 16;
-          const uint64_t v0 = out_ld_guard(g, cpos, n, cap);
-          const uint64_t v1 = n > 8 ? out_ld_guard(g, cpos + 8, n - 8, cap) : 0;
+    for (uint32_t ps = rb; ps < endp; ps += 1024) {
+      const uint32_t a0 = ps > pos ? ps : pos;
+      const uint32_t b0 = ps + 1024 < endp ? ps + 1024 : endp;
+      const uint32_t cpos = ps + lane * 16;
+      const uint32_t lo = cpos > a0 ? cpos : a0;
+      const uint32_t hi = cpos + 16 < b0 ? cpos + 16 : b0;
+      uint32_t s1 = 0, s2 = 0;
+      if (lo < hi) {
+        const lds_u32 *sp = reinterpret_cast<const lds_u32 *>(stage + (cpos - rb));  // 16-byte aligned
+        const uint32_t w[4] = {sp[0], sp[1], sp[2], sp[3]};
+        if (hi - lo == 16) {
+          const uint4 v = make_uint4(w[0], w[1], w[2], w[3]);
+          __builtin_memcpy(g + cpos, &v, 16);
+          if (want_adler) {
 #pragma unroll
-          for (uint32_t k = 0; k < 16; k++) {
-            uint32_t d = (uint32_t)((k < 8 ? v0 >> (8 * k) : v1 >> (8 * (k - 8))) & 0xff);
-            if (k >= n) d = 0;
+            for (int k = 0; k < 16; k++) {
+              uint32_t d = (w[k >> 2] >> (8 * (k & 3))) & 0xff;
+              s1 += d;
+              s2 += (b0 - (cpos + k)) * d;
+            }
+          }
+        } else {
+          for (uint32_t x = lo; x < hi; x++) {
+            uint32_t k = x - cpos;
+            uint32_t d = (w[k >> 2] >> (8 * (k & 3))) & 0xff;
+            g[x] = (uint8_t)d;
             s1 += d;
-            s2 += (b0 - (cpos + k)) * d;
+            s2 += (b0 - x) * d;
           }
         }
-        adler_fold(s1, s2, b0 - ps);
       }
+      if (want_adler) adler_fold(s1, s2, b0 - a0);
     }
     pos = endp;
   }
 };
 
 // ---------------------------------------------------------------------------
-// Phase B of a round: place the accepted tokens.  Returns MD_OK or the status of
-// the first failing token (stream order); *emitted = bytes produced.
+// Phase B of a round: place the accepted tokens into the staging buffer.  Returns
+// MD_OK or the status of the first failing token (stream order); *emitted = bytes
+// produced; *nvalid_out = lanes actually accepted.
 template <class C, class PF>
-__device__ __forceinline__ int emit_round(lds_u32 *mrec, const lds_u8 *lits, Sink &sk, uint32_t lane,
-                                          uint32_t nvalid, const LaneState &ls, uint32_t *nvalid_out,
-                                          uint32_t *emitted, PF &pf) {
-  const uint32_t R0 = sk.pos, cap = sk.cap;
-  uint8_t *g = sk.g;
-  const bool mine = lane < nvalid;
-  const uint32_t mynb = mine ? ls.nb : 0;
+__device__ __forceinline__ int emit_round(lds_u32 *mrec, const lds_u8 *lits, lds_u8 *owner, Sink &sk,
+                                          uint32_t lane, uint32_t nvalid, const LaneState &ls,
+                                          uint32_t *nvalid_out, uint32_t *emitted, PF &pf) {
+  lds_u8 *stage = sk.stage;
+  const uint32_t R0 = sk.pos, rb = sk.sbase(), cap = sk.cap;
+  const uint8_t *g = sk.g;
+
+  uint32_t mynb = lane < nvalid ? ls.nb : 0;
   const uint32_t off = wave_excl_scan(mynb, lane);
+  {  // staging capacity: keep the largest prefix of lanes that fits
+    const uint64_t fits = __ballot(off + mynb <= C::STAGE - 16);
+    const uint32_t nfit = fits == ~0ull ? 64 : (uint32_t)__builtin_ctzll(~fits);
+    if (nfit < nvalid) nvalid = nfit;  // lane 0 always fits (BMAX)
+  }
+  const bool mine = lane < nvalid;
+  if (!mine) mynb = 0;
   const uint32_t q0 = R0 + off;
   const uint32_t ntok = mine ? ls.nlit + ls.nmat : 0;
 
-  // (a) literals straight to their final place; matches become records (gap of
-  //     literals in front, near/far flag); position-dependent checks in stream order
+  // owner table: the lane that produces the first byte of every 32-byte staging
+  // block — a lower bound of the producer of any byte in that block
+  if (mynb) {
+    const uint32_t b0 = (q0 - rb + 31) >> 5, b1 = (q0 + mynb - 1 - rb) >> 5;
+    for (uint32_t bb = b0; bb <= b1; bb++) owner[bb] = (uint8_t)lane;
+  }
+  if (lane == 0) owner[0] = 0;
+
+  // (a) literals into the staging buffer; matches become records (gap of literals
+  //     in front, near/far flag); position-dependent checks in stream order
   uint32_t q = q0, li = 0, nm = 0, gap = 0, fail = 0, good = 0;  // good = bytes before the failing token
   for (uint32_t t = 0; t < C::LMAX + C::MMAX; t++) {
     if (!__any(t < ntok && !fail)) break;
@@ -395,7 +476,7 @@ __device__ __forceinline__ int emit_round(lds_u32 *mrec, const lds_u8 *lits, Sin
       if (!((ls.tmask >> t) & 1)) {
         if (q >= cap) fail = MD_UNEXPECTED_END_OF_OUTPUT;
         else {
-          g[q] = lits[li * kWave + lane];
+          stage[q - rb] = lits[li * kWave + lane];
           li++;
           q++;
           gap++;
@@ -420,9 +501,9 @@ __device__ __forceinline__ int emit_round(lds_u32 *mrec, const lds_u8 *lits, Sin
   int rc = MD_OK;
   uint32_t total;
   {
-    uint64_t fm = __ballot(fail != 0);
+    const uint64_t fm = __ballot(fail != 0);
     if (fm) {
-      uint32_t fl = __builtin_ctzll(fm);
+      const uint32_t fl = __builtin_ctzll(fm);
       rc = (int)rdlane(fail, fl);
       total = rdlane(off, fl) + rdlane(good, fl);
       if (lane > fl) nm = 0;  // later lanes are void
@@ -433,22 +514,23 @@ __device__ __forceinline__ int emit_round(lds_u32 *mrec, const lds_u8 *lits, Sin
   }
   pf.tick(P_EMIT_A);
 
-  // (b) far matches: the whole source is older than this round — final, and visible
-  //     once the stores of earlier rounds have been waited for; never overlapping
-  //     (d >= ml).  The loads of up to 4 short matches per lane are in flight together.
+  // (b) far matches: the whole source is older than this round — final in HBM/L2,
+  //     visible once the flush of earlier rounds has been waited for; d >= ml.
+  //     The loads of up to 4 matches per lane are in flight together.
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   {
     uint32_t qq = q0, m = 0;
     while (__any(m < nm)) {
       uint64_t v0[4], v1[4];
-      uint32_t dq[4], dl[4];
+      uint32_t dq[4], dl[4], ds[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         dl[u] = 0;
         dq[u] = 0;
+        ds[u] = 0;
         v0[u] = 0;
         v1[u] = 0;
-        while (m < nm) {  // advance to this lane's next short far record
+        while (m < nm) {  // advance to this lane's next far record
           const uint32_t tk = mrec[m * kWave + lane];
           const uint32_t d = (tk & 0x7fff) + 1, ml = ((tk >> 16) & 0xff) + 3;
           qq += tk >> 24;
@@ -456,34 +538,34 @@ __device__ __forceinline__ int emit_round(lds_u32 *mrec, const lds_u8 *lits, Sin
           qq += ml;
           m++;
           if (tk & kNear) continue;
-          if (ml > 16) {
-            copy_match(g, cq, ml, d, cap);  // long far match: rare
-            continue;
-          }
           v0[u] = out_ld_guard(g, cq - d, ml, cap);
           if (ml > 8) v1[u] = out_ld_guard(g, cq - d + 8, ml - 8, cap);
           dq[u] = cq;
           dl[u] = ml;
+          ds[u] = cq - d;
           break;
         }
       }
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         if (dl[u]) {
-          out_st(g + dq[u], v0[u], dl[u]);
-          if (dl[u] > 8) out_st(g + dq[u] + 8, v1[u], dl[u] - 8);
+          lds_u8 *dd = stage + (dq[u] - rb);
+          const uint32_t ml = dl[u];
+          lds_st(dd, v0[u], ml);
+          if (ml > 8) lds_st(dd + 8, v1[u], ml - 8);
+          for (uint32_t j = 16; j < ml; j += 8)  // long far match: stream the rest (rare)
+            lds_st(dd + j, out_ld_guard(g, ds[u] + j, ml - j, cap), ml - j);
         }
       }
     }
   }
   pf.tick(P_FAR);
 
-  // (c) near matches: the source reaches into this round.  `done` is the position
-  //     of this lane's first unresolved match: everything the lane produces before
-  //     it is final.  A match may run when the first unresolved lane at or after
-  //     the producer of its source is itself, or has progressed beyond the source.
-  //     One match per lane per step; the wave waits for the step's stores so the
-  //     next step can read them (L1 bypassed).
+  // (c) near matches: the source reaches into this round's staging buffer.  `done`
+  //     is the position of this lane's first unresolved match: everything the lane
+  //     produces before it is final.  A match may run when the first unresolved
+  //     lane at or after the producer of its source is itself, or has progressed
+  //     beyond the source's end.
   {
     uint32_t m = 0, qq = q0;
     uint32_t d = 0, ml = 0, qm = 0, ja = 0;
@@ -498,41 +580,35 @@ __device__ __forceinline__ int emit_round(lds_u32 *mrec, const lds_u8 *lits, Sin
         m++;
         qq = qm + ml;
         if (tk & kNear) {
+          const uint32_t src = qm - d;
+          ja = src >= rb ? owner[(src - rb) >> 5] : 0;
           pending = true;
           break;
         }
       }
     };
     advance();
-    bool need_ja = pending;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the far copies have landed
     for (;;) {
       const uint64_t pm = __ballot(pending);
       if (!pm) break;
       pf.count(C_NEAR_IT);
-      if (__any(need_ja)) {
-        // producer of the first source byte: the last lane whose q0 <= src
-        const uint32_t src = (pending && qm - d > R0) ? qm - d : R0;
-        uint32_t lo = 0;
-#pragma unroll
-        for (int step = 32; step > 0; step >>= 1) {
-          const uint32_t cand = lo + step;
-          const uint32_t qc = __shfl(q0, cand & 63);
-          if (cand < 64 && qc <= src) lo = cand;
-        }
-        if (need_ja) ja = lo;
-        need_ja = false;
-      }
       const uint32_t done = pending ? qm : 0xffffffffu;
       uint32_t f = lane;
       if (pending) f = ja + (uint32_t)__builtin_ctzll(pm >> ja);  // bit `lane` is set: pm >> ja != 0
       const uint32_t df = __shfl(done, f);
       if (pending && (f >= lane || df >= qm - d + ml)) {
-        copy_match(g, qm, ml, d, cap);
+        const uint32_t src = qm - d;
+        lds_u8 *dd = stage + (qm - rb);
+        if (src >= R0) {
+          copy_near(dd, stage + (src - rb), ml, d);
+        } else {
+          // straddles the round start: the first bytes come from HBM
+          const uint32_t ng = R0 - src;
+          for (uint32_t j = 0; j < ng; j++) dd[j] = (uint8_t)out_ld8(g + src + j);
+          copy_near(dd + ng, stage + (R0 - rb), ml - ng, d);
+        }
         advance();
-        need_ja = pending;
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this step's stores have landed
     }
   }
   pf.tick(P_NEAR);
@@ -579,9 +655,8 @@ __device__ __forceinline__ int inflate_block(Smem<C> *smg, Input<C> &in, Sink &s
       nvalid = bad ? (uint32_t)__builtin_ctzll(bad) : 64;
     }
     uint32_t emitted;
-    int rc = emit_round<C>(mrec, lits, sk, lane, nvalid, ls, &nvalid, &emitted, pf);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the round's stores have landed
-    sk.account(emitted);
+    int rc = emit_round<C>(mrec, lits, (lds_u8 *)smg->u.t.owner, sk, lane, nvalid, ls, &nvalid, &emitted, pf);
+    sk.flush(emitted);
     pf.tick(P_ADLER);
     pf.count(C_LANES, nvalid);
     pf.count(C_TOKENS, wave_sum(lane < nvalid ? ls.nlit + ls.nmat : 0));
@@ -692,6 +767,7 @@ __global__ __launch_bounds__(kWave) void inflate_v4_kernel(
   }
 
   Sink sk;
+  sk.stage = (lds_u8 *)smg->u.t.stage;
   sk.g = out + out_off[sid];
   sk.cap = cap;
   sk.pos = 0;
@@ -738,16 +814,15 @@ __global__ __launch_bounds__(kWave) void inflate_v4_kernel(
         else if (len > sk.cap - sk.pos) rc = MD_UNEXPECTED_END_OF_OUTPUT;
         else {
           const uint8_t *q = inp.p + p;
-          uint8_t *dd = sk.g + sk.pos;
-          for (uint32_t j = lane * 8; j < len; j += kWave * 8) {
-            const uint32_t m = len - j < 8 ? len - j : 8;
-            uint64_t v = 0;
-            if (m == 8) v = *reinterpret_cast<const u64_u *>(q + j);
-            else for (uint32_t k = 0; k < m; k++) v |= (uint64_t)q[j + k] << (8 * k);
-            out_st(dd + j, v, m);
+          uint32_t left = len;
+          while (left) {
+            const uint32_t seg = left < C::STAGE - 16 ? left : C::STAGE - 16;
+            const uint32_t s0 = sk.pos - sk.sbase();
+            for (uint32_t j = lane; j < seg; j += kWave) sk.stage[s0 + j] = q[j];
+            sk.flush(seg);
+            q += seg;
+            left -= seg;
           }
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-          sk.account(len);
           p += len;
           bp = p * 8;
           inp.reset(p);
@@ -816,10 +891,10 @@ extern "C" int md_launch_inflate_v2(int variant, int format, uint32_t n, const u
                          sizeof(md::v4::Smem<CFG>), stream, format, n, in, in_off, in_len, out,  \
                          out_off, out_cap, out_len, consumed, status, checksum, dbg);            \
   } while (0)
-  //                      S   LMAX MMAX KMAX IN_BYTES PASSES
-  using A = md::v4::Cfg<256, 40, 20, 72, 4096, 3>;
-  using B = md::v4::Cfg<128, 24, 12, 40, 2048, 3>;
-  using Cc = md::v4::Cfg<384, 44, 20, 96, 8192, 2>;
+  //                      S   LMAX MMAX KMAX IN_BYTES PASSES STAGE
+  using A = md::v4::Cfg<256, 40, 16, 72, 4096, 3, 6144>;
+  using B = md::v4::Cfg<256, 40, 16, 72, 4096, 2, 6144>;
+  using Cc = md::v4::Cfg<320, 44, 18, 88, 4096, 2, 7168>;
   switch (variant) {
   case 0: MD_LAUNCH_V4(A); break;
   case 1: MD_LAUNCH_V4(B); break;
