@@ -212,7 +212,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                "kernel": "inflate_v2_kernel" if (args.kernel or 2) == 2 else "inflate_kernel", "kernel_ms": round(kernel_ms, 4),
+                "kernel": "inflate_v4_kernel" if (args.kernel or 2) == 2 else "inflate_kernel", "kernel_ms": round(kernel_ms, 4),
                 "algorithmic_bytes_per_launch": algo_bytes,
             },
         }

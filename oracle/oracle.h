@@ -57,6 +57,23 @@ int orc_inf_huffman(int kind, const uint8_t *lens, int codes, uint32_t *tbl,
 
 const char *orc_status_string(int status);
 
+/* ---- deflate (oracle/de_deflate.c) ---- */
+enum { ORC_DRV_ZL = 0, ORC_DRV_HIGHER = 1, ORC_DRV_CLI = 2 };
+/* Raw DEFLATE body of De.Lz77 (lib/de.ml:4013-4515) + De.Def (lib/de.ml:2354-3038)
+ * under one of the reference's three drivers.  malloc'ed result. */
+uint8_t *orc_deflate_raw(const uint8_t *src, size_t n, int level, int queue_len, int driver,
+                         int dynamic, size_t *out_len, uint32_t *adler);
+/* Zl.Def.encode / Zl.Higher.compress (lib/zl.ml:509-555, 634-648) */
+uint8_t *orc_zl_deflate(const uint8_t *src, size_t n, int level, int queue_len, int dynamic,
+                        size_t *out_len);
+void orc_free(void *p);
+/* De.T.make (lib/de.ml:2013-2068) on a histogram (mutated in place) */
+int orc_tree_make(int length, int max_length, int *freqs, int nfreqs, int *lengths, int *codes);
+/* test/test.ml `encode` / `encode_dynamic`: a command list in one last block */
+uint8_t *orc_encode_cmds(const int *cmds, int ncmds, int kind, size_t *out_len);
+/* De.Lz77.compress on an input that fits one queue fill (test/test.ml:798-813) */
+int orc_lz77_cmds(const uint8_t *src, size_t n, int level, int queue_len, int *out, int max);
+
 #ifdef __cplusplus
 }
 #endif

@@ -268,12 +268,64 @@ def gen_stream_and_zlib():
     return stream, zl
 
 
+def parse_cmds(body, start):
+    """[`Literal 'c'; `Copy (off, len); `End] -> queue commands (lib/de.ml:2245-2266)."""
+    i = body.index("[", start)
+    j = body.index("]", i)
+    cmds = []
+    for m in re.finditer(r"`Literal '((?:\\x[0-9a-fA-F]{2})|(?:\\[0-9]{3})|.)'|`Copy \((\d+), (\d+)\)|`End", body[i:j]):
+        if m.group(0) == "`End":
+            cmds.append(256)
+        elif m.group(1) is not None:
+            c = m.group(1)
+            cmds.append(int(c[2:], 16) if c.startswith("\\x") else int(c[1:]) if c.startswith("\\") else ord(c))
+        else:
+            off, ln = int(m.group(2)), int(m.group(3))
+            cmds.append(((ln - 3) << 16) | (off - 1) | 0x2000000)
+    return cmds
+
+
+def gen_deflate_kat():
+    text = open(os.path.join(REF, "test.ml")).read()
+    cases = {n: (t, b) for n, t, b in split_cases(text)}
+    out = []
+    # encoder bytes: test/test.ml:507-531 and :1037-1055
+    t, b = cases["huffman_length_extra"]
+    exp, _ = parse_string_expr(b, re.search(r'"encoding" res', b).end())
+    out.append({"name": "huffman_length_extra", "ref": "test/test.ml:507", "kind": "dynamic",
+                "cmds": parse_cmds(b, b.index("encode ~block")), "out": exp.hex(),
+                "inflated": (b"\x00" * 516).hex()})
+    t, b = cases["flat"]
+    exp, _ = parse_string_expr(b, re.search(r'"deadbeef deflated"', b).end())
+    out.append({"name": "flat", "ref": "test/test.ml:1037", "kind": "flat",
+                "cmds": parse_cmds(b, b.index("Queue.of_list")), "out": exp.hex(), "inflated": "deadbeef"})
+    # Huffman trees: test/test.ml:1169-1237
+    lits0 = [0] * 573
+    lits0[256] = 1
+    out.append({"name": "tree_0", "ref": "test/test.ml:1169", "kind": "tree", "length": 286, "freqs": lits0,
+                "lengths": {"0": 1, "256": 1}, "codes": {"0": 0, "256": 1}})
+    t, b = cases["tree_rfc5322_corpus"]
+    arr = re.search(r"let literals =\s*\[\|(.*?)\|\]", b, re.S).group(1)
+    freqs = [int(x) for x in re.findall(r"\d+", arr)]
+    assert len(freqs) == 573
+    out.append({"name": "tree_rfc5322_corpus", "ref": "test/test.ml:1191", "kind": "tree", "length": 286,
+                "freqs": freqs, "lengths": {"54": 10, "256": 15}, "codes": {"54": 0x35f, "256": 0x6fff}})
+    # LZ77 command list: test/test.ml:798-813 (lz77_0 is disabled upstream, test/test.ml:2139-2143)
+    t, b = cases["lz77_1"]
+    src, _ = parse_string_expr(b, re.search(r"Lz77\.state \(`String ", b).end())
+    out.append({"name": "lz77_1", "ref": "test/test.ml:798", "kind": "lz77", "src": src.hex(),
+                "cmds": parse_cmds(b, b.index('"result" lst'))})
+    return out
+
+
 def main():
     if not os.path.isdir(REF):
         sys.exit("reference tree not present; fixtures are already committed")
     ns = gen_ns()
     stream, zl = gen_stream_and_zlib()
-    for fn, data in (("inflate_ns.json", ns), ("inflate_stream.json", stream), ("zlib_frames.json", zl)):
+    kat = gen_deflate_kat()
+    for fn, data in (("inflate_ns.json", ns), ("inflate_stream.json", stream), ("zlib_frames.json", zl),
+                     ("deflate_kat.json", kat)):
         with open(os.path.join(OUT, fn), "w") as f:
             json.dump(data, f, indent=1)
         print(fn, len(data), "cases")

@@ -45,6 +45,19 @@ class Oracle:
         lib.orc_adler32.restype = ctypes.c_uint32
         lib.orc_crc32.argtypes = [ctypes.c_uint32, ctypes.c_char_p, sz]
         lib.orc_crc32.restype = ctypes.c_uint32
+        ci = ctypes.c_int
+        lib.orc_deflate_raw.restype = ctypes.c_void_p
+        lib.orc_deflate_raw.argtypes = [ctypes.c_char_p, sz, ci, ci, ci, ci, ctypes.POINTER(sz),
+                                        ctypes.POINTER(ctypes.c_uint32)]
+        lib.orc_zl_deflate.restype = ctypes.c_void_p
+        lib.orc_zl_deflate.argtypes = [ctypes.c_char_p, sz, ci, ci, ci, ctypes.POINTER(sz)]
+        lib.orc_free.argtypes = [ctypes.c_void_p]
+        lib.orc_tree_make.argtypes = [ci, ci, ctypes.POINTER(ci), ci, ctypes.POINTER(ci), ctypes.POINTER(ci)]
+        lib.orc_tree_make.restype = ci
+        lib.orc_encode_cmds.restype = ctypes.c_void_p
+        lib.orc_encode_cmds.argtypes = [ctypes.POINTER(ci), ci, ci, ctypes.POINTER(sz)]
+        lib.orc_lz77_cmds.restype = ci
+        lib.orc_lz77_cmds.argtypes = [ctypes.c_char_p, sz, ci, ci, ctypes.POINTER(ci), ci]
 
     def _inflate(self, fn, src, cap):
         dst = ctypes.create_string_buffer(max(cap, 1))
@@ -65,3 +78,44 @@ class Oracle:
 
     def crc32(self, data, init=0):
         return self.lib.orc_crc32(init, bytes(data), len(data))
+
+    # ------------------------------------------------------------------ deflate
+    DRV_ZL, DRV_HIGHER, DRV_CLI = 0, 1, 2
+
+    def _take(self, p, n):
+        out = ctypes.string_at(p, n)
+        self.lib.orc_free(p)
+        return out
+
+    def deflate_raw(self, data, level=6, queue=4096, driver=0, dynamic=True):
+        """De.Lz77 + De.Def under one of the reference's drivers -> (raw DEFLATE, adler32 of input)"""
+        n, a = ctypes.c_size_t(), ctypes.c_uint32()
+        p = self.lib.orc_deflate_raw(bytes(data), len(data), level, queue, driver, int(dynamic),
+                                     ctypes.byref(n), ctypes.byref(a))
+        assert p
+        return self._take(p, n.value), a.value
+
+    def zl_deflate(self, data, level=6, queue=4096, dynamic=True):
+        """Zl.Higher.compress ~level ~dynamic (lib/zl.ml:634-648)"""
+        n = ctypes.c_size_t()
+        p = self.lib.orc_zl_deflate(bytes(data), len(data), level, queue, int(dynamic), ctypes.byref(n))
+        assert p
+        return self._take(p, n.value)
+
+    def tree_make(self, length, freqs, max_length=15):
+        f = (ctypes.c_int * len(freqs))(*freqs)
+        lens = (ctypes.c_int * length)()
+        codes = (ctypes.c_int * length)()
+        mc = self.lib.orc_tree_make(length, max_length, f, len(freqs), lens, codes)
+        return mc, list(lens), list(codes), list(f)
+
+    def encode_cmds(self, cmds, kind):
+        arr = (ctypes.c_int * len(cmds))(*cmds)
+        n = ctypes.c_size_t()
+        p = self.lib.orc_encode_cmds(arr, len(cmds), {"flat": 0, "fixed": 1, "dynamic": 2}[kind], ctypes.byref(n))
+        return self._take(p, n.value)
+
+    def lz77_cmds(self, data, level=4, queue=4096):
+        out = (ctypes.c_int * queue)()
+        n = self.lib.orc_lz77_cmds(bytes(data), len(data), level, queue, out, queue)
+        return None if n < 0 else list(out[:n])
