@@ -28,6 +28,15 @@ SYMBOLS = [
      [c_vp, ctypes.c_int, c_sz] + [c_vp] * 10),
     ("md_inflate_batch_host", ctypes.c_int,
      [c_vp, ctypes.c_int, c_sz, c_vp, c_sz, c_vp, c_vp, c_vp, c_sz, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    ("md_deflate_batch_device", ctypes.c_int,
+     [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_sz] + [c_vp] * 9),
+    ("md_deflate_batch_host", ctypes.c_int,
+     [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_sz, c_vp, c_sz, c_vp, c_vp,
+      c_vp, c_sz, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    ("md_de_higher_compress", ctypes.c_int,
+     [c_vp, ctypes.c_int, c_vp, c_sz, c_vp, c_sz, ctypes.POINTER(c_sz)]),
+    ("md_zl_higher_compress", ctypes.c_int,
+     [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp, c_sz, c_vp, c_sz, ctypes.POINTER(c_sz)]),
     ("md_de_inf_ns_inflate", ctypes.c_int,
      [c_vp, c_vp, c_sz, c_vp, c_sz, ctypes.POINTER(c_sz), ctypes.POINTER(c_sz)]),
     ("md_zl_inf_ns_inflate", ctypes.c_int,

@@ -23,6 +23,13 @@ extern "C" int md_launch_inflate_v2(int variant, int format, uint32_t n, const u
                                     uint64_t *out_len, uint64_t *consumed, int32_t *status,
                                     uint32_t *checksum, uint64_t *dbg, hipStream_t stream);
 
+extern "C" size_t md_deflate_ws_bytes(uint32_t n, int qcap);
+extern "C" int md_launch_deflate(int format, int level, int qcap, int driver, int dynamic, uint32_t n,
+                                 const uint8_t *in, const uint64_t *in_off, const uint64_t *in_len,
+                                 uint8_t *out, const uint64_t *out_off, const uint64_t *out_cap,
+                                 uint64_t *out_len, int32_t *status, uint32_t *checksum, void *ws,
+                                 hipStream_t stream);
+
 struct md_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -32,6 +39,8 @@ struct md_ctx {
   int kernel = 2;   // 1 = serial-per-wave (inflate_kernel.hip), 2 = lane-parallel (inflate_v2.hip)
   int variant = 0;  // v2 geometry
   uint64_t *dbg = nullptr;  // device buffer of the optional in-kernel profile (32 x u64)
+  void *ws = nullptr;       // deflate workspace (hash heads / chains / command queues)
+  size_t ws_bytes = 0;
   std::string err;
 };
 
@@ -148,6 +157,8 @@ void md_destroy(md_ctx *ctx) {
   hipSetDevice(ctx->device);
   if (ctx->ev0) hipEventDestroy(ctx->ev0);
   if (ctx->ev1) hipEventDestroy(ctx->ev1);
+  if (ctx->ws) hipFree(ctx->ws);
+  if (ctx->dbg) hipFree(ctx->dbg);
   if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -287,6 +298,105 @@ int md_inflate_batch_host(md_ctx *ctx, int format, size_t n, const uint8_t *h_in
   if (checksum) HIP_TRY(ctx, hipMemcpyAsync(checksum, dsum, n * 4, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
   return MD_OK;
+}
+
+int md_deflate_batch_device(md_ctx *ctx, int format, int level, int queue_len, int driver,
+                            int dynamic, size_t n, const uint8_t *d_in, const uint64_t *d_in_off,
+                            const uint64_t *d_in_len, uint8_t *d_out, const uint64_t *d_out_off,
+                            const uint64_t *d_out_cap, uint64_t *d_out_len, int32_t *d_status,
+                            uint32_t *d_checksum) {
+  if (!ctx) return MD_E_INVALID_ARGUMENT;
+  if (format != MD_FORMAT_DEFLATE && format != MD_FORMAT_ZLIB)
+    return fail(ctx, MD_E_INVALID_ARGUMENT, "unknown format");
+  if (level < 0 || level > 9)  // Lz77.state: "Invalid level of compression", lib/de.ml:4477
+    return fail(ctx, MD_E_INVALID_ARGUMENT, "Invalid level of compression");
+  if (queue_len < 4 || queue_len > (1 << 20) || (queue_len & (queue_len - 1)))  // lib/de.ml:2286-2288
+    return fail(ctx, MD_E_INVALID_ARGUMENT, "Length of queue MUST be a power of two");
+  if (driver < MD_DRIVER_ZL || driver > MD_DRIVER_CLI) return fail(ctx, MD_E_INVALID_ARGUMENT, "unknown driver");
+  if (n == 0) return MD_OK;
+  if (n > 0x7fffffffull) return fail(ctx, MD_E_INVALID_ARGUMENT, "too many streams in one batch");
+  if (!d_in_off || !d_in_len || !d_out_off || !d_out_cap || !d_out_len || !d_status)
+    return fail(ctx, MD_E_INVALID_ARGUMENT, "null descriptor array");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  size_t need = md_deflate_ws_bytes((uint32_t)n, queue_len);
+  if (need > ctx->ws_bytes) {
+    if (ctx->ws) {
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+      HIP_TRY(ctx, hipFree(ctx->ws));
+      ctx->ws = nullptr;
+      ctx->ws_bytes = 0;
+    }
+    if (hipMalloc(&ctx->ws, need) != hipSuccess) return fail(ctx, MD_E_OUT_OF_MEMORY, "hipMalloc(deflate workspace)");
+    ctx->ws_bytes = need;
+  }
+  int rc = md_launch_deflate(format, level, queue_len, driver, dynamic ? 1 : 0, (uint32_t)n, d_in, d_in_off,
+                             d_in_len, d_out, d_out_off, d_out_cap, d_out_len, d_status, d_checksum,
+                             ctx->ws, ctx->stream);
+  if (rc != 0) return fail(ctx, MD_E_HIP, "deflate kernel launch", (hipError_t)rc);
+  return MD_OK;
+}
+
+int md_deflate_batch_host(md_ctx *ctx, int format, int level, int queue_len, int driver, int dynamic,
+                          size_t n, const uint8_t *h_in, size_t in_bytes, const uint64_t *in_off,
+                          const uint64_t *in_len, uint8_t *h_out, size_t out_bytes,
+                          const uint64_t *out_off, const uint64_t *out_cap, uint64_t *out_len,
+                          int32_t *status, uint32_t *checksum) {
+  if (!ctx) return MD_E_INVALID_ARGUMENT;
+  if (n == 0) return MD_OK;
+  if (!in_off || !in_len || !out_off || !out_cap || !out_len || !status)
+    return fail(ctx, MD_E_INVALID_ARGUMENT, "null descriptor array");
+  for (size_t i = 0; i < n; i++) {
+    if (in_off[i] > in_bytes || in_len[i] > in_bytes - in_off[i])
+      return fail(ctx, MD_E_INVALID_ARGUMENT, "input range out of bounds");
+    if (out_off[i] > out_bytes || out_cap[i] > out_bytes - out_off[i])
+      return fail(ctx, MD_E_INVALID_ARGUMENT, "output range out of bounds");
+  }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  DevBuf din, dout, ddesc;
+  if (din.alloc(in_bytes + 8) != hipSuccess || dout.alloc(out_bytes) != hipSuccess ||
+      ddesc.alloc(5 * n * 8 + n * 8) != hipSuccess)
+    return fail(ctx, MD_E_OUT_OF_MEMORY, "hipMalloc");
+  uint64_t *d64 = (uint64_t *)ddesc.p;
+  int32_t *dstatus = (int32_t *)(d64 + 5 * n);
+  uint32_t *dsum = (uint32_t *)(dstatus + n);
+  hipStream_t st = ctx->stream;
+  HIP_TRY(ctx, hipMemcpyAsync(din.p, h_in, in_bytes, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(d64 + 0 * n, in_off, n * 8, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(d64 + 1 * n, in_len, n * 8, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(d64 + 2 * n, out_off, n * 8, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(d64 + 3 * n, out_cap, n * 8, hipMemcpyHostToDevice, st));
+  int rc = md_deflate_batch_device(ctx, format, level, queue_len, driver, dynamic, n, (const uint8_t *)din.p,
+                                   d64, d64 + n, (uint8_t *)dout.p, d64 + 2 * n, d64 + 3 * n, d64 + 4 * n,
+                                   dstatus, dsum);
+  if (rc != MD_OK) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(h_out, dout.p, out_bytes, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipMemcpyAsync(out_len, d64 + 4 * n, n * 8, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipMemcpyAsync(status, dstatus, n * 4, hipMemcpyDeviceToHost, st));
+  if (checksum) HIP_TRY(ctx, hipMemcpyAsync(checksum, dsum, n * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  return MD_OK;
+}
+
+static int deflate_one(md_ctx *ctx, int format, int level, int queue_len, int driver, int dynamic,
+                       const uint8_t *src, size_t src_len, uint8_t *dst, size_t dst_cap, size_t *written) {
+  if (!ctx || !written || (!src && src_len) || (!dst && dst_cap)) return MD_E_INVALID_ARGUMENT;
+  uint64_t in_off = 0, in_len = src_len, out_off = 0, out_cap = dst_cap, out_len = 0;
+  int32_t status = 0;
+  int rc = md_deflate_batch_host(ctx, format, level, queue_len, driver, dynamic, 1, src, src_len, &in_off,
+                                 &in_len, dst, dst_cap, &out_off, &out_cap, &out_len, &status, nullptr);
+  if (rc != MD_OK) return rc;
+  *written = (size_t)out_len;
+  return status;
+}
+
+int md_de_higher_compress(md_ctx *ctx, int queue_len, const uint8_t *src, size_t src_len,
+                          uint8_t *dst, size_t dst_cap, size_t *written) {
+  return deflate_one(ctx, MD_FORMAT_DEFLATE, 4, queue_len, MD_DRIVER_HIGHER, 1, src, src_len, dst, dst_cap, written);
+}
+
+int md_zl_higher_compress(md_ctx *ctx, int level, int dynamic, int queue_len, const uint8_t *src,
+                          size_t src_len, uint8_t *dst, size_t dst_cap, size_t *written) {
+  return deflate_one(ctx, MD_FORMAT_ZLIB, level, queue_len, MD_DRIVER_ZL, dynamic, src, src_len, dst, dst_cap, written);
 }
 
 static int inflate_one(md_ctx *ctx, int format, const uint8_t *src, size_t src_len, uint8_t *dst,

@@ -1,0 +1,868 @@
+// deflate_kernel.hip — batched RFC1951 deflate for gfx950 (MI355X), v1.
+//
+// Bit-exact with the reference's streaming compressor:
+//   De.Lz77 (zlib deflate_slow, 4-byte multiplicative hash)      lib/de.ml:4013-4515
+//   De.Queue command encoding                                    lib/de.ml:2245-2266
+//   De.T     Huffman tree construction                           lib/de.ml:1828-2192
+//   De.Def   block choice + LSB-first bit encoder                 lib/de.ml:2354-3038
+//   drivers  Zl.Def (lib/zl.ml:509-555), De.Higher (lib/de.ml:4518-4553), CLI (bin/decompress.ml:47-75)
+// including the parity hazards H1-H8 of SURVEY.md 8(c) (queue-sized blocks,
+// cumulative and mutated histograms, the odd cost formula, driver-dependent
+// empty blocks, deterministic stale bytes past the end of input).
+//
+// v1 layout: one independent stream per wavefront.  The match finder and the
+// encoder of a stream are sequential state machines (every decision depends on
+// the previous one), so in this first version lane 0 runs them while the wave
+// cooperates on the bulk work (clearing the hash heads, Adler-32 of the input).
+// Hash heads / chains (abs positions, 2 x 128 KiB) and the command queue live in
+// a per-stream HBM workspace; histograms, heap and code tables live in LDS.
+// The window is the input buffer itself: w[rel] = in[base + rel]; bytes the
+// reference reads beyond the data (H7) follow its 64 KiB sliding buffer exactly
+// (zero before the first slide, the byte 32 KiB earlier after it).
+//
+// This version is correct first; the parallel formulation (decision-independent
+// hash chains built 64 positions at a time, speculative per-position matches,
+// wave-parallel bit packing) is the next step — see DESIGN.md.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mdeflate.h"
+
+namespace md {
+namespace defl {
+
+constexpr int kWave = 64;
+constexpr int MAX_BITS = 15, L_CODES = 286, D_CODES = 30, BL_CODES = 19, HEAP_SIZE = 2 * L_CODES + 1;
+constexpr int MIN_MATCH = 3, MAX_MATCH = 258, MIN_LOOKAHEAD = MAX_MATCH + MIN_MATCH + 1;
+constexpr int HASH_BITS = 15, HASH_SIZE = 1 << HASH_BITS, TOO_FAR = 4096;
+constexpr int WSIZE = 1 << 15, WMASK = WSIZE - 1, MAX_DIST = WSIZE - MIN_LOOKAHEAD;
+constexpr int Q_EOB = 256, Q_COPY = 0x2000000;
+
+__constant__ uint8_t c_zigzag[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+__constant__ uint8_t c_base_length[32] = {0,  1,  2,  3,  4,  5,  6,   7,   8,   10,  12,
+                                          14, 16, 20, 24, 28, 32, 40,  48,  56,  64,  80,
+                                          96, 112, 128, 160, 192, 224, 255, 0,   0,   0};
+__constant__ uint8_t c_extra_lbits[32] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2,
+                                          3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0, 0, 0, 0};
+__constant__ uint8_t c_extra_dbits[32] = {0, 0, 0, 0, 1, 1, 2,  2,  3,  3,  4,
+                                          4, 5, 5, 6, 6, 7, 7,  8,  8,  9,  9,
+                                          10, 10, 11, 11, 12, 12, 13, 13, 0, 0};
+__constant__ uint16_t c_base_dist[32] = {0,    1,    2,    3,    4,    6,     8,     12,
+                                         16,   24,   32,   48,   64,   96,    128,   192,
+                                         256,  384,  512,  768,  1024, 1536,  2048,  3072,
+                                         4096, 6144, 8192, 12288, 16384, 24576, 0,   0};
+// level table lib/de.ml:4030-4049: {max_chain, max_lazy, good_length, nice_length}
+__constant__ uint16_t c_levels[10][4] = {{0, 0, 0, 0},         {4, 4, 4, 8},        {8, 5, 4, 16},
+                                         {32, 6, 4, 32},       {16, 4, 4, 16},      {32, 16, 8, 32},
+                                         {128, 16, 8, 128},    {256, 32, 8, 128},   {1024, 128, 32, 258},
+                                         {4096, 258, 32, 258}};
+
+enum { KIND_FLAT = 0, KIND_FIXED = 1, KIND_DYNAMIC = 2 };
+enum { DRV_ZL = 0, DRV_HIGHER = 1, DRV_CLI = 2 };
+enum { K_FIRST_ENTRY, K_ENCODE, K_BLOCK, K_FLAT_DONE };
+enum { R_OK, R_BLOCK };
+enum { V_AWAIT, V_FLUSH, V_BLOCK };
+enum { LZ_FLUSH, LZ_END };
+enum { LK_ENOUGH, LK_FILL };
+
+struct Tree {  // one Huffman tree as the encoder needs it
+  uint16_t lengths[L_CODES + 2];  // T.tree.lengths (patched by T.scan's 0xffff guard)
+  uint8_t clen[L_CODES + 2];      // Lookup lengths as of T.make
+  uint16_t codes[L_CODES + 2];
+  int max_code;
+};
+
+// LDS scratch of one stream
+struct DS {
+  int lits[HEAP_SIZE];   // live literal/length histogram (make_literals, lib/de.ml:2333), mutated by T.make
+  int dsts[2 * D_CODES + 1];
+  int blf[2 * BL_CODES + 1];
+  uint16_t heap[HEAP_SIZE];
+  uint16_t depth[HEAP_SIZE];
+  uint16_t dads[HEAP_SIZE];
+  uint16_t tlen[HEAP_SIZE];  // tree_lengths of the tree being built (leaves and internal nodes)
+  int bl_count[MAX_BITS + 1];
+  Tree lt, dt, bt;             // trees of the CURRENT block (e.blk)
+  uint16_t symbols[L_CODES + D_CODES + 8];  // (len << 8) | code of the code-length stream
+  int nsymbols, h_lit, h_dst, h_len;
+  uint8_t length_code[259];
+  uint8_t dist_lo[256], dist_hi[256];
+};
+
+__device__ __forceinline__ int distance_code(const DS *s, int d1) {
+  return d1 < 256 ? s->dist_lo[d1] : s->dist_hi[d1 >> 7];
+}
+__device__ void static_lit(int sym, int *len, int *code) {  // lib/de.ml:373-409
+  int l, c;
+  if (sym < 144) { l = 8; c = 0x30 + sym; }
+  else if (sym < 256) { l = 9; c = 0x190 + (sym - 144); }
+  else if (sym < 280) { l = 7; c = sym - 256; }
+  else { l = 8; c = 0xc0 + (sym - 280); }
+  *len = l;
+  *code = (int)(__brev((unsigned)c) >> (32 - l));
+}
+
+// ---------------------------------------------------------------------------
+// De.T (lib/de.ml:1828-2068): heap, lengths with overflow fix-up, reversed codes.
+__device__ bool smaller(const int *f, const uint16_t *depth, int n, int m) {
+  return f[n] < f[m] || (f[n] == f[m] && depth[n] <= depth[m]);
+}
+__device__ void pqdownheap(DS *s, const int *f, int hlen, int k) {
+  int v = s->heap[k], j = k << 1;
+  while (j <= hlen) {
+    if (j < hlen && smaller(f, s->depth, s->heap[j + 1], s->heap[j])) j++;
+    if (smaller(f, s->depth, v, s->heap[j])) break;
+    s->heap[k] = s->heap[j];
+    k = j;
+    j <<= 1;
+  }
+  s->heap[k] = (uint16_t)v;
+}
+__device__ void tree_make(DS *s, int length, int max_length, int *f, Tree *t) {
+  int hlen = 0, hmax = HEAP_SIZE, max_code = -1;
+  for (int n = 0; n < HEAP_SIZE; n++) {
+    s->tlen[n] = 0;
+    s->depth[n] = 0;
+    s->dads[n] = 0;
+    s->heap[n] = 0;
+  }
+  for (int n = 0; n < length; n++)
+    if (f[n] != 0) {
+      s->heap[++hlen] = (uint16_t)n;
+      max_code = n;
+    }
+  while (hlen < 2) {  // pkzip, lib/de.ml:1863-1874 (writes into the live histogram: H2)
+    int node = max_code < 2 ? ++max_code : 0;
+    f[node] = 1;
+    s->heap[++hlen] = (uint16_t)node;
+    s->depth[node] = 0;
+  }
+  for (int n = hlen / 2; n >= 1; n--) pqdownheap(s, f, hlen, n);
+  int node = length;
+  do {
+    int n = s->heap[1];
+    s->heap[1] = s->heap[hlen--];
+    pqdownheap(s, f, hlen, 1);
+    int m = s->heap[1];
+    s->heap[--hmax] = (uint16_t)n;
+    s->heap[--hmax] = (uint16_t)m;
+    f[node] = f[n] + f[m];
+    s->depth[node] = (uint16_t)((s->depth[n] >= s->depth[m] ? s->depth[n] : s->depth[m]) + 1);
+    s->dads[n] = s->dads[m] = (uint16_t)node;
+    s->heap[1] = (uint16_t)node++;
+    pqdownheap(s, f, hlen, 1);
+  } while (hlen >= 2);
+  s->heap[--hmax] = s->heap[1];
+  // generate_lengths, lib/de.ml:1952-2009
+  s->tlen[s->heap[hmax]] = 0;
+  int overflow = 0;
+  for (int i = 0; i <= MAX_BITS; i++) s->bl_count[i] = 0;
+  for (int h = hmax + 1; h < HEAP_SIZE; h++) {
+    int n = s->heap[h];
+    int bits = s->tlen[s->dads[n]] + 1;
+    if (bits > max_length) {
+      overflow++;
+      bits = max_length;
+    }
+    s->tlen[n] = (uint16_t)bits;
+    if (n <= max_code) s->bl_count[bits]++;
+  }
+  if (overflow != 0) {
+    do {
+      int bits = max_length - 1;
+      while (s->bl_count[bits] == 0) bits--;
+      s->bl_count[bits]--;
+      s->bl_count[bits + 1] += 2;
+      s->bl_count[max_length]--;
+      overflow -= 2;
+    } while (overflow > 0);
+    int h = HEAP_SIZE;
+    for (int bits = max_length; bits >= 1; bits--) {
+      int n = s->bl_count[bits];
+      while (n != 0) {
+        int m = s->heap[--h];
+        if (m <= max_code) {
+          s->tlen[m] = (uint16_t)bits;
+          n--;
+        }
+      }
+    }
+  }
+  // generate_codes, lib/de.ml:1926-1950
+  int next_code[MAX_BITS + 1];
+  unsigned code = 0;
+  next_code[0] = 0;
+  for (int bits = 1; bits <= MAX_BITS; bits++) {
+    code = (code + (unsigned)s->bl_count[bits - 1]) << 1;
+    next_code[bits] = (int)(code & 0xffff);
+  }
+  for (int n = 0; n < length + 2 && n < L_CODES + 2; n++) {
+    int len = n < length ? s->tlen[n] : 0;
+    t->lengths[n] = (uint16_t)(n < HEAP_SIZE ? s->tlen[n] : 0);
+    t->clen[n] = (uint8_t)len;
+    t->codes[n] = 0;
+    if (n <= max_code && len > 0) t->codes[n] = (uint16_t)(__brev((unsigned)next_code[len]++) >> (32 - len));
+  }
+  t->max_code = max_code;
+}
+// T.scan, lib/de.ml:2070-2117
+__device__ void tree_scan(Tree *t, int *blf) {
+  int max_code = t->max_code;
+  int prevlen = -1, nextlen = t->lengths[0], curlen, count = 0, max_count = 7, min_count = 4;
+  if (nextlen == 0) { max_count = 138; min_count = 3; }
+  t->lengths[max_code + 1] = 0xffff;
+  for (int n = 0; n <= max_code; n++) {
+    curlen = nextlen;
+    nextlen = t->lengths[n + 1];
+    if (++count < max_count && curlen == nextlen) continue;
+    else if (count < min_count) blf[curlen] += count;
+    else if (curlen != 0) {
+      if (curlen != prevlen) blf[curlen]++;
+      blf[16]++;
+    } else if (count <= 10) blf[17]++;
+    else blf[18]++;
+    count = 0;
+    prevlen = curlen;
+    if (nextlen == 0) { max_count = 138; min_count = 3; }
+    else if (curlen == nextlen) { max_count = 6; min_count = 3; }
+    else { max_count = 7; min_count = 4; }
+  }
+}
+// T.symbols, lib/de.ml:2122-2191; entries (len << 8) | code
+__device__ int tree_symbols(DS *s, int i, const Tree *t) {
+#define BLSYM(c) (uint16_t)((s->bt.clen[c] << 8) | s->bt.codes[c])
+  int max_code = t->max_code;
+  int prevlen = -1, nextlen = t->lengths[0], curlen, count = 0, max_count = 7, min_count = 4;
+  if (nextlen == 0) { max_count = 138; min_count = 3; }
+  for (int n = 0; n <= max_code; n++) {
+    curlen = nextlen;
+    nextlen = t->lengths[n + 1];
+    if (++count < max_count && curlen == nextlen) continue;
+    else if (count < min_count) {
+      do s->symbols[i++] = BLSYM(curlen); while (--count != 0);
+    } else if (curlen != 0) {
+      if (curlen != prevlen) {
+        s->symbols[i++] = BLSYM(curlen);
+        count--;
+      }
+      s->symbols[i++] = BLSYM(16);
+      s->symbols[i++] = (uint16_t)((2 << 8) | (count - 3));
+    } else if (count <= 10) {
+      s->symbols[i++] = BLSYM(17);
+      s->symbols[i++] = (uint16_t)((3 << 8) | (count - 3));
+    } else {
+      s->symbols[i++] = BLSYM(18);
+      s->symbols[i++] = (uint16_t)((7 << 8) | (count - 11));
+    }
+    count = 0;
+    prevlen = curlen;
+    if (nextlen == 0) { max_count = 138; min_count = 3; }
+    else if (curlen == nextlen) { max_count = 6; min_count = 3; }
+    else { max_count = 7; min_count = 4; }
+  }
+  return i;
+#undef BLSYM
+}
+// Def.dynamic_of_frequencies, lib/de.ml:2387-2407 (into the current block's trees)
+__device__ void dynamic_of_frequencies(DS *s) {
+  tree_make(s, L_CODES, MAX_BITS, s->lits, &s->lt);
+  tree_make(s, D_CODES, MAX_BITS, s->dsts, &s->dt);
+  for (int i = 0; i < 2 * BL_CODES + 1; i++) s->blf[i] = 0;
+  tree_scan(&s->lt, s->blf);
+  tree_scan(&s->dt, s->blf);
+  tree_make(s, BL_CODES, 7, s->blf, &s->bt);
+  int max_blindex = BL_CODES - 1;
+  while (max_blindex >= 3 && s->bt.clen[c_zigzag[max_blindex]] == 0) max_blindex--;
+  int i = tree_symbols(s, 0, &s->lt);
+  i = tree_symbols(s, i, &s->dt);
+  s->nsymbols = i;
+  s->h_lit = s->lt.max_code + 1;
+  s->h_dst = s->dt.max_code + 1;
+  s->h_len = max_blindex + 1;
+}
+// lib/de.ml:2415-2449 with the H3 quirk (`distances[i] + len`); returns the block kind
+__device__ int block_of_frequencies(DS *s) {
+  dynamic_of_frequencies(s);
+  long dyn = 5 + 5 + 4 + s->h_len * 3, sta = 0;
+  for (int i = 0; i < s->nsymbols; i++) dyn += s->symbols[i] >> 8;
+  for (int i = 0; i < L_CODES; i++)
+    if (s->lits[i] != 0) {
+      int l, c;
+      static_lit(i, &l, &c);
+      sta += (long)s->lits[i] * l;
+      dyn += (long)s->lits[i] * s->lt.lengths[i];
+    }
+  for (int i = 0; i < D_CODES; i++)
+    if (s->dsts[i] != 0) {
+      sta += s->dsts[i] + 5;
+      dyn += s->dsts[i] + s->dt.lengths[i];
+    }
+  return dyn <= sta ? KIND_DYNAMIC : KIND_FIXED;
+}
+
+// ---------------------------------------------------------------------------
+// workspace in HBM, per stream
+struct Ws {
+  uint32_t *head;  // [HASH_SIZE] absolute position + 0 = NIL (position 0 can never match, like the reference)
+  uint32_t *prev;  // [WSIZE]
+  int *queue;      // [qcap]
+};
+__device__ __forceinline__ uint32_t g_ld(const uint32_t *p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ int g_ldi(const int *p) { return __builtin_nontemporal_load(p); }
+
+struct Enc {  // De.Def.encoder, lib/de.ml:2465-2478
+  int kind, last;
+  uint64_t hold;
+  int bits, flat, fmax, k;
+  uint8_t *o;
+  uint32_t o_pos, o_cap;
+  bool overflow;
+  unsigned qw, qr, qc;  // the queue's cursors (shared with the matcher)
+  int *q;
+};
+__device__ __forceinline__ void out_byte(Enc *e, unsigned b) {
+  if (e->o_pos < e->o_cap) e->o[e->o_pos] = (uint8_t)b;
+  else e->overflow = true;
+  e->o_pos++;
+}
+__device__ void put_bits(Enc *e, unsigned v, int n) {
+  e->hold |= (uint64_t)v << e->bits;
+  e->bits += n;
+  while (e->bits >= 16) {
+    out_byte(e, (unsigned)e->hold & 0xff);
+    out_byte(e, (unsigned)(e->hold >> 8) & 0xff);
+    e->hold >>= 16;
+    e->bits -= 16;
+  }
+}
+__device__ void align_bits(Enc *e) {
+  if (e->bits > 8) {
+    out_byte(e, (unsigned)e->hold & 0xff);
+    out_byte(e, (unsigned)(e->hold >> 8) & 0xff);
+  } else if (e->bits > 0) out_byte(e, (unsigned)e->hold & 0xff);
+  e->hold = 0;
+  e->bits = 0;
+}
+__device__ void lit_code(const DS *s, const Enc *e, int sym, int *len, int *code) {
+  if (e->kind == KIND_DYNAMIC) {
+    *len = s->lt.clen[sym];
+    *code = s->lt.codes[sym];
+  } else static_lit(sym, len, code);
+}
+__device__ void dst_code(const DS *s, const Enc *e, int sym, int *len, int *code) {
+  if (e->kind == KIND_DYNAMIC) {
+    *len = s->dt.clen[sym];
+    *code = s->dt.codes[sym];
+  } else {
+    *len = 5;
+    *code = (int)(__brev((unsigned)sym) >> 27);
+  }
+}
+__device__ bool cmd_exists(const DS *s, const Enc *e, int cmd) {  // Def.exists, lib/de.ml:2451-2463
+  if (e->kind != KIND_DYNAMIC || cmd == Q_EOB) return true;
+  if (!(cmd & Q_COPY)) return s->lt.clen[cmd & 0xff] > 0;
+  int off = cmd & 0xffff, len = (cmd >> 16) & 0x1ff;
+  return s->lt.clen[257 + s->length_code[len + 3]] > 0 && s->dt.clen[distance_code(s, off)] > 0;
+}
+__device__ void emit_eob(const DS *s, Enc *e) {
+  int l, c;
+  lit_code(s, e, 256, &l, &c);
+  put_bits(e, (unsigned)c, l);
+}
+// write, lib/de.ml:2708-2897
+__device__ int enc_write(const DS *s, Enc *e) {
+  while (e->qw != e->qr) {
+    int cmd = g_ldi(e->q + (e->qr & (e->qc - 1)));
+    if (!cmd_exists(s, e, cmd)) {  // Leave
+      emit_eob(s, e);
+      e->k = K_BLOCK;
+      return R_BLOCK;
+    }
+    e->qr++;
+    if (cmd == Q_EOB) {  // End
+      emit_eob(s, e);
+      if (e->last) {
+        align_bits(e);
+        e->k = K_ENCODE;
+        return R_OK;
+      }
+      e->k = K_BLOCK;
+      return R_BLOCK;
+    }
+    int l, c;
+    if (!(cmd & Q_COPY)) {
+      lit_code(s, e, cmd, &l, &c);
+      put_bits(e, (unsigned)c, l);
+    } else {
+      int off = cmd & 0xffff, len = (cmd >> 16) & 0x1ff;
+      int code = s->length_code[len + 3];
+      lit_code(s, e, code + 257, &l, &c);
+      put_bits(e, (unsigned)c, l);
+      put_bits(e, (unsigned)(len - c_base_length[code & 0x1f]), c_extra_lbits[code]);
+      code = distance_code(s, off);
+      dst_code(s, e, code, &l, &c);
+      put_bits(e, (unsigned)c, l);
+      put_bits(e, (unsigned)(off - c_base_dist[code]), c_extra_dbits[code & 0x1f]);
+    }
+  }
+  e->k = K_ENCODE;
+  return R_OK;
+}
+__device__ void emit_header(const DS *s, Enc *e) {  // lib/de.ml:2566-2633
+  put_bits(e, e->last ? 1 : 0, 1);
+  if (e->kind == KIND_FIXED) put_bits(e, 1, 2);
+  else if (e->kind == KIND_DYNAMIC) {
+    put_bits(e, 2, 2);
+    put_bits(e, (unsigned)(s->h_lit - 257), 5);
+    put_bits(e, (unsigned)(s->h_dst - 1), 5);
+    put_bits(e, (unsigned)(s->h_len - 4), 4);
+    for (int r = 0; r < s->h_len; r++) put_bits(e, s->bt.clen[c_zigzag[r]], 3);
+    for (int r = 0; r < s->nsymbols; r++) put_bits(e, s->symbols[r] & 0xff, s->symbols[r] >> 8);
+  } else {
+    put_bits(e, 0, 2);
+    align_bits(e);
+    out_byte(e, e->fmax & 0xff);
+    out_byte(e, (e->fmax >> 8) & 0xff);
+    out_byte(e, (~e->fmax) & 0xff);
+    out_byte(e, ((~e->fmax) >> 8) & 0xff);
+    e->flat = 0;
+  }
+}
+__device__ int enc_write_flat(Enc *e) {  // lib/de.ml:2927-2962
+  while (e->qw != e->qr && e->flat < e->fmax) {
+    int cmd = g_ldi(e->q + (e->qr++ & (e->qc - 1)));
+    if (cmd != Q_EOB) {
+      out_byte(e, cmd & 0xff);
+      e->flat++;
+    }
+  }
+  if (e->flat == e->fmax) {
+    e->fmax = 0;
+    if (!e->last) e->k = K_FLAT_DONE;
+  }
+  return R_OK;
+}
+__device__ void flat_len(Enc *e) {
+  if (e->qw != e->qr && g_ldi(e->q + ((e->qw - 1) & (e->qc - 1))) == Q_EOB) e->qw--;
+  unsigned len = e->qw - e->qr;
+  e->fmax = len < 0xffff ? (int)len : 0xffff;
+}
+// block, lib/de.ml:2657-2684.  The block's trees are already in DS (kind/last given).
+__device__ int enc_block(const DS *s, Enc *e, int kind, int last) {
+  e->kind = kind;
+  e->last = last;
+  if (kind == KIND_FLAT) flat_len(e);
+  emit_header(s, e);
+  e->k = K_ENCODE;
+  return kind == KIND_FLAT ? enc_write_flat(e) : enc_write(s, e);
+}
+
+// Def.encode, lib/de.ml:2965-3038.  For `Block the caller has already built the new
+// block's trees in DS — but force must close the OLD block first, whose EOB code comes
+// from the old trees; the caller passes it in (old_eob_len/old_eob_code).
+__device__ int enc_encode(const DS *s, Enc *e, int v, int kind, int last, int old_eob_len, int old_eob_code) {
+  for (;;) {
+    switch (e->k) {
+    case K_FIRST_ENTRY:
+      if (v == V_BLOCK) return enc_block(s, e, kind, last);
+      emit_header(s, e);  // the initial {Fixed; last = false} block
+      e->k = K_ENCODE;
+      continue;
+    case K_BLOCK:
+      if (v == V_BLOCK) return enc_block(s, e, kind, last);
+      e->k = K_ENCODE;
+      continue;
+    case K_FLAT_DONE:
+      if (v == V_BLOCK) return enc_block(s, e, kind, last);
+      e->k = K_BLOCK;
+      return R_BLOCK;
+    default:
+      if (v == V_AWAIT) return R_OK;
+      if (v == V_FLUSH) return e->kind == KIND_FLAT ? enc_write_flat(e) : enc_write(s, e);
+      // force, lib/de.ml:2899-2924: close the open block with ITS end-of-block code
+      if (e->kind != KIND_FLAT) put_bits(e, (unsigned)old_eob_code, old_eob_len);
+      return enc_block(s, e, kind, last);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// De.Lz77, lib/de.ml:4013-4515, in absolute positions.
+struct Lz {
+  int level;
+  int max_chain, max_lazy, good_length, nice_length;
+  const uint8_t *in;
+  uint32_t n;
+  uint32_t base;     // absolute position of window index 0 (32 KiB per slide)
+  uint32_t filled;   // absolute end of the data copied into the window
+  uint32_t strstart; // absolute
+  int lookahead;
+  uint32_t match_start, prev_match;
+  int match_length, prev_length, match_available;
+  bool eoi;
+  int k;
+};
+// window byte at absolute position a (H7: beyond the data the reference reads what its
+// 64 KiB buffer holds: zero before the first slide, the byte 32 KiB earlier after it)
+__device__ __forceinline__ unsigned W(const Lz *z, uint32_t a) {
+  if (a < z->filled) return z->in[a];
+  if (z->base == 0 || a < (uint32_t)WSIZE) return 0;
+  return a - WSIZE < z->filled ? z->in[a - WSIZE] : 0;
+}
+__device__ __forceinline__ unsigned W16(const Lz *z, uint32_t a) {
+  if (a + 2 <= z->filled) return z->in[a] | (z->in[a + 1] << 8);
+  return W(z, a) | (W(z, a + 1) << 8);
+}
+__device__ __forceinline__ uint32_t W32(const Lz *z, uint32_t a) {
+  if (a + 4 <= z->filled) {
+    uint32_t v;
+    __builtin_memcpy(&v, z->in + a, 4);
+    return v;
+  }
+  return W(z, a) | (W(z, a + 1) << 8) | (W(z, a + 2) << 16) | (W(z, a + 3) << 24);
+}
+__device__ __forceinline__ unsigned hash4(const Lz *z, uint32_t a) {
+  return (uint32_t)(W32(z, a) * 0x9e3779b1u) >> (32 - HASH_BITS);
+}
+__device__ uint32_t insert_string(const Lz *z, const Ws *ws, uint32_t str) {
+  unsigned h = hash4(z, str);
+  uint32_t res = g_ld(ws->head + h);
+  ws->prev[str & WMASK] = res;
+  ws->head[h] = str;
+  return res;
+}
+// longest_match, lib/de.ml:4110-4174
+__device__ int longest_match(Lz *z, const Ws *ws, uint32_t cur_match) {
+  const uint32_t ss = z->strstart;
+  const uint32_t str_end = ss + (MAX_MATCH - 1);
+  const uint32_t rel = ss - z->base;
+  const uint32_t limit = z->base + (rel > (uint32_t)MAX_DIST ? rel - MAX_DIST : 0);
+  int chain_length = z->prev_length >= z->good_length ? z->max_chain >> 2 : z->max_chain;
+  const unsigned scan_start = W16(z, ss);
+  unsigned scan_end = W16(z, ss + z->prev_length - 1);
+  int best_len = z->prev_length;
+  for (;;) {
+    uint32_t m = cur_match;
+    if (W16(z, m + best_len - 1) == scan_end && W16(z, m) == scan_start) {
+      uint32_t scan = ss + 1;
+      m++;
+      while (scan < str_end && W32(z, scan) == W32(z, m)) { scan += 4; m += 4; }
+      while (scan < str_end && W16(z, scan) == W16(z, m)) { scan += 2; m += 2; }
+      while (scan < str_end && W(z, scan) == W(z, m)) { scan++; m++; }
+      if (W(z, scan) == W(z, m)) scan++;
+      int len = MAX_MATCH - 1 - (int)(str_end - scan);
+      if (len > best_len) {
+        z->match_start = cur_match;
+        best_len = len;
+        if (len >= z->nice_length) break;
+        scan_end = W16(z, ss + best_len - 1);
+      }
+    }
+    cur_match = g_ld(ws->prev + (cur_match & WMASK));
+    chain_length--;
+    if (!(cur_match > limit && chain_length != 0)) break;
+  }
+  return best_len <= z->lookahead ? best_len : z->lookahead;
+}
+__device__ bool q_push_auto(DS *s, Enc *e, int v) {  // emit_*: push + auto EOB when one cell is left
+  e->q[e->qw++ & (e->qc - 1)] = v;
+  if (e->qc - (e->qw - e->qr) == 1) {
+    e->q[e->qw++ & (e->qc - 1)] = Q_EOB;
+    return true;
+  }
+  return false;
+}
+__device__ bool emit_match(DS *s, Enc *e, int off, int len) {
+  s->lits[257 + s->length_code[len]]++;
+  s->dsts[distance_code(s, off - 1)]++;
+  return q_push_auto(s, e, ((len - 3) << 16) | (off - 1) | Q_COPY);
+}
+__device__ bool emit_literal(DS *s, Enc *e, int chr) {
+  s->lits[chr]++;
+  return q_push_auto(s, e, chr);
+}
+// deflate (one position), lib/de.ml:4351-4410
+__device__ bool lz_deflate(DS *s, Enc *e, Lz *z, const Ws *ws) {
+  uint32_t hash_head = 0;
+  if (z->lookahead >= MIN_MATCH) hash_head = insert_string(z, ws, z->strstart);
+  z->prev_length = z->match_length;
+  z->prev_match = z->match_start;
+  z->match_length = MIN_MATCH - 1;
+  // hash_head != 0 in window terms: absolute position strictly above the window base
+  if (hash_head > z->base && z->prev_length < z->max_lazy && z->strstart - hash_head <= (uint32_t)MAX_DIST) {
+    int ml = longest_match(z, ws, hash_head);
+    if (ml <= 5 && ml == MIN_MATCH && z->strstart - z->match_start > (uint32_t)TOO_FAR) z->match_length = MIN_MATCH - 1;
+    else z->match_length = ml;
+  }
+  if (z->prev_length >= MIN_MATCH && z->match_length <= z->prev_length) {
+    uint32_t max_insert = z->strstart + z->lookahead - MIN_MATCH;
+    bool flush = emit_match(s, e, (int)(z->strstart - 1 - z->prev_match), z->prev_length);
+    z->lookahead -= z->prev_length - 1;
+    z->prev_length -= 2;
+    do {
+      z->strstart++;
+      if (z->strstart <= max_insert) insert_string(z, ws, z->strstart);
+    } while (--z->prev_length != 0);
+    z->match_available = 0;
+    z->match_length = MIN_MATCH - 1;
+    z->strstart++;
+    return flush;
+  } else if (z->match_available) {
+    bool flush = emit_literal(s, e, (int)W(z, z->strstart - 1));
+    z->strstart++;
+    z->lookahead--;
+    return flush;
+  }
+  z->match_available = 1;
+  z->strstart++;
+  z->lookahead--;
+  return false;
+}
+__device__ bool lz_copy(DS *s, Enc *e, Lz *z) {  // level 0, lib/de.ml:4412-4423
+  bool flush = (e->qc - (e->qw - e->qr)) <= 1;
+  while (!flush && z->lookahead > 0) {
+    flush = emit_literal(s, e, (int)W(z, z->strstart));
+    z->strstart++;
+    z->lookahead--;
+  }
+  return flush;
+}
+// Lz77.compress until `Flush or `End; the whole input is available, `Await = end of input
+__device__ int lz_compress(DS *s, Enc *e, Lz *z, const Ws *ws) {
+  for (;;) {
+    if (!(z->k == LK_ENOUGH && z->lookahead >= MIN_LOOKAHEAD)) {
+      // fill_window, lib/de.ml:4294-4342
+      uint32_t rel = z->strstart - z->base;
+      int more = 2 * WSIZE - z->lookahead - (int)rel;
+      if (rel >= (uint32_t)(WSIZE + MAX_DIST)) {
+        z->base += WSIZE;  // the slide: heads/chains hold absolute positions, nothing to rewrite
+        more += WSIZE;
+      }
+      if (z->filled >= z->n) {
+        if (z->eoi) {
+          if (z->lookahead == 0) {
+            // trailing, lib/de.ml:4257-4266
+            if (z->match_available) {
+              if (!emit_literal(s, e, (int)W(z, z->strstart - 1))) e->q[e->qw++ & (e->qc - 1)] = Q_EOB;
+            } else e->q[e->qw++ & (e->qc - 1)] = Q_EOB;
+            return LZ_END;
+          }
+        } else {
+          z->eoi = true;
+          z->k = LK_FILL;
+          continue;
+        }
+      } else {
+        uint32_t rem = z->n - z->filled;
+        uint32_t len = (uint32_t)more < rem ? (uint32_t)more : rem;
+        z->filled += len;
+        z->lookahead += (int)len;
+        if (z->lookahead < MIN_LOOKAHEAD) {
+          z->eoi = z->filled >= z->n;
+          z->k = LK_FILL;
+          continue;
+        }
+      }
+    }
+    z->k = LK_ENOUGH;
+    if (z->level == 0 ? lz_copy(s, e, z) : lz_deflate(s, e, z, ws)) return LZ_FLUSH;
+  }
+}
+
+// make_block of the three drivers; builds the trees in DS and returns the kind
+__device__ int make_block(DS *s, int driver, int dynamic, int level, int last) {
+  if (driver == DRV_CLI) {
+    if (last) return KIND_FIXED;
+    dynamic_of_frequencies(s);
+    return KIND_DYNAMIC;
+  }
+  if (driver == DRV_ZL && level == 0) return KIND_FLAT;
+  if (driver == DRV_ZL && !dynamic) return KIND_FIXED;
+  return block_of_frequencies(s);
+}
+
+__device__ void run_stream(DS *s, const Ws *ws, const uint8_t *in, uint32_t n, uint8_t *out, uint32_t cap,
+                           int level, int qcap, int driver, int dynamic, uint32_t *out_len, int *status) {
+  Enc e;
+  e.kind = KIND_FIXED;
+  e.last = 0;
+  e.hold = 0;
+  e.bits = 0;
+  e.flat = 0;
+  e.fmax = 0;
+  e.k = K_FIRST_ENTRY;
+  e.o = out;
+  e.o_pos = 0;
+  e.o_cap = cap;
+  e.overflow = false;
+  e.qw = e.qr = 0;
+  e.qc = (unsigned)qcap;
+  e.q = ws->queue;
+  Lz z;
+  z.level = driver == DRV_HIGHER ? 4 : level;  // H6: De.Higher.compress has no ?level
+  z.max_chain = c_levels[z.level][0];
+  z.max_lazy = c_levels[z.level][1];
+  z.good_length = c_levels[z.level][2];
+  z.nice_length = c_levels[z.level][3];
+  z.in = in;
+  z.n = n;
+  z.base = 0;
+  z.filled = 0;
+  z.strstart = 0;
+  z.lookahead = 0;
+  z.match_start = z.prev_match = 0;
+  z.match_length = z.prev_length = z.match_available = 0;
+  z.eoi = n == 0;
+  z.k = LK_ENOUGH;
+  bool first = true;
+  for (;;) {
+    int r = lz_compress(s, &e, &z, ws);
+    // the end-of-block code of the block that is open right now (force needs it after the
+    // new trees have replaced the old ones in DS)
+    int ol, oc;
+    lit_code(s, &e, 256, &ol, &oc);
+    int rc;
+    if (r == LZ_FLUSH) {
+      if (driver == DRV_ZL && !first) rc = enc_encode(s, &e, V_FLUSH, 0, 0, ol, oc);
+      else {
+        first = false;
+        int kind = make_block(s, driver, dynamic, z.level, 0);
+        rc = enc_encode(s, &e, V_BLOCK, kind, 0, ol, oc);
+      }
+      while (rc == R_BLOCK && driver != DRV_CLI) {
+        lit_code(s, &e, 256, &ol, &oc);
+        int kind = make_block(s, driver, dynamic, z.level, 0);
+        rc = enc_encode(s, &e, V_BLOCK, kind, 0, ol, oc);
+      }
+    } else {
+      if (driver == DRV_CLI) e.q[e.qw++ & (e.qc - 1)] = Q_EOB;  // bin/decompress.ml:67
+      int kind = make_block(s, driver, dynamic, z.level, 1);
+      enc_encode(s, &e, V_BLOCK, kind, 1, ol, oc);
+      break;
+    }
+  }
+  *out_len = e.o_pos;
+  *status = e.overflow ? MD_UNEXPECTED_END_OF_OUTPUT : MD_OK;
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__global__ __launch_bounds__(kWave) void deflate_kernel(
+    int format, int level, int qcap, int driver, int dynamic, uint32_t n, const uint8_t *__restrict__ in,
+    const uint64_t *__restrict__ in_off, const uint64_t *__restrict__ in_len, uint8_t *__restrict__ out,
+    const uint64_t *__restrict__ out_off, const uint64_t *__restrict__ out_cap,
+    uint64_t *__restrict__ out_len, int32_t *__restrict__ status, uint32_t *__restrict__ checksum,
+    uint32_t *__restrict__ ws_head, uint32_t *__restrict__ ws_prev, int *__restrict__ ws_queue) {
+  __shared__ DS ds;
+  __shared__ uint32_t res_len;
+  __shared__ int res_status;
+  const uint32_t lane = threadIdx.x, sid = blockIdx.x;
+  if (sid >= n) return;
+  const uint8_t *src = in + in_off[sid];
+  const uint32_t slen = (uint32_t)in_len[sid];
+  uint8_t *dst = out + out_off[sid];
+  uint64_t cap64 = out_cap[sid];
+  uint32_t cap = cap64 > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)cap64;
+  Ws ws{ws_head + (size_t)sid * HASH_SIZE, ws_prev + (size_t)sid * WSIZE, ws_queue + (size_t)sid * qcap};
+
+  // ---- cooperative setup: NIL heads, histograms, code tables, Adler-32 of the input
+  for (uint32_t i = lane; i < (uint32_t)HASH_SIZE; i += kWave) ws.head[i] = 0;
+  for (uint32_t i = lane; i < (uint32_t)HEAP_SIZE; i += kWave) ds.lits[i] = i == 256 ? 1 : 0;  // make_literals
+  if (lane < 2 * D_CODES + 1) ds.dsts[lane] = 0;
+  for (uint32_t len = lane; len < 259; len += kWave) {  // _length, lib/de.ml:240-256
+    int c = 0;
+    if (len >= 3) {
+      int l = (int)len - 3;
+      if (l == 255) c = 28;
+      else for (c = 27; c > 0 && c_base_length[c] > l; c--) {}
+    }
+    ds.length_code[len] = (uint8_t)c;
+  }
+  for (uint32_t d = lane; d < 256; d += kWave) {  // _distance, lib/de.ml:258-291
+    int c;
+    for (c = 29; c > 0 && (int)c_base_dist[c] > (int)d; c--) {}
+    ds.dist_lo[d] = (uint8_t)c;
+    for (c = 29; c > 0 && (int)c_base_dist[c] > (int)(d << 7); c--) {}
+    ds.dist_hi[d] = (uint8_t)c;
+  }
+  uint32_t a = 1, b = 0;  // Lz77's update_crc (Adler-32 of the input), lib/de.ml:4217-4218
+  for (uint32_t ps = 0; ps < slen; ps += 1024) {
+    const uint32_t b0 = ps + 1024 < slen ? ps + 1024 : slen;
+    uint32_t s1 = 0, s2 = 0;
+    for (uint32_t k = 0; k < 16; k++) {
+      uint32_t x = ps + lane * 16 + k;
+      if (x < b0) {
+        uint32_t d = src[x];
+        s1 += d;
+        s2 += (b0 - x) * d;
+      }
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    b = (b + (b0 - ps) * a + s2) % 65521u;
+    a = (a + s1) % 65521u;
+  }
+  const uint32_t adler = (b << 16) | a;
+  __threadfence_block();
+  __syncthreads();
+
+  uint32_t hdr = 0;
+  if (format == MD_FORMAT_ZLIB) {
+    // Zl.Def header, lib/zl.ml:511-517 (FLEVEL map lib/zl.ml:580-581)
+    int flevel = level == 0 ? 0 : level <= 5 ? 1 : level == 6 ? 2 : 3;
+    unsigned h = (8 + ((15 - 8) << 4)) << 8;
+    h |= (unsigned)flevel << 6;
+    h += 31 - (h % 31);
+    if (lane == 0 && cap >= 2) {
+      dst[0] = (uint8_t)(h >> 8);
+      dst[1] = (uint8_t)h;
+    }
+    hdr = 2;
+  }
+  if (lane == 0) {
+    uint32_t body = 0;
+    int st = MD_OK;
+    if (cap < hdr) st = MD_UNEXPECTED_END_OF_OUTPUT;
+    else run_stream(&ds, &ws, src, slen, dst + hdr, cap - hdr, level, qcap, driver, dynamic, &body, &st);
+    uint32_t total = hdr + body;
+    if (format == MD_FORMAT_ZLIB && st == MD_OK) {
+      if (cap - total < 4) st = MD_UNEXPECTED_END_OF_OUTPUT;
+      else {
+        dst[total] = (uint8_t)(adler >> 24);
+        dst[total + 1] = (uint8_t)(adler >> 16);
+        dst[total + 2] = (uint8_t)(adler >> 8);
+        dst[total + 3] = (uint8_t)adler;
+        total += 4;
+      }
+    }
+    out_len[sid] = st == MD_OK ? total : 0;
+    status[sid] = st;
+    if (checksum) checksum[sid] = adler;
+  }
+}
+
+}  // namespace defl
+}  // namespace md
+
+extern "C" size_t md_deflate_ws_bytes(uint32_t n, int qcap) {
+  return (size_t)n * ((size_t)md::defl::HASH_SIZE * 4 + (size_t)md::defl::WSIZE * 4 + (size_t)qcap * 4);
+}
+
+extern "C" int md_launch_deflate(int format, int level, int qcap, int driver, int dynamic, uint32_t n,
+                                 const uint8_t *in, const uint64_t *in_off, const uint64_t *in_len,
+                                 uint8_t *out, const uint64_t *out_off, const uint64_t *out_cap,
+                                 uint64_t *out_len, int32_t *status, uint32_t *checksum, void *ws,
+                                 hipStream_t stream) {
+  if (n == 0) return 0;
+  uint32_t *head = (uint32_t *)ws;
+  uint32_t *prev = head + (size_t)n * md::defl::HASH_SIZE;
+  int *queue = (int *)(prev + (size_t)n * md::defl::WSIZE);
+  hipLaunchKernelGGL(md::defl::deflate_kernel, dim3(n), dim3(md::defl::kWave), 0, stream, format, level,
+                     qcap, driver, dynamic, n, in, in_off, in_len, out, out_off, out_cap, out_len, status,
+                     checksum, head, prev, queue);
+  return (int)hipGetLastError();
+}

@@ -21,3 +21,23 @@ class Inf:
         @staticmethod
         def inflate_batch(srcs, dst_lens, device=0):
             return _engine.default_engine(device).inflate_many(srcs, dst_lens, _engine.FORMAT_DEFLATE)
+
+
+class Higher:
+    """De.Higher (lib/de.ml:4517-4612): refill/flush callbacks become whole buffers."""
+
+    @staticmethod
+    def compress(src, queue=4096, device=0):
+        """`De.Higher.compress ~w ~q ~refill ~flush i o` / `to_string`: raw DEFLATE at level 4
+        (the reference's default: De.Higher has no ?level, lib/de.ml:4519)."""
+        st, out, _ = _engine.default_engine(device).deflate_many(
+            [src], _engine.FORMAT_DEFLATE, level=4, queue=queue, driver=_engine.DRIVER_HIGHER)[0]
+        if st != 0:
+            raise _engine.Error(_engine.STATUS_NAMES[st])
+        return out
+
+    @staticmethod
+    def uncompress(src, dst_len, device=0):
+        """`De.Higher.uncompress`: Ok bytes | Error (`Msg string)."""
+        r = Inf.Ns.inflate(src, dst_len, device)
+        return r[2] if r[0] == "Ok" else r

@@ -6,6 +6,7 @@ from . import _lib
 
 FORMAT_DEFLATE = 0
 FORMAT_ZLIB = 1
+DRIVER_ZL, DRIVER_HIGHER, DRIVER_CLI = 0, 1, 2
 
 # variant names of De.Inf.Ns.error (lib/de.ml:1548-1555) + Zl.Inf.Ns.error (lib/zl.ml:383)
 STATUS_NAMES = {
@@ -123,6 +124,57 @@ class Engine:
         checksum = checksum.cpu().numpy().view(np.uint32)
         return [(int(status[i]), int(consumed[i]),
                  out[out_off[i]:out_off[i] + out_len[i]].tobytes(), int(checksum[i]))
+                for i in range(n)]
+
+
+    # ------------------------------------------------------------------ deflate
+    def deflate_batch(self, fmt, d_in, in_off, in_len, d_out, out_off, out_cap, level=6, queue=4096,
+                      driver=DRIVER_ZL, dynamic=True, results=None):
+        """All arguments are CUDA tensors (uint8 data, int64 descriptors).
+        Returns (out_len, status, adler32_of_input) CUDA tensors (async)."""
+        torch = self.torch
+        n = in_off.numel()
+        if results is None:
+            results = (torch.empty(n, dtype=torch.int64, device=self.device),
+                       torch.empty(n, dtype=torch.int32, device=self.device),
+                       torch.empty(n, dtype=torch.int32, device=self.device))
+        out_len, status, checksum = results
+        self._check(self.lib.md_deflate_batch_device(
+            self.ctx, fmt, level, queue, driver, int(bool(dynamic)), n, _ptr(d_in), _ptr(in_off), _ptr(in_len),
+            _ptr(d_out), _ptr(out_off), _ptr(out_cap), _ptr(out_len), _ptr(status), _ptr(checksum)))
+        return results
+
+    def deflate_many(self, bufs, fmt=FORMAT_DEFLATE, level=6, queue=4096, driver=DRIVER_ZL, dynamic=True,
+                     caps=None):
+        """Convenience for tests: list of bytes -> list of (status, compressed bytes, adler32 of input)."""
+        import numpy as np
+
+        torch = self.torch
+        n = len(bufs)
+        if n == 0:
+            return []
+        in_len = np.array([len(s) for s in bufs], dtype=np.int64)
+        in_off = np.zeros(n, dtype=np.int64)
+        np.cumsum(((in_len + 15) // 16 * 16)[:-1], out=in_off[1:])
+        if caps is None:
+            caps = [2 * len(s) + 8192 for s in bufs]
+        cap = np.array(caps, dtype=np.int64)
+        out_off = np.zeros(n, dtype=np.int64)
+        np.cumsum(((cap + 255) // 256 * 256)[:-1], out=out_off[1:])
+        blob = np.zeros(int(in_off[-1] + in_len[-1]) + 16, dtype=np.uint8)
+        for s, o in zip(bufs, in_off):
+            blob[o:o + len(s)] = np.frombuffer(bytes(s), dtype=np.uint8)
+        dev = self.device
+        d_in = torch.from_numpy(blob).to(dev)
+        d_out = torch.zeros(int(out_off[-1] + cap[-1]) + 16, dtype=torch.uint8, device=dev)
+        t = lambda a: torch.from_numpy(a).to(dev)
+        out_len, status, checksum = self.deflate_batch(fmt, d_in, t(in_off), t(in_len), d_out, t(out_off), t(cap),
+                                                       level, queue, driver, dynamic)
+        torch.cuda.synchronize(dev)
+        out = d_out.cpu().numpy()
+        out_len, status = out_len.cpu().numpy(), status.cpu().numpy()
+        checksum = checksum.cpu().numpy().view(np.uint32)
+        return [(int(status[i]), out[out_off[i]:out_off[i] + out_len[i]].tobytes(), int(checksum[i]))
                 for i in range(n)]
 
 

@@ -18,3 +18,21 @@ class Inf:
         @staticmethod
         def inflate_batch(srcs, dst_lens, device=0):
             return _engine.default_engine(device).inflate_many(srcs, dst_lens, _engine.FORMAT_ZLIB)
+
+
+class Higher:
+    """Zl.Higher (lib/zl.ml:633-667)."""
+
+    @staticmethod
+    def compress(src, level=6, dynamic=True, queue=4096, device=0):
+        """`Zl.Higher.compress ?level ?dynamic ~w ~q ~refill ~flush i o`: a zlib stream."""
+        st, out, _ = _engine.default_engine(device).deflate_many(
+            [src], _engine.FORMAT_ZLIB, level=level, queue=queue, driver=_engine.DRIVER_ZL, dynamic=dynamic)[0]
+        if st != 0:
+            raise _engine.Error(_engine.STATUS_NAMES[st])
+        return out
+
+    @staticmethod
+    def uncompress(src, dst_len, device=0):
+        r = Inf.Ns.inflate(src, dst_len, device)
+        return r[2] if r[0] == "Ok" else r

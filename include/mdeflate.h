@@ -59,6 +59,14 @@ enum {
   MD_FORMAT_ZLIB = 1     /* RFC1950: Zl.Inf.Ns.inflate, lib/zl.ml:400-417 */
 };
 
+/* The reference's three encoder drivers: they decide WHEN a new block is sent, hence the
+ * block structure of the stream. */
+enum {
+  MD_DRIVER_ZL = 0,     /* Zl.Def.encode / Zl.Higher.compress, lib/zl.ml:509-555 */
+  MD_DRIVER_HIGHER = 1, /* De.Higher.compress / to_string, lib/de.ml:4518-4553 (always level 4) */
+  MD_DRIVER_CLI = 2     /* bin/decompress.ml:47-75 (Dynamic per fill, Fixed last block) */
+};
+
 typedef struct md_ctx md_ctx;
 
 int md_version(void);
@@ -122,6 +130,39 @@ int md_de_inf_ns_inflate(md_ctx *ctx, const uint8_t *src, size_t src_len,
 int md_zl_inf_ns_inflate(md_ctx *ctx, const uint8_t *src, size_t src_len,
                          uint8_t *dst, size_t dst_cap, size_t *consumed,
                          size_t *written);
+
+/* Batched deflate of n independent buffers, everything resident in HBM.
+ *   stream i reads d_in[in_off[i], +in_len[i]), writes d_out[out_off[i], +out_cap[i]).
+ * Per stream the output is byte-identical to the reference's De.Lz77 (lib/de.ml:4013-4515)
+ * + De.Def (lib/de.ml:2354-3038) run by `driver` with a command queue of `queue_len`
+ * entries (power of two; 4096 in the reference's bench/CLI) at `level` 0..9:
+ *   MD_FORMAT_DEFLATE  the raw body,
+ *   MD_FORMAT_ZLIB     Zl.Def framing: 0x78xx header + body + Adler-32 (lib/zl.ml:511-522, 494-499).
+ * `dynamic` = Zl.Def's ?dynamic (false -> Fixed blocks).  Results: out_len[i], status[i]
+ * (MD_OK or MD_UNEXPECTED_END_OF_OUTPUT when out_cap[i] is too small), checksum[i] =
+ * Adler-32 of the input (may be NULL).  Asynchronous on the context's stream. */
+int md_deflate_batch_device(md_ctx *ctx, int format, int level, int queue_len, int driver,
+                            int dynamic, size_t n, const uint8_t *d_in, const uint64_t *d_in_off,
+                            const uint64_t *d_in_len, uint8_t *d_out, const uint64_t *d_out_off,
+                            const uint64_t *d_out_cap, uint64_t *d_out_len, int32_t *d_status,
+                            uint32_t *d_checksum);
+
+/* Same with HOST pointers (H2D, kernels, D2H, synchronise). */
+int md_deflate_batch_host(md_ctx *ctx, int format, int level, int queue_len, int driver, int dynamic,
+                          size_t n, const uint8_t *h_in, size_t in_bytes, const uint64_t *in_off,
+                          const uint64_t *in_len, uint8_t *h_out, size_t out_bytes,
+                          const uint64_t *out_off, const uint64_t *out_cap, uint64_t *out_len,
+                          int32_t *status, uint32_t *checksum);
+
+/* Single-buffer mirrors of the reference's drivers (host pointers, batch of one):
+ *   De.Higher.compress ~w ~q ~refill ~flush i o   (lib/de.mli:533-600): raw DEFLATE, level 4
+ *   Zl.Higher.compress ?level ?dynamic ~w ~q ...  (lib/zl.mli, lib/zl.ml:634-648): zlib stream
+ * The reference's refill/flush callbacks become one source and one destination buffer;
+ * *written is the compressed size.  Returns MD_OK / MD_UNEXPECTED_END_OF_OUTPUT / call error. */
+int md_de_higher_compress(md_ctx *ctx, int queue_len, const uint8_t *src, size_t src_len,
+                          uint8_t *dst, size_t dst_cap, size_t *written);
+int md_zl_higher_compress(md_ctx *ctx, int level, int dynamic, int queue_len, const uint8_t *src,
+                          size_t src_len, uint8_t *dst, size_t dst_cap, size_t *written);
 
 #ifdef __cplusplus
 }

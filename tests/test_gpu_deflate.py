@@ -1,0 +1,107 @@
+"""Parity of the HIP deflate path (through the C ABI) with the CPU oracle: identical
+compressed bytes at the same level / queue / driver.  Needs an MI355X: `pytest -m gpu`."""
+import ctypes
+import random
+import zlib
+
+import pytest
+
+from tests.conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import decompress_amd
+    return decompress_amd.Engine(0)
+
+
+def _datasets():
+    from decompress_amd import workloads
+    rng = random.Random(5)
+    return {
+        "empty": b"", "one": b"x", "abcde": b"abcde", "aaaaa": b"aaaaa", "runs": b"a" * 70000 + b"b" * 300,
+        "text": workloads.text(3, 150000), "ascii": workloads.ascii_uniform(4, 70000),
+        "rand": bytes(rng.getrandbits(8) for _ in range(66000)), "zeros": bytes(100000),
+        "tail33k": workloads.text(7, 33000), "tail65300": workloads.text(8, 65300),
+        "tail98500": workloads.text(9, 98500),
+    }
+
+
+@pytest.mark.parametrize("driver", [0, 1, 2], ids=["Zl.Def", "De.Higher", "CLI"])
+def test_bytes_equal_oracle(eng, oracle, driver):
+    data = _datasets()
+    names = list(data)
+    for level in range(10):
+        if driver == 1 and level != 4:
+            continue
+        for q in (16, 4096):
+            wants = [oracle.deflate_raw(data[k], level, q, driver) for k in names]
+            res = eng.deflate_many([data[k] for k in names], level=level, queue=q, driver=driver,
+                                   caps=[len(w[0]) + 3 for w in wants])
+            for k, (st, out, adler), (want, wadler) in zip(names, res, wants):
+                assert st == 0, (k, level, q)
+                assert out == want, (k, level, q, len(out), len(want))
+                assert adler == wadler == zlib.adler32(data[k])
+
+
+def test_zlib_frame_and_fixed(eng, oracle):
+    import decompress_amd
+    from decompress_amd import workloads
+    bufs = [workloads.text(20 + i, 40000 + 1000 * i) for i in range(6)]
+    for level, dyn in ((6, True), (6, False), (1, True), (0, True), (9, True)):
+        res = eng.deflate_many(bufs, fmt=decompress_amd.FORMAT_ZLIB, level=level, dynamic=dyn)
+        for b, (st, out, _) in zip(bufs, res):
+            assert st == 0
+            assert out == oracle.zl_deflate(b, level, 4096, dyn)
+            assert zlib.decompress(out) == b
+
+
+def test_round_trip_on_gpu(eng):
+    """deflate on the GPU, inflate on the GPU: the reference's own corpus test shape."""
+    import decompress_amd
+    from decompress_amd import workloads
+    bufs = [workloads.text(40 + i, 100000) for i in range(4)] + [workloads.ascii_uniform(50, 120000)]
+    res = eng.deflate_many(bufs, fmt=decompress_amd.FORMAT_ZLIB, level=6)
+    back = eng.inflate_many([r[1] for r in res], [len(b) for b in bufs], decompress_amd.FORMAT_ZLIB)
+    for b, (st, used, out, adler) in zip(bufs, back):
+        assert st == 0 and out == b and adler == zlib.adler32(b)
+
+
+def test_output_too_small(eng):
+    from decompress_amd import workloads
+    b = workloads.ascii_uniform(1, 10000)
+    st, out, _ = eng.deflate_many([b], caps=[100])[0]
+    assert st == 2  # Unexpected_end_of_output
+
+
+def test_kats_through_gpu(eng):
+    """test/test.ml:798-813: "abcde" is five literals and End -> one fixed/dynamic block."""
+    st, out, _ = eng.deflate_many([b"abcde"], level=4, driver=1)[0]
+    assert st == 0 and zlib.decompress(out, -15) == b"abcde"
+
+
+def test_c_abi_single(eng):
+    from decompress_amd import _lib
+    lib = _lib.load()
+    ctx = lib.md_create(0, None)
+    data = b"Zl.Higher.compress " * 400
+    dst = ctypes.create_string_buffer(2 * len(data) + 64)
+    n = ctypes.c_size_t()
+    rc = lib.md_zl_higher_compress(ctx, 6, 1, 4096, data, len(data), dst, len(dst), ctypes.byref(n))
+    assert rc == 0 and zlib.decompress(dst.raw[: n.value]) == data
+    rc = lib.md_de_higher_compress(ctx, 4096, data, len(data), dst, len(dst), ctypes.byref(n))
+    assert rc == 0 and zlib.decompress(dst.raw[: n.value], -15) == data
+    assert lib.md_zl_higher_compress(ctx, 11, 1, 4096, data, len(data), dst, len(dst), ctypes.byref(n)) == -1
+    assert lib.md_zl_higher_compress(ctx, 6, 1, 1000, data, len(data), dst, len(dst), ctypes.byref(n)) == -1
+    lib.md_destroy(ctx)
+
+
+def test_python_mirror(eng):
+    from decompress_amd import de, zl
+    data = b"mirror " * 3000
+    z = zl.Higher.compress(data, level=6)
+    assert zl.Higher.uncompress(z, len(data)) == data
+    r = de.Higher.compress(data)
+    assert de.Higher.uncompress(r, len(data)) == data
