@@ -12,7 +12,7 @@ inflates its own 4096 streams; value = total uncompressed MiB / s over all GPUs.
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel
-(inflate_kernel): algorithmic bytes = compressed bytes read + uncompressed
+(md::v4::inflate_v4_kernel): algorithmic bytes = compressed bytes read + uncompressed
 bytes written per launch, over the average launch duration measured with HIP
 events on the kernel's stream; peak = 8 TB/s HBM3E (MI355X_MICROARCH.md).
 `cpu_baseline` is the repo's C restatement of lib/de.ml (oracle/, kind "port")
@@ -174,9 +174,9 @@ def main():
     digest = int(checksum.to(torch.int64).bitwise_and(0xffffffff).sum().item())
     if world > 1:
         # the path's only exchange: gather per-rank result digests (RCCL all_gather)
+        from decompress_amd import shard
         g = torch.tensor([digest, int(ok)], dtype=torch.int64, device=dev)
-        gl = [torch.zeros_like(g) for _ in range(world)]
-        dist.all_gather(gl, g)
+        gl = shard.gather_results(dist, g, world)
         ok = all(int(x[1].item()) for x in gl)
         digest = sum(int(x[0].item()) for x in gl) & 0xffffffffffff
     if not ok:
