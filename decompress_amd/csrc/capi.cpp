@@ -21,7 +21,13 @@ extern "C" int md_launch_inflate_v2(int variant, int format, uint32_t n, const u
                                     const uint64_t *in_off, const uint64_t *in_len, uint8_t *out,
                                     const uint64_t *out_off, const uint64_t *out_cap,
                                     uint64_t *out_len, uint64_t *consumed, int32_t *status,
-                                    uint32_t *checksum, uint64_t *dbg, hipStream_t stream);
+                                    uint32_t *checksum, uint64_t *dbg, int only_status, hipStream_t stream);
+extern "C" size_t md_inflate_log_record_bytes(void);
+extern "C" int md_launch_inflate_split(int format, uint32_t n, const uint8_t *in, const uint64_t *in_off,
+                                       const uint64_t *in_len, uint8_t *out, const uint64_t *out_off,
+                                       const uint64_t *out_cap, uint64_t *out_len, uint64_t *consumed,
+                                       int32_t *status, uint32_t *checksum, uint8_t *log,
+                                       uint32_t log_cap, hipStream_t stream);
 
 extern "C" size_t md_deflate_ws_bytes(uint32_t n, int qcap);
 extern "C" int md_launch_deflate(int format, int level, int qcap, int driver, int dynamic, uint32_t n,
@@ -36,11 +42,14 @@ struct md_ctx {
   bool own_stream = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int ring_log2 = 13;
-  int kernel = 2;   // 1 = serial-per-wave (inflate_kernel.hip), 2 = lane-parallel (inflate_v2.hip)
+  int kernel = 2;   // 1 = serial per wave, 2 = lane-parallel fused (inflate_v4.hip), 3 = lane-parallel split
   int variant = 0;  // v2 geometry
   uint64_t *dbg = nullptr;  // device buffer of the optional in-kernel profile (32 x u64)
   void *ws = nullptr;       // deflate workspace (hash heads / chains / command queues)
   size_t ws_bytes = 0;
+  void *log = nullptr;      // inflate split path: per-stream token log
+  size_t log_bytes = 0;
+  int log_records = 128;    // records per stream (a stream that needs more is redone by the fused kernel)
   std::string err;
 };
 
@@ -143,7 +152,7 @@ md_ctx *md_create(int device, void *hip_stream) {
   }
   if (const char *e = getenv("MD_KERNEL")) {
     int v = atoi(e);
-    if (v == 1 || v == 2) ctx->kernel = v;
+    if (v >= 1 && v <= 3) ctx->kernel = v;
   }
   if (const char *e = getenv("MD_VARIANT")) {
     int v = atoi(e);
@@ -158,6 +167,7 @@ void md_destroy(md_ctx *ctx) {
   if (ctx->ev0) hipEventDestroy(ctx->ev0);
   if (ctx->ev1) hipEventDestroy(ctx->ev1);
   if (ctx->ws) hipFree(ctx->ws);
+  if (ctx->log) hipFree(ctx->log);
   if (ctx->dbg) hipFree(ctx->dbg);
   if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -191,7 +201,7 @@ int md_set_option(md_ctx *ctx, const char *key, int value) {
     return MD_OK;
   }
   if (!strcmp(key, "kernel")) {
-    if (value != 1 && value != 2) return fail(ctx, MD_E_INVALID_ARGUMENT, "kernel must be 1 or 2");
+    if (value < 1 || value > 3) return fail(ctx, MD_E_INVALID_ARGUMENT, "kernel must be 1, 2 or 3");
     ctx->kernel = value;
     return MD_OK;
   }
@@ -203,6 +213,11 @@ int md_set_option(md_ctx *ctx, const char *key, int value) {
       hipFree(ctx->dbg);
       ctx->dbg = nullptr;
     }
+    return MD_OK;
+  }
+  if (!strcmp(key, "log_records")) {
+    if (value < 4 || value > 65536) return fail(ctx, MD_E_INVALID_ARGUMENT, "log_records must be 4..65536");
+    ctx->log_records = value;
     return MD_OK;
   }
   if (!strcmp(key, "variant")) {
@@ -235,10 +250,29 @@ int md_inflate_batch_device(md_ctx *ctx, int format, size_t n, const uint8_t *d_
     return fail(ctx, MD_E_INVALID_ARGUMENT, "null descriptor array");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   int rc;
-  if (ctx->kernel == 2)
+  if (ctx->kernel == 3) {
+    size_t need = n * (size_t)ctx->log_records * md_inflate_log_record_bytes();
+    if (need > ctx->log_bytes) {
+      if (ctx->log) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipFree(ctx->log));
+        ctx->log = nullptr;
+        ctx->log_bytes = 0;
+      }
+      if (hipMalloc(&ctx->log, need) != hipSuccess) return fail(ctx, MD_E_OUT_OF_MEMORY, "hipMalloc(token log)");
+      ctx->log_bytes = need;
+    }
+    rc = md_launch_inflate_split(format, (uint32_t)n, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap,
+                                 d_out_len, d_consumed, d_status, d_checksum, (uint8_t *)ctx->log,
+                                 (uint32_t)ctx->log_records, ctx->stream);
+    // streams whose token log overflowed (status 50) are redone by the fused kernel
+    if (rc == 0)
+      rc = md_launch_inflate_v2(0, format, (uint32_t)n, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap,
+                                d_out_len, d_consumed, d_status, d_checksum, nullptr, 50, ctx->stream);
+  } else if (ctx->kernel == 2)
     rc = md_launch_inflate_v2(ctx->variant, format, (uint32_t)n, d_in, d_in_off, d_in_len, d_out,
                               d_out_off, d_out_cap, d_out_len, d_consumed, d_status, d_checksum,
-                              ctx->dbg, ctx->stream);
+                              ctx->dbg, -1, ctx->stream);
   else
     rc = md_launch_inflate(ctx->ring_log2, format, (uint32_t)n, d_in, d_in_off, d_in_len, d_out,
                            d_out_off, d_out_cap, d_out_len, d_consumed, d_status, d_checksum,

@@ -23,7 +23,7 @@ def eng():
 
 
 # every kernel geometry must be bit-exact: (kernel, option, value)
-GEOMETRIES = [(2, "variant", 0), (2, "variant", 1), (2, "variant", 2),
+GEOMETRIES = [(3, "log_records", 128), (3, "log_records", 6), (2, "variant", 0), (2, "variant", 1), (2, "variant", 2),
               (1, "ring_log2", 12), (1, "ring_log2", 13), (1, "ring_log2", 15)]
 
 
@@ -36,6 +36,7 @@ def eng_ring(request, eng):
     eng.set_option("kernel", 2)
     eng.set_option("variant", 0)
     eng.set_option("ring_log2", 13)
+    eng.set_option("log_records", 128)
 
 
 def test_golden_ns(eng_ring):
