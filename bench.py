@@ -43,7 +43,8 @@ def parse():
     ap.add_argument("--unique", type=int, default=0, help="distinct streams to generate (0 = all)")
     ap.add_argument("--level", type=int, default=6)
     ap.add_argument("--ring-log2", type=int, default=0)
-    ap.add_argument("--kernel", type=int, default=0, help="1 = serial per wave, 2 = lane-parallel (default)")
+    ap.add_argument("--kernel", type=int, default=0,
+                    help="1 = serial per wave, 2 = lane-parallel fused, 3 = lane-parallel split (default)")
     ap.add_argument("--variant", type=int, default=-1, help="v2 geometry")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -206,13 +207,14 @@ def main():
                             "Zl.Inf.Ns semantics, one stream per wavefront" % (n, args.stream_kib, args.level),
                 "streams_per_gpu": n, "stream_bytes": nbytes, "unique_streams": unique,
                 "compressed_ratio": round(comp_bytes / (n * nbytes), 4),
-                "kernel": args.kernel or 2, "variant": max(args.variant, 0), "gen_seconds": round(t_gen, 1),
+                "kernel": args.kernel or 3, "variant": max(args.variant, 0), "gen_seconds": round(t_gen, 1),
                 "result_digest": digest,
             },
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                "kernel": "inflate_v4_kernel" if (args.kernel or 2) == 2 else "inflate_kernel", "kernel_ms": round(kernel_ms, 4),
+                "kernel": {1: "inflate_kernel", 2: "inflate_v4_kernel", 3: "decode_kernel + resolve_kernel"}[args.kernel or 3],
+                "kernel_ms": round(kernel_ms, 4),
                 "algorithmic_bytes_per_launch": algo_bytes,
             },
         }

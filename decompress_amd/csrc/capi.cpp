@@ -42,7 +42,7 @@ struct md_ctx {
   bool own_stream = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int ring_log2 = 13;
-  int kernel = 2;   // 1 = serial per wave, 2 = lane-parallel fused (inflate_v4.hip), 3 = lane-parallel split
+  int kernel = 3;   // 1 = serial per wave, 2 = lane-parallel fused (inflate_v4.hip), 3 = lane-parallel split (default)
   int variant = 0;  // v2 geometry
   uint64_t *dbg = nullptr;  // device buffer of the optional in-kernel profile (32 x u64)
   void *ws = nullptr;       // deflate workspace (hash heads / chains / command queues)

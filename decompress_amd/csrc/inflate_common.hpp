@@ -62,8 +62,10 @@ struct Scratch {
 // Runs wave-uniform; lane 0 performs the LDS stores.  Returns false for
 // Invalid_huffman.  `lens` are the code lengths of `codes` symbols.
 __device__ __noinline__ bool build_lut(int kind, const uint8_t *lens, uint32_t codes, Scratch *s, Lut *out,
-                          uint32_t lane) {
-  uint16_t *tbl = kind == K_LENS ? s->lit : kind == K_DISTS ? s->dist : s->codes;
+                          uint32_t lane, uint16_t *tbl_override = nullptr) {
+  // tbl_override: build the lit/len or distance table somewhere else than Scratch::lit/dist
+  // (the split decode kernel builds them inside its fat-LUT area and never touches s->lit/dist)
+  uint16_t *tbl = tbl_override ? tbl_override : kind == K_LENS ? s->lit : kind == K_DISTS ? s->dist : s->codes;
   uint16_t *cnt = s->cnt, *offs = s->offs, *work = s->work;
   if (lane < 16) cnt[lane] = 0;
   // histogram of code lengths (one lane: the table is tiny)

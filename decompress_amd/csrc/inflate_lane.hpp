@@ -649,7 +649,8 @@ __device__ __forceinline__ int inflate_block(Smem<C> *smg, Input<C> &in, Sink &s
 
 // Dynamic block header (lib/de.ml:1733-1793), wave-uniform over the LDS ring.
 template <class C>
-__device__ __noinline__ int dynamic_header(UReader<C> &ur, Scratch *s, Lut *lit, Lut *dist, uint32_t lane) {
+__device__ __noinline__ int dynamic_header(UReader<C> &ur, Scratch *s, Lut *lit, Lut *dist, uint32_t lane,
+                                           uint16_t *lit_tbl = nullptr, uint16_t *dist_tbl = nullptr) {
   if (ur.avail() < 14) return MD_UNEXPECTED_END_OF_INPUT;
   uint32_t hlit = ur.peek(5) + 257;
   ur.drop(5);
@@ -692,16 +693,18 @@ __device__ __noinline__ int dynamic_header(UReader<C> &ur, Scratch *s, Lut *lit,
     }
   }
   if (uni(s->lens[256]) == 0) return MD_INVALID_DICTIONARY;
-  if (!build_lut(K_LENS, s->lens, hlit, s, lit, lane)) return MD_INVALID_DICTIONARY;
-  if (!build_lut(K_DISTS, s->lens + hlit, hdist, s, dist, lane)) return MD_INVALID_DICTIONARY;
+  if (!build_lut(K_LENS, s->lens, hlit, s, lit, lane, lit_tbl)) return MD_INVALID_DICTIONARY;
+  if (!build_lut(K_DISTS, s->lens + hlit, hdist, s, dist, lane, dist_tbl)) return MD_INVALID_DICTIONARY;
   return MD_OK;
 }
 
-__device__ __noinline__ void fixed_tables(Scratch *s, Lut *lit, Lut *dist, uint32_t lane) {
+__device__ __noinline__ void fixed_tables(Scratch *s, Lut *lit, Lut *dist, uint32_t lane,
+                                          uint16_t *lit_tbl = nullptr, uint16_t *dist_tbl = nullptr) {
   for (uint32_t n = lane; n < 288; n += kWave) s->lens[n] = n < 144 ? 8 : n < 256 ? 9 : n < 280 ? 7 : 8;
-  build_lut(K_LENS, s->lens, 288, s, lit, lane);
-  if (lane < 32) s->dist[lane] = (uint16_t)((5u << 9) | (__brev(lane) >> 27));
-  dist->t = s->dist;
+  build_lut(K_LENS, s->lens, 288, s, lit, lane, lit_tbl);
+  uint16_t *dt = dist_tbl ? dist_tbl : s->dist;
+  if (lane < 32) dt[lane] = (uint16_t)((5u << 9) | (__brev(lane) >> 27));
+  dist->t = dt;
   dist->mask = 31;
   dist->root = 5;
   dist->maxl = 5;

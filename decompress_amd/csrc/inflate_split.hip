@@ -35,11 +35,25 @@ struct Rec {
   static constexpr uint32_t BYTES = (OFF_MREC + C::MMAX * 256 + 255) & ~255u;
 };
 
+// LUT construction scratch without the two big 16-bit tables: those are built INSIDE the
+// fat-LUT area (upper half of each region) and widened in place.  Same field order as the
+// tail of Scratch, so a Scratch* that points sizeof(lit)+sizeof(dist) below it sees them.
+struct ScratchTail {
+  uint16_t codes[128];
+  uint16_t work[320];
+  uint8_t lens[320];
+  uint16_t cnt[16];
+  uint16_t offs[16];
+};
+static_assert(sizeof(Scratch) == (852 + 592) * 2 + sizeof(ScratchTail), "ScratchTail must mirror Scratch's tail");
+typedef uint16_t __attribute__((may_alias)) u16a;
+typedef uint32_t __attribute__((may_alias)) u32a;
+
 template <class C>
 struct Smem1 {
   uint32_t inring[C::IN_WORDS + 4];
   uint32_t lut[852 + 592];
-  Scratch sc;
+  ScratchTail st;
 };
 template <class C>
 struct Smem2 {
@@ -145,14 +159,38 @@ __global__ __launch_bounds__(kWave) void decode_kernel(
       rc = MD_INVALID_KIND_OF_BLOCK;
     } else {
       Lut lit, dist;
-      if (type == 1) fixed_tables(&smg->sc, &lit, &dist, lane);
+      // 16-bit tables in the upper half of each fat region; Scratch* is only a view of the tail
+      Scratch *sc = reinterpret_cast<Scratch *>(reinterpret_cast<uint8_t *>(&smg->st) - (852 + 592) * 2);
+      uint16_t *lit16 = reinterpret_cast<uint16_t *>(smg->lut) + 852;
+      uint16_t *dist16 = reinterpret_cast<uint16_t *>(smg->lut + kDistBase) + 592;
+      if (type == 1) fixed_tables(sc, &lit, &dist, lane, lit16, dist16);
       else {
-        rc = dynamic_header<C>(ur, &smg->sc, &lit, &dist, lane);
+        rc = dynamic_header<C>(ur, sc, &lit, &dist, lane, lit16, dist16);
         bp = ur.bp;
       }
       if (rc != MD_OK) break;
-      for (uint32_t i = lane; i < 852; i += kWave) smg->lut[i] = fat_lit(smg->sc.lit[i]);
-      for (uint32_t i = lane; i < 592; i += kWave) smg->lut[kDistBase + i] = fat_dist(smg->sc.dist[i]);
+      // widen in place, 64 entries per step: a step reads its 16-bit entries before it writes the
+      // 32-bit ones, and never overwrites a later step's unread entries (4c + 256 <= half + 2c + 128)
+      {
+        const u16a *a16 = reinterpret_cast<const u16a *>(lit16);
+        u32a *a32 = reinterpret_cast<u32a *>(smg->lut);
+        for (uint32_t c = 0; c < 852; c += kWave) {
+          const uint32_t i = c + lane;
+          const uint32_t e = i < 852 ? a16[i] : 0;
+          const uint32_t f = fat_lit(e);
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          if (i < 852) a32[i] = f;
+        }
+        const u16a *b16 = reinterpret_cast<const u16a *>(dist16);
+        u32a *b32 = reinterpret_cast<u32a *>(smg->lut + kDistBase);
+        for (uint32_t c = 0; c < 592; c += kWave) {
+          const uint32_t i = c + lane;
+          const uint32_t e = i < 592 ? b16[i] : 0;
+          const uint32_t f = fat_dist(e);
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          if (i < 592) b32[i] = f;
+        }
+      }
       const uint32_t lmask = uni(lit.mask), lroot = uni(lit.root), dmask = uni(dist.mask), droot = uni(dist.root);
       // rounds of this Huffman block
       for (;;) {

@@ -33,7 +33,7 @@ def eng_ring(request, eng):
     eng.set_option("kernel", k)
     eng.set_option(opt, val)
     yield eng
-    eng.set_option("kernel", 2)
+    eng.set_option("kernel", 3)
     eng.set_option("variant", 0)
     eng.set_option("ring_log2", 13)
     eng.set_option("log_records", 128)
