@@ -10,10 +10,17 @@
 // cumulative and mutated histograms, the odd cost formula, driver-dependent
 // empty blocks, deterministic stale bytes past the end of input).
 //
-// v1 layout: one independent stream per wavefront.  The match finder and the
+// Layout: one independent stream per wavefront.  The lazy matcher and the bit
 // encoder of a stream are sequential state machines (every decision depends on
-// the previous one), so in this first version lane 0 runs them while the wave
-// cooperates on the bulk work (clearing the hash heads, Adler-32 of the input).
+// the previous one): lane 0 runs them.  What does NOT depend on decisions is done
+// by the whole wave ahead of the machine: in deflate_slow every position p <= n-4
+// is inserted into the hash chains exactly once and in order, so hash_head(p) —
+// the latest earlier position with the same hash4 — is a pure function of the
+// input.  The wave computes it 64 positions per step (coalesced hash, gather of
+// the old heads, in-register duplicate resolution, atomic-max head update) into
+// an LDS ring, and also pre-walks the first three chain candidates of every
+// position (3-byte pre-filter of longest_match, lib/de.ml:4133-4137), so that on
+// literal-dominated input (BASELINE config 3) the machine never waits for HBM.
 // Hash heads / chains (abs positions, 2 x 128 KiB) and the command queue live in
 // a per-stream HBM workspace; histograms, heap and code tables live in LDS.
 // The window is the input buffer itself: w[rel] = in[base + rel]; bytes the
@@ -62,7 +69,7 @@ enum { DRV_ZL = 0, DRV_HIGHER = 1, DRV_CLI = 2 };
 enum { K_FIRST_ENTRY, K_ENCODE, K_BLOCK, K_FLAT_DONE };
 enum { R_OK, R_BLOCK };
 enum { V_AWAIT, V_FLUSH, V_BLOCK };
-enum { LZ_FLUSH, LZ_END };
+enum { LZ_FLUSH, LZ_END, LZ_NEED };
 enum { LK_ENOUGH, LK_FILL };
 
 struct Tree {  // one Huffman tree as the encoder needs it
@@ -87,7 +94,13 @@ struct DS {
   int nsymbols, h_lit, h_dst, h_len;
   uint8_t length_code[259];
   uint8_t dist_lo[256], dist_hi[256];
+  // look-ahead ring of decision-independent matcher inputs, indexed by position & (RING-1)
+  uint32_t hh[512];      // hash_head(p): chain candidate 1
+  uint32_t cn[3][512];   // chain candidates 2, 3, 4 (links of 1, 2, 3)
+  uint8_t pass[512];     // bit k: candidate k+1 has the same first 3 bytes as p
+  uint32_t ctl[4];       // [0] machine strstart, [1] machine state (1 = finished)
 };
+constexpr uint32_t RING = 512;
 
 __device__ __forceinline__ int distance_code(const DS *s, int d1) {
   return d1 < 256 ? s->dist_lo[d1] : s->dist_hi[d1 >> 7];
@@ -501,6 +514,8 @@ struct Lz {
   int match_length, prev_length, match_available;
   bool eoi;
   int k;
+  uint32_t prepared_end;  // positions < prepared_end have their hash_head in the LDS ring
+  uint32_t p_end;         // positions < p_end (= n - 3) can be prepared ahead
 };
 // window byte at absolute position a (H7: beyond the data the reference reads what its
 // 64 KiB buffer holds: zero before the first slide, the byte 32 KiB earlier after it)
@@ -524,7 +539,12 @@ __device__ __forceinline__ uint32_t W32(const Lz *z, uint32_t a) {
 __device__ __forceinline__ unsigned hash4(const Lz *z, uint32_t a) {
   return (uint32_t)(W32(z, a) * 0x9e3779b1u) >> (32 - HASH_BITS);
 }
-__device__ uint32_t insert_string(const Lz *z, const Ws *ws, uint32_t str) {
+__device__ uint32_t insert_string(const DS *s, const Lz *z, const Ws *ws, uint32_t str) {
+  if (str < z->prepared_end) {  // precomputed by the wave; the chain link is published now, in order
+    uint32_t res = s->hh[str & (RING - 1)];
+    ws->prev[str & WMASK] = res;
+    return res;
+  }
   unsigned h = hash4(z, str);
   uint32_t res = g_ld(ws->head + h);
   ws->prev[str & WMASK] = res;
@@ -584,13 +604,37 @@ __device__ bool emit_literal(DS *s, Enc *e, int chr) {
 // deflate (one position), lib/de.ml:4351-4410
 __device__ bool lz_deflate(DS *s, Enc *e, Lz *z, const Ws *ws) {
   uint32_t hash_head = 0;
-  if (z->lookahead >= MIN_MATCH) hash_head = insert_string(z, ws, z->strstart);
+  if (z->lookahead >= MIN_MATCH) hash_head = insert_string(s, z, ws, z->strstart);
   z->prev_length = z->match_length;
   z->prev_match = z->match_start;
   z->match_length = MIN_MATCH - 1;
   // hash_head != 0 in window terms: absolute position strictly above the window base
   if (hash_head > z->base && z->prev_length < z->max_lazy && z->strstart - hash_head <= (uint32_t)MAX_DIST) {
-    int ml = longest_match(z, ws, hash_head);
+    int ml;
+    bool fast = false;
+    if (z->prev_length == 2 && z->strstart < z->prepared_end && z->lookahead >= MIN_LOOKAHEAD) {
+      // pre-walked chain: with best_len = 2 a candidate is examined further only when its first
+      // 3 bytes match (lib/de.ml:4133-4137); if no pre-walked candidate does and the chain ends
+      // within them, longest_match returns prev_length unchanged
+      const uint32_t r = z->strstart & (RING - 1);
+      const uint32_t rel = z->strstart - z->base;
+      const uint32_t limit = z->base + (rel > (uint32_t)MAX_DIST ? rel - MAX_DIST : 0);
+      const uint32_t pb = s->pass[r];
+      if (!(pb & 1)) {
+        uint32_t c2 = s->cn[0][r];
+        if (!(c2 > limit)) fast = true;
+        else if (!(pb & 2)) {
+          uint32_t c3 = s->cn[1][r];
+          if (!(c3 > limit)) fast = true;
+          else if (!(pb & 4)) {
+            uint32_t c4 = s->cn[2][r];
+            if (!(c4 > limit)) fast = true;
+          }
+        }
+      }
+    }
+    if (fast) ml = z->prev_length;
+    else ml = longest_match(z, ws, hash_head);
     if (ml <= 5 && ml == MIN_MATCH && z->strstart - z->match_start > (uint32_t)TOO_FAR) z->match_length = MIN_MATCH - 1;
     else z->match_length = ml;
   }
@@ -601,7 +645,7 @@ __device__ bool lz_deflate(DS *s, Enc *e, Lz *z, const Ws *ws) {
     z->prev_length -= 2;
     do {
       z->strstart++;
-      if (z->strstart <= max_insert) insert_string(z, ws, z->strstart);
+      if (z->strstart <= max_insert) insert_string(s, z, ws, z->strstart);
     } while (--z->prev_length != 0);
     z->match_available = 0;
     z->match_length = MIN_MATCH - 1;
@@ -665,6 +709,8 @@ __device__ int lz_compress(DS *s, Enc *e, Lz *z, const Ws *ws) {
       }
     }
     z->k = LK_ENOUGH;
+    // one step may insert up to 258 positions: make sure the ring covers them (or the tail began)
+    if (z->level != 0 && z->prepared_end < z->p_end && z->strstart + 260 > z->prepared_end) return LZ_NEED;
     if (z->level == 0 ? lz_copy(s, e, z) : lz_deflate(s, e, z, ws)) return LZ_FLUSH;
   }
 }
@@ -681,9 +727,15 @@ __device__ int make_block(DS *s, int driver, int dynamic, int level, int last) {
   return block_of_frequencies(s);
 }
 
-__device__ void run_stream(DS *s, const Ws *ws, const uint8_t *in, uint32_t n, uint8_t *out, uint32_t cap,
-                           int level, int qcap, int driver, int dynamic, uint32_t *out_len, int *status) {
+struct Run {  // the two state machines of one stream (lane 0's registers)
   Enc e;
+  Lz z;
+  bool first;
+};
+
+__device__ void stream_begin(Run *r, const Ws *ws, const uint8_t *in, uint32_t n, uint8_t *out, uint32_t cap,
+                             int level, int qcap, int driver) {
+  Enc &e = r->e;
   e.kind = KIND_FIXED;
   e.last = 0;
   e.hold = 0;
@@ -698,7 +750,7 @@ __device__ void run_stream(DS *s, const Ws *ws, const uint8_t *in, uint32_t n, u
   e.qw = e.qr = 0;
   e.qc = (unsigned)qcap;
   e.q = ws->queue;
-  Lz z;
+  Lz &z = r->z;
   z.level = driver == DRV_HIGHER ? 4 : level;  // H6: De.Higher.compress has no ?level
   z.max_chain = c_levels[z.level][0];
   z.max_lazy = c_levels[z.level][1];
@@ -714,18 +766,27 @@ __device__ void run_stream(DS *s, const Ws *ws, const uint8_t *in, uint32_t n, u
   z.match_length = z.prev_length = z.match_available = 0;
   z.eoi = n == 0;
   z.k = LK_ENOUGH;
-  bool first = true;
+  z.prepared_end = 0;
+  z.p_end = (z.level != 0 && n >= 4) ? n - 3 : 0;
+  r->first = true;
+}
+
+// Runs both machines until the matcher needs more look-ahead (false) or the stream ends (true).
+__device__ bool stream_run(DS *s, const Ws *ws, Run *r, int driver, int dynamic) {
+  Enc &e = r->e;
+  Lz &z = r->z;
   for (;;) {
-    int r = lz_compress(s, &e, &z, ws);
+    int res = lz_compress(s, &e, &z, ws);
+    if (res == LZ_NEED) return false;
     // the end-of-block code of the block that is open right now (force needs it after the
     // new trees have replaced the old ones in DS)
     int ol, oc;
     lit_code(s, &e, 256, &ol, &oc);
     int rc;
-    if (r == LZ_FLUSH) {
-      if (driver == DRV_ZL && !first) rc = enc_encode(s, &e, V_FLUSH, 0, 0, ol, oc);
+    if (res == LZ_FLUSH) {
+      if (driver == DRV_ZL && !r->first) rc = enc_encode(s, &e, V_FLUSH, 0, 0, ol, oc);
       else {
-        first = false;
+        r->first = false;
         int kind = make_block(s, driver, dynamic, z.level, 0);
         rc = enc_encode(s, &e, V_BLOCK, kind, 0, ol, oc);
       }
@@ -738,11 +799,9 @@ __device__ void run_stream(DS *s, const Ws *ws, const uint8_t *in, uint32_t n, u
       if (driver == DRV_CLI) e.q[e.qw++ & (e.qc - 1)] = Q_EOB;  // bin/decompress.ml:67
       int kind = make_block(s, driver, dynamic, z.level, 1);
       enc_encode(s, &e, V_BLOCK, kind, 1, ol, oc);
-      break;
+      return true;
     }
   }
-  *out_len = e.o_pos;
-  *status = e.overflow ? MD_UNEXPECTED_END_OF_OUTPUT : MD_OK;
 }
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
@@ -758,8 +817,6 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
     uint64_t *__restrict__ out_len, int32_t *__restrict__ status, uint32_t *__restrict__ checksum,
     uint32_t *__restrict__ ws_head, uint32_t *__restrict__ ws_prev, int *__restrict__ ws_queue) {
   __shared__ DS ds;
-  __shared__ uint32_t res_len;
-  __shared__ int res_status;
   const uint32_t lane = threadIdx.x, sid = blockIdx.x;
   if (sid >= n) return;
   const uint8_t *src = in + in_off[sid];
@@ -823,11 +880,71 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
     }
     hdr = 2;
   }
+  Run run;
+  const bool room = cap >= hdr;
   if (lane == 0) {
-    uint32_t body = 0;
-    int st = MD_OK;
-    if (cap < hdr) st = MD_UNEXPECTED_END_OF_OUTPUT;
-    else run_stream(&ds, &ws, src, slen, dst + hdr, cap - hdr, level, qcap, driver, dynamic, &body, &st);
+    if (room) stream_begin(&run, &ws, src, slen, dst + hdr, cap - hdr, level, qcap, driver);
+    ds.ctl[0] = 0;
+    ds.ctl[1] = room ? 0 : 1;
+    ds.ctl[2] = 0;
+  }
+  const uint32_t eff_level = driver == DRV_HIGHER ? 4 : level;
+  const uint32_t p_end = (eff_level != 0 && slen >= 4) ? slen - 3 : 0;
+  __syncthreads();
+  for (;;) {
+    if (ds.ctl[1]) break;
+    const uint32_t ss = ds.ctl[0];
+    uint32_t pe = ds.ctl[2];
+    // ---- the wave runs ahead of the matcher: hash heads + 3 chain candidates per position
+    while (pe < p_end && pe + kWave <= ss + RING) {
+      const uint32_t pos = pe + lane;
+      const bool valid = pos < p_end;
+      uint32_t w4 = 0;
+      if (valid) __builtin_memcpy(&w4, src + pos, 4);
+      const uint32_t h = (uint32_t)(w4 * 0x9e3779b1u) >> (32 - HASH_BITS);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // head updates of the previous step have landed
+      const uint32_t old = valid ? g_ld(ws.head + h) : 0;
+      bool found = false;
+      uint32_t pred = 0;
+      for (uint32_t k = 1; k < kWave; k++) {  // nearest earlier position of this step with the same hash
+        const uint32_t hk = __shfl_up(h, k);
+        if (!found && lane >= k && hk == h) {
+          found = true;
+          pred = lane - k;
+        }
+      }
+      const uint32_t c1 = valid ? (found ? pe + pred : old) : 0;
+      if (valid) atomicMax(ws.head + h, pos);
+      ds.hh[pos & (RING - 1)] = c1;
+      __syncthreads();
+      uint32_t c = c1, pb = 0;
+      for (int lv = 0; lv < 3; lv++) {
+        if (c != 0) {
+          uint32_t v;
+          __builtin_memcpy(&v, src + c, 4);  // c < pos <= n - 4
+          if (((v ^ w4) & 0xffffffu) == 0) pb |= 1u << lv;
+          // link of c: still in the ring if the matcher has not published it yet
+          c = c >= ss ? ds.hh[c & (RING - 1)] : g_ld(ws.prev + (c & WMASK));
+        }
+        ds.cn[lv][pos & (RING - 1)] = c;
+      }
+      ds.pass[pos & (RING - 1)] = (uint8_t)pb;
+      pe = pe + kWave < p_end ? pe + kWave : p_end;
+    }
+    __syncthreads();
+    if (lane == 0) {
+      run.z.prepared_end = pe;
+      bool fin = stream_run(&ds, &ws, &run, driver, dynamic);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the published chain links have landed
+      ds.ctl[0] = run.z.strstart;
+      ds.ctl[1] = fin ? 1 : 0;
+      ds.ctl[2] = pe;
+    }
+    __syncthreads();
+  }
+  if (lane == 0) {
+    uint32_t body = room ? run.e.o_pos : 0;
+    int st = !room || run.e.overflow ? MD_UNEXPECTED_END_OF_OUTPUT : MD_OK;
     uint32_t total = hdr + body;
     if (format == MD_FORMAT_ZLIB && st == MD_OK) {
       if (cap - total < 4) st = MD_UNEXPECTED_END_OF_OUTPUT;
