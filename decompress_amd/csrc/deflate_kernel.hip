@@ -98,7 +98,17 @@ struct DS {
   uint32_t hh[512];      // hash_head(p): chain candidate 1
   uint32_t cn[3][512];   // chain candidates 2, 3, 4 (links of 1, 2, 3)
   uint8_t pass[512];     // bit k: candidate k+1 has the same first 3 bytes as p
-  uint32_t ctl[4];       // [0] machine strstart, [1] machine state (1 = finished)
+  uint32_t ctl[4];       // [0] machine strstart, [1] machine state (1 = finished), [2] prepared_end, [3] action
+  // wave-parallel bit packing of one queue fill (enc_write_wave)
+  uint8_t t_xl[32], t_bl[32], t_xd[32];
+  uint16_t t_bd[32];
+  uint32_t bb[104];      // bit buffer of one 64-command step (<= 15 + 64*48 bits)
+  struct WCtl {
+    uint64_t hold;
+    uint32_t bits, o_pos, o_cap, qr, qw, qc, kind, last, overflow, rc, k;
+    uint8_t *o;
+    int *q;
+  } w;
 };
 constexpr uint32_t RING = 512;
 
@@ -470,32 +480,168 @@ __device__ int enc_block(const DS *s, Enc *e, int kind, int last) {
   return kind == KIND_FLAT ? enc_write_flat(e) : enc_write(s, e);
 }
 
-// Def.encode, lib/de.ml:2965-3038.  For `Block the caller has already built the new
-// block's trees in DS — but force must close the OLD block first, whose EOB code comes
-// from the old trees; the caller passes it in (old_eob_len/old_eob_code).
-__device__ int enc_encode(const DS *s, Enc *e, int v, int kind, int last, int old_eob_len, int old_eob_code) {
+constexpr int W_PENDING = 2;  // enc_begin: the command loop (write, lib/de.ml:2708-2897) is still to run
+
+// block, lib/de.ml:2657-2684, up to the command loop
+__device__ int enc_block_begin(const DS *s, Enc *e, int kind, int last) {
+  e->kind = kind;
+  e->last = last;
+  if (kind == KIND_FLAT) flat_len(e);
+  emit_header(s, e);
+  e->k = K_ENCODE;
+  return kind == KIND_FLAT ? enc_write_flat(e) : W_PENDING;
+}
+// Def.encode, lib/de.ml:2965-3038.  For `Block the caller has already built the new block's
+// trees in DS — but force must close the OLD block first, whose EOB code comes from the old
+// trees; the caller passes it in.  Returns R_OK / R_BLOCK, or W_PENDING when the command
+// loop of a Fixed/Dynamic block has to run next (enc_write_wave, all lanes).
+__device__ int enc_begin(const DS *s, Enc *e, int v, int kind, int last, int old_eob_len, int old_eob_code) {
   for (;;) {
     switch (e->k) {
     case K_FIRST_ENTRY:
-      if (v == V_BLOCK) return enc_block(s, e, kind, last);
+      if (v == V_BLOCK) return enc_block_begin(s, e, kind, last);
       emit_header(s, e);  // the initial {Fixed; last = false} block
       e->k = K_ENCODE;
       continue;
     case K_BLOCK:
-      if (v == V_BLOCK) return enc_block(s, e, kind, last);
+      if (v == V_BLOCK) return enc_block_begin(s, e, kind, last);
       e->k = K_ENCODE;
       continue;
     case K_FLAT_DONE:
-      if (v == V_BLOCK) return enc_block(s, e, kind, last);
+      if (v == V_BLOCK) return enc_block_begin(s, e, kind, last);
       e->k = K_BLOCK;
       return R_BLOCK;
     default:
       if (v == V_AWAIT) return R_OK;
-      if (v == V_FLUSH) return e->kind == KIND_FLAT ? enc_write_flat(e) : enc_write(s, e);
+      if (v == V_FLUSH) return e->kind == KIND_FLAT ? enc_write_flat(e) : W_PENDING;
       // force, lib/de.ml:2899-2924: close the open block with ITS end-of-block code
       if (e->kind != KIND_FLAT) put_bits(e, (unsigned)old_eob_code, old_eob_len);
-      return enc_block(s, e, kind, last);
+      return enc_block_begin(s, e, kind, last);
     }
+  }
+}
+
+// write, lib/de.ml:2708-2897, by the whole wave: 64 queue commands per step.  Every lane
+// turns its command into (bits, length) — a literal code, or length code + extra + distance
+// code + extra (<= 48 bits) — a wave prefix sum of the lengths gives each its bit offset, the
+// codes are OR-ed into an LDS bit buffer and the finished bytes go out 4 per lane.  The
+// step stops at the first command without a code in the current tree (Leave) or at the
+// end-of-block command (End); that lane contributes the EOB code.
+__device__ void enc_write_wave(DS *s, uint32_t lane) {
+  uint64_t hold = s->w.hold;
+  uint32_t bits = s->w.bits, o_pos = s->w.o_pos, qr = s->w.qr, overflow = s->w.overflow;
+  const uint32_t o_cap = s->w.o_cap, qw = s->w.qw, qc = s->w.qc, kind = s->w.kind, last = s->w.last;
+  uint8_t *o = s->w.o;
+  const int *q = s->w.q;
+  uint32_t rc = R_OK, knew = K_ENCODE;
+  for (;;) {
+    const uint32_t avail = qw - qr;
+    if (avail == 0) break;
+    const bool act = lane < avail;
+    const int cmd = act ? g_ldi(q + ((qr + lane) & (qc - 1))) : 0;
+    const bool is_eob = act && cmd == Q_EOB;
+    const bool is_copy = act && (cmd & Q_COPY) != 0;
+    const int off = cmd & 0xffff, ml = (cmd >> 16) & 0x1ff;
+    const int lcode = is_copy ? s->length_code[ml + 3] : 0;
+    const int dcode = is_copy ? distance_code(s, off) : 0;
+    bool ex = true;  // Def.exists, lib/de.ml:2451-2463
+    if (act && kind == KIND_DYNAMIC && !is_eob)
+      ex = is_copy ? (s->lt.clen[257 + lcode] > 0 && s->dt.clen[dcode] > 0) : s->lt.clen[cmd & 0xff] > 0;
+    const uint64_t stopm = __ballot(act && (is_eob || !ex));
+    const uint32_t stopl = stopm ? (uint32_t)__builtin_ctzll(stopm) : 64u;
+    uint64_t v = 0;
+    uint32_t nb = 0;
+    if (act && lane <= stopl) {
+      const int sym = lane == stopl ? 256 : is_copy ? 257 + lcode : cmd;
+      int l0, c0;
+      if (kind == KIND_DYNAMIC) {
+        l0 = s->lt.clen[sym];
+        c0 = s->lt.codes[sym];
+      } else static_lit(sym, &l0, &c0);
+      v = (uint64_t)(uint32_t)c0;
+      nb = (uint32_t)l0;
+      if (lane < stopl && is_copy) {
+        const uint32_t l1 = s->t_xl[lcode], v1 = (uint32_t)(ml - s->t_bl[lcode & 0x1f]);
+        int l2, c2;
+        if (kind == KIND_DYNAMIC) {
+          l2 = s->dt.clen[dcode];
+          c2 = s->dt.codes[dcode];
+        } else {
+          l2 = 5;
+          c2 = (int)(__brev((unsigned)dcode) >> 27);
+        }
+        const uint32_t l3 = s->t_xd[dcode & 0x1f], v3 = (uint32_t)(off - s->t_bd[dcode]);
+        v |= (uint64_t)v1 << nb;
+        nb += l1;
+        v |= (uint64_t)(uint32_t)c2 << nb;
+        nb += (uint32_t)l2;
+        v |= (uint64_t)v3 << nb;
+        nb += l3;
+      }
+    }
+    // bit offsets: exclusive prefix sum of the code lengths
+    uint32_t incl = nb;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      uint32_t t = __shfl_up(incl, d);
+      if (lane >= (uint32_t)d) incl += t;
+    }
+    const uint32_t total = bits + (uint32_t)__shfl((int)incl, 63);
+    const uint32_t boff = bits + incl - nb;
+    const uint32_t nwords = (total + 31) / 32 + 1;
+    for (uint32_t i = lane; i < nwords; i += kWave) s->bb[i] = i == 0 ? (uint32_t)hold : 0u;
+    __syncthreads();
+    if (nb) {
+      const uint32_t w = boff >> 5, sh = boff & 31;
+      const uint64_t lo = v << sh;
+      atomicOr(&s->bb[w], (uint32_t)lo);
+      if ((lo >> 32) != 0) atomicOr(&s->bb[w + 1], (uint32_t)(lo >> 32));
+      if (sh + nb > 64) atomicOr(&s->bb[w + 2], (uint32_t)(v >> (64 - sh)));
+    }
+    __syncthreads();
+    const bool stop = stopl < 64;
+    // was the stopping command the end-of-block command (End) or one without a code (Leave)?
+    const bool end_cmd = stop && (__shfl((int)is_eob, (int)stopl) != 0);
+    uint32_t nbytes = total >> 3, rem = total & 7;
+    if (end_cmd && last) {  // pending_bits, lib/de.ml:2635-2653: pad the last byte
+      nbytes = (total + 7) >> 3;
+      rem = 0;
+    }
+    for (uint32_t i = lane * 4; i < nbytes; i += kWave * 4) {
+      const uint32_t wv = s->bb[i >> 2];
+      if (i + 4 <= nbytes && o_pos + i + 4 <= o_cap) {
+        __builtin_memcpy(o + o_pos + i, &wv, 4);
+      } else {
+        for (uint32_t k = 0; k < 4 && i + k < nbytes; k++) {
+          if (o_pos + i + k < o_cap) o[o_pos + i + k] = (uint8_t)(wv >> (8 * k));
+        }
+      }
+    }
+    if (o_pos + nbytes > o_cap) overflow = 1;
+    hold = rem ? ((s->bb[nbytes >> 2] >> (8 * (nbytes & 3))) & ((1u << rem) - 1)) : 0;
+    bits = rem;
+    o_pos += nbytes;
+    qr += stop ? stopl + (end_cmd ? 1u : 0u) : (avail < (uint32_t)kWave ? avail : (uint32_t)kWave);
+    __syncthreads();
+    if (stop) {
+      if (end_cmd && last) {
+        rc = R_OK;
+        knew = K_ENCODE;
+      } else {
+        rc = R_BLOCK;
+        knew = K_BLOCK;
+      }
+      break;
+    }
+  }
+  if (lane == 0) {
+    s->w.hold = hold;
+    s->w.bits = bits;
+    s->w.o_pos = o_pos;
+    s->w.qr = qr;
+    s->w.overflow = overflow;
+    s->w.rc = rc;
+    s->w.k = knew;
   }
 }
 
@@ -727,10 +873,14 @@ __device__ int make_block(DS *s, int driver, int dynamic, int level, int last) {
   return block_of_frequencies(s);
 }
 
+enum { ACT_PREP = 0, ACT_WRITE = 1, ACT_DONE = 2 };
+enum { PH_LZ = 0, PH_FLUSH = 1, PH_END = 2 };
+
 struct Run {  // the two state machines of one stream (lane 0's registers)
   Enc e;
   Lz z;
   bool first;
+  int phase;
 };
 
 __device__ void stream_begin(Run *r, const Ws *ws, const uint8_t *in, uint32_t n, uint8_t *out, uint32_t cap,
@@ -769,37 +919,68 @@ __device__ void stream_begin(Run *r, const Ws *ws, const uint8_t *in, uint32_t n
   z.prepared_end = 0;
   z.p_end = (z.level != 0 && n >= 4) ? n - 3 : 0;
   r->first = true;
+  r->phase = PH_LZ;
 }
 
-// Runs both machines until the matcher needs more look-ahead (false) or the stream ends (true).
-__device__ bool stream_run(DS *s, const Ws *ws, Run *r, int driver, int dynamic) {
+// Lane 0: runs the matcher and the encoder's serial parts until the wave has to do something:
+// more look-ahead (ACT_PREP), the command loop of a block (ACT_WRITE), or nothing more (ACT_DONE).
+// `phase` remembers which driver step a pending command loop belongs to.
+__device__ int stream_step(DS *s, const Ws *ws, Run *r, int driver, int dynamic) {
   Enc &e = r->e;
   Lz &z = r->z;
+  int rc;
+  if (r->phase != PH_LZ) {
+    // a command loop just finished: take its result
+    e.hold = s->w.hold;
+    e.bits = (int)s->w.bits;
+    e.o_pos = s->w.o_pos;
+    e.qr = s->w.qr;
+    e.overflow = e.overflow || s->w.overflow;
+    e.k = (int)s->w.k;
+    rc = (int)s->w.rc;
+    if (r->phase == PH_END) return ACT_DONE;
+    goto after_flush_write;
+  }
   for (;;) {
-    int res = lz_compress(s, &e, &z, ws);
-    if (res == LZ_NEED) return false;
-    // the end-of-block code of the block that is open right now (force needs it after the
-    // new trees have replaced the old ones in DS)
-    int ol, oc;
-    lit_code(s, &e, 256, &ol, &oc);
-    int rc;
-    if (res == LZ_FLUSH) {
-      if (driver == DRV_ZL && !r->first) rc = enc_encode(s, &e, V_FLUSH, 0, 0, ol, oc);
+    {
+      int res = lz_compress(s, &e, &z, ws);
+      if (res == LZ_NEED) return ACT_PREP;
+      // the end-of-block code of the block that is open right now (force needs it after the
+      // new trees have replaced the old ones in DS)
+      int ol, oc;
+      lit_code(s, &e, 256, &ol, &oc);
+      if (res == LZ_END) {
+        if (driver == DRV_CLI) e.q[e.qw++ & (e.qc - 1)] = Q_EOB;  // bin/decompress.ml:67
+        int kind = make_block(s, driver, dynamic, z.level, 1);
+        rc = enc_begin(s, &e, V_BLOCK, kind, 1, ol, oc);
+        if (rc == W_PENDING) {
+          r->phase = PH_END;
+          return ACT_WRITE;
+        }
+        return ACT_DONE;
+      }
+      if (driver == DRV_ZL && !r->first) rc = enc_begin(s, &e, V_FLUSH, 0, 0, ol, oc);
       else {
         r->first = false;
         int kind = make_block(s, driver, dynamic, z.level, 0);
-        rc = enc_encode(s, &e, V_BLOCK, kind, 0, ol, oc);
+        rc = enc_begin(s, &e, V_BLOCK, kind, 0, ol, oc);
       }
-      while (rc == R_BLOCK && driver != DRV_CLI) {
+    }
+    for (;;) {
+      if (rc == W_PENDING) {
+        r->phase = PH_FLUSH;
+        return ACT_WRITE;
+      }
+    after_flush_write:
+      r->phase = PH_LZ;
+      if (rc == R_BLOCK && driver != DRV_CLI) {  // `Block reply: send a block again
+        int ol, oc;
         lit_code(s, &e, 256, &ol, &oc);
         int kind = make_block(s, driver, dynamic, z.level, 0);
-        rc = enc_encode(s, &e, V_BLOCK, kind, 0, ol, oc);
+        rc = enc_begin(s, &e, V_BLOCK, kind, 0, ol, oc);
+        continue;
       }
-    } else {
-      if (driver == DRV_CLI) e.q[e.qw++ & (e.qc - 1)] = Q_EOB;  // bin/decompress.ml:67
-      int kind = make_block(s, driver, dynamic, z.level, 1);
-      enc_encode(s, &e, V_BLOCK, kind, 1, ol, oc);
-      return true;
+      break;
     }
   }
 }
@@ -845,6 +1026,12 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
     ds.dist_lo[d] = (uint8_t)c;
     for (c = 29; c > 0 && (int)c_base_dist[c] > (int)(d << 7); c--) {}
     ds.dist_hi[d] = (uint8_t)c;
+  }
+  if (lane < 32) {
+    ds.t_xl[lane] = c_extra_lbits[lane];
+    ds.t_bl[lane] = c_base_length[lane];
+    ds.t_xd[lane] = c_extra_dbits[lane];
+    ds.t_bd[lane] = c_base_dist[lane];
   }
   uint32_t a = 1, b = 0;  // Lz77's update_crc (Adler-32 of the input), lib/de.ml:4217-4218
   for (uint32_t ps = 0; ps < slen; ps += 1024) {
@@ -934,13 +1121,33 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
     __syncthreads();
     if (lane == 0) {
       run.z.prepared_end = pe;
-      bool fin = stream_run(&ds, &ws, &run, driver, dynamic);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the published chain links have landed
+      int act = stream_step(&ds, &ws, &run, driver, dynamic);
+      if (act == ACT_WRITE) {
+        Enc &e = run.e;
+        ds.w.hold = e.hold;
+        ds.w.bits = (uint32_t)e.bits;
+        ds.w.o_pos = e.o_pos;
+        ds.w.o_cap = e.o_cap;
+        ds.w.qr = e.qr;
+        ds.w.qw = e.qw;
+        ds.w.qc = e.qc;
+        ds.w.kind = (uint32_t)e.kind;
+        ds.w.last = (uint32_t)e.last;
+        ds.w.overflow = 0;
+        ds.w.o = e.o;
+        ds.w.q = e.q;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // chain links / queue commands have landed
       ds.ctl[0] = run.z.strstart;
-      ds.ctl[1] = fin ? 1 : 0;
+      ds.ctl[1] = act == ACT_DONE ? 1 : 0;
       ds.ctl[2] = pe;
+      ds.ctl[3] = (uint32_t)act;
     }
     __syncthreads();
+    if (ds.ctl[3] == ACT_WRITE) {
+      enc_write_wave(&ds, lane);
+      __syncthreads();
+    }
   }
   if (lane == 0) {
     uint32_t body = room ? run.e.o_pos : 0;
