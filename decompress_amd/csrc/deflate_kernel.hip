@@ -103,6 +103,9 @@ struct DS {
   uint8_t t_xl[32], t_bl[32], t_xd[32];
   uint16_t t_bd[32];
   uint32_t bb[104];      // bit buffer of one 64-command step (<= 15 + 64*48 bits)
+  struct ZS {            // matcher state the wave needs for bulk literal runs (lane 0 <-> wave)
+    uint32_t strstart, lookahead, base, trivial, qw, qr, bulked;
+  } zs;
   struct WCtl {
     uint64_t hold;
     uint32_t bits, o_pos, o_cap, qr, qw, qc, kind, last, overflow, rc, k;
@@ -662,6 +665,7 @@ struct Lz {
   int k;
   uint32_t prepared_end;  // positions < prepared_end have their hash_head in the LDS ring
   uint32_t p_end;         // positions < p_end (= n - 3) can be prepared ahead
+  int steps;              // steps executed in this lz_compress call (bulk-yield policy)
 };
 // window byte at absolute position a (H7: beyond the data the reference reads what its
 // 64 KiB buffer holds: zero before the first slide, the byte 32 KiB earlier after it)
@@ -857,6 +861,12 @@ __device__ int lz_compress(DS *s, Enc *e, Lz *z, const Ws *ws) {
     z->k = LK_ENOUGH;
     // one step may insert up to 258 positions: make sure the ring covers them (or the tail began)
     if (z->level != 0 && z->prepared_end < z->p_end && z->strstart + 260 > z->prepared_end) return LZ_NEED;
+    // literal-run state (previous position had no match, its literal is pending): the wave can
+    // take the following no-match positions 64 at a time — hand over after one step
+    if (z->level != 0 && z->steps > 0 && z->match_available && z->match_length == MIN_MATCH - 1 &&
+        z->lookahead > MIN_LOOKAHEAD && z->strstart < z->prepared_end && e->qc - (e->qw - e->qr) >= 3)
+      return LZ_NEED;
+    z->steps++;
     if (z->level == 0 ? lz_copy(s, e, z) : lz_deflate(s, e, z, ws)) return LZ_FLUSH;
   }
 }
@@ -917,6 +927,7 @@ __device__ void stream_begin(Run *r, const Ws *ws, const uint8_t *in, uint32_t n
   z.eoi = n == 0;
   z.k = LK_ENOUGH;
   z.prepared_end = 0;
+  z.steps = 0;
   z.p_end = (z.level != 0 && n >= 4) ? n - 3 : 0;
   r->first = true;
   r->phase = PH_LZ;
@@ -1074,6 +1085,8 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
     ds.ctl[0] = 0;
     ds.ctl[1] = room ? 0 : 1;
     ds.ctl[2] = 0;
+    ds.zs.trivial = 0;
+    ds.zs.bulked = 0;
   }
   const uint32_t eff_level = driver == DRV_HIGHER ? 4 : level;
   const uint32_t p_end = (eff_level != 0 && slen >= 4) ? slen - 3 : 0;
@@ -1119,8 +1132,60 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
       pe = pe + kWave < p_end ? pe + kWave : p_end;
     }
     __syncthreads();
+    // ---- bulk literal run: in the literal-run state a position is trivial when its chain is
+    //      empty / out of reach, or none of its pre-walked candidates passes the 3-byte filter
+    //      and the chain ends within them (longest_match would return prev_length = 2)
+    if (ds.zs.trivial) {
+      const uint32_t s0 = ds.zs.strstart, la = ds.zs.lookahead, base = ds.zs.base;
+      const uint32_t qw = ds.zs.qw, avail = (uint32_t)qcap - (qw - ds.zs.qr);
+      uint32_t maxk = la > (uint32_t)MIN_LOOKAHEAD ? la - MIN_LOOKAHEAD + 1 : 0;
+      if (maxk > (uint32_t)kWave) maxk = kWave;
+      if (avail < 3) maxk = 0;
+      else if (maxk > avail - 2) maxk = avail - 2;
+      if (s0 >= pe) maxk = 0;
+      else if (maxk > pe - s0) maxk = pe - s0;
+      const uint32_t p = s0 + lane, r = p & (RING - 1);
+      const uint32_t hhv = ds.hh[r];
+      bool triv = lane < maxk;
+      if (triv && hhv > base && p - hhv <= (uint32_t)MAX_DIST) {
+        const uint32_t rel = p - base;
+        const uint32_t limit = base + (rel > (uint32_t)MAX_DIST ? rel - MAX_DIST : 0);
+        const uint32_t pb = ds.pass[r];
+        triv = false;
+        if (!(pb & 1)) {
+          if (!(ds.cn[0][r] > limit)) triv = true;
+          else if (!(pb & 2)) {
+            if (!(ds.cn[1][r] > limit)) triv = true;
+            else if (!(pb & 4) && !(ds.cn[2][r] > limit)) triv = true;
+          }
+        }
+      }
+      const uint64_t nt = __ballot(!triv);
+      const uint32_t K = nt ? (uint32_t)__builtin_ctzll(nt) : (uint32_t)kWave;
+      if (lane < K) {
+        const uint32_t byte = src[p - 1];  // the pending literal of the previous position
+        ws.queue[(qw + lane) & ((uint32_t)qcap - 1)] = (int)byte;
+        atomicAdd(&ds.lits[byte], 1);
+        ws.prev[p & WMASK] = hhv;  // the chain link of p is published in order
+      }
+      if (lane == 0) {
+        ds.zs.strstart = s0 + K;
+        ds.zs.lookahead = la - K;
+        ds.zs.qw = qw + K;
+        ds.zs.bulked = K;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __syncthreads();
+    }
     if (lane == 0) {
       run.z.prepared_end = pe;
+      if (ds.zs.trivial) {
+        run.z.strstart = ds.zs.strstart;
+        run.z.lookahead = (int)ds.zs.lookahead;
+        run.e.qw = ds.zs.qw;
+      }
+      // after a bulk run that made progress the wave gets another go before the matcher steps
+      run.z.steps = (ds.zs.trivial && ds.zs.bulked > 0) ? 1 : 0;
       int act = stream_step(&ds, &ws, &run, driver, dynamic);
       if (act == ACT_WRITE) {
         Enc &e = run.e;
@@ -1142,6 +1207,16 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
       ds.ctl[1] = act == ACT_DONE ? 1 : 0;
       ds.ctl[2] = pe;
       ds.ctl[3] = (uint32_t)act;
+      ds.zs.strstart = run.z.strstart;
+      ds.zs.lookahead = (uint32_t)run.z.lookahead;
+      ds.zs.base = run.z.base;
+      ds.zs.qw = run.e.qw;
+      ds.zs.qr = run.e.qr;
+      ds.zs.bulked = 0;
+      ds.zs.trivial = (act == ACT_PREP && run.z.level != 0 && run.z.match_available &&
+                       run.z.match_length == MIN_MATCH - 1 && run.phase == PH_LZ)
+                          ? 1u
+                          : 0u;
     }
     __syncthreads();
     if (ds.ctl[3] == ACT_WRITE) {
