@@ -96,8 +96,10 @@ struct DS {
   uint8_t dist_lo[256], dist_hi[256];
   // look-ahead ring of decision-independent matcher inputs, indexed by position & (RING-1)
   uint32_t hh[512];      // hash_head(p): chain candidate 1
-  uint32_t cn[3][512];   // chain candidates 2, 3, 4 (links of 1, 2, 3)
-  uint8_t pass[512];     // bit k: candidate k+1 has the same first 3 bytes as p
+  uint8_t flg[512];      // chain pre-walk of p: FL_PASS a candidate shares p's first 3 bytes, FL_ENDED the
+                         // chain left the reach of p within the walked links
+  uint8_t byt[512];      // the byte at p (pending literal of the next position)
+  uint32_t gmin[64];     // per hash group of one look-ahead step: head value before the step
   uint32_t ctl[4];       // [0] machine strstart, [1] machine state (1 = finished), [2] prepared_end, [3] action
   // wave-parallel bit packing of one queue fill (enc_write_wave)
   uint8_t t_xl[32], t_bl[32], t_xd[32];
@@ -114,6 +116,8 @@ struct DS {
   } w;
 };
 constexpr uint32_t RING = 512;
+enum { FL_PASS = 1, FL_ENDED = 2 };
+constexpr int WALK = 6;  // chain links pre-walked per position
 
 __device__ __forceinline__ int distance_code(const DS *s, int d1) {
   return d1 < 256 ? s->dist_lo[d1] : s->dist_hi[d1 >> 7];
@@ -766,22 +770,9 @@ __device__ bool lz_deflate(DS *s, Enc *e, Lz *z, const Ws *ws) {
       // pre-walked chain: with best_len = 2 a candidate is examined further only when its first
       // 3 bytes match (lib/de.ml:4133-4137); if no pre-walked candidate does and the chain ends
       // within them, longest_match returns prev_length unchanged
-      const uint32_t r = z->strstart & (RING - 1);
-      const uint32_t rel = z->strstart - z->base;
-      const uint32_t limit = z->base + (rel > (uint32_t)MAX_DIST ? rel - MAX_DIST : 0);
-      const uint32_t pb = s->pass[r];
-      if (!(pb & 1)) {
-        uint32_t c2 = s->cn[0][r];
-        if (!(c2 > limit)) fast = true;
-        else if (!(pb & 2)) {
-          uint32_t c3 = s->cn[1][r];
-          if (!(c3 > limit)) fast = true;
-          else if (!(pb & 4)) {
-            uint32_t c4 = s->cn[2][r];
-            if (!(c4 > limit)) fast = true;
-          }
-        }
-      }
+      // a candidate the real walk would visit is among the pre-walked ones (the pre-walk's reach
+      // bound p - MAX_DIST is never above the real limit)
+      fast = s->flg[z->strstart & (RING - 1)] == FL_ENDED;
     }
     if (fast) ml = z->prev_length;
     else ml = longest_match(z, ws, hash_head);
@@ -1096,39 +1087,54 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
     const uint32_t ss = ds.ctl[0];
     uint32_t pe = ds.ctl[2];
     // ---- the wave runs ahead of the matcher: hash heads + 3 chain candidates per position
-    while (pe < p_end && pe + kWave <= ss + RING) {
+    while (pe < p_end && pe + kWave < ss + RING) {
       const uint32_t pos = pe + lane;
       const bool valid = pos < p_end;
       uint32_t w4 = 0;
       if (valid) __builtin_memcpy(&w4, src + pos, 4);
       const uint32_t h = (uint32_t)(w4 * 0x9e3779b1u) >> (32 - HASH_BITS);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // head updates of the previous step have landed
-      const uint32_t old = valid ? g_ld(ws.head + h) : 0;
+      // head[h] <- max(pos) for the whole step in one round trip; the returned values of a group of
+      // equal hashes are >= the head before the step, and one of them is exactly that value
+      const uint32_t ret = valid ? atomicMax(ws.head + h, pos) : 0xffffffffu;
       bool found = false;
-      uint32_t pred = 0;
-      for (uint32_t k = 1; k < kWave; k++) {  // nearest earlier position of this step with the same hash
+      uint32_t pred = 0, first = lane;
+      for (uint32_t k = 1; k < kWave; k++) {  // nearest / first earlier position of this step with the same hash
         const uint32_t hk = __shfl_up(h, k);
-        if (!found && lane >= k && hk == h) {
+        if (lane >= k && hk == h) {
+          if (!found) pred = lane - k;
           found = true;
-          pred = lane - k;
+          first = lane - k;
         }
       }
-      const uint32_t c1 = valid ? (found ? pe + pred : old) : 0;
-      if (valid) atomicMax(ws.head + h, pos);
-      ds.hh[pos & (RING - 1)] = c1;
+      ds.gmin[lane] = 0xffffffffu;
       __syncthreads();
-      uint32_t c = c1, pb = 0;
-      for (int lv = 0; lv < 3; lv++) {
-        if (c != 0) {
+      if (valid) atomicMin(&ds.gmin[first], ret);
+      __syncthreads();
+      const uint32_t c1 = valid ? (found ? pe + pred : ds.gmin[lane]) : 0;
+      const uint32_t r = pos & (RING - 1);
+      ds.hh[r] = c1;
+      ds.byt[r] = (uint8_t)w4;
+      __syncthreads();
+      // pre-walk: stop at the first candidate sharing 3 bytes (the matcher will look for real) or
+      // when the chain leaves the reach of pos
+      const uint32_t lower = pos > (uint32_t)MAX_DIST ? pos - MAX_DIST : 0;
+      uint32_t c = c1, fl = 0;
+      for (int lv = 0; lv < WALK; lv++) {
+        // the head candidate is admitted at distance == MAX_DIST, links only above the limit
+        // (lib/de.ml:4367-4369 vs :4165)
+        const bool act = fl == 0 && (lv == 0 ? (c != 0 && pos - c <= (uint32_t)MAX_DIST) : c > lower);
+        if (__ballot(act) == 0) break;
+        if (act) {
           uint32_t v;
           __builtin_memcpy(&v, src + c, 4);  // c < pos <= n - 4
-          if (((v ^ w4) & 0xffffffu) == 0) pb |= 1u << lv;
           // link of c: still in the ring if the matcher has not published it yet
-          c = c >= ss ? ds.hh[c & (RING - 1)] : g_ld(ws.prev + (c & WMASK));
+          const uint32_t nx = c >= ss ? ds.hh[c & (RING - 1)] : g_ld(ws.prev + (c & WMASK));
+          if (((v ^ w4) & 0xffffffu) == 0) fl = FL_PASS;
+          c = nx;
         }
-        ds.cn[lv][pos & (RING - 1)] = c;
       }
-      ds.pass[pos & (RING - 1)] = (uint8_t)pb;
+      if (fl == 0 && !(c > lower) && !(c == c1 && c != 0 && pos - c <= (uint32_t)MAX_DIST)) fl = FL_ENDED;
+      ds.flg[r] = (uint8_t)fl;
       pe = pe + kWave < p_end ? pe + kWave : p_end;
     }
     __syncthreads();
@@ -1147,23 +1153,11 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
       const uint32_t p = s0 + lane, r = p & (RING - 1);
       const uint32_t hhv = ds.hh[r];
       bool triv = lane < maxk;
-      if (triv && hhv > base && p - hhv <= (uint32_t)MAX_DIST) {
-        const uint32_t rel = p - base;
-        const uint32_t limit = base + (rel > (uint32_t)MAX_DIST ? rel - MAX_DIST : 0);
-        const uint32_t pb = ds.pass[r];
-        triv = false;
-        if (!(pb & 1)) {
-          if (!(ds.cn[0][r] > limit)) triv = true;
-          else if (!(pb & 2)) {
-            if (!(ds.cn[1][r] > limit)) triv = true;
-            else if (!(pb & 4) && !(ds.cn[2][r] > limit)) triv = true;
-          }
-        }
-      }
+      if (triv && hhv > base && p - hhv <= (uint32_t)MAX_DIST) triv = ds.flg[r] == FL_ENDED;
       const uint64_t nt = __ballot(!triv);
       const uint32_t K = nt ? (uint32_t)__builtin_ctzll(nt) : (uint32_t)kWave;
       if (lane < K) {
-        const uint32_t byte = src[p - 1];  // the pending literal of the previous position
+        const uint32_t byte = ds.byt[(p - 1) & (RING - 1)];  // the pending literal of the previous position
         ws.queue[(qw + lane) & ((uint32_t)qcap - 1)] = (int)byte;
         atomicAdd(&ds.lits[byte], 1);
         ws.prev[p & WMASK] = hhv;  // the chain link of p is published in order

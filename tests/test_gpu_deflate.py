@@ -17,10 +17,27 @@ def eng():
     return decompress_amd.Engine(0)
 
 
+def _planted(seed, n, dists):
+    """random ASCII with short matches planted at exact distances (window-edge cases:
+    the head candidate is admitted at distance MAX_DIST = 32506, chain links only below it)"""
+    from decompress_amd import workloads
+    rng = random.Random(seed)
+    b = bytearray(workloads.ascii_uniform(seed, n))
+    p = 33000
+    while p + 300 < n:
+        d = rng.choice(dists)
+        ln = rng.choice((3, 4, 5, 9, 40, 258))
+        b[p:p + ln] = b[p - d:p - d + ln]
+        p += ln + rng.randrange(1, 700)
+    return bytes(b)
+
+
 def _datasets():
     from decompress_amd import workloads
     rng = random.Random(5)
     return {
+        "edge": _planted(11, 140000, (32504, 32505, 32506, 32507, 32508, 32768, 4096, 4097, 1)),
+        "planted": _planted(12, 100000, (1, 2, 3, 100, 5000, 20000, 32000, 32506)),
         "empty": b"", "one": b"x", "abcde": b"abcde", "aaaaa": b"aaaaa", "runs": b"a" * 70000 + b"b" * 300,
         "text": workloads.text(3, 150000), "ascii": workloads.ascii_uniform(4, 70000),
         "rand": bytes(rng.getrandbits(8) for _ in range(66000)), "zeros": bytes(100000),
