@@ -34,7 +34,7 @@ extern "C" int md_launch_deflate(int format, int level, int qcap, int driver, in
                                  const uint8_t *in, const uint64_t *in_off, const uint64_t *in_len,
                                  uint8_t *out, const uint64_t *out_off, const uint64_t *out_cap,
                                  uint64_t *out_len, int32_t *status, uint32_t *checksum, void *ws,
-                                 hipStream_t stream);
+                                 uint64_t *dbg, hipStream_t stream);
 
 struct md_ctx {
   int device = 0;
@@ -365,7 +365,7 @@ int md_deflate_batch_device(md_ctx *ctx, int format, int level, int queue_len, i
   }
   int rc = md_launch_deflate(format, level, queue_len, driver, dynamic ? 1 : 0, (uint32_t)n, d_in, d_in_off,
                              d_in_len, d_out, d_out_off, d_out_cap, d_out_len, d_status, d_checksum,
-                             ctx->ws, ctx->stream);
+                             ctx->ws, ctx->dbg, ctx->stream);
   if (rc != 0) return fail(ctx, MD_E_HIP, "deflate kernel launch", (hipError_t)rc);
   return MD_OK;
 }

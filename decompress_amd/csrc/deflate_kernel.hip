@@ -72,24 +72,37 @@ enum { V_AWAIT, V_FLUSH, V_BLOCK };
 enum { LZ_FLUSH, LZ_END, LZ_NEED };
 enum { LK_ENOUGH, LK_FILL };
 
-struct Tree {  // one Huffman tree as the encoder needs it
-  uint16_t lengths[L_CODES + 2];  // T.tree.lengths (patched by T.scan's 0xffff guard)
-  uint8_t clen[L_CODES + 2];      // Lookup lengths as of T.make
-  uint16_t codes[L_CODES + 2];
+template <int N>
+struct TreeT {  // one Huffman tree as the encoder needs it
+  uint16_t lengths[N + 2];  // T.tree.lengths (patched by T.scan's 0xffff guard)
+  uint16_t codes[N + 2];
+  uint8_t clen[N + 2];      // Lookup lengths as of T.make
   int max_code;
 };
+struct TreeRef {
+  uint16_t *lengths, *codes;
+  uint8_t *clen;
+  int *max_code;
+};
+template <int N>
+__device__ __forceinline__ TreeRef tref(TreeT<N> *t) {
+  return TreeRef{t->lengths, t->codes, t->clen, &t->max_code};
+}
 
 // LDS scratch of one stream
 struct DS {
   int lits[HEAP_SIZE];   // live literal/length histogram (make_literals, lib/de.ml:2333), mutated by T.make
   int dsts[2 * D_CODES + 1];
   int blf[2 * BL_CODES + 1];
-  uint16_t heap[HEAP_SIZE];
-  uint16_t depth[HEAP_SIZE];
+  alignas(16) uint64_t hk[L_CODES + 2];  // T.make's heap as keys (freq << 32 | depth << 16 | node), 1-based
+  uint16_t heap[HEAP_SIZE];              // its sorted tail: nodes in the order they left the heap
   uint16_t dads[HEAP_SIZE];
   uint16_t tlen[HEAP_SIZE];  // tree_lengths of the tree being built (leaves and internal nodes)
   int bl_count[MAX_BITS + 1];
-  Tree lt, dt, bt;             // trees of the CURRENT block (e.blk)
+  TreeT<L_CODES> lt;           // trees of the CURRENT block (e.blk)
+  TreeT<D_CODES> dt;
+  TreeT<BL_CODES> bt;
+  int kind_result;             // block kind chosen by trees_wave
   uint16_t symbols[L_CODES + D_CODES + 8];  // (len << 8) | code of the code-length stream
   int nsymbols, h_lit, h_dst, h_len;
   uint8_t length_code[259];
@@ -100,7 +113,8 @@ struct DS {
                          // chain left the reach of p within the walked links
   uint8_t byt[512];      // the byte at p (pending literal of the next position)
   uint32_t gmin[64];     // per hash group of one look-ahead step: head value before the step
-  uint32_t ctl[4];       // [0] machine strstart, [1] machine state (1 = finished), [2] prepared_end, [3] action
+  uint32_t ctl[5];       // [0] machine strstart, [1] machine state (1 = finished), [2] prepared_end, [3] action,
+                         // [4] tree mode of ACT_TREES
   // wave-parallel bit packing of one queue fill (enc_write_wave)
   uint8_t t_xl[32], t_bl[32], t_xd[32];
   uint16_t t_bd[32];
@@ -110,7 +124,7 @@ struct DS {
   } zs;
   struct WCtl {
     uint64_t hold;
-    uint32_t bits, o_pos, o_cap, qr, qw, qc, kind, last, overflow, rc, k;
+    uint32_t bits, o_pos, o_cap, qr, qw, qc, kind, last, overflow, rc, k, hdr;
     uint8_t *o;
     int *q;
   } w;
@@ -133,201 +147,320 @@ __device__ void static_lit(int sym, int *len, int *code) {  // lib/de.ml:373-409
 }
 
 // ---------------------------------------------------------------------------
-// De.T (lib/de.ml:1828-2068): heap, lengths with overflow fix-up, reversed codes.
-__device__ bool smaller(const int *f, const uint16_t *depth, int n, int m) {
-  return f[n] < f[m] || (f[n] == f[m] && depth[n] <= depth[m]);
+// De.T (lib/de.ml:1828-2068): heap, lengths with overflow fix-up, reversed codes — built by the
+// whole wave.  Only the merge loop (two smallest out, their parent in) is inherently serial and
+// stays on lane 0, on packed 64-bit keys so that `smaller` is one compare and both children of
+// a heap node come in one 16-byte LDS read.  Everything else is data-parallel: compaction of the
+// used symbols (ballot), heapify level by level (the sub-heaps of one level are disjoint), code
+// lengths as parent-chain depths, codes by per-length ranks, the run-length pass by position.
+typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint64_t hkey(uint32_t f, uint32_t depth, uint32_t n) {
+  return ((uint64_t)f << 32) | (uint64_t)((depth << 16) | n);
 }
-__device__ void pqdownheap(DS *s, const int *f, int hlen, int k) {
-  int v = s->heap[k], j = k << 1;
+// smaller, lib/de.ml:1876-1877: freq, then depth, ties count as smaller
+__device__ __forceinline__ bool hsmaller(uint64_t a, uint64_t b) { return (a >> 16) <= (b >> 16); }
+__device__ void heap_down(DS *s, int hlen, int k) {  // pqdownheap, lib/de.ml:1879-1899
+  const uint64_t v = s->hk[k];
+  int j = k << 1;
   while (j <= hlen) {
-    if (j < hlen && smaller(f, s->depth, s->heap[j + 1], s->heap[j])) j++;
-    if (smaller(f, s->depth, v, s->heap[j])) break;
-    s->heap[k] = s->heap[j];
+    const u64x2 ab = *(const u64x2 *)&s->hk[j];  // children j, j+1 (j even: 16-byte aligned)
+    uint64_t a = ab.x;
+    if (j < hlen && hsmaller(ab.y, a)) {
+      j++;
+      a = ab.y;
+    }
+    if (hsmaller(v, a)) break;
+    s->hk[k] = a;
     k = j;
     j <<= 1;
   }
-  s->heap[k] = (uint16_t)v;
+  s->hk[k] = v;
 }
-__device__ void tree_make(DS *s, int length, int max_length, int *f, Tree *t) {
-  int hlen = 0, hmax = HEAP_SIZE, max_code = -1;
-  for (int n = 0; n < HEAP_SIZE; n++) {
+__device__ __forceinline__ uint64_t lanes_below(uint32_t lane) { return (1ull << lane) - 1; }
+__device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, o), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), o);
+    v += ((uint64_t)hi << 32) | lo;
+  }
+  return v;
+}
+
+__device__ void tree_make_wave(DS *s, int length, int max_length, int *f, TreeRef t, uint32_t lane) {
+  for (int n = (int)lane; n < HEAP_SIZE; n += kWave) {
     s->tlen[n] = 0;
-    s->depth[n] = 0;
     s->dads[n] = 0;
-    s->heap[n] = 0;
   }
-  for (int n = 0; n < length; n++)
-    if (f[n] != 0) {
-      s->heap[++hlen] = (uint16_t)n;
-      max_code = n;
-    }
+  if (lane <= (uint32_t)MAX_BITS) s->bl_count[lane] = 0;
+  int hlen = 0, max_code = -1;
+  for (int base = 0; base < length; base += kWave) {
+    const int n = base + (int)lane;
+    const bool nz = n < length && f[n] != 0;
+    const uint64_t m = __ballot(nz);
+    if (nz) s->hk[hlen + 1 + __popcll(m & lanes_below(lane))] = hkey((uint32_t)f[n], 0, (uint32_t)n);
+    hlen += __popcll(m);
+    if (m) max_code = base + 63 - __builtin_clzll(m);
+  }
   while (hlen < 2) {  // pkzip, lib/de.ml:1863-1874 (writes into the live histogram: H2)
-    int node = max_code < 2 ? ++max_code : 0;
-    f[node] = 1;
-    s->heap[++hlen] = (uint16_t)node;
-    s->depth[node] = 0;
-  }
-  for (int n = hlen / 2; n >= 1; n--) pqdownheap(s, f, hlen, n);
-  int node = length;
-  do {
-    int n = s->heap[1];
-    s->heap[1] = s->heap[hlen--];
-    pqdownheap(s, f, hlen, 1);
-    int m = s->heap[1];
-    s->heap[--hmax] = (uint16_t)n;
-    s->heap[--hmax] = (uint16_t)m;
-    f[node] = f[n] + f[m];
-    s->depth[node] = (uint16_t)((s->depth[n] >= s->depth[m] ? s->depth[n] : s->depth[m]) + 1);
-    s->dads[n] = s->dads[m] = (uint16_t)node;
-    s->heap[1] = (uint16_t)node++;
-    pqdownheap(s, f, hlen, 1);
-  } while (hlen >= 2);
-  s->heap[--hmax] = s->heap[1];
-  // generate_lengths, lib/de.ml:1952-2009
-  s->tlen[s->heap[hmax]] = 0;
-  int overflow = 0;
-  for (int i = 0; i <= MAX_BITS; i++) s->bl_count[i] = 0;
-  for (int h = hmax + 1; h < HEAP_SIZE; h++) {
-    int n = s->heap[h];
-    int bits = s->tlen[s->dads[n]] + 1;
-    if (bits > max_length) {
-      overflow++;
-      bits = max_length;
+    const int node = max_code < 2 ? ++max_code : 0;
+    if (lane == 0) {
+      f[node] = 1;
+      s->hk[hlen + 1] = hkey(1, 0, (uint32_t)node);
     }
-    s->tlen[n] = (uint16_t)bits;
-    if (n <= max_code) s->bl_count[bits]++;
+    hlen++;
   }
-  if (overflow != 0) {
+  const int hlen0 = hlen;
+  __syncthreads();
+  for (int top = 1 << (31 - __builtin_clz((unsigned)(hlen >> 1))); top >= 1; top >>= 1) {
+    for (int k = top + (int)lane; k < 2 * top && k <= (hlen >> 1); k += kWave) heap_down(s, hlen, k);
+    __syncthreads();
+  }
+  const int hmax = HEAP_SIZE - (2 * hlen0 - 1);
+  if (lane == 0) {
+    int hm = HEAP_SIZE, node = length;
     do {
-      int bits = max_length - 1;
-      while (s->bl_count[bits] == 0) bits--;
-      s->bl_count[bits]--;
-      s->bl_count[bits + 1] += 2;
-      s->bl_count[max_length]--;
-      overflow -= 2;
-    } while (overflow > 0);
-    int h = HEAP_SIZE;
-    for (int bits = max_length; bits >= 1; bits--) {
-      int n = s->bl_count[bits];
-      while (n != 0) {
-        int m = s->heap[--h];
-        if (m <= max_code) {
-          s->tlen[m] = (uint16_t)bits;
-          n--;
+      const uint64_t n = s->hk[1];
+      s->hk[1] = s->hk[hlen--];
+      heap_down(s, hlen, 1);
+      const uint64_t m = s->hk[1];
+      const uint32_t ni = (uint32_t)n & 0xffff, mi = (uint32_t)m & 0xffff;
+      s->heap[--hm] = (uint16_t)ni;
+      s->heap[--hm] = (uint16_t)mi;
+      const uint32_t fs = (uint32_t)(n >> 32) + (uint32_t)(m >> 32);
+      const uint32_t dn = ((uint32_t)n >> 16), dm = ((uint32_t)m >> 16);
+      f[node] = (int)fs;
+      s->dads[ni] = s->dads[mi] = (uint16_t)node;
+      s->hk[1] = hkey(fs, (dn >= dm ? dn : dm) + 1, (uint32_t)node);
+      node++;
+      heap_down(s, hlen, 1);
+    } while (hlen >= 2);
+    s->heap[--hm] = (uint16_t)((uint32_t)s->hk[1] & 0xffff);
+  }
+  __syncthreads();
+  // generate_lengths, lib/de.ml:1952-2009: a node's length is its depth below the root
+  const int root = s->heap[hmax];
+  bool over = false;
+  for (int h = hmax + 1 + (int)lane; h < HEAP_SIZE; h += kWave) {
+    const int n = s->heap[h];
+    int d = 0;
+    for (int p = n; p != root; p = s->dads[p]) d++;
+    if (d > max_length) over = true;
+    else {
+      s->tlen[n] = (uint16_t)d;
+      if (n <= max_code) atomicAdd(&s->bl_count[d], 1);
+    }
+  }
+  if (__ballot(over)) {  // too deep: the reference's serial fix-up, as it stands
+    __syncthreads();
+    if (lane == 0) {
+      int overflow = 0;
+      for (int i = 0; i <= MAX_BITS; i++) s->bl_count[i] = 0;
+      for (int h = hmax + 1; h < HEAP_SIZE; h++) {
+        int n = s->heap[h];
+        int bits = s->tlen[s->dads[n]] + 1;
+        if (bits > max_length) {
+          overflow++;
+          bits = max_length;
+        }
+        s->tlen[n] = (uint16_t)bits;
+        if (n <= max_code) s->bl_count[bits]++;
+      }
+      do {
+        int bits = max_length - 1;
+        while (s->bl_count[bits] == 0) bits--;
+        s->bl_count[bits]--;
+        s->bl_count[bits + 1] += 2;
+        s->bl_count[max_length]--;
+        overflow -= 2;
+      } while (overflow > 0);
+      int h = HEAP_SIZE;
+      for (int bits = max_length; bits >= 1; bits--) {
+        int n = s->bl_count[bits];
+        while (n != 0) {
+          int m = s->heap[--h];
+          if (m <= max_code) {
+            s->tlen[m] = (uint16_t)bits;
+            n--;
+          }
         }
       }
     }
   }
-  // generate_codes, lib/de.ml:1926-1950
-  int next_code[MAX_BITS + 1];
-  unsigned code = 0;
-  next_code[0] = 0;
-  for (int bits = 1; bits <= MAX_BITS; bits++) {
-    code = (code + (unsigned)s->bl_count[bits - 1]) << 1;
-    next_code[bits] = (int)(code & 0xffff);
-  }
-  for (int n = 0; n < length + 2 && n < L_CODES + 2; n++) {
-    int len = n < length ? s->tlen[n] : 0;
-    t->lengths[n] = (uint16_t)(n < HEAP_SIZE ? s->tlen[n] : 0);
-    t->clen[n] = (uint8_t)len;
-    t->codes[n] = 0;
-    if (n <= max_code && len > 0) t->codes[n] = (uint16_t)(__brev((unsigned)next_code[len]++) >> (32 - len));
-  }
-  t->max_code = max_code;
-}
-// T.scan, lib/de.ml:2070-2117
-__device__ void tree_scan(Tree *t, int *blf) {
-  int max_code = t->max_code;
-  int prevlen = -1, nextlen = t->lengths[0], curlen, count = 0, max_count = 7, min_count = 4;
-  if (nextlen == 0) { max_count = 138; min_count = 3; }
-  t->lengths[max_code + 1] = 0xffff;
-  for (int n = 0; n <= max_code; n++) {
-    curlen = nextlen;
-    nextlen = t->lengths[n + 1];
-    if (++count < max_count && curlen == nextlen) continue;
-    else if (count < min_count) blf[curlen] += count;
-    else if (curlen != 0) {
-      if (curlen != prevlen) blf[curlen]++;
-      blf[16]++;
-    } else if (count <= 10) blf[17]++;
-    else blf[18]++;
-    count = 0;
-    prevlen = curlen;
-    if (nextlen == 0) { max_count = 138; min_count = 3; }
-    else if (curlen == nextlen) { max_count = 6; min_count = 3; }
-    else { max_count = 7; min_count = 4; }
-  }
-}
-// T.symbols, lib/de.ml:2122-2191; entries (len << 8) | code
-__device__ int tree_symbols(DS *s, int i, const Tree *t) {
-#define BLSYM(c) (uint16_t)((s->bt.clen[c] << 8) | s->bt.codes[c])
-  int max_code = t->max_code;
-  int prevlen = -1, nextlen = t->lengths[0], curlen, count = 0, max_count = 7, min_count = 4;
-  if (nextlen == 0) { max_count = 138; min_count = 3; }
-  for (int n = 0; n <= max_code; n++) {
-    curlen = nextlen;
-    nextlen = t->lengths[n + 1];
-    if (++count < max_count && curlen == nextlen) continue;
-    else if (count < min_count) {
-      do s->symbols[i++] = BLSYM(curlen); while (--count != 0);
-    } else if (curlen != 0) {
-      if (curlen != prevlen) {
-        s->symbols[i++] = BLSYM(curlen);
-        count--;
-      }
-      s->symbols[i++] = BLSYM(16);
-      s->symbols[i++] = (uint16_t)((2 << 8) | (count - 3));
-    } else if (count <= 10) {
-      s->symbols[i++] = BLSYM(17);
-      s->symbols[i++] = (uint16_t)((3 << 8) | (count - 3));
-    } else {
-      s->symbols[i++] = BLSYM(18);
-      s->symbols[i++] = (uint16_t)((7 << 8) | (count - 11));
+  __syncthreads();
+  // generate_codes, lib/de.ml:1926-1950: lane b keeps next_code[b]; a symbol's code is that plus
+  // the number of earlier symbols of the same length
+  uint32_t ncr = 0;
+  {
+    uint32_t code = 0;
+#pragma unroll
+    for (int bits = 1; bits <= MAX_BITS; bits++) {
+      code = (code + (uint32_t)s->bl_count[bits - 1]) << 1;
+      if (lane == (uint32_t)bits) ncr = code & 0xffff;
     }
-    count = 0;
-    prevlen = curlen;
-    if (nextlen == 0) { max_count = 138; min_count = 3; }
-    else if (curlen == nextlen) { max_count = 6; min_count = 3; }
-    else { max_count = 7; min_count = 4; }
   }
-  return i;
+  const int lim = length + 2 < L_CODES + 2 ? length + 2 : L_CODES + 2;
+  for (int base = 0; base < lim; base += kWave) {
+    const int n = base + (int)lane;
+    const bool inr = n < lim;
+    const uint32_t tl = inr ? s->tlen[n] : 0;
+    const uint32_t len = n < length ? tl : 0;
+    const bool valid = inr && n <= max_code && len > 0;
+    const uint32_t basec = (uint32_t)__shfl((int)ncr, (int)(len & 15));
+    uint32_t rank = 0, add = 0;
+#pragma unroll
+    for (uint32_t L = 1; L <= (uint32_t)MAX_BITS; L++) {
+      const uint64_t m = __ballot(valid && len == L);
+      if (len == L) rank = (uint32_t)__popcll(m & lanes_below(lane));
+      if (lane == L) add = (uint32_t)__popcll(m);
+    }
+    ncr += add;
+    if (inr) {
+      t.lengths[n] = (uint16_t)tl;
+      t.clen[n] = (uint8_t)len;
+      t.codes[n] = valid ? (uint16_t)(__brev(basec + rank) >> (32 - len)) : (uint16_t)0;
+    }
+  }
+  if (lane == 0) *t.max_code = max_code;
+  __syncthreads();
+}
+
+// T.scan (lib/de.ml:2070-2117) and T.symbols (lib/de.ml:2122-2191) by position.  The serial state
+// machine cuts every run of equal lengths into chunks: zero runs into 138s, other runs into a
+// first chunk of up to 7 and then 6s.  A position knows from its offset in its run whether it
+// closes a chunk and how long that chunk is, so every chunk is emitted independently:
+// emit == false counts into blf (scan), emit == true writes (len << 8) | code entries from
+// out_i on and returns the new end.
+__device__ int tree_rle_wave(DS *s, TreeRef t, int out_i, bool emit, uint32_t lane) {
+#define BLSYM(c) (uint16_t)((s->bt.clen[c] << 8) | s->bt.codes[c])
+  const int max_code = *t.max_code;
+  if (!emit) {
+    if (lane == 0) t.lengths[max_code + 1] = 0xffff;  // the guard T.scan leaves in the lengths
+    __syncthreads();
+  }
+  int carry_rs = 0;
+  for (int base = 0; base <= max_code; base += kWave) {
+    const int n = base + (int)lane;
+    const bool in = n <= max_code;
+    const uint32_t cur = in ? t.lengths[n] : 0xfffeu;
+    const uint32_t nxt = in ? t.lengths[n + 1] : 0u;
+    const bool is_start = in && (n == 0 || t.lengths[n - 1] != cur);
+    const uint64_t sm = __ballot(is_start);
+    const uint64_t mine = sm & (~0ull >> (63 - lane));
+    const int rs = mine ? base + 63 - __builtin_clzll(mine) : carry_rs;
+    if (sm) carry_rs = base + 63 - __builtin_clzll(sm);
+    const int i = n - rs;  // offset in the run
+    const bool run_end = nxt != cur;
+    bool first = false, chunk_end;
+    int count;
+    if (cur == 0) {
+      const int k = i % 138;
+      chunk_end = run_end || k == 137;
+      count = k + 1;
+    } else if (i <= 6) {
+      first = true;
+      chunk_end = run_end || i == 6;
+      count = i + 1;
+    } else {
+      const int k = (i - 7) % 6;
+      chunk_end = run_end || k == 5;
+      count = k + 1;
+    }
+    const bool em = in && chunk_end;
+    const int min_count = cur == 0 ? 3 : first ? 4 : 3;
+    if (!emit) {
+      if (em) {
+        if (count < min_count) atomicAdd(&s->blf[cur], count);
+        else if (cur != 0) {
+          if (first) atomicAdd(&s->blf[cur], 1);
+          atomicAdd(&s->blf[16], 1);
+        } else if (count <= 10) atomicAdd(&s->blf[17], 1);
+        else atomicAdd(&s->blf[18], 1);
+      }
+    } else {
+      int cnt = 0;
+      if (em) cnt = count < min_count ? count : cur != 0 ? (first ? 3 : 2) : 2;
+      int incl = cnt;
+#pragma unroll
+      for (int d = 1; d < kWave; d <<= 1) {
+        const int u = __shfl_up(incl, d);
+        if (lane >= (uint32_t)d) incl += u;
+      }
+      int o = out_i + incl - cnt;
+      out_i += __shfl(incl, kWave - 1);
+      if (em) {
+        if (count < min_count) {
+          for (int r = 0; r < count; r++) s->symbols[o + r] = BLSYM(cur);
+        } else if (cur != 0) {
+          int c = count;
+          if (first) {
+            s->symbols[o++] = BLSYM(cur);
+            c--;
+          }
+          s->symbols[o++] = BLSYM(16);
+          s->symbols[o] = (uint16_t)((2 << 8) | (c - 3));
+        } else if (count <= 10) {
+          s->symbols[o++] = BLSYM(17);
+          s->symbols[o] = (uint16_t)((3 << 8) | (count - 3));
+        } else {
+          s->symbols[o++] = BLSYM(18);
+          s->symbols[o] = (uint16_t)((7 << 8) | (count - 11));
+        }
+      }
+    }
+  }
+  __syncthreads();
+  return out_i;
 #undef BLSYM
 }
-// Def.dynamic_of_frequencies, lib/de.ml:2387-2407 (into the current block's trees)
-__device__ void dynamic_of_frequencies(DS *s) {
-  tree_make(s, L_CODES, MAX_BITS, s->lits, &s->lt);
-  tree_make(s, D_CODES, MAX_BITS, s->dsts, &s->dt);
-  for (int i = 0; i < 2 * BL_CODES + 1; i++) s->blf[i] = 0;
-  tree_scan(&s->lt, s->blf);
-  tree_scan(&s->dt, s->blf);
-  tree_make(s, BL_CODES, 7, s->blf, &s->bt);
-  int max_blindex = BL_CODES - 1;
-  while (max_blindex >= 3 && s->bt.clen[c_zigzag[max_blindex]] == 0) max_blindex--;
-  int i = tree_symbols(s, 0, &s->lt);
-  i = tree_symbols(s, i, &s->dt);
-  s->nsymbols = i;
-  s->h_lit = s->lt.max_code + 1;
-  s->h_dst = s->dt.max_code + 1;
-  s->h_len = max_blindex + 1;
-}
-// lib/de.ml:2415-2449 with the H3 quirk (`distances[i] + len`); returns the block kind
-__device__ int block_of_frequencies(DS *s) {
-  dynamic_of_frequencies(s);
-  long dyn = 5 + 5 + 4 + s->h_len * 3, sta = 0;
-  for (int i = 0; i < s->nsymbols; i++) dyn += s->symbols[i] >> 8;
-  for (int i = 0; i < L_CODES; i++)
-    if (s->lits[i] != 0) {
-      int l, c;
-      static_lit(i, &l, &c);
-      sta += (long)s->lits[i] * l;
-      dyn += (long)s->lits[i] * s->lt.lengths[i];
+
+enum { TM_NONE = 0, TM_DYNAMIC = 1, TM_CHOOSE = 2 };
+
+// Def.dynamic_of_frequencies, lib/de.ml:2387-2407 (into the current block's trees); with
+// TM_CHOOSE also the cost comparison of lib/de.ml:2415-2449 with the H3 quirk
+// (`distances[i] + len`).  Leaves the block kind in s->kind_result.
+__device__ void trees_wave(DS *s, int mode, uint32_t lane) {
+  tree_make_wave(s, L_CODES, MAX_BITS, s->lits, tref(&s->lt), lane);
+  tree_make_wave(s, D_CODES, MAX_BITS, s->dsts, tref(&s->dt), lane);
+  if (lane < 2 * BL_CODES + 1) s->blf[lane] = 0;
+  __syncthreads();
+  tree_rle_wave(s, tref(&s->lt), 0, false, lane);
+  tree_rle_wave(s, tref(&s->dt), 0, false, lane);
+  tree_make_wave(s, BL_CODES, 7, s->blf, tref(&s->bt), lane);
+  const uint64_t used = __ballot(lane < (uint32_t)BL_CODES && s->bt.clen[c_zigzag[lane < 19 ? lane : 0]] != 0);
+  int max_blindex = used ? 63 - __builtin_clzll(used) : 0;
+  if (max_blindex < 2) max_blindex = 2;
+  int i = tree_rle_wave(s, tref(&s->lt), 0, true, lane);
+  i = tree_rle_wave(s, tref(&s->dt), i, true, lane);
+  const int h_len = max_blindex + 1;
+  int kind = KIND_DYNAMIC;
+  if (mode == TM_CHOOSE) {
+    uint64_t dyn = 0, sta = 0;
+    for (int k = (int)lane; k < i; k += kWave) dyn += s->symbols[k] >> 8;
+    for (int k = (int)lane; k < L_CODES; k += kWave) {
+      const uint32_t fq = (uint32_t)s->lits[k];
+      if (fq != 0) {
+        int l, c;
+        static_lit(k, &l, &c);
+        sta += (uint64_t)fq * (uint32_t)l;
+        dyn += (uint64_t)fq * s->lt.lengths[k];
+      }
     }
-  for (int i = 0; i < D_CODES; i++)
-    if (s->dsts[i] != 0) {
-      sta += s->dsts[i] + 5;
-      dyn += s->dsts[i] + s->dt.lengths[i];
+    if (lane < (uint32_t)D_CODES && s->dsts[lane] != 0) {
+      sta += (uint64_t)(uint32_t)s->dsts[lane] + 5;
+      dyn += (uint64_t)(uint32_t)s->dsts[lane] + s->dt.lengths[lane];
     }
-  return dyn <= sta ? KIND_DYNAMIC : KIND_FIXED;
+    dyn = wave_sum64(dyn) + (uint64_t)(5 + 5 + 4 + h_len * 3);
+    sta = wave_sum64(sta);
+    kind = dyn <= sta ? KIND_DYNAMIC : KIND_FIXED;
+  }
+  if (lane == 0) {
+    s->nsymbols = i;
+    s->h_lit = s->lt.max_code + 1;
+    s->h_dst = s->dt.max_code + 1;
+    s->h_len = h_len;
+    s->kind_result = kind;
+  }
+  __syncthreads();
 }
 
 // ---------------------------------------------------------------------------
@@ -347,6 +480,7 @@ struct Enc {  // De.Def.encoder, lib/de.ml:2465-2478
   uint8_t *o;
   uint32_t o_pos, o_cap;
   bool overflow;
+  bool hdr;             // the code-length part of a dynamic header is still to be packed (by the wave)
   unsigned qw, qr, qc;  // the queue's cursors (shared with the matcher)
   int *q;
 };
@@ -399,45 +533,6 @@ __device__ void emit_eob(const DS *s, Enc *e) {
   lit_code(s, e, 256, &l, &c);
   put_bits(e, (unsigned)c, l);
 }
-// write, lib/de.ml:2708-2897
-__device__ int enc_write(const DS *s, Enc *e) {
-  while (e->qw != e->qr) {
-    int cmd = g_ldi(e->q + (e->qr & (e->qc - 1)));
-    if (!cmd_exists(s, e, cmd)) {  // Leave
-      emit_eob(s, e);
-      e->k = K_BLOCK;
-      return R_BLOCK;
-    }
-    e->qr++;
-    if (cmd == Q_EOB) {  // End
-      emit_eob(s, e);
-      if (e->last) {
-        align_bits(e);
-        e->k = K_ENCODE;
-        return R_OK;
-      }
-      e->k = K_BLOCK;
-      return R_BLOCK;
-    }
-    int l, c;
-    if (!(cmd & Q_COPY)) {
-      lit_code(s, e, cmd, &l, &c);
-      put_bits(e, (unsigned)c, l);
-    } else {
-      int off = cmd & 0xffff, len = (cmd >> 16) & 0x1ff;
-      int code = s->length_code[len + 3];
-      lit_code(s, e, code + 257, &l, &c);
-      put_bits(e, (unsigned)c, l);
-      put_bits(e, (unsigned)(len - c_base_length[code & 0x1f]), c_extra_lbits[code]);
-      code = distance_code(s, off);
-      dst_code(s, e, code, &l, &c);
-      put_bits(e, (unsigned)c, l);
-      put_bits(e, (unsigned)(off - c_base_dist[code]), c_extra_dbits[code & 0x1f]);
-    }
-  }
-  e->k = K_ENCODE;
-  return R_OK;
-}
 __device__ void emit_header(const DS *s, Enc *e) {  // lib/de.ml:2566-2633
   put_bits(e, e->last ? 1 : 0, 1);
   if (e->kind == KIND_FIXED) put_bits(e, 1, 2);
@@ -446,8 +541,7 @@ __device__ void emit_header(const DS *s, Enc *e) {  // lib/de.ml:2566-2633
     put_bits(e, (unsigned)(s->h_lit - 257), 5);
     put_bits(e, (unsigned)(s->h_dst - 1), 5);
     put_bits(e, (unsigned)(s->h_len - 4), 4);
-    for (int r = 0; r < s->h_len; r++) put_bits(e, s->bt.clen[c_zigzag[r]], 3);
-    for (int r = 0; r < s->nsymbols; r++) put_bits(e, s->symbols[r] & 0xff, s->symbols[r] >> 8);
+    e->hdr = true;  // h_len x 3 bits + the code-length symbols: enc_write_wave, before the commands
   } else {
     put_bits(e, 0, 2);
     align_bits(e);
@@ -477,20 +571,10 @@ __device__ void flat_len(Enc *e) {
   unsigned len = e->qw - e->qr;
   e->fmax = len < 0xffff ? (int)len : 0xffff;
 }
-// block, lib/de.ml:2657-2684.  The block's trees are already in DS (kind/last given).
-__device__ int enc_block(const DS *s, Enc *e, int kind, int last) {
-  e->kind = kind;
-  e->last = last;
-  if (kind == KIND_FLAT) flat_len(e);
-  emit_header(s, e);
-  e->k = K_ENCODE;
-  return kind == KIND_FLAT ? enc_write_flat(e) : enc_write(s, e);
-}
-
 constexpr int W_PENDING = 2;  // enc_begin: the command loop (write, lib/de.ml:2708-2897) is still to run
 
 // block, lib/de.ml:2657-2684, up to the command loop
-__device__ int enc_block_begin(const DS *s, Enc *e, int kind, int last) {
+__device__ __forceinline__ int enc_block_begin(const DS *s, Enc *e, int kind, int last) {
   e->kind = kind;
   e->last = last;
   if (kind == KIND_FLAT) flat_len(e);
@@ -502,7 +586,7 @@ __device__ int enc_block_begin(const DS *s, Enc *e, int kind, int last) {
 // trees in DS — but force must close the OLD block first, whose EOB code comes from the old
 // trees; the caller passes it in.  Returns R_OK / R_BLOCK, or W_PENDING when the command
 // loop of a Fixed/Dynamic block has to run next (enc_write_wave, all lanes).
-__device__ int enc_begin(const DS *s, Enc *e, int v, int kind, int last, int old_eob_len, int old_eob_code) {
+__device__ __forceinline__ int enc_begin(const DS *s, Enc *e, int v, int kind, int last, int old_eob_len, int old_eob_code) {
   for (;;) {
     switch (e->k) {
     case K_FIRST_ENTRY:
@@ -528,19 +612,86 @@ __device__ int enc_begin(const DS *s, Enc *e, int v, int kind, int last, int old
   }
 }
 
+// The output side of the encoder while the wave owns it.
+struct Pack {
+  uint64_t hold;
+  uint32_t bits, o_pos, o_cap, overflow;
+  uint8_t *o;
+};
+// Appends one item of nb <= 48 bits per lane, in lane order: a wave prefix sum of the lengths
+// gives each item its bit offset, the items are OR-ed into an LDS bit buffer behind the bits
+// still held, and the finished bytes go out 4 per lane.  pad = pending_bits of the last block
+// (lib/de.ml:2635-2653): the final partial byte goes out too.
+__device__ void pack_step(DS *s, uint32_t lane, uint64_t v, uint32_t nb, bool pad, Pack &p) {
+  uint32_t incl = nb;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t t = __shfl_up(incl, d);
+    if (lane >= (uint32_t)d) incl += t;
+  }
+  const uint32_t total = p.bits + (uint32_t)__shfl((int)incl, 63);
+  const uint32_t boff = p.bits + incl - nb;
+  const uint32_t nwords = (total + 31) / 32 + 1;
+  for (uint32_t i = lane; i < nwords; i += kWave) s->bb[i] = i == 0 ? (uint32_t)p.hold : 0u;
+  __syncthreads();
+  if (nb) {
+    const uint32_t w = boff >> 5, sh = boff & 31;
+    const uint64_t lo = v << sh;
+    atomicOr(&s->bb[w], (uint32_t)lo);
+    if ((lo >> 32) != 0) atomicOr(&s->bb[w + 1], (uint32_t)(lo >> 32));
+    if (sh + nb > 64) atomicOr(&s->bb[w + 2], (uint32_t)(v >> (64 - sh)));
+  }
+  __syncthreads();
+  uint32_t nbytes = total >> 3, rem = total & 7;
+  if (pad) {
+    nbytes = (total + 7) >> 3;
+    rem = 0;
+  }
+  for (uint32_t i = lane * 4; i < nbytes; i += kWave * 4) {
+    const uint32_t wv = s->bb[i >> 2];
+    if (i + 4 <= nbytes && p.o_pos + i + 4 <= p.o_cap) {
+      __builtin_memcpy(p.o + p.o_pos + i, &wv, 4);
+    } else {
+      for (uint32_t k = 0; k < 4 && i + k < nbytes; k++) {
+        if (p.o_pos + i + k < p.o_cap) p.o[p.o_pos + i + k] = (uint8_t)(wv >> (8 * k));
+      }
+    }
+  }
+  if (p.o_pos + nbytes > p.o_cap) p.overflow = 1;
+  p.hold = rem ? ((s->bb[nbytes >> 2] >> (8 * (nbytes & 3))) & ((1u << rem) - 1)) : 0;
+  p.bits = rem;
+  p.o_pos += nbytes;
+  __syncthreads();
+}
+
 // write, lib/de.ml:2708-2897, by the whole wave: 64 queue commands per step.  Every lane
 // turns its command into (bits, length) — a literal code, or length code + extra + distance
-// code + extra (<= 48 bits) — a wave prefix sum of the lengths gives each its bit offset, the
-// codes are OR-ed into an LDS bit buffer and the finished bytes go out 4 per lane.  The
-// step stops at the first command without a code in the current tree (Leave) or at the
-// end-of-block command (End); that lane contributes the EOB code.
+// code + extra (<= 48 bits).  The step stops at the first command without a code in the
+// current tree (Leave) or at the end-of-block command (End); that lane contributes the EOB
+// code.  A dynamic header's code lengths (lib/de.ml:2585-2633) go first when still pending.
 __device__ void enc_write_wave(DS *s, uint32_t lane) {
-  uint64_t hold = s->w.hold;
-  uint32_t bits = s->w.bits, o_pos = s->w.o_pos, qr = s->w.qr, overflow = s->w.overflow;
-  const uint32_t o_cap = s->w.o_cap, qw = s->w.qw, qc = s->w.qc, kind = s->w.kind, last = s->w.last;
-  uint8_t *o = s->w.o;
+  Pack p{s->w.hold, s->w.bits, s->w.o_pos, s->w.o_cap, s->w.overflow, s->w.o};
+  uint32_t qr = s->w.qr;
+  const uint32_t qw = s->w.qw, qc = s->w.qc, kind = s->w.kind, last = s->w.last;
   const int *q = s->w.q;
   uint32_t rc = R_OK, knew = K_ENCODE;
+  if (s->w.hdr) {
+    const uint32_t h_len = (uint32_t)s->h_len, items = h_len + (uint32_t)s->nsymbols;
+    for (uint32_t base = 0; base < items; base += kWave) {
+      const uint32_t k = base + lane;
+      uint64_t v = 0;
+      uint32_t nb = 0;
+      if (k < h_len) {
+        v = s->bt.clen[c_zigzag[k]];
+        nb = 3;
+      } else if (k < items) {
+        const uint32_t sym = s->symbols[k - h_len];
+        v = sym & 0xff;
+        nb = sym >> 8;
+      }
+      pack_step(s, lane, v, nb, false, p);
+    }
+  }
   for (;;) {
     const uint32_t avail = qw - qr;
     if (avail == 0) break;
@@ -586,50 +737,11 @@ __device__ void enc_write_wave(DS *s, uint32_t lane) {
         nb += l3;
       }
     }
-    // bit offsets: exclusive prefix sum of the code lengths
-    uint32_t incl = nb;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      uint32_t t = __shfl_up(incl, d);
-      if (lane >= (uint32_t)d) incl += t;
-    }
-    const uint32_t total = bits + (uint32_t)__shfl((int)incl, 63);
-    const uint32_t boff = bits + incl - nb;
-    const uint32_t nwords = (total + 31) / 32 + 1;
-    for (uint32_t i = lane; i < nwords; i += kWave) s->bb[i] = i == 0 ? (uint32_t)hold : 0u;
-    __syncthreads();
-    if (nb) {
-      const uint32_t w = boff >> 5, sh = boff & 31;
-      const uint64_t lo = v << sh;
-      atomicOr(&s->bb[w], (uint32_t)lo);
-      if ((lo >> 32) != 0) atomicOr(&s->bb[w + 1], (uint32_t)(lo >> 32));
-      if (sh + nb > 64) atomicOr(&s->bb[w + 2], (uint32_t)(v >> (64 - sh)));
-    }
-    __syncthreads();
     const bool stop = stopl < 64;
     // was the stopping command the end-of-block command (End) or one without a code (Leave)?
     const bool end_cmd = stop && (__shfl((int)is_eob, (int)stopl) != 0);
-    uint32_t nbytes = total >> 3, rem = total & 7;
-    if (end_cmd && last) {  // pending_bits, lib/de.ml:2635-2653: pad the last byte
-      nbytes = (total + 7) >> 3;
-      rem = 0;
-    }
-    for (uint32_t i = lane * 4; i < nbytes; i += kWave * 4) {
-      const uint32_t wv = s->bb[i >> 2];
-      if (i + 4 <= nbytes && o_pos + i + 4 <= o_cap) {
-        __builtin_memcpy(o + o_pos + i, &wv, 4);
-      } else {
-        for (uint32_t k = 0; k < 4 && i + k < nbytes; k++) {
-          if (o_pos + i + k < o_cap) o[o_pos + i + k] = (uint8_t)(wv >> (8 * k));
-        }
-      }
-    }
-    if (o_pos + nbytes > o_cap) overflow = 1;
-    hold = rem ? ((s->bb[nbytes >> 2] >> (8 * (nbytes & 3))) & ((1u << rem) - 1)) : 0;
-    bits = rem;
-    o_pos += nbytes;
+    pack_step(s, lane, v, nb, end_cmd && last, p);
     qr += stop ? stopl + (end_cmd ? 1u : 0u) : (avail < (uint32_t)kWave ? avail : (uint32_t)kWave);
-    __syncthreads();
     if (stop) {
       if (end_cmd && last) {
         rc = R_OK;
@@ -642,13 +754,14 @@ __device__ void enc_write_wave(DS *s, uint32_t lane) {
     }
   }
   if (lane == 0) {
-    s->w.hold = hold;
-    s->w.bits = bits;
-    s->w.o_pos = o_pos;
+    s->w.hold = p.hold;
+    s->w.bits = p.bits;
+    s->w.o_pos = p.o_pos;
     s->w.qr = qr;
-    s->w.overflow = overflow;
+    s->w.overflow = p.overflow;
     s->w.rc = rc;
     s->w.k = knew;
+    s->w.hdr = 0;
   }
 }
 
@@ -756,7 +869,7 @@ __device__ bool emit_literal(DS *s, Enc *e, int chr) {
   return q_push_auto(s, e, chr);
 }
 // deflate (one position), lib/de.ml:4351-4410
-__device__ bool lz_deflate(DS *s, Enc *e, Lz *z, const Ws *ws) {
+__device__ __forceinline__ bool lz_deflate(DS *s, Enc *e, Lz *z, const Ws *ws) {
   uint32_t hash_head = 0;
   if (z->lookahead >= MIN_MATCH) hash_head = insert_string(s, z, ws, z->strstart);
   z->prev_length = z->match_length;
@@ -813,7 +926,7 @@ __device__ bool lz_copy(DS *s, Enc *e, Lz *z) {  // level 0, lib/de.ml:4412-4423
   return flush;
 }
 // Lz77.compress until `Flush or `End; the whole input is available, `Await = end of input
-__device__ int lz_compress(DS *s, Enc *e, Lz *z, const Ws *ws) {
+__device__ __forceinline__ int lz_compress(DS *s, Enc *e, Lz *z, const Ws *ws) {
   for (;;) {
     if (!(z->k == LK_ENOUGH && z->lookahead >= MIN_LOOKAHEAD)) {
       // fill_window, lib/de.ml:4294-4342
@@ -862,26 +975,25 @@ __device__ int lz_compress(DS *s, Enc *e, Lz *z, const Ws *ws) {
   }
 }
 
-// make_block of the three drivers; builds the trees in DS and returns the kind
-__device__ int make_block(DS *s, int driver, int dynamic, int level, int last) {
-  if (driver == DRV_CLI) {
-    if (last) return KIND_FIXED;
-    dynamic_of_frequencies(s);
-    return KIND_DYNAMIC;
-  }
+// make_block of the three drivers: the kind when it is known without trees (negated tree mode
+// otherwise: the wave builds the trees and, for TM_CHOOSE, picks the kind)
+__device__ __forceinline__ int block_plan(int driver, int dynamic, int level, int last) {
+  if (driver == DRV_CLI) return last ? KIND_FIXED : -TM_DYNAMIC;
   if (driver == DRV_ZL && level == 0) return KIND_FLAT;
   if (driver == DRV_ZL && !dynamic) return KIND_FIXED;
-  return block_of_frequencies(s);
+  return -TM_CHOOSE;
 }
 
-enum { ACT_PREP = 0, ACT_WRITE = 1, ACT_DONE = 2 };
-enum { PH_LZ = 0, PH_FLUSH = 1, PH_END = 2 };
+enum { ACT_PREP = 0, ACT_WRITE = 1, ACT_DONE = 2, ACT_TREES = 3 };
+enum { PH_LZ = 0, PH_FLUSH = 1, PH_END = 2, PH_TREES = 3, PH_TREES_END = 4 };
 
 struct Run {  // the two state machines of one stream (lane 0's registers)
   Enc e;
   Lz z;
   bool first;
   int phase;
+  int ol, oc;  // end-of-block code of the block that was open when new trees were asked for
+  int mode;    // tree mode asked for (TM_*)
 };
 
 __device__ void stream_begin(Run *r, const Ws *ws, const uint8_t *in, uint32_t n, uint8_t *out, uint32_t cap,
@@ -898,6 +1010,7 @@ __device__ void stream_begin(Run *r, const Ws *ws, const uint8_t *in, uint32_t n
   e.o_pos = 0;
   e.o_cap = cap;
   e.overflow = false;
+  e.hdr = false;
   e.qw = e.qr = 0;
   e.qc = (unsigned)qcap;
   e.q = ws->queue;
@@ -927,10 +1040,18 @@ __device__ void stream_begin(Run *r, const Ws *ws, const uint8_t *in, uint32_t n
 // Lane 0: runs the matcher and the encoder's serial parts until the wave has to do something:
 // more look-ahead (ACT_PREP), the command loop of a block (ACT_WRITE), or nothing more (ACT_DONE).
 // `phase` remembers which driver step a pending command loop belongs to.
-__device__ int stream_step(DS *s, const Ws *ws, Run *r, int driver, int dynamic) {
+__device__ __forceinline__ int stream_step(DS *s, const Ws *ws, Run *r, int driver, int dynamic) {
   Enc &e = r->e;
   Lz &z = r->z;
-  int rc;
+  int rc, res, kind;
+  if (r->phase == PH_TREES_END) {  // the last block's trees are there
+    rc = enc_begin(s, &e, V_BLOCK, s->kind_result, 1, r->ol, r->oc);
+    goto last_block_sent;
+  }
+  if (r->phase == PH_TREES) {  // trees of a new block are there
+    rc = enc_begin(s, &e, V_BLOCK, s->kind_result, 0, r->ol, r->oc);
+    goto block_sent;
+  }
   if (r->phase != PH_LZ) {
     // a command loop just finished: take its result
     e.hold = s->w.hold;
@@ -945,30 +1066,41 @@ __device__ int stream_step(DS *s, const Ws *ws, Run *r, int driver, int dynamic)
   }
   for (;;) {
     {
-      int res = lz_compress(s, &e, &z, ws);
+      res = lz_compress(s, &e, &z, ws);
       if (res == LZ_NEED) return ACT_PREP;
       // the end-of-block code of the block that is open right now (force needs it after the
       // new trees have replaced the old ones in DS)
-      int ol, oc;
-      lit_code(s, &e, 256, &ol, &oc);
+      lit_code(s, &e, 256, &r->ol, &r->oc);
       if (res == LZ_END) {
         if (driver == DRV_CLI) e.q[e.qw++ & (e.qc - 1)] = Q_EOB;  // bin/decompress.ml:67
-        int kind = make_block(s, driver, dynamic, z.level, 1);
-        rc = enc_begin(s, &e, V_BLOCK, kind, 1, ol, oc);
+        kind = block_plan(driver, dynamic, z.level, 1);
+        if (kind < 0) {
+          r->mode = -kind;
+          r->phase = PH_TREES_END;
+          return ACT_TREES;
+        }
+        rc = enc_begin(s, &e, V_BLOCK, kind, 1, r->ol, r->oc);
+      last_block_sent:
         if (rc == W_PENDING) {
           r->phase = PH_END;
           return ACT_WRITE;
         }
         return ACT_DONE;
       }
-      if (driver == DRV_ZL && !r->first) rc = enc_begin(s, &e, V_FLUSH, 0, 0, ol, oc);
+      if (driver == DRV_ZL && !r->first) rc = enc_begin(s, &e, V_FLUSH, 0, 0, r->ol, r->oc);
       else {
         r->first = false;
-        int kind = make_block(s, driver, dynamic, z.level, 0);
-        rc = enc_begin(s, &e, V_BLOCK, kind, 0, ol, oc);
+        kind = block_plan(driver, dynamic, z.level, 0);
+        if (kind < 0) {
+          r->mode = -kind;
+          r->phase = PH_TREES;
+          return ACT_TREES;
+        }
+        rc = enc_begin(s, &e, V_BLOCK, kind, 0, r->ol, r->oc);
       }
     }
     for (;;) {
+    block_sent:
       if (rc == W_PENDING) {
         r->phase = PH_FLUSH;
         return ACT_WRITE;
@@ -976,10 +1108,14 @@ __device__ int stream_step(DS *s, const Ws *ws, Run *r, int driver, int dynamic)
     after_flush_write:
       r->phase = PH_LZ;
       if (rc == R_BLOCK && driver != DRV_CLI) {  // `Block reply: send a block again
-        int ol, oc;
-        lit_code(s, &e, 256, &ol, &oc);
-        int kind = make_block(s, driver, dynamic, z.level, 0);
-        rc = enc_begin(s, &e, V_BLOCK, kind, 0, ol, oc);
+        lit_code(s, &e, 256, &r->ol, &r->oc);
+        kind = block_plan(driver, dynamic, z.level, 0);
+        if (kind < 0) {
+          r->mode = -kind;
+          r->phase = PH_TREES;
+          return ACT_TREES;
+        }
+        rc = enc_begin(s, &e, V_BLOCK, kind, 0, r->ol, r->oc);
         continue;
       }
       break;
@@ -998,8 +1134,20 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
     const uint64_t *__restrict__ in_off, const uint64_t *__restrict__ in_len, uint8_t *__restrict__ out,
     const uint64_t *__restrict__ out_off, const uint64_t *__restrict__ out_cap,
     uint64_t *__restrict__ out_len, int32_t *__restrict__ status, uint32_t *__restrict__ checksum,
-    uint32_t *__restrict__ ws_head, uint32_t *__restrict__ ws_prev, int *__restrict__ ws_queue) {
+    uint32_t *__restrict__ ws_head, uint32_t *__restrict__ ws_prev, int *__restrict__ ws_queue,
+    uint64_t *__restrict__ dbg) {
   __shared__ DS ds;
+  // optional phase profile of stream 0 (md_set_option "profile"): [0] setup [1] look-ahead [2] bulk
+  // literal runs [3] matcher/driver (lane 0) [4] bit packing [5] trees, in clock ticks; [8..] event counts
+  const bool prof = dbg != nullptr && blockIdx.x == 0;
+  uint64_t pt[6] = {0, 0, 0, 0, 0, 0}, pc[4] = {0, 0, 0, 0};
+  uint64_t t_prev = prof ? wall_clock64() : 0;
+#define PROF_MARK(i)                      \
+  if (prof) {                             \
+    const uint64_t t_now = wall_clock64(); \
+    pt[i] += t_now - t_prev;              \
+    t_prev = t_now;                       \
+  }
   const uint32_t lane = threadIdx.x, sid = blockIdx.x;
   if (sid >= n) return;
   const uint8_t *src = in + in_off[sid];
@@ -1082,6 +1230,7 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
   const uint32_t eff_level = driver == DRV_HIGHER ? 4 : level;
   const uint32_t p_end = (eff_level != 0 && slen >= 4) ? slen - 3 : 0;
   __syncthreads();
+  PROF_MARK(0)
   for (;;) {
     if (ds.ctl[1]) break;
     const uint32_t ss = ds.ctl[0];
@@ -1136,8 +1285,10 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
       if (fl == 0 && !(c > lower) && !(c == c1 && c != 0 && pos - c <= (uint32_t)MAX_DIST)) fl = FL_ENDED;
       ds.flg[r] = (uint8_t)fl;
       pe = pe + kWave < p_end ? pe + kWave : p_end;
+      pc[0]++;
     }
     __syncthreads();
+    PROF_MARK(1)
     // ---- bulk literal run: in the literal-run state a position is trivial when its chain is
     //      empty / out of reach, or none of its pre-walked candidates passes the 3-byte filter
     //      and the chain ends within them (longest_match would return prev_length = 2)
@@ -1170,7 +1321,10 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __syncthreads();
+      pc[1]++;
+      pc[2] += K;
     }
+    PROF_MARK(2)
     if (lane == 0) {
       run.z.prepared_end = pe;
       if (ds.zs.trivial) {
@@ -1195,7 +1349,10 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
         ds.w.overflow = 0;
         ds.w.o = e.o;
         ds.w.q = e.q;
+        ds.w.hdr = e.hdr ? 1u : 0u;
+        e.hdr = false;
       }
+      if (act == ACT_TREES) ds.ctl[4] = (uint32_t)run.mode;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // chain links / queue commands have landed
       ds.ctl[0] = run.z.strstart;
       ds.ctl[1] = act == ACT_DONE ? 1 : 0;
@@ -1213,11 +1370,22 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
                           : 0u;
     }
     __syncthreads();
+    PROF_MARK(3)
+    pc[3]++;
     if (ds.ctl[3] == ACT_WRITE) {
       enc_write_wave(&ds, lane);
       __syncthreads();
+      PROF_MARK(4)
+    } else if (ds.ctl[3] == ACT_TREES) {
+      trees_wave(&ds, (int)ds.ctl[4], lane);
+      PROF_MARK(5)
     }
   }
+  if (prof && lane == 0) {
+    for (int i = 0; i < 6; i++) dbg[i] = pt[i];
+    for (int i = 0; i < 4; i++) dbg[8 + i] = pc[i];
+  }
+#undef PROF_MARK
   if (lane == 0) {
     uint32_t body = room ? run.e.o_pos : 0;
     int st = !room || run.e.overflow ? MD_UNEXPECTED_END_OF_OUTPUT : MD_OK;
@@ -1249,13 +1417,13 @@ extern "C" int md_launch_deflate(int format, int level, int qcap, int driver, in
                                  const uint8_t *in, const uint64_t *in_off, const uint64_t *in_len,
                                  uint8_t *out, const uint64_t *out_off, const uint64_t *out_cap,
                                  uint64_t *out_len, int32_t *status, uint32_t *checksum, void *ws,
-                                 hipStream_t stream) {
+                                 uint64_t *dbg, hipStream_t stream) {
   if (n == 0) return 0;
   uint32_t *head = (uint32_t *)ws;
   uint32_t *prev = head + (size_t)n * md::defl::HASH_SIZE;
   int *queue = (int *)(prev + (size_t)n * md::defl::WSIZE);
   hipLaunchKernelGGL(md::defl::deflate_kernel, dim3(n), dim3(md::defl::kWave), 0, stream, format, level,
                      qcap, driver, dynamic, n, in, in_off, in_len, out, out_off, out_cap, out_len, status,
-                     checksum, head, prev, queue);
+                     checksum, head, prev, queue, dbg);
   return (int)hipGetLastError();
 }

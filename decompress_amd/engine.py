@@ -67,6 +67,12 @@ class Engine:
         self._check(self.lib.md_get_profile(self.ctx, buf))
         return dict(zip(self.PROFILE_FIELDS, list(buf)))
 
+    def get_profile_raw(self):
+        """The 32 raw profile words (the deflate kernel's layout differs from the inflate one)."""
+        buf = (ctypes.c_uint64 * 32)()
+        self._check(self.lib.md_get_profile(self.ctx, buf))
+        return list(buf)
+
     def synchronize(self):
         self._check(self.lib.md_synchronize(self.ctx))
 
