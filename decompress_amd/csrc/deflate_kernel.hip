@@ -783,6 +783,7 @@ struct Lz {
   uint32_t prepared_end;  // positions < prepared_end have their hash_head in the LDS ring
   uint32_t p_end;         // positions < p_end (= n - 3) can be prepared ahead
   int steps;              // steps executed in this lz_compress call (bulk-yield policy)
+  uint32_t n_steps, n_lm, n_chain;  // profile: matcher steps, longest_match calls, chain links walked
 };
 // window byte at absolute position a (H7: beyond the data the reference reads what its
 // 64 KiB buffer holds: zero before the first slide, the byte 32 KiB earlier after it)
@@ -825,6 +826,7 @@ __device__ int longest_match(Lz *z, const Ws *ws, uint32_t cur_match) {
   const uint32_t rel = ss - z->base;
   const uint32_t limit = z->base + (rel > (uint32_t)MAX_DIST ? rel - MAX_DIST : 0);
   int chain_length = z->prev_length >= z->good_length ? z->max_chain >> 2 : z->max_chain;
+  z->n_lm++;
   const unsigned scan_start = W16(z, ss);
   unsigned scan_end = W16(z, ss + z->prev_length - 1);
   int best_len = z->prev_length;
@@ -846,6 +848,7 @@ __device__ int longest_match(Lz *z, const Ws *ws, uint32_t cur_match) {
       }
     }
     cur_match = g_ld(ws->prev + (cur_match & WMASK));
+    z->n_chain++;
     chain_length--;
     if (!(cur_match > limit && chain_length != 0)) break;
   }
@@ -971,6 +974,7 @@ __device__ __forceinline__ int lz_compress(DS *s, Enc *e, Lz *z, const Ws *ws) {
         z->lookahead > MIN_LOOKAHEAD && z->strstart < z->prepared_end && e->qc - (e->qw - e->qr) >= 3)
       return LZ_NEED;
     z->steps++;
+    z->n_steps++;
     if (z->level == 0 ? lz_copy(s, e, z) : lz_deflate(s, e, z, ws)) return LZ_FLUSH;
   }
 }
@@ -1032,6 +1036,7 @@ __device__ void stream_begin(Run *r, const Ws *ws, const uint8_t *in, uint32_t n
   z.k = LK_ENOUGH;
   z.prepared_end = 0;
   z.steps = 0;
+  z.n_steps = z.n_lm = z.n_chain = 0;
   z.p_end = (z.level != 0 && n >= 4) ? n - 3 : 0;
   r->first = true;
   r->phase = PH_LZ;
@@ -1140,7 +1145,7 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
   // optional phase profile of stream 0 (md_set_option "profile"): [0] setup [1] look-ahead [2] bulk
   // literal runs [3] matcher/driver (lane 0) [4] bit packing [5] trees, in clock ticks; [8..] event counts
   const bool prof = dbg != nullptr && blockIdx.x == 0;
-  uint64_t pt[6] = {0, 0, 0, 0, 0, 0}, pc[4] = {0, 0, 0, 0};
+  uint64_t pt[6] = {0, 0, 0, 0, 0, 0}, pc[4] = {0, 0, 0, 0}, pa[4] = {0, 0, 0, 0}, pn[4] = {0, 0, 0, 0}, pmax = 0, pq[3] = {0, 0, 0};
   uint64_t t_prev = prof ? wall_clock64() : 0;
 #define PROF_MARK(i)                      \
   if (prof) {                             \
@@ -1325,6 +1330,23 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
       pc[2] += K;
     }
     PROF_MARK(2)
+    // would the matcher hand straight back (lz_compress's two LZ_NEED exits)?  Then don't run it:
+    // its state machine is a long walk through divergent code even when it has nothing to do
+    if (ds.zs.trivial && ds.zs.bulked > 0) {
+      const uint32_t la = ds.zs.lookahead, s2 = ds.zs.strstart;
+      const uint32_t avail = (uint32_t)qcap - (ds.zs.qw - ds.zs.qr);
+      const bool need_ring = pe < p_end && s2 + 260 > pe;
+      const bool next_bulk = la > (uint32_t)MIN_LOOKAHEAD && s2 < pe && avail >= 3;
+      if (la >= (uint32_t)MIN_LOOKAHEAD && (need_ring || next_bulk)) {
+        __syncthreads();
+        if (lane == 0) {
+          ds.ctl[0] = s2;
+          ds.ctl[2] = pe;
+        }
+        __syncthreads();
+        continue;
+      }
+    }
     if (lane == 0) {
       run.z.prepared_end = pe;
       if (ds.zs.trivial) {
@@ -1334,7 +1356,13 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
       }
       // after a bulk run that made progress the wave gets another go before the matcher steps
       run.z.steps = (ds.zs.trivial && ds.zs.bulked > 0) ? 1 : 0;
+      const uint64_t q0 = prof ? wall_clock64() : 0;
       int act = stream_step(&ds, &ws, &run, driver, dynamic);
+      const uint64_t q1 = prof ? wall_clock64() : 0;
+      if (prof) {
+        pq[0] += q0 - t_prev;
+        pq[1] += q1 - q0;
+      }
       if (act == ACT_WRITE) {
         Enc &e = run.e;
         ds.w.hold = e.hold;
@@ -1368,8 +1396,16 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
                        run.z.match_length == MIN_MATCH - 1 && run.phase == PH_LZ)
                           ? 1u
                           : 0u;
+      if (prof) pq[2] += wall_clock64() - q1;
     }
     __syncthreads();
+    if (prof) {  // lane-0 turn time by the action it ended with
+      const uint64_t t_now = wall_clock64(), dt = t_now - t_prev;
+      const uint32_t a = ds.ctl[3] & 3;
+      pa[a] += dt;
+      pn[a]++;
+      if (dt > pmax) pmax = dt;
+    }
     PROF_MARK(3)
     pc[3]++;
     if (ds.ctl[3] == ACT_WRITE) {
@@ -1384,6 +1420,15 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
   if (prof && lane == 0) {
     for (int i = 0; i < 6; i++) dbg[i] = pt[i];
     for (int i = 0; i < 4; i++) dbg[8 + i] = pc[i];
+    for (int i = 0; i < 4; i++) {
+      dbg[16 + i] = pa[i];
+      dbg[20 + i] = pn[i];
+    }
+    dbg[24] = pmax;
+    for (int i = 0; i < 3; i++) dbg[25 + i] = pq[i];
+    dbg[12] = run.z.n_steps;
+    dbg[13] = run.z.n_lm;
+    dbg[14] = run.z.n_chain;
   }
 #undef PROF_MARK
   if (lane == 0) {
