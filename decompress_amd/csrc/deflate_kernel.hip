@@ -132,6 +132,7 @@ struct DS {
 constexpr uint32_t RING = 512;
 enum { FL_PASS = 1, FL_ENDED = 2 };
 constexpr int WALK = 6;  // chain links pre-walked per position
+constexpr int PG = 4;    // look-ahead steps (of 64 positions) prepared together
 
 __device__ __forceinline__ int distance_code(const DS *s, int d1) {
   return d1 < 256 ? s->dist_lo[d1] : s->dist_hi[d1 >> 7];
@@ -1240,57 +1241,107 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
     if (ds.ctl[1]) break;
     const uint32_t ss = ds.ctl[0];
     uint32_t pe = ds.ctl[2];
-    // ---- the wave runs ahead of the matcher: hash heads + 3 chain candidates per position
-    while (pe < p_end && pe + kWave < ss + RING) {
-      const uint32_t pos = pe + lane;
-      const bool valid = pos < p_end;
-      uint32_t w4 = 0;
-      if (valid) __builtin_memcpy(&w4, src + pos, 4);
-      const uint32_t h = (uint32_t)(w4 * 0x9e3779b1u) >> (32 - HASH_BITS);
-      // head[h] <- max(pos) for the whole step in one round trip; the returned values of a group of
-      // equal hashes are >= the head before the step, and one of them is exactly that value
-      const uint32_t ret = valid ? atomicMax(ws.head + h, pos) : 0xffffffffu;
-      bool found = false;
-      uint32_t pred = 0, first = lane;
-      for (uint32_t k = 1; k < kWave; k++) {  // nearest / first earlier position of this step with the same hash
-        const uint32_t hk = __shfl_up(h, k);
-        if (lane >= k && hk == h) {
-          if (!found) pred = lane - k;
-          found = true;
-          first = lane - k;
-        }
+    // ---- the wave runs ahead of the matcher: hash heads + pre-walked chains, PG steps of 64
+    //      positions at a time so that the chain walks of the steps overlap in flight
+    for (;;) {
+      uint32_t nb = 0;
+      if (pe < p_end) {
+        const uint32_t room = (ss + RING - 1 - pe) / kWave;  // slot of position ss - 1 stays intact
+        const uint32_t left = (p_end - pe + kWave - 1) / kWave;
+        nb = room < left ? room : left;
+        if (nb > (uint32_t)PG) nb = PG;
+        // wait for a full group unless the matcher is about to run dry or this is the tail
+        if (nb < (uint32_t)PG && nb != left && pe >= ss + 324) nb = 0;
       }
-      ds.gmin[lane] = 0xffffffffu;
-      __syncthreads();
-      if (valid) atomicMin(&ds.gmin[first], ret);
-      __syncthreads();
-      const uint32_t c1 = valid ? (found ? pe + pred : ds.gmin[lane]) : 0;
-      const uint32_t r = pos & (RING - 1);
-      ds.hh[r] = c1;
-      ds.byt[r] = (uint8_t)w4;
-      __syncthreads();
+      if (nb == 0) break;
+      uint32_t w4[PG], c1[PG], cw[PG], fl[PG];
+#pragma unroll
+      for (int g = 0; g < PG; g++) {
+        const uint32_t pos = pe + g * kWave + lane;
+        w4[g] = 0;
+        if ((uint32_t)g < nb && pos < p_end) __builtin_memcpy(&w4[g], src + pos, 4);
+      }
+#pragma unroll
+      for (int g = 0; g < PG; g++) {
+        if ((uint32_t)g < nb) {  // uniform
+          const uint32_t pos = pe + g * kWave + lane;
+          const bool valid = pos < p_end;
+          const uint32_t h = (uint32_t)(w4[g] * 0x9e3779b1u) >> (32 - HASH_BITS);
+          // head[h] <- max(pos) for the whole step in one round trip; the returned values of a group
+          // of equal hashes are >= the head before the step, and one of them is exactly that value
+          const uint32_t ret = valid ? atomicMax(ws.head + h, pos) : 0xffffffffu;
+          bool found = false;
+          uint32_t pred = 0, first = lane;
+          for (uint32_t k = 1; k < kWave; k++) {  // nearest / first earlier position of this step with the same hash
+            const uint32_t hk = __shfl_up(h, k);
+            if (lane >= k && hk == h) {
+              if (!found) pred = lane - k;
+              found = true;
+              first = lane - k;
+            }
+          }
+          ds.gmin[lane] = 0xffffffffu;
+          __syncthreads();
+          if (valid) atomicMin(&ds.gmin[first], ret);
+          __syncthreads();
+          c1[g] = valid ? (found ? pe + g * kWave + pred : ds.gmin[lane]) : 0;
+          const uint32_t r = pos & (RING - 1);
+          ds.hh[r] = c1[g];
+          ds.byt[r] = (uint8_t)w4[g];
+          __syncthreads();
+        } else c1[g] = 0;
+        cw[g] = c1[g];
+        fl[g] = 0;
+      }
       // pre-walk: stop at the first candidate sharing 3 bytes (the matcher will look for real) or
-      // when the chain leaves the reach of pos
-      const uint32_t lower = pos > (uint32_t)MAX_DIST ? pos - MAX_DIST : 0;
-      uint32_t c = c1, fl = 0;
+      // when the chain leaves the reach of the position
       for (int lv = 0; lv < WALK; lv++) {
-        // the head candidate is admitted at distance == MAX_DIST, links only above the limit
-        // (lib/de.ml:4367-4369 vs :4165)
-        const bool act = fl == 0 && (lv == 0 ? (c != 0 && pos - c <= (uint32_t)MAX_DIST) : c > lower);
-        if (__ballot(act) == 0) break;
-        if (act) {
-          uint32_t v;
-          __builtin_memcpy(&v, src + c, 4);  // c < pos <= n - 4
-          // link of c: still in the ring if the matcher has not published it yet
-          const uint32_t nx = c >= ss ? ds.hh[c & (RING - 1)] : g_ld(ws.prev + (c & WMASK));
-          if (((v ^ w4) & 0xffffffu) == 0) fl = FL_PASS;
-          c = nx;
+        bool act[PG];
+        bool any = false;
+#pragma unroll
+        for (int g = 0; g < PG; g++) {
+          const uint32_t pos = pe + g * kWave + lane;
+          const uint32_t lower = pos > (uint32_t)MAX_DIST ? pos - MAX_DIST : 0;
+          // the head candidate is admitted at distance == MAX_DIST, links only above the limit
+          // (lib/de.ml:4367-4369 vs :4165)
+          act[g] = (uint32_t)g < nb && fl[g] == 0 &&
+                   (lv == 0 ? (cw[g] != 0 && pos - cw[g] <= (uint32_t)MAX_DIST) : cw[g] > lower);
+          any = any || act[g];
+        }
+        if (__ballot(any) == 0) break;
+        uint32_t v[PG], nx[PG];
+#pragma unroll
+        for (int g = 0; g < PG; g++) {
+          v[g] = 0;
+          nx[g] = 0;
+          if (act[g]) {
+            __builtin_memcpy(&v[g], src + cw[g], 4);  // candidate < pos <= n - 4
+            // link of the candidate: still in the ring if the matcher has not published it yet
+            nx[g] = cw[g] >= ss ? ds.hh[cw[g] & (RING - 1)] : g_ld(ws.prev + (cw[g] & WMASK));
+          }
+        }
+#pragma unroll
+        for (int g = 0; g < PG; g++) {
+          if (act[g]) {
+            if (((v[g] ^ w4[g]) & 0xffffffu) == 0) fl[g] = FL_PASS;
+            cw[g] = nx[g];
+          }
         }
       }
-      if (fl == 0 && !(c > lower) && !(c == c1 && c != 0 && pos - c <= (uint32_t)MAX_DIST)) fl = FL_ENDED;
-      ds.flg[r] = (uint8_t)fl;
-      pe = pe + kWave < p_end ? pe + kWave : p_end;
-      pc[0]++;
+#pragma unroll
+      for (int g = 0; g < PG; g++) {
+        if ((uint32_t)g < nb) {
+          const uint32_t pos = pe + g * kWave + lane;
+          const uint32_t lower = pos > (uint32_t)MAX_DIST ? pos - MAX_DIST : 0;
+          uint32_t f = fl[g];
+          if (f == 0 && !(cw[g] > lower) &&
+              !(cw[g] == c1[g] && cw[g] != 0 && pos - cw[g] <= (uint32_t)MAX_DIST))
+            f = FL_ENDED;
+          ds.flg[pos & (RING - 1)] = (uint8_t)f;
+        }
+      }
+      pe = pe + nb * kWave < p_end ? pe + nb * kWave : p_end;
+      pc[0] += nb;
     }
     __syncthreads();
     PROF_MARK(1)
