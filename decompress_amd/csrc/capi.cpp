@@ -34,7 +34,7 @@ extern "C" int md_launch_deflate(int format, int level, int qcap, int driver, in
                                  const uint8_t *in, const uint64_t *in_off, const uint64_t *in_len,
                                  uint8_t *out, const uint64_t *out_off, const uint64_t *out_cap,
                                  uint64_t *out_len, int32_t *status, uint32_t *checksum, void *ws,
-                                 uint64_t *dbg, hipStream_t stream);
+                                 uint64_t *dbg, int test_flags, hipStream_t stream);
 
 struct md_ctx {
   int device = 0;
@@ -44,6 +44,7 @@ struct md_ctx {
   int ring_log2 = 13;
   int kernel = 3;   // 1 = serial per wave, 2 = lane-parallel fused (inflate_v4.hip), 3 = lane-parallel split (default)
   int variant = 0;  // v2 geometry
+  int test_flags = 0;       // deflate: bit 0 = always take the order-free head reconstruction (tests)
   uint64_t *dbg = nullptr;  // device buffer of the optional in-kernel profile (32 x u64)
   void *ws = nullptr;       // deflate workspace (hash heads / chains / command queues)
   size_t ws_bytes = 0;
@@ -215,6 +216,10 @@ int md_set_option(md_ctx *ctx, const char *key, int value) {
     }
     return MD_OK;
   }
+  if (!strcmp(key, "deflate_test_flags")) {
+    ctx->test_flags = value;
+    return MD_OK;
+  }
   if (!strcmp(key, "log_records")) {
     if (value < 4 || value > 65536) return fail(ctx, MD_E_INVALID_ARGUMENT, "log_records must be 4..65536");
     ctx->log_records = value;
@@ -365,7 +370,7 @@ int md_deflate_batch_device(md_ctx *ctx, int format, int level, int queue_len, i
   }
   int rc = md_launch_deflate(format, level, queue_len, driver, dynamic ? 1 : 0, (uint32_t)n, d_in, d_in_off,
                              d_in_len, d_out, d_out_off, d_out_cap, d_out_len, d_status, d_checksum,
-                             ctx->ws, ctx->dbg, ctx->stream);
+                             ctx->ws, ctx->dbg, ctx->test_flags, ctx->stream);
   if (rc != 0) return fail(ctx, MD_E_HIP, "deflate kernel launch", (hipError_t)rc);
   return MD_OK;
 }

@@ -103,15 +103,16 @@ struct DS {
   TreeT<D_CODES> dt;
   TreeT<BL_CODES> bt;
   int kind_result;             // block kind chosen by trees_wave
+  uint32_t tp[8];              // profile of trees_wave (ticks), only when profiling
   uint16_t symbols[L_CODES + D_CODES + 8];  // (len << 8) | code of the code-length stream
   int nsymbols, h_lit, h_dst, h_len;
   uint8_t length_code[259];
   uint8_t dist_lo[256], dist_hi[256];
   // look-ahead ring of decision-independent matcher inputs, indexed by position & (RING-1)
-  uint32_t hh[512];      // hash_head(p): chain candidate 1
-  uint8_t flg[512];      // chain pre-walk of p: FL_PASS a candidate shares p's first 3 bytes, FL_ENDED the
+  uint32_t hh[1024];     // hash_head(p): chain candidate 1
+  uint8_t flg[1024];     // chain pre-walk of p: FL_PASS a candidate shares p's first 3 bytes, FL_ENDED the
                          // chain left the reach of p within the walked links
-  uint8_t byt[512];      // the byte at p (pending literal of the next position)
+  uint8_t byt[1024];     // the byte at p (pending literal of the next position)
   uint32_t gmin[64];     // per hash group of one look-ahead step: head value before the step
   uint32_t ctl[5];       // [0] machine strstart, [1] machine state (1 = finished), [2] prepared_end, [3] action,
                          // [4] tree mode of ACT_TREES
@@ -129,10 +130,10 @@ struct DS {
     int *q;
   } w;
 };
-constexpr uint32_t RING = 512;
+constexpr uint32_t RING = 1024;
 enum { FL_PASS = 1, FL_ENDED = 2 };
 constexpr int WALK = 6;  // chain links pre-walked per position
-constexpr int PG = 4;    // look-ahead steps (of 64 positions) prepared together
+constexpr int PG = 8;    // look-ahead steps (of 64 positions) prepared together
 
 __device__ __forceinline__ int distance_code(const DS *s, int d1) {
   return d1 < 256 ? s->dist_lo[d1] : s->dist_hi[d1 >> 7];
@@ -187,7 +188,15 @@ __device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
   return v;
 }
 
+#define TP_MARK(i)                                          \
+  if (TPROF) {                                              \
+    const uint64_t t_now = wall_clock64();                  \
+    if (lane == 0) s->tp[i] += (uint32_t)(t_now - t_prev);  \
+    t_prev = t_now;                                         \
+  }
+template <bool TPROF>
 __device__ void tree_make_wave(DS *s, int length, int max_length, int *f, TreeRef t, uint32_t lane) {
+  uint64_t t_prev = TPROF ? wall_clock64() : 0;
   for (int n = (int)lane; n < HEAP_SIZE; n += kWave) {
     s->tlen[n] = 0;
     s->dads[n] = 0;
@@ -217,6 +226,7 @@ __device__ void tree_make_wave(DS *s, int length, int max_length, int *f, TreeRe
     __syncthreads();
   }
   const int hmax = HEAP_SIZE - (2 * hlen0 - 1);
+  TP_MARK(0)
   if (lane == 0) {
     int hm = HEAP_SIZE, node = length;
     do {
@@ -238,6 +248,7 @@ __device__ void tree_make_wave(DS *s, int length, int max_length, int *f, TreeRe
     s->heap[--hm] = (uint16_t)((uint32_t)s->hk[1] & 0xffff);
   }
   __syncthreads();
+  TP_MARK(1)
   // generate_lengths, lib/de.ml:1952-2009: a node's length is its depth below the root
   const int root = s->heap[hmax];
   bool over = false;
@@ -288,6 +299,7 @@ __device__ void tree_make_wave(DS *s, int length, int max_length, int *f, TreeRe
     }
   }
   __syncthreads();
+  TP_MARK(2)
   // generate_codes, lib/de.ml:1926-1950: lane b keeps next_code[b]; a symbol's code is that plus
   // the number of earlier symbols of the same length
   uint32_t ncr = 0;
@@ -323,6 +335,7 @@ __device__ void tree_make_wave(DS *s, int length, int max_length, int *f, TreeRe
   }
   if (lane == 0) *t.max_code = max_code;
   __syncthreads();
+  TP_MARK(3)
 }
 
 // T.scan (lib/de.ml:2070-2117) and T.symbols (lib/de.ml:2122-2191) by position.  The serial state
@@ -419,14 +432,18 @@ enum { TM_NONE = 0, TM_DYNAMIC = 1, TM_CHOOSE = 2 };
 // Def.dynamic_of_frequencies, lib/de.ml:2387-2407 (into the current block's trees); with
 // TM_CHOOSE also the cost comparison of lib/de.ml:2415-2449 with the H3 quirk
 // (`distances[i] + len`).  Leaves the block kind in s->kind_result.
+template <bool TPROF>
 __device__ void trees_wave(DS *s, int mode, uint32_t lane) {
-  tree_make_wave(s, L_CODES, MAX_BITS, s->lits, tref(&s->lt), lane);
-  tree_make_wave(s, D_CODES, MAX_BITS, s->dsts, tref(&s->dt), lane);
+  tree_make_wave<TPROF>(s, L_CODES, MAX_BITS, s->lits, tref(&s->lt), lane);
+  tree_make_wave<TPROF>(s, D_CODES, MAX_BITS, s->dsts, tref(&s->dt), lane);
+  uint64_t t_prev = TPROF ? wall_clock64() : 0;
   if (lane < 2 * BL_CODES + 1) s->blf[lane] = 0;
   __syncthreads();
   tree_rle_wave(s, tref(&s->lt), 0, false, lane);
   tree_rle_wave(s, tref(&s->dt), 0, false, lane);
-  tree_make_wave(s, BL_CODES, 7, s->blf, tref(&s->bt), lane);
+  TP_MARK(4)
+  tree_make_wave<TPROF>(s, BL_CODES, 7, s->blf, tref(&s->bt), lane);
+  if (TPROF) t_prev = wall_clock64();
   const uint64_t used = __ballot(lane < (uint32_t)BL_CODES && s->bt.clen[c_zigzag[lane < 19 ? lane : 0]] != 0);
   int max_blindex = used ? 63 - __builtin_clzll(used) : 0;
   if (max_blindex < 2) max_blindex = 2;
@@ -462,7 +479,9 @@ __device__ void trees_wave(DS *s, int mode, uint32_t lane) {
     s->kind_result = kind;
   }
   __syncthreads();
+  TP_MARK(5)
 }
+#undef TP_MARK
 
 // ---------------------------------------------------------------------------
 // workspace in HBM, per stream
@@ -1141,7 +1160,7 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
     const uint64_t *__restrict__ out_off, const uint64_t *__restrict__ out_cap,
     uint64_t *__restrict__ out_len, int32_t *__restrict__ status, uint32_t *__restrict__ checksum,
     uint32_t *__restrict__ ws_head, uint32_t *__restrict__ ws_prev, int *__restrict__ ws_queue,
-    uint64_t *__restrict__ dbg) {
+    uint64_t *__restrict__ dbg, int test_flags) {
   __shared__ DS ds;
   // optional phase profile of stream 0 (md_set_option "profile"): [0] setup [1] look-ahead [2] bulk
   // literal runs [3] matcher/driver (lane 0) [4] bit packing [5] trees, in clock ticks; [8..] event counts
@@ -1232,6 +1251,7 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
     ds.ctl[2] = 0;
     ds.zs.trivial = 0;
     ds.zs.bulked = 0;
+    for (int i = 0; i < 8; i++) ds.tp[i] = 0;
   }
   const uint32_t eff_level = driver == DRV_HIGHER ? 4 : level;
   const uint32_t p_end = (eff_level != 0 && slen >= 4) ? slen - 3 : 0;
@@ -1254,45 +1274,91 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
         if (nb < (uint32_t)PG && nb != left && pe >= ss + 324) nb = 0;
       }
       if (nb == 0) break;
-      uint32_t w4[PG], c1[PG], cw[PG], fl[PG];
+      uint32_t w4[PG], c1[PG], cw[PG], fl[PG], hv[PG], ret[PG];
 #pragma unroll
       for (int g = 0; g < PG; g++) {
         const uint32_t pos = pe + g * kWave + lane;
         w4[g] = 0;
         if ((uint32_t)g < nb && pos < p_end) __builtin_memcpy(&w4[g], src + pos, 4);
       }
+      // head[h] <- max(pos), one atomic per position, all steps of the group in flight together.
+      // The returned values of a set of equal hashes are >= the head before the set, and one of them
+      // is exactly that value.  Steps are expected to reach a head in program order (same wave,
+      // same address); `bad` catches a step overtaken by a later one and the group is then redone
+      // from the raw (hash, returned value) pairs, which does not depend on any order.
+#pragma unroll
+      for (int g = 0; g < PG; g++) {
+        const uint32_t pos = pe + g * kWave + lane;
+        hv[g] = (uint32_t)(w4[g] * 0x9e3779b1u) >> (32 - HASH_BITS);
+        ret[g] = ((uint32_t)g < nb && pos < p_end) ? atomicMax(ws.head + hv[g], pos) : 0xffffffffu;
+      }
+      bool bad = (test_flags & 1) != 0;
 #pragma unroll
       for (int g = 0; g < PG; g++) {
         if ((uint32_t)g < nb) {  // uniform
           const uint32_t pos = pe + g * kWave + lane;
           const bool valid = pos < p_end;
-          const uint32_t h = (uint32_t)(w4[g] * 0x9e3779b1u) >> (32 - HASH_BITS);
-          // head[h] <- max(pos) for the whole step in one round trip; the returned values of a group
-          // of equal hashes are >= the head before the step, and one of them is exactly that value
-          const uint32_t ret = valid ? atomicMax(ws.head + h, pos) : 0xffffffffu;
-          bool found = false;
-          uint32_t pred = 0, first = lane;
-          for (uint32_t k = 1; k < kWave; k++) {  // nearest / first earlier position of this step with the same hash
-            const uint32_t hk = __shfl_up(h, k);
-            if (lane >= k && hk == h) {
-              if (!found) pred = lane - k;
-              found = true;
-              first = lane - k;
-            }
+          const uint32_t h = hv[g];
+          // lanes of this step with the same hash: intersect the ballots of the 15 hash bits
+          uint64_t same = __ballot(valid);
+#pragma unroll
+          for (int bit = 0; bit < HASH_BITS; bit++) {
+            const bool mine = (h >> bit) & 1;
+            const uint64_t bal = __ballot(mine);
+            same &= mine ? bal : ~bal;
           }
+          const uint64_t below = same & lanes_below(lane);
+          const bool found = valid && below != 0;
+          const uint32_t pred = below ? 63u - (uint32_t)__builtin_clzll(below) : 0u;
+          const uint32_t first = valid ? (uint32_t)__builtin_ctzll(same) : lane;
           ds.gmin[lane] = 0xffffffffu;
           __syncthreads();
-          if (valid) atomicMin(&ds.gmin[first], ret);
+          if (valid) atomicMin(&ds.gmin[first], ret[g]);
           __syncthreads();
+          if (valid && ret[g] >= pe + (g + 1) * kWave) bad = true;  // a later step got there first
           c1[g] = valid ? (found ? pe + g * kWave + pred : ds.gmin[lane]) : 0;
-          const uint32_t r = pos & (RING - 1);
-          ds.hh[r] = c1[g];
-          ds.byt[r] = (uint8_t)w4[g];
           __syncthreads();
         } else c1[g] = 0;
+      }
+      if (__ballot(bad)) {
+        // order-free reconstruction: predecessor = nearest earlier position of the group with the
+        // same hash, else the smallest value any of them got back (the head before the group)
+        uint16_t *rh = (uint16_t *)ds.hk;             // [PG * 64] hashes (tree scratch is idle here)
+        uint32_t *rr = (uint32_t *)(ds.hk + 128);     // [PG * 64] returned values
+#pragma unroll
+        for (int g = 0; g < PG; g++) {
+          const uint32_t pos = pe + g * kWave + lane;
+          const bool valid = (uint32_t)g < nb && pos < p_end;
+          rh[g * kWave + lane] = valid ? (uint16_t)hv[g] : (uint16_t)0xffff;
+          rr[g * kWave + lane] = ret[g];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < PG; g++) {
+          const uint32_t me = g * kWave + lane;
+          uint32_t vmin = 0xffffffffu, pred = 0xffffffffu;
+          for (uint32_t k = 0; k < nb * kWave; k++) {
+            if (rh[k] == hv[g]) {
+              if (rr[k] < vmin) vmin = rr[k];
+              if (k < me) pred = k;
+            }
+          }
+          const uint32_t pos = pe + me;
+          if ((uint32_t)g < nb) c1[g] = pos < p_end ? (pred != 0xffffffffu ? pe + pred : vmin) : 0;
+        }
+        __syncthreads();
+      }
+#pragma unroll
+      for (int g = 0; g < PG; g++) {
+        if ((uint32_t)g < nb) {
+          const uint32_t r = (pe + g * kWave + lane) & (RING - 1);
+          ds.hh[r] = c1[g];
+          ds.byt[r] = (uint8_t)w4[g];
+        }
         cw[g] = c1[g];
         fl[g] = 0;
       }
+      __syncthreads();
       // pre-walk: stop at the first candidate sharing 3 bytes (the matcher will look for real) or
       // when the chain leaves the reach of the position
       for (int lv = 0; lv < WALK; lv++) {
@@ -1464,7 +1530,8 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
       __syncthreads();
       PROF_MARK(4)
     } else if (ds.ctl[3] == ACT_TREES) {
-      trees_wave(&ds, (int)ds.ctl[4], lane);
+      if (prof) trees_wave<true>(&ds, (int)ds.ctl[4], lane);
+      else trees_wave<false>(&ds, (int)ds.ctl[4], lane);
       PROF_MARK(5)
     }
   }
@@ -1476,6 +1543,7 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
       dbg[20 + i] = pn[i];
     }
     dbg[24] = pmax;
+    for (int i = 0; i < 4; i++) dbg[28 + i] = ((uint64_t)ds.tp[2 * i + 1] << 32) | ds.tp[2 * i];
     for (int i = 0; i < 3; i++) dbg[25 + i] = pq[i];
     dbg[12] = run.z.n_steps;
     dbg[13] = run.z.n_lm;
@@ -1513,13 +1581,13 @@ extern "C" int md_launch_deflate(int format, int level, int qcap, int driver, in
                                  const uint8_t *in, const uint64_t *in_off, const uint64_t *in_len,
                                  uint8_t *out, const uint64_t *out_off, const uint64_t *out_cap,
                                  uint64_t *out_len, int32_t *status, uint32_t *checksum, void *ws,
-                                 uint64_t *dbg, hipStream_t stream) {
+                                 uint64_t *dbg, int test_flags, hipStream_t stream) {
   if (n == 0) return 0;
   uint32_t *head = (uint32_t *)ws;
   uint32_t *prev = head + (size_t)n * md::defl::HASH_SIZE;
   int *queue = (int *)(prev + (size_t)n * md::defl::WSIZE);
   hipLaunchKernelGGL(md::defl::deflate_kernel, dim3(n), dim3(md::defl::kWave), 0, stream, format, level,
                      qcap, driver, dynamic, n, in, in_off, in_len, out, out_off, out_cap, out_len, status,
-                     checksum, head, prev, queue, dbg);
+                     checksum, head, prev, queue, dbg, test_flags);
   return (int)hipGetLastError();
 }

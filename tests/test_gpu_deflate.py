@@ -86,6 +86,18 @@ def test_round_trip_on_gpu(eng):
         assert st == 0 and out == b and adler == zlib.adler32(b)
 
 
+def test_order_free_head_reconstruction(oracle):
+    """The look-ahead normally trusts same-address atomics of one wave to land in program order and
+    checks it; force the fallback that rebuilds the hash heads without that assumption."""
+    import decompress_amd
+    from decompress_amd import workloads
+    e = decompress_amd.Engine(0)
+    e.set_option("deflate_test_flags", 1)
+    bufs = [workloads.text(60, 90000), workloads.ascii_uniform(61, 150000), b"abc" * 30000, b"q" * 5]
+    for b, (st, out, _) in zip(bufs, e.deflate_many(bufs, level=6)):
+        assert st == 0 and out == oracle.deflate_raw(b, 6)[0]
+
+
 def test_output_too_small(eng):
     from decompress_amd import workloads
     b = workloads.ascii_uniform(1, 10000)
