@@ -1,4 +1,4 @@
-// deflate_kernel.hip — batched RFC1951 deflate for gfx950 (MI355X), v1.
+// deflate_kernel.hip — batched RFC1951 deflate for gfx950 (MI355X).
 //
 // Bit-exact with the reference's streaming compressor:
 //   De.Lz77 (zlib deflate_slow, 4-byte multiplicative hash)      lib/de.ml:4013-4515
@@ -10,26 +10,22 @@
 // cumulative and mutated histograms, the odd cost formula, driver-dependent
 // empty blocks, deterministic stale bytes past the end of input).
 //
-// Layout: one independent stream per wavefront.  The lazy matcher and the bit
-// encoder of a stream are sequential state machines (every decision depends on
-// the previous one): lane 0 runs them.  What does NOT depend on decisions is done
-// by the whole wave ahead of the machine: in deflate_slow every position p <= n-4
-// is inserted into the hash chains exactly once and in order, so hash_head(p) —
-// the latest earlier position with the same hash4 — is a pure function of the
-// input.  The wave computes it 64 positions per step (coalesced hash, gather of
-// the old heads, in-register duplicate resolution, atomic-max head update) into
-// an LDS ring, and also pre-walks the first three chain candidates of every
-// position (3-byte pre-filter of longest_match, lib/de.ml:4133-4137), so that on
-// literal-dominated input (BASELINE config 3) the machine never waits for HBM.
+// Layout: one independent stream per wavefront.  The lazy matcher and the driver
+// of a stream are sequential state machines (every decision depends on the
+// previous one): lane 0 runs them.  What does NOT depend on decisions is done by
+// the whole wave: in deflate_slow every position p <= n-4 is inserted into the hash
+// chains exactly once and in order, so hash_head(p) — the latest earlier position
+// with the same hash4 — is a pure function of the input.  The wave computes it 8 x 64
+// positions per group (coalesced hash, atomic-max head update returning the old
+// head, equal hashes matched by ballots) into an LDS ring, pre-walks 6 chain links
+// per position (3-byte pre-filter of longest_match, lib/de.ml:4133-4137), takes
+// literal runs 64 positions at a time, builds the Huffman trees (all but zlib's
+// heap merge loop) and packs the bits of a queue fill 64 commands per step.
 // Hash heads / chains (abs positions, 2 x 128 KiB) and the command queue live in
 // a per-stream HBM workspace; histograms, heap and code tables live in LDS.
 // The window is the input buffer itself: w[rel] = in[base + rel]; bytes the
 // reference reads beyond the data (H7) follow its 64 KiB sliding buffer exactly
-// (zero before the first slide, the byte 32 KiB earlier after it).
-//
-// This version is correct first; the parallel formulation (decision-independent
-// hash chains built 64 positions at a time, speculative per-position matches,
-// wave-parallel bit packing) is the next step — see DESIGN.md.
+// (zero before the first slide, the byte 32 KiB earlier after it).  See DESIGN.md 4.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
