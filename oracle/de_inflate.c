@@ -465,6 +465,9 @@ const char *orc_status_string(int s) {
   case ORC_INVALID_DISTANCE_CODE: return "Invalid distance code";
   case ORC_INVALID_HEADER: return "Invalid header";
   case ORC_INVALID_CHECKSUM: return "Invalid checksum";
+  case ORC_INVALID_GZIP_HEADER: return "Invalid GZip header";
+  case ORC_INVALID_GZIP_HEADER_CHECKSUM: return "Invalid GZip header checksum";
+  case ORC_INVALID_SIZE: return "Invalid input size";
   default: return "?";
   }
 }

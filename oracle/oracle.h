@@ -34,7 +34,11 @@ enum {
   ORC_INVALID_DISTANCE = 6,
   ORC_INVALID_DISTANCE_CODE = 7,
   ORC_INVALID_HEADER = 8,
-  ORC_INVALID_CHECKSUM = 9
+  ORC_INVALID_CHECKSUM = 9,
+  /* Gz.Inf's `Malformed strings (lib/gz.ml:284-296) */
+  ORC_INVALID_GZIP_HEADER = 10,          /* "Invalid GZip header" */
+  ORC_INVALID_GZIP_HEADER_CHECKSUM = 11, /* "Invalid GZip header checksum" */
+  ORC_INVALID_SIZE = 12                  /* "Invalid input size (expect:.., inflated:..)" */
 };
 
 /* Checkseum.Adler32 (external dep, RFC1950 §8.2); call sites lib/de.ml:453-455 */
@@ -57,6 +61,18 @@ int orc_inf_huffman(int kind, const uint8_t *lens, int codes, uint32_t *tbl,
 
 const char *orc_status_string(int status);
 
+/* ---- GZip framing (oracle/gz.c) ---- */
+typedef struct {
+  uint32_t cm, flg, mtime, xfl, os;
+  int has_extra, has_name, has_comment;
+  size_t extra_off, extra_len, name_off, name_len, comment_off, comment_len; /* into src */
+} orc_gz_meta;
+/* Gz.Inf header (lib/gz.ml:465-491) */
+int orc_gz_header(const uint8_t *src, size_t n, size_t *body, orc_gz_meta *m);
+/* Gz.Inf / Gz.Higher.uncompress over a whole buffer (lib/gz.ml:248-633, :959-982) */
+int orc_gz_inflate(const uint8_t *src, size_t n, uint8_t *dst, size_t dst_cap, size_t *consumed,
+                   size_t *written, orc_gz_meta *m);
+
 /* ---- deflate (oracle/de_deflate.c) ---- */
 enum { ORC_DRV_ZL = 0, ORC_DRV_HIGHER = 1, ORC_DRV_CLI = 2 };
 /* Raw DEFLATE body of De.Lz77 (lib/de.ml:4013-4515) + De.Def (lib/de.ml:2354-3038)
@@ -66,6 +82,9 @@ uint8_t *orc_deflate_raw(const uint8_t *src, size_t n, int level, int queue_len,
 /* Zl.Def.encode / Zl.Higher.compress (lib/zl.ml:509-555, 634-648) */
 uint8_t *orc_zl_deflate(const uint8_t *src, size_t n, int level, int queue_len, int dynamic,
                         size_t *out_len);
+/* Gz.Def / Gz.Higher.compress over a whole buffer (lib/gz.ml:636-918, :927-950) */
+uint8_t *orc_gz_deflate(const uint8_t *src, size_t n, int level, int queue_len, uint32_t mtime, int os,
+                        int hcrc, int ascii, const char *name, const char *comment, size_t *out_len);
 void orc_free(void *p);
 /* De.T.make (lib/de.ml:2013-2068) on a histogram (mutated in place) */
 int orc_tree_make(int length, int max_length, int *freqs, int nfreqs, int *lengths, int *codes);

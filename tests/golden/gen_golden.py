@@ -318,7 +318,47 @@ def gen_deflate_kat():
     return out
 
 
+def gen_gzip():
+    """test/test.ml:1659-1989: the GZip decoder's vectors (input strings + what the test checks)."""
+    text = open(os.path.join(REF, "test.ml"), encoding="latin-1").read()
+    want = {
+        "test_empty_gzip": dict(out=b"", status=0),
+        "test_empty_gzip_with_name": dict(out=b"", status=0, filename=b"test"),
+        "test_foo_gzip": dict(out=b"foo", status=0, filename=b"foo"),
+        "test_invalid_hcrc": dict(status=11, error="Invalid GZip header checksum"),
+        "test_gzip_extra": dict(out=b"foo\n", status=0, extra_key=b"lx", extra_value=b"ubuntu"),
+    }
+    cases = []
+    for fn, exp in want.items():
+        m = re.search(r"let %s \(\) =" % fn, text)
+        assert m, fn
+        line = text.count("\n", 0, m.start()) + 1
+        lst = text.index("[", text.index("let input", m.start()))
+        end = text.index("] in", lst)
+        i, parts = lst + 1, []
+        while True:
+            i = skip_ws_comments(text, i)
+            if i >= end:
+                break
+            if text[i] == ";":
+                i += 1
+                continue
+            b, i = parse_ocaml_string(text, i)
+            parts.append(b)
+        case = {"name": fn[5:], "src": b"".join(parts).hex(), "status": exp["status"], "ref": "test/test.ml:%d" % line}
+        for k in ("out", "filename", "extra_key", "extra_value"):
+            if k in exp:
+                case[k] = exp[k].hex()
+        if "error" in exp:
+            case["error"] = exp["error"]
+        cases.append(case)
+    with open(os.path.join(OUT, "gzip.json"), "w") as f:
+        json.dump(cases, f, indent=1)
+    print("gzip.json", len(cases))
+
+
 def main():
+    gen_gzip()
     if not os.path.isdir(REF):
         sys.exit("reference tree not present; fixtures are already committed")
     ns = gen_ns()

@@ -59,6 +59,45 @@ class Oracle:
         lib.orc_lz77_cmds.restype = ci
         lib.orc_lz77_cmds.argtypes = [ctypes.c_char_p, sz, ci, ci, ctypes.POINTER(ci), ci]
 
+        class GzMeta(ctypes.Structure):
+            _fields_ = [(k, ctypes.c_uint32) for k in ("cm", "flg", "mtime", "xfl", "os")] + \
+                       [(k, ctypes.c_int) for k in ("has_extra", "has_name", "has_comment")] + \
+                       [(k, ctypes.c_size_t) for k in ("extra_off", "extra_len", "name_off", "name_len",
+                                                       "comment_off", "comment_len")]
+        self.GzMeta = GzMeta
+        lib.orc_gz_inflate.restype = ci
+        lib.orc_gz_inflate.argtypes = [ctypes.c_char_p, sz, ctypes.c_char_p, sz, ctypes.POINTER(sz),
+                                       ctypes.POINTER(sz), ctypes.POINTER(GzMeta)]
+        lib.orc_gz_deflate.restype = ctypes.c_void_p
+        lib.orc_gz_deflate.argtypes = [ctypes.c_char_p, sz, ci, ci, ctypes.c_uint32, ci, ci, ci, ctypes.c_char_p,
+                                       ctypes.c_char_p, ctypes.POINTER(sz)]
+        lib.orc_status_string.restype = ctypes.c_char_p
+        lib.orc_status_string.argtypes = [ci]
+
+    def gz_inflate(self, src, cap):
+        """Gz.Inf over a whole buffer -> (status, consumed, bytes, meta dict)."""
+        src = bytes(src)
+        dst = ctypes.create_string_buffer(max(cap, 1))
+        c, w = ctypes.c_size_t(), ctypes.c_size_t()
+        m = self.GzMeta()
+        rc = self.lib.orc_gz_inflate(src, len(src), dst, cap, ctypes.byref(c), ctypes.byref(w), ctypes.byref(m))
+        meta = {"flg": m.flg, "os": m.os, "mtime": m.mtime, "xfl": m.xfl,
+                "name": src[m.name_off:m.name_off + m.name_len] if m.has_name else None,
+                "comment": src[m.comment_off:m.comment_off + m.comment_len] if m.has_comment else None,
+                "extra": src[m.extra_off:m.extra_off + m.extra_len] if m.has_extra else None}
+        return rc, c.value, dst.raw[: w.value], meta
+
+    def gz_deflate(self, src, level=4, queue=4096, mtime=0, os=3, hcrc=False, ascii=False, name=None, comment=None):
+        n = ctypes.c_size_t()
+        p = self.lib.orc_gz_deflate(bytes(src), len(src), level, queue, mtime, os, int(hcrc), int(ascii),
+                                    name, comment, ctypes.byref(n))
+        out = ctypes.string_at(p, n.value)
+        self.lib.orc_free(p)
+        return out
+
+    def status_string(self, st):
+        return self.lib.orc_status_string(st).decode()
+
     def _inflate(self, fn, src, cap):
         dst = ctypes.create_string_buffer(max(cap, 1))
         c, w = ctypes.c_size_t(), ctypes.c_size_t()
