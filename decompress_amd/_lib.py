@@ -41,7 +41,21 @@ SYMBOLS = [
      [c_vp, c_vp, c_sz, c_vp, c_sz, ctypes.POINTER(c_sz), ctypes.POINTER(c_sz)]),
     ("md_zl_inf_ns_inflate", ctypes.c_int,
      [c_vp, c_vp, c_sz, c_vp, c_sz, ctypes.POINTER(c_sz), ctypes.POINTER(c_sz)]),
+    ("md_gz_set_header", ctypes.c_int,
+     [c_vp, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p]),
+    ("md_gz_higher_compress", ctypes.c_int,
+     [c_vp, ctypes.c_int, ctypes.c_int, c_vp, c_sz, c_vp, c_sz, ctypes.POINTER(c_sz)]),
+    ("md_gz_higher_uncompress", ctypes.c_int,
+     [c_vp, c_vp, c_sz, c_vp, c_sz, ctypes.POINTER(c_sz), ctypes.POINTER(c_sz), c_vp]),
+    ("md_crc32_batch_device", ctypes.c_int, [c_vp, c_sz, c_vp, c_vp, c_vp, c_vp]),
 ]
+
+
+class GzMeta(ctypes.Structure):
+    """md_gz_meta of include/mdeflate.h"""
+    _fields_ = [(k, ctypes.c_uint32) for k in ("flg", "mtime", "xfl", "os")] + \
+               [(k, ctypes.c_int) for k in ("has_extra", "has_name", "has_comment")] + \
+               [(k, c_sz) for k in ("extra_off", "extra_len", "name_off", "name_len", "comment_off", "comment_len")]
 # exported but not part of the public header (tuning knobs)
 EXTRA = [("md_set_option", ctypes.c_int, [c_vp, ctypes.c_char_p, ctypes.c_int]),
          ("md_get_profile", ctypes.c_int, [c_vp, c_vp])]

@@ -34,7 +34,17 @@ extern "C" int md_launch_deflate(int format, int level, int qcap, int driver, in
                                  const uint8_t *in, const uint64_t *in_off, const uint64_t *in_len,
                                  uint8_t *out, const uint64_t *out_off, const uint64_t *out_cap,
                                  uint64_t *out_len, int32_t *status, uint32_t *checksum, void *ws,
-                                 uint64_t *dbg, int test_flags, hipStream_t stream);
+                                 uint64_t *dbg, int test_flags, const uint8_t *gz_hdr, uint32_t gz_hdr_len,
+                                 const uint32_t *gz_crc, hipStream_t stream);
+
+extern "C" int md_launch_gz_header(uint32_t n, const uint8_t *in, const uint64_t *in_off, const uint64_t *in_len,
+                                   uint64_t *body_off, uint64_t *body_len, int32_t *hstatus, hipStream_t stream);
+extern "C" int md_launch_crc32(uint32_t n, const uint8_t *data, const uint64_t *off, const uint64_t *len,
+                               uint32_t *crc_out, hipStream_t stream);
+extern "C" int md_launch_gz_finish(uint32_t n, const uint8_t *in, const uint64_t *in_off, const uint64_t *in_len,
+                                   const uint64_t *body_off, const int32_t *hstatus, const uint8_t *out,
+                                   const uint64_t *out_off, uint64_t *out_len, uint64_t *consumed, int32_t *status,
+                                   uint32_t *checksum, hipStream_t stream);
 
 struct md_ctx {
   int device = 0;
@@ -44,6 +54,13 @@ struct md_ctx {
   int ring_log2 = 13;
   int kernel = 3;   // 1 = serial per wave, 2 = lane-parallel fused (inflate_v4.hip), 3 = lane-parallel split (default)
   int variant = 0;  // v2 geometry
+  // GZip: per-stream scratch (body offsets/lengths, header status, CRCs) and the header to write
+  void *gz_tmp = nullptr;
+  size_t gz_tmp_bytes = 0;
+  uint8_t *gz_hdr_dev = nullptr;  // device copy of gz_hdr (530 bytes max)
+  uint8_t gz_hdr[544] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 3};
+  uint32_t gz_hdr_len = 10;
+  bool gz_hdr_dirty = true;
   int test_flags = 0;       // deflate: bit 0 = always take the order-free head reconstruction (tests)
   uint64_t *dbg = nullptr;  // device buffer of the optional in-kernel profile (32 x u64)
   void *ws = nullptr;       // deflate workspace (hash heads / chains / command queues)
@@ -97,6 +114,9 @@ const char *md_status_string(int s) {
   case MD_INVALID_DISTANCE_CODE: return "Invalid distance code";
   case MD_INVALID_HEADER: return "Invalid Zlib header";
   case MD_INVALID_CHECKSUM: return "Invalid checksum";
+  case MD_INVALID_GZIP_HEADER: return "Invalid GZip header";
+  case MD_INVALID_GZIP_HEADER_CHECKSUM: return "Invalid GZip header checksum";
+  case MD_INVALID_SIZE: return "Invalid input size";
   case MD_E_INVALID_ARGUMENT: return "Invalid argument";
   case MD_E_NO_DEVICE: return "No gfx950 device";
   case MD_E_HIP: return "HIP runtime error";
@@ -170,6 +190,8 @@ void md_destroy(md_ctx *ctx) {
   if (ctx->ws) hipFree(ctx->ws);
   if (ctx->log) hipFree(ctx->log);
   if (ctx->dbg) hipFree(ctx->dbg);
+  if (ctx->gz_tmp) hipFree(ctx->gz_tmp);
+  if (ctx->gz_hdr_dev) hipFree(ctx->gz_hdr_dev);
   if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -241,19 +263,51 @@ int md_get_profile(md_ctx *ctx, uint64_t *out32) {
   return MD_OK;
 }
 
+// per-stream GZip scratch: body_off[n] u64, body_len[n] u64, hstatus[n] i32, crc[n] u32
+static int gz_scratch(md_ctx *ctx, size_t n) {
+  const size_t need = n * 24;
+  if (need > ctx->gz_tmp_bytes) {
+    if (ctx->gz_tmp) {
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+      HIP_TRY(ctx, hipFree(ctx->gz_tmp));
+      ctx->gz_tmp = nullptr;
+      ctx->gz_tmp_bytes = 0;
+    }
+    if (hipMalloc(&ctx->gz_tmp, need) != hipSuccess) return fail(ctx, MD_E_OUT_OF_MEMORY, "hipMalloc(gzip scratch)");
+    ctx->gz_tmp_bytes = need;
+  }
+  return MD_OK;
+}
+
 int md_inflate_batch_device(md_ctx *ctx, int format, size_t n, const uint8_t *d_in,
                             const uint64_t *d_in_off, const uint64_t *d_in_len, uint8_t *d_out,
                             const uint64_t *d_out_off, const uint64_t *d_out_cap,
                             uint64_t *d_out_len, uint64_t *d_consumed, int32_t *d_status,
                             uint32_t *d_checksum) {
   if (!ctx) return MD_E_INVALID_ARGUMENT;
-  if (format != MD_FORMAT_DEFLATE && format != MD_FORMAT_ZLIB)
+  if (format != MD_FORMAT_DEFLATE && format != MD_FORMAT_ZLIB && format != MD_FORMAT_GZIP)
     return fail(ctx, MD_E_INVALID_ARGUMENT, "unknown format");
   if (n == 0) return MD_OK;
   if (n > 0x7fffffffull) return fail(ctx, MD_E_INVALID_ARGUMENT, "too many streams in one batch");
   if (!d_in_off || !d_in_len || !d_out_off || !d_out_cap || !d_out_len || !d_consumed || !d_status)
     return fail(ctx, MD_E_INVALID_ARGUMENT, "null descriptor array");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (format == MD_FORMAT_GZIP) {
+    // Gz.Inf = header, De.Inf on the body, checksum (lib/gz.ml:463-531, :344-356)
+    int rc = gz_scratch(ctx, n);
+    if (rc != MD_OK) return rc;
+    uint64_t *body_off = (uint64_t *)ctx->gz_tmp, *body_len = body_off + n;
+    int32_t *hstatus = (int32_t *)(body_len + n);
+    int e = md_launch_gz_header((uint32_t)n, d_in, d_in_off, d_in_len, body_off, body_len, hstatus, ctx->stream);
+    if (e != 0) return fail(ctx, MD_E_HIP, "gz header kernel launch", (hipError_t)e);
+    rc = md_inflate_batch_device(ctx, MD_FORMAT_DEFLATE, n, d_in, body_off, body_len, d_out, d_out_off, d_out_cap,
+                                 d_out_len, d_consumed, d_status, nullptr);
+    if (rc != MD_OK) return rc;
+    e = md_launch_gz_finish((uint32_t)n, d_in, d_in_off, d_in_len, body_off, hstatus, d_out, d_out_off, d_out_len,
+                            d_consumed, d_status, d_checksum, ctx->stream);
+    if (e != 0) return fail(ctx, MD_E_HIP, "gz finish kernel launch", (hipError_t)e);
+    return MD_OK;
+  }
   int rc;
   if (ctx->kernel == 3) {
     size_t need = n * (size_t)ctx->log_records * md_inflate_log_record_bytes();
@@ -339,14 +393,76 @@ int md_inflate_batch_host(md_ctx *ctx, int format, size_t n, const uint8_t *h_in
   return MD_OK;
 }
 
+// host-side CRC-32 of the few header bytes (the CRC16 of lib/gz.ml:771-789 is its upper half)
+static uint32_t host_crc32(const uint8_t *p, size_t n) {
+  uint32_t c = 0xffffffffu;
+  for (size_t i = 0; i < n; i++) {
+    c ^= p[i];
+    for (int k = 0; k < 8; k++) c = (c >> 1) ^ (0xedb88320u & (0u - (c & 1)));
+  }
+  return c ^ 0xffffffffu;
+}
+static void gz_hdr_crc16(md_ctx *ctx) {
+  const uint32_t body = ctx->gz_hdr_len - 2;  // fixed bytes + name\0 + comment\0
+  const uint32_t c16 = (host_crc32(ctx->gz_hdr, body) & 0xffff0000u) >> 16;
+  ctx->gz_hdr[body] = (uint8_t)(c16 >> 8);
+  ctx->gz_hdr[body + 1] = (uint8_t)c16;
+}
+
+int md_gz_set_header(md_ctx *ctx, uint32_t mtime, int os, int hcrc, int ascii, const char *filename,
+                     const char *comment) {
+  if (!ctx) return MD_E_INVALID_ARGUMENT;
+  const size_t nl = filename ? strlen(filename) : 0, cl = comment ? strlen(comment) : 0;
+  if (nl > 255 || cl > 255 || os < 0 || os > 255) return fail(ctx, MD_E_INVALID_ARGUMENT, "gzip header field out of range");
+  uint8_t *h = ctx->gz_hdr;
+  // flg, lib/gz.ml:851-857; mtime big-endian, lib/gz.ml:801
+  h[0] = 0x1f;
+  h[1] = 0x8b;
+  h[2] = 8;
+  h[3] = (uint8_t)((ascii ? 1 : 0) | (hcrc ? 2 : 0) | (filename ? 8 : 0) | (comment ? 16 : 0));
+  h[4] = (uint8_t)(mtime >> 24);
+  h[5] = (uint8_t)(mtime >> 16);
+  h[6] = (uint8_t)(mtime >> 8);
+  h[7] = (uint8_t)mtime;
+  h[8] = 0;
+  h[9] = (uint8_t)os;
+  uint32_t p = 10;
+  if (filename) {
+    memcpy(h + p, filename, nl + 1);
+    p += (uint32_t)nl + 1;
+  }
+  if (comment) {
+    memcpy(h + p, comment, cl + 1);
+    p += (uint32_t)cl + 1;
+  }
+  if (hcrc) p += 2;
+  ctx->gz_hdr_len = p;
+  return MD_OK;
+}
+
+int md_crc32_batch_device(md_ctx *ctx, size_t n, const uint8_t *d_data, const uint64_t *d_off,
+                          const uint64_t *d_len, uint32_t *d_crc) {
+  if (!ctx) return MD_E_INVALID_ARGUMENT;
+  if (n == 0) return MD_OK;
+  if (n > 0x7fffffffull || !d_off || !d_len || !d_crc) return fail(ctx, MD_E_INVALID_ARGUMENT, "bad crc32 batch");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int e = md_launch_crc32((uint32_t)n, d_data, d_off, d_len, d_crc, ctx->stream);
+  if (e != 0) return fail(ctx, MD_E_HIP, "crc32 kernel launch", (hipError_t)e);
+  return MD_OK;
+}
+
 int md_deflate_batch_device(md_ctx *ctx, int format, int level, int queue_len, int driver,
                             int dynamic, size_t n, const uint8_t *d_in, const uint64_t *d_in_off,
                             const uint64_t *d_in_len, uint8_t *d_out, const uint64_t *d_out_off,
                             const uint64_t *d_out_cap, uint64_t *d_out_len, int32_t *d_status,
                             uint32_t *d_checksum) {
   if (!ctx) return MD_E_INVALID_ARGUMENT;
-  if (format != MD_FORMAT_DEFLATE && format != MD_FORMAT_ZLIB)
+  if (format != MD_FORMAT_DEFLATE && format != MD_FORMAT_ZLIB && format != MD_FORMAT_GZIP)
     return fail(ctx, MD_E_INVALID_ARGUMENT, "unknown format");
+  if (format == MD_FORMAT_GZIP) {  // Gz.Def's driver is Zl's with block_of_frequencies (lib/gz.ml:724-729)
+    driver = MD_DRIVER_ZL;
+    dynamic = 1;
+  }
   if (level < 0 || level > 9)  // Lz77.state: "Invalid level of compression", lib/de.ml:4477
     return fail(ctx, MD_E_INVALID_ARGUMENT, "Invalid level of compression");
   if (queue_len < 4 || queue_len > (1 << 20) || (queue_len & (queue_len - 1)))  // lib/de.ml:2286-2288
@@ -368,9 +484,26 @@ int md_deflate_batch_device(md_ctx *ctx, int format, int level, int queue_len, i
     if (hipMalloc(&ctx->ws, need) != hipSuccess) return fail(ctx, MD_E_OUT_OF_MEMORY, "hipMalloc(deflate workspace)");
     ctx->ws_bytes = need;
   }
+  const uint8_t *gz_hdr = nullptr;
+  uint32_t *gz_crc = nullptr;
+  if (format == MD_FORMAT_GZIP) {
+    int grc = gz_scratch(ctx, n);
+    if (grc != MD_OK) return grc;
+    gz_crc = (uint32_t *)((uint8_t *)ctx->gz_tmp + n * 20);
+    if (!ctx->gz_hdr_dev && hipMalloc((void **)&ctx->gz_hdr_dev, sizeof ctx->gz_hdr) != hipSuccess)
+      return fail(ctx, MD_E_OUT_OF_MEMORY, "hipMalloc(gzip header)");
+    ctx->gz_hdr[8] = level == 9 ? 2 : 0;  // xfl, lib/gz.ml:888-890
+    if (ctx->gz_hdr[3] & 2) gz_hdr_crc16(ctx);
+    // the stream orders this copy before the kernel; the host buffer lives in the context
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->gz_hdr_dev, ctx->gz_hdr, ctx->gz_hdr_len, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    gz_hdr = ctx->gz_hdr_dev;
+    int e = md_launch_crc32((uint32_t)n, d_in, d_in_off, d_in_len, gz_crc, ctx->stream);
+    if (e != 0) return fail(ctx, MD_E_HIP, "crc32 kernel launch", (hipError_t)e);
+  }
   int rc = md_launch_deflate(format, level, queue_len, driver, dynamic ? 1 : 0, (uint32_t)n, d_in, d_in_off,
                              d_in_len, d_out, d_out_off, d_out_cap, d_out_len, d_status, d_checksum,
-                             ctx->ws, ctx->dbg, ctx->test_flags, ctx->stream);
+                             ctx->ws, ctx->dbg, ctx->test_flags, gz_hdr, ctx->gz_hdr_len, gz_crc, ctx->stream);
   if (rc != 0) return fail(ctx, MD_E_HIP, "deflate kernel launch", (hipError_t)rc);
   return MD_OK;
 }
@@ -460,6 +593,59 @@ int md_de_inf_ns_inflate(md_ctx *ctx, const uint8_t *src, size_t src_len, uint8_
 int md_zl_inf_ns_inflate(md_ctx *ctx, const uint8_t *src, size_t src_len, uint8_t *dst,
                          size_t dst_cap, size_t *consumed, size_t *written) {
   return inflate_one(ctx, MD_FORMAT_ZLIB, src, src_len, dst, dst_cap, consumed, written);
+}
+
+int md_gz_higher_compress(md_ctx *ctx, int level, int queue_len, const uint8_t *src, size_t src_len,
+                          uint8_t *dst, size_t dst_cap, size_t *written) {
+  return deflate_one(ctx, MD_FORMAT_GZIP, level, queue_len, MD_DRIVER_ZL, 1, src, src_len, dst, dst_cap, written);
+}
+
+// The accessors of a finished Gz.Inf decoder (filename / comment / os / extra, lib/gz.ml:612-633):
+// where the header fields sit in src.  Framing only — the kernels have validated the header.
+static void gz_meta_of(const uint8_t *s, size_t n, md_gz_meta *m) {
+  memset(m, 0, sizeof *m);
+  if (n < 10) return;
+  m->flg = s[3];
+  m->mtime = ((uint32_t)s[4] << 24) | ((uint32_t)s[5] << 16) | ((uint32_t)s[6] << 8) | s[7];
+  m->xfl = s[8];
+  m->os = s[9];
+  size_t p = 10;
+  if (m->flg & 4) {
+    if (n - p < 2) return;
+    const size_t xl = ((size_t)s[p] << 8) | s[p + 1];
+    p += 2;
+    if (n - p < xl) return;
+    m->has_extra = 1;
+    m->extra_off = p;
+    m->extra_len = xl;
+    p += xl;
+  }
+  for (int which = 0; which < 2; which++) {
+    if (!(m->flg & (which == 0 ? 8u : 16u))) continue;
+    size_t q = p;
+    while (q < n && s[q] != 0) q++;
+    if (q >= n) return;
+    if (which == 0) {
+      m->has_name = 1;
+      m->name_off = p;
+      m->name_len = q - p;
+    } else {
+      m->has_comment = 1;
+      m->comment_off = p;
+      m->comment_len = q - p;
+    }
+    p = q + 1;
+  }
+}
+
+int md_gz_higher_uncompress(md_ctx *ctx, const uint8_t *src, size_t src_len, uint8_t *dst, size_t dst_cap,
+                            size_t *consumed, size_t *written, md_gz_meta *meta) {
+  int st = inflate_one(ctx, MD_FORMAT_GZIP, src, src_len, dst, dst_cap, consumed, written);
+  if (meta) {
+    memset(meta, 0, sizeof *meta);
+    if (st == MD_OK) gz_meta_of(src, src_len, meta);
+  }
+  return st;
 }
 
 }  // extern "C"

@@ -1156,7 +1156,8 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
     const uint64_t *__restrict__ out_off, const uint64_t *__restrict__ out_cap,
     uint64_t *__restrict__ out_len, int32_t *__restrict__ status, uint32_t *__restrict__ checksum,
     uint32_t *__restrict__ ws_head, uint32_t *__restrict__ ws_prev, int *__restrict__ ws_queue,
-    uint64_t *__restrict__ dbg, int test_flags) {
+    uint64_t *__restrict__ dbg, int test_flags, const uint8_t *__restrict__ gz_hdr, uint32_t gz_hdr_len,
+    const uint32_t *__restrict__ gz_crc) {
   __shared__ DS ds;
   // optional phase profile of stream 0 (md_set_option "profile"): [0] setup [1] look-ahead [2] bulk
   // literal runs [3] matcher/driver (lane 0) [4] bit packing [5] trees, in clock ticks; [8..] event counts
@@ -1237,6 +1238,10 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
       dst[1] = (uint8_t)h;
     }
     hdr = 2;
+  } else if (format == MD_FORMAT_GZIP) {
+    // Gz.Def header (lib/gz.ml:796-812), prepared by md_gz_set_header
+    for (uint32_t i = lane; i < gz_hdr_len && i < cap; i += kWave) dst[i] = gz_hdr[i];
+    hdr = gz_hdr_len;
   }
   Run run;
   const bool room = cap >= hdr;
@@ -1560,9 +1565,24 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
         total += 4;
       }
     }
+    uint32_t sum = adler;
+    if (format == MD_FORMAT_GZIP) {
+      sum = gz_crc[sid];
+      if (st == MD_OK) {
+        // Gz.Def checksum (lib/gz.ml:715-722): CRC-32, then the input size mod 2^32, little-endian
+        if (cap - total < 8) st = MD_UNEXPECTED_END_OF_OUTPUT;
+        else {
+          for (int k = 0; k < 4; k++) {
+            dst[total + k] = (uint8_t)(sum >> (8 * k));
+            dst[total + 4 + k] = (uint8_t)(slen >> (8 * k));
+          }
+          total += 8;
+        }
+      }
+    }
     out_len[sid] = st == MD_OK ? total : 0;
     status[sid] = st;
-    if (checksum) checksum[sid] = adler;
+    if (checksum) checksum[sid] = sum;
   }
 }
 
@@ -1577,13 +1597,14 @@ extern "C" int md_launch_deflate(int format, int level, int qcap, int driver, in
                                  const uint8_t *in, const uint64_t *in_off, const uint64_t *in_len,
                                  uint8_t *out, const uint64_t *out_off, const uint64_t *out_cap,
                                  uint64_t *out_len, int32_t *status, uint32_t *checksum, void *ws,
-                                 uint64_t *dbg, int test_flags, hipStream_t stream) {
+                                 uint64_t *dbg, int test_flags, const uint8_t *gz_hdr, uint32_t gz_hdr_len,
+                                 const uint32_t *gz_crc, hipStream_t stream) {
   if (n == 0) return 0;
   uint32_t *head = (uint32_t *)ws;
   uint32_t *prev = head + (size_t)n * md::defl::HASH_SIZE;
   int *queue = (int *)(prev + (size_t)n * md::defl::WSIZE);
   hipLaunchKernelGGL(md::defl::deflate_kernel, dim3(n), dim3(md::defl::kWave), 0, stream, format, level,
                      qcap, driver, dynamic, n, in, in_off, in_len, out, out_off, out_cap, out_len, status,
-                     checksum, head, prev, queue, dbg, test_flags);
+                     checksum, head, prev, queue, dbg, test_flags, gz_hdr, gz_hdr_len, gz_crc);
   return (int)hipGetLastError();
 }

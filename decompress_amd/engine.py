@@ -6,6 +6,7 @@ from . import _lib
 
 FORMAT_DEFLATE = 0
 FORMAT_ZLIB = 1
+FORMAT_GZIP = 2
 DRIVER_ZL, DRIVER_HIGHER, DRIVER_CLI = 0, 1, 2
 
 # variant names of De.Inf.Ns.error (lib/de.ml:1548-1555) + Zl.Inf.Ns.error (lib/zl.ml:383)
@@ -14,6 +15,7 @@ STATUS_NAMES = {
     3: "Invalid_kind_of_block", 4: "Invalid_dictionary",
     5: "Invalid_complement_of_length", 6: "Invalid_distance",
     7: "Invalid_distance_code", 8: "Invalid_header", 9: "Invalid_checksum",
+    10: "Invalid GZip header", 11: "Invalid GZip header checksum", 12: "Invalid input size",
 }
 
 
@@ -53,6 +55,18 @@ class Engine:
         if rc != 0:
             raise Error("%s: %s" % (self.lib.md_status_string(rc).decode(),
                                     self.lib.md_last_error_string(self.ctx).decode()))
+
+    def gz_set_header(self, mtime=0, os=3, hcrc=False, ascii=False, filename=None, comment=None):
+        """Header fields of every later FORMAT_GZIP deflate (Gz.Def.encoder's, lib/gz.ml:859-918)."""
+        self._check(self.lib.md_gz_set_header(self.ctx, int(mtime) & 0xffffffff, int(os), int(hcrc), int(ascii),
+                                              filename, comment))
+
+    def crc32_batch(self, d_data, d_off, d_len):
+        """Checkseum.Crc32 of n device-resident buffers -> uint32 tensor (device)."""
+        n = d_off.numel()
+        crc = self.torch.empty(n, dtype=self.torch.int32, device=self.device)
+        self._check(self.lib.md_crc32_batch_device(self.ctx, n, _ptr(d_data), _ptr(d_off), _ptr(d_len), _ptr(crc)))
+        return crc
 
     def set_option(self, key, value):
         self._check(self.lib.md_set_option(self.ctx, key.encode(), int(value)))

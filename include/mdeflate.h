@@ -41,7 +41,11 @@ enum {
   MD_INVALID_DISTANCE = 6,
   MD_INVALID_DISTANCE_CODE = 7,
   MD_INVALID_HEADER = 8,   /* Zl: "Invalid Zlib header", lib/zl.ml:183 */
-  MD_INVALID_CHECKSUM = 9  /* Zl: "Invalid checksum", lib/zl.ml:179-181 */
+  MD_INVALID_CHECKSUM = 9, /* Zl: "Invalid checksum", lib/zl.ml:179-181; Gz: lib/gz.ml:287-289 */
+  /* Gz.Inf's `Malformed strings, lib/gz.ml:284-296 */
+  MD_INVALID_GZIP_HEADER = 10,          /* "Invalid GZip header" */
+  MD_INVALID_GZIP_HEADER_CHECKSUM = 11, /* "Invalid GZip header checksum" */
+  MD_INVALID_SIZE = 12                  /* "Invalid input size (expect:.., inflated:..)" */
 };
 
 /* Call-level errors (negative): misuse raises Invalid_argument in the
@@ -56,7 +60,13 @@ enum {
 /* Container formats */
 enum {
   MD_FORMAT_DEFLATE = 0, /* raw RFC1951: De.Inf.Ns.inflate, lib/de.ml:1807-1822 */
-  MD_FORMAT_ZLIB = 1     /* RFC1950: Zl.Inf.Ns.inflate, lib/zl.ml:400-417 */
+  MD_FORMAT_ZLIB = 1,    /* RFC1950: Zl.Inf.Ns.inflate, lib/zl.ml:400-417 */
+  MD_FORMAT_GZIP = 2     /* RFC1952 as lib/gz.ml reads and writes it: Gz.Inf (lib/gz.ml:248-633),
+                          * Gz.Def (lib/gz.ml:636-918).  Inflate: checksum[i] = CRC-32 of the output;
+                          * the body follows De.Inf.Ns status semantics.  Deflate: header from
+                          * md_gz_set_header, body = the Zl driver's with dynamic blocks (Gz.Def's
+                          * make_block, lib/gz.ml:724-729), CRC-32 + ISIZE trailer; `driver` and
+                          * `dynamic` are ignored, checksum[i] = CRC-32 of the input. */
 };
 
 /* The reference's three encoder drivers: they decide WHEN a new block is sent, hence the
@@ -163,6 +173,36 @@ int md_de_higher_compress(md_ctx *ctx, int queue_len, const uint8_t *src, size_t
                           uint8_t *dst, size_t dst_cap, size_t *written);
 int md_zl_higher_compress(md_ctx *ctx, int level, int dynamic, int queue_len, const uint8_t *src,
                           size_t src_len, uint8_t *dst, size_t dst_cap, size_t *written);
+
+/* ---- GZip (lib/gz.ml) ---- */
+
+/* The header fields Gz.Def.encoder takes (lib/gz.ml:859-918): ?ascii ?hcrc ?filename ?comment
+ * ~mtime os; used by every later MD_FORMAT_GZIP deflate of this context.  filename / comment
+ * may be NULL (absent; both must be NUL-free and < 256 bytes).  Default: mtime 0, os 3 (Unix),
+ * nothing else.  XFL follows the level (2 for level 9, else 0, lib/gz.ml:888-890). */
+int md_gz_set_header(md_ctx *ctx, uint32_t mtime, int os, int hcrc, int ascii, const char *filename,
+                     const char *comment);
+
+/* What Gz.Inf.filename / comment / os / extra report (lib/gz.ml:612-633): offsets into src. */
+typedef struct md_gz_meta {
+  uint32_t flg, mtime, xfl, os;
+  int has_extra, has_name, has_comment;
+  size_t extra_off, extra_len, name_off, name_len, comment_off, comment_len;
+} md_gz_meta;
+
+/* Single-buffer mirrors (host pointers, batch of one):
+ *   Gz.Higher.compress ?level ?filename ?comment ~w ~q ... (lib/gz.ml:927-950; NB its ?level
+ *   defaults to 0 there — pass the level you mean)
+ *   Gz.Higher.uncompress ~refill ~flush i o            (lib/gz.ml:959-982); meta may be NULL. */
+int md_gz_higher_compress(md_ctx *ctx, int level, int queue_len, const uint8_t *src, size_t src_len,
+                          uint8_t *dst, size_t dst_cap, size_t *written);
+int md_gz_higher_uncompress(md_ctx *ctx, const uint8_t *src, size_t src_len, uint8_t *dst, size_t dst_cap,
+                            size_t *consumed, size_t *written, md_gz_meta *meta);
+
+/* Checkseum.Crc32 of n buffers resident in HBM (call sites lib/gz.ml:503, :682): crc[i] =
+ * CRC-32 of d_data[off[i], off[i] + len[i]).  Asynchronous on the context's stream. */
+int md_crc32_batch_device(md_ctx *ctx, size_t n, const uint8_t *d_data, const uint64_t *d_off,
+                          const uint64_t *d_len, uint32_t *d_crc);
 
 #ifdef __cplusplus
 }
