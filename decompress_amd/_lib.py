@@ -48,6 +48,7 @@ SYMBOLS = [
     ("md_gz_higher_uncompress", ctypes.c_int,
      [c_vp, c_vp, c_sz, c_vp, c_sz, ctypes.POINTER(c_sz), ctypes.POINTER(c_sz), c_vp]),
     ("md_crc32_batch_device", ctypes.c_int, [c_vp, c_sz, c_vp, c_vp, c_vp, c_vp]),
+    ("md_deflate_set_matcher", ctypes.c_int, [c_vp, ctypes.c_int]),
 ]
 
 

@@ -35,7 +35,7 @@ extern "C" int md_launch_deflate(int format, int level, int qcap, int driver, in
                                  uint8_t *out, const uint64_t *out_off, const uint64_t *out_cap,
                                  uint64_t *out_len, int32_t *status, uint32_t *checksum, void *ws,
                                  uint64_t *dbg, int test_flags, const uint8_t *gz_hdr, uint32_t gz_hdr_len,
-                                 const uint32_t *gz_crc, hipStream_t stream);
+                                 const uint32_t *gz_crc, int matcher, hipStream_t stream);
 
 extern "C" int md_launch_gz_header(uint32_t n, const uint8_t *in, const uint64_t *in_off, const uint64_t *in_len,
                                    uint64_t *body_off, uint64_t *body_len, int32_t *hstatus, hipStream_t stream);
@@ -61,6 +61,7 @@ struct md_ctx {
   uint8_t gz_hdr[544] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 3};
   uint32_t gz_hdr_len = 10;
   bool gz_hdr_dirty = true;
+  int matcher = MD_MATCHER_DE;
   int test_flags = 0;       // deflate: bit 0 = always take the order-free head reconstruction (tests)
   uint64_t *dbg = nullptr;  // device buffer of the optional in-kernel profile (32 x u64)
   void *ws = nullptr;       // deflate workspace (hash heads / chains / command queues)
@@ -440,6 +441,13 @@ int md_gz_set_header(md_ctx *ctx, uint32_t mtime, int os, int hcrc, int ascii, c
   return MD_OK;
 }
 
+int md_deflate_set_matcher(md_ctx *ctx, int matcher) {
+  if (!ctx) return MD_E_INVALID_ARGUMENT;
+  if (matcher != MD_MATCHER_DE && matcher != MD_MATCHER_LZ) return fail(ctx, MD_E_INVALID_ARGUMENT, "unknown matcher");
+  ctx->matcher = matcher;
+  return MD_OK;
+}
+
 int md_crc32_batch_device(md_ctx *ctx, size_t n, const uint8_t *d_data, const uint64_t *d_off,
                           const uint64_t *d_len, uint32_t *d_crc) {
   if (!ctx) return MD_E_INVALID_ARGUMENT;
@@ -503,7 +511,8 @@ int md_deflate_batch_device(md_ctx *ctx, int format, int level, int queue_len, i
   }
   int rc = md_launch_deflate(format, level, queue_len, driver, dynamic ? 1 : 0, (uint32_t)n, d_in, d_in_off,
                              d_in_len, d_out, d_out_off, d_out_cap, d_out_len, d_status, d_checksum,
-                             ctx->ws, ctx->dbg, ctx->test_flags, gz_hdr, ctx->gz_hdr_len, gz_crc, ctx->stream);
+                             ctx->ws, ctx->dbg, ctx->test_flags, gz_hdr, ctx->gz_hdr_len, gz_crc, ctx->matcher,
+                             ctx->stream);
   if (rc != 0) return fail(ctx, MD_E_HIP, "deflate kernel launch", (hipError_t)rc);
   return MD_OK;
 }

@@ -797,7 +797,8 @@ struct Lz {
   bool eoi;
   int k;
   uint32_t prepared_end;  // positions < prepared_end have their hash_head in the LDS ring
-  uint32_t p_end;         // positions < p_end (= n - 3) can be prepared ahead
+  uint32_t p_end;         // positions < p_end (= n - 3; n - 2 for the Lz matcher) can be prepared ahead
+  int matcher;            // MD_MATCHER_DE: De.Lz77 (lib/de.ml:4013-4515); MD_MATCHER_LZ: Lz (lib/lz.ml)
   int steps;              // steps executed in this lz_compress call (bulk-yield policy)
   uint32_t n_steps, n_lm, n_chain;  // profile: matcher steps, longest_match calls, chain links walked
 };
@@ -820,9 +821,18 @@ __device__ __forceinline__ uint32_t W32(const Lz *z, uint32_t a) {
   }
   return W(z, a) | (W(z, a + 1) << 8) | (W(z, a + 2) << 16) | (W(z, a + 3) << 24);
 }
-__device__ __forceinline__ unsigned hash4(const Lz *z, uint32_t a) {
-  return (uint32_t)(W32(z, a) * 0x9e3779b1u) >> (32 - HASH_BITS);
+// hash of the string at a, from its little-endian first 4 bytes:
+//   De.Lz77  hash4, lib/de.ml:4067-4071: 4 bytes multiplied by 0x9e3779b1, top 15 bits;
+//   Lz       update_hash (lib/lz.ml:153-155, shift 5, 15 bits) rolled over 3 bytes by fill_window's
+//            priming (lib/lz.ml:399-401) + insert_string (lib/lz.ml:297-304) — every string that is
+//            inserted at all is inserted right after its predecessor, so the rolled state is this
+//            pure function of the 3 bytes.
+__device__ __forceinline__ uint32_t hash_of(int matcher, uint32_t w4) {
+  if (matcher == MD_MATCHER_LZ)
+    return (((w4 & 0xff) << 10) ^ (((w4 >> 8) & 0xff) << 5) ^ ((w4 >> 16) & 0xff)) & (HASH_SIZE - 1);
+  return (uint32_t)(w4 * 0x9e3779b1u) >> (32 - HASH_BITS);
 }
+__device__ __forceinline__ unsigned hash4(const Lz *z, uint32_t a) { return hash_of(z->matcher, W32(z, a)); }
 __device__ uint32_t insert_string(const DS *s, const Lz *z, const Ws *ws, uint32_t str) {
   if (str < z->prepared_end) {  // precomputed by the wave; the chain link is published now, in order
     uint32_t res = s->hh[str & (RING - 1)];
@@ -959,9 +969,11 @@ __device__ __forceinline__ int lz_compress(DS *s, Enc *e, Lz *z, const Ws *ws) {
         if (z->eoi) {
           if (z->lookahead == 0) {
             // trailing, lib/de.ml:4257-4266
+            // (Lz.trailing pushes no end-of-block command, lib/lz.ml:348-354: the driver does)
             if (z->match_available) {
-              if (!emit_literal(s, e, (int)W(z, z->strstart - 1))) e->q[e->qw++ & (e->qc - 1)] = Q_EOB;
-            } else e->q[e->qw++ & (e->qc - 1)] = Q_EOB;
+              if (!emit_literal(s, e, (int)W(z, z->strstart - 1)) && z->matcher == MD_MATCHER_DE)
+                e->q[e->qw++ & (e->qc - 1)] = Q_EOB;
+            } else if (z->matcher == MD_MATCHER_DE) e->q[e->qw++ & (e->qc - 1)] = Q_EOB;
             return LZ_END;
           }
         } else {
@@ -1017,7 +1029,7 @@ struct Run {  // the two state machines of one stream (lane 0's registers)
 };
 
 __device__ void stream_begin(Run *r, const Ws *ws, const uint8_t *in, uint32_t n, uint8_t *out, uint32_t cap,
-                             int level, int qcap, int driver) {
+                             int level, int qcap, int driver, int matcher) {
   Enc &e = r->e;
   e.kind = KIND_FIXED;
   e.last = 0;
@@ -1036,6 +1048,8 @@ __device__ void stream_begin(Run *r, const Ws *ws, const uint8_t *in, uint32_t n
   e.q = ws->queue;
   Lz &z = r->z;
   z.level = driver == DRV_HIGHER ? 4 : level;  // H6: De.Higher.compress has no ?level
+  z.matcher = matcher;
+  if (matcher == MD_MATCHER_LZ && z.level < 4) z.level = 4;  // Lz.state: 0..4 are _4, no copy mode (lib/lz.ml:535)
   z.max_chain = c_levels[z.level][0];
   z.max_lazy = c_levels[z.level][1];
   z.good_length = c_levels[z.level][2];
@@ -1047,13 +1061,14 @@ __device__ void stream_begin(Run *r, const Ws *ws, const uint8_t *in, uint32_t n
   z.strstart = 0;
   z.lookahead = 0;
   z.match_start = z.prev_match = 0;
-  z.match_length = z.prev_length = z.match_available = 0;
+  z.match_length = z.prev_length = matcher == MD_MATCHER_LZ ? MIN_MATCH - 1 : 0;  // lib/lz.ml:563-566
+  z.match_available = 0;
   z.eoi = n == 0;
   z.k = LK_ENOUGH;
   z.prepared_end = 0;
   z.steps = 0;
   z.n_steps = z.n_lm = z.n_chain = 0;
-  z.p_end = (z.level != 0 && n >= 4) ? n - 3 : 0;
+  z.p_end = matcher == MD_MATCHER_LZ ? (n >= 3 ? n - 2 : 0) : (z.level != 0 && n >= 4) ? n - 3 : 0;
   r->first = true;
   r->phase = PH_LZ;
 }
@@ -1094,6 +1109,9 @@ __device__ __forceinline__ int stream_step(DS *s, const Ws *ws, Run *r, int driv
       lit_code(s, &e, 256, &r->ol, &r->oc);
       if (res == LZ_END) {
         if (driver == DRV_CLI) e.q[e.qw++ & (e.qc - 1)] = Q_EOB;  // bin/decompress.ml:67
+        else if (z.matcher == MD_MATCHER_LZ &&
+                 !(e.qw != e.qr && g_ldi(e.q + ((e.qw - 1) & (e.qc - 1))) == Q_EOB))
+          e.q[e.qw++ & (e.qc - 1)] = Q_EOB;  // Lz leaves the end-of-block command to its driver
         kind = block_plan(driver, dynamic, z.level, 1);
         if (kind < 0) {
           r->mode = -kind;
@@ -1157,7 +1175,7 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
     uint64_t *__restrict__ out_len, int32_t *__restrict__ status, uint32_t *__restrict__ checksum,
     uint32_t *__restrict__ ws_head, uint32_t *__restrict__ ws_prev, int *__restrict__ ws_queue,
     uint64_t *__restrict__ dbg, int test_flags, const uint8_t *__restrict__ gz_hdr, uint32_t gz_hdr_len,
-    const uint32_t *__restrict__ gz_crc) {
+    const uint32_t *__restrict__ gz_crc, int matcher) {
   __shared__ DS ds;
   // optional phase profile of stream 0 (md_set_option "profile"): [0] setup [1] look-ahead [2] bulk
   // literal runs [3] matcher/driver (lane 0) [4] bit packing [5] trees, in clock ticks; [8..] event counts
@@ -1246,7 +1264,7 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
   Run run;
   const bool room = cap >= hdr;
   if (lane == 0) {
-    if (room) stream_begin(&run, &ws, src, slen, dst + hdr, cap - hdr, level, qcap, driver);
+    if (room) stream_begin(&run, &ws, src, slen, dst + hdr, cap - hdr, level, qcap, driver, matcher);
     ds.ctl[0] = 0;
     ds.ctl[1] = room ? 0 : 1;
     ds.ctl[2] = 0;
@@ -1254,8 +1272,9 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
     ds.zs.bulked = 0;
     for (int i = 0; i < 8; i++) ds.tp[i] = 0;
   }
-  const uint32_t eff_level = driver == DRV_HIGHER ? 4 : level;
-  const uint32_t p_end = (eff_level != 0 && slen >= 4) ? slen - 3 : 0;
+  const uint32_t eff_level = driver == DRV_HIGHER ? 4 : (matcher == MD_MATCHER_LZ && level < 4) ? 4 : level;
+  const uint32_t p_end = matcher == MD_MATCHER_LZ ? (slen >= 3 ? slen - 2 : 0)
+                                                  : (eff_level != 0 && slen >= 4) ? slen - 3 : 0;
   __syncthreads();
   PROF_MARK(0)
   for (;;) {
@@ -1280,7 +1299,10 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
       for (int g = 0; g < PG; g++) {
         const uint32_t pos = pe + g * kWave + lane;
         w4[g] = 0;
-        if ((uint32_t)g < nb && pos < p_end) __builtin_memcpy(&w4[g], src + pos, 4);
+        if ((uint32_t)g < nb && pos < p_end) {
+          if (pos + 4 <= slen) __builtin_memcpy(&w4[g], src + pos, 4);
+          else w4[g] = (uint32_t)src[pos] | ((uint32_t)src[pos + 1] << 8) | ((uint32_t)src[pos + 2] << 16);  // Lz's last string
+        }
       }
       // head[h] <- max(pos), one atomic per position, all steps of the group in flight together.
       // The returned values of a set of equal hashes are >= the head before the set, and one of them
@@ -1290,7 +1312,7 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
 #pragma unroll
       for (int g = 0; g < PG; g++) {
         const uint32_t pos = pe + g * kWave + lane;
-        hv[g] = (uint32_t)(w4[g] * 0x9e3779b1u) >> (32 - HASH_BITS);
+        hv[g] = hash_of(matcher, w4[g]);
         ret[g] = ((uint32_t)g < nb && pos < p_end) ? atomicMax(ws.head + hv[g], pos) : 0xffffffffu;
       }
       bool bad = (test_flags & 1) != 0;
@@ -1598,13 +1620,13 @@ extern "C" int md_launch_deflate(int format, int level, int qcap, int driver, in
                                  uint8_t *out, const uint64_t *out_off, const uint64_t *out_cap,
                                  uint64_t *out_len, int32_t *status, uint32_t *checksum, void *ws,
                                  uint64_t *dbg, int test_flags, const uint8_t *gz_hdr, uint32_t gz_hdr_len,
-                                 const uint32_t *gz_crc, hipStream_t stream) {
+                                 const uint32_t *gz_crc, int matcher, hipStream_t stream) {
   if (n == 0) return 0;
   uint32_t *head = (uint32_t *)ws;
   uint32_t *prev = head + (size_t)n * md::defl::HASH_SIZE;
   int *queue = (int *)(prev + (size_t)n * md::defl::WSIZE);
   hipLaunchKernelGGL(md::defl::deflate_kernel, dim3(n), dim3(md::defl::kWave), 0, stream, format, level,
                      qcap, driver, dynamic, n, in, in_off, in_len, out, out_off, out_cap, out_len, status,
-                     checksum, head, prev, queue, dbg, test_flags, gz_hdr, gz_hdr_len, gz_crc);
+                     checksum, head, prev, queue, dbg, test_flags, gz_hdr, gz_hdr_len, gz_crc, matcher);
   return (int)hipGetLastError();
 }

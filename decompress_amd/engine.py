@@ -7,6 +7,7 @@ from . import _lib
 FORMAT_DEFLATE = 0
 FORMAT_ZLIB = 1
 FORMAT_GZIP = 2
+MATCHER_DE, MATCHER_LZ = 0, 1
 DRIVER_ZL, DRIVER_HIGHER, DRIVER_CLI = 0, 1, 2
 
 # variant names of De.Inf.Ns.error (lib/de.ml:1548-1555) + Zl.Inf.Ns.error (lib/zl.ml:383)
@@ -55,6 +56,10 @@ class Engine:
         if rc != 0:
             raise Error("%s: %s" % (self.lib.md_status_string(rc).decode(),
                                     self.lib.md_last_error_string(self.ctx).decode()))
+
+    def set_matcher(self, matcher):
+        """0 = De.Lz77 (default), 1 = Lz (lib/lz.ml) for every later deflate of this engine."""
+        self._check(self.lib.md_deflate_set_matcher(self.ctx, int(matcher)))
 
     def gz_set_header(self, mtime=0, os=3, hcrc=False, ascii=False, filename=None, comment=None):
         """Header fields of every later FORMAT_GZIP deflate (Gz.Def.encoder's, lib/gz.ml:859-918)."""

@@ -77,6 +77,13 @@ enum {
   MD_DRIVER_CLI = 2     /* bin/decompress.ml:47-75 (Dynamic per fill, Fixed last block) */
 };
 
+/* The reference's two match finders (same queue / histograms / drivers around them). */
+enum {
+  MD_MATCHER_DE = 0, /* De.Lz77, lib/de.ml:4013-4515: 4-byte multiplicative hash (default) */
+  MD_MATCHER_LZ = 1  /* Lz (decompress.lz), lib/lz.ml:136-573: zlib's 3-byte rolling hash, levels 0..4 = 4,
+                      * no copy mode, `End without an end-of-block command (the driver pushes it) */
+};
+
 typedef struct md_ctx md_ctx;
 
 int md_version(void);
@@ -156,6 +163,10 @@ int md_deflate_batch_device(md_ctx *ctx, int format, int level, int queue_len, i
                             const uint64_t *d_in_len, uint8_t *d_out, const uint64_t *d_out_off,
                             const uint64_t *d_out_cap, uint64_t *d_out_len, int32_t *d_status,
                             uint32_t *d_checksum);
+
+/* Match finder of every later deflate of this context: `Lz.state` instead of `De.Lz77.state`
+ * (lib/lz.mli:1-19 has the same shape).  Default MD_MATCHER_DE. */
+int md_deflate_set_matcher(md_ctx *ctx, int matcher);
 
 /* Same with HOST pointers (H2D, kernels, D2H, synchronise). */
 int md_deflate_batch_host(md_ctx *ctx, int format, int level, int queue_len, int driver, int dynamic,

@@ -605,6 +605,7 @@ typedef struct {
   queue_t *q;
   uint32_t crc;
   int k;
+  int matcher; /* ORC_MATCHER_DE (De.Lz77) or ORC_MATCHER_LZ (lib/lz.ml) */
 } lz_t;
 
 static unsigned rd16(const uint8_t *p) { return p[0] | (p[1] << 8); }
@@ -612,6 +613,14 @@ static uint32_t rd32(const uint8_t *p) { return p[0] | (p[1] << 8) | (p[2] << 16
 /* hash4, lib/de.ml:4067-4071 */
 static unsigned hash4(const uint8_t *w, int off) {
   return (uint32_t)(rd32(w + off) * 0x9e3779b1u) >> (32 - HASH_BITS);
+}
+/* lib/lz.ml:153-155 update_hash (shift 5, 15 bits), rolled over the 3 bytes of a string:
+ * insert_string (lib/lz.ml:297-304) updates with w[str + 2] a state that fill_window primed
+ * with the two bytes at strstart (lib/lz.ml:399-401); every string that is inserted at all is
+ * inserted right after its predecessor (skipped inserts only happen within the last
+ * MIN_MATCH - 1 positions of the input), so the rolled value is this pure function. */
+static unsigned hash3(const uint8_t *w, int off) {
+  return (((unsigned)w[off] << 10) ^ ((unsigned)w[off + 1] << 5) ^ w[off + 2]) & (HASH_SIZE - 1);
 }
 static long lz_rem(const lz_t *s) { return s->i_len - s->i_pos + 1; }
 static void lz_eoi(lz_t *s) {
@@ -651,7 +660,7 @@ static int longest_match(lz_t *s, int cur_match) {
   return best_len <= s->lookahead ? best_len : s->lookahead;
 }
 static int insert_string(lz_t *s, int str) {
-  unsigned h = hash4(s->w, str);
+  unsigned h = s->matcher ? hash3(s->w, str) : hash4(s->w, str);
   int res = s->head[h];
   s->prev[str & WMASK] = res;
   s->head[h] = str;
@@ -748,8 +757,8 @@ static int lz_compress(lz_t *s) {
           if (s->match_available) {
             int flush = emit_literal(s, s->w[s->strstart - 1]);
             s->insert = s->strstart < MIN_MATCH - 1 ? s->strstart : MIN_MATCH - 1;
-            if (!flush) q_push(s->q, Q_EOB);
-          } else q_push(s->q, Q_EOB);
+            if (!flush && !s->matcher) q_push(s->q, Q_EOB);
+          } else if (!s->matcher) q_push(s->q, Q_EOB); /* Lz.trailing pushes no EOB, lib/lz.ml:348-354 */
           return LZ_END;
         }
         lz_eoi(s); /* `Await -> the driver signals end of input */
@@ -765,7 +774,7 @@ static int lz_compress(lz_t *s) {
       if (s->lookahead + s->insert >= MIN_MATCH) {
         int str = s->strstart - s->insert, ins = s->insert;
         while (s->lookahead + ins >= MIN_MATCH && ins != 0) {
-          unsigned h = hash4(s->w, str);
+          unsigned h = s->matcher ? hash3(s->w, str) : hash4(s->w, str);
           s->prev[str & WMASK] = s->head[h];
           s->head[h] = str;
           str++;
@@ -789,8 +798,11 @@ static int lz_compress(lz_t *s) {
   }
 }
 
-static lz_t *lz_new(int level, queue_t *q, const uint8_t *src, size_t n) {
+static lz_t *lz_new(int level, queue_t *q, const uint8_t *src, size_t n, int matcher) {
   lz_t *s = (lz_t *)calloc(1, sizeof *s);
+  if (matcher && level < 4) level = 4; /* Lz.state: levels 0..4 are _4, no Copy mode (lib/lz.ml:535) */
+  s->matcher = matcher;
+  if (matcher) s->match_length = s->prev_length = MIN_MATCH - 1; /* lib/lz.ml:563-566 */
   s->level = level;
   s->cfg = lz_levels[level];
   s->i = src;
@@ -835,11 +847,21 @@ static void make_block(int driver, int dynamic, int last, lz_t *s, block_t *b) {
  * Returns a malloc'ed buffer (*out_len bytes); *adler = Adler-32 of the input. */
 uint8_t *orc_deflate_raw(const uint8_t *src, size_t n, int level, int queue_len, int driver,
                          int dynamic, size_t *out_len, uint32_t *adler) {
+  return orc_deflate_raw_m(src, n, level, queue_len, driver, dynamic, ORC_MATCHER_DE, out_len, adler);
+}
+
+/* Same with the match finder chosen: ORC_MATCHER_LZ = lib/lz.ml (`Lz.state` / `Lz.compress`,
+ * SURVEY 8(a) D12) feeding De.Def under the same drivers.  lib/lz.ml has no caller and no test
+ * in the reference; the driver conventions assumed here: the driver pushes the end-of-block
+ * command at `End when the queue does not already end with one (Lz.trailing does not), and
+ * there is no Flat mode (Lz has no level-0 copy). */
+uint8_t *orc_deflate_raw_m(const uint8_t *src, size_t n, int level, int queue_len, int driver,
+                           int dynamic, int matcher, size_t *out_len, uint32_t *adler) {
   init_tables();
   if (level < 0 || level > 9 || queue_len < 4 || (queue_len & (queue_len - 1))) return NULL;
   queue_t q = {(int *)calloc((size_t)queue_len, sizeof(int)), 0, 0, (unsigned)queue_len};
   out_t o = {NULL, 0, 0};
-  lz_t *s = lz_new(driver == DRV_HIGHER ? 4 : level, &q, src, n); /* H6: De.Higher has no ?level */
+  lz_t *s = lz_new(driver == DRV_HIGHER ? 4 : level, &q, src, n, matcher); /* H6: De.Higher has no ?level */
   enc_t e;
   memset(&e, 0, sizeof e);
   e.blk.kind = KIND_FIXED;
@@ -872,6 +894,7 @@ uint8_t *orc_deflate_raw(const uint8_t *src, size_t n, int level, int queue_len,
       }
     } else {
       if (driver == DRV_CLI) q_push(&q, Q_EOB); /* bin/decompress.ml:67: extra EOB */
+      else if (matcher && !q_end_with_eob(&q)) q_push(&q, Q_EOB);
       make_block(driver, dynamic, 1, s, b);
       rc = enc_encode(&e, V_BLOCK, b);
       (void)rc;
@@ -983,7 +1006,7 @@ uint8_t *orc_encode_cmds(const int *cmds, int ncmds, int kind, size_t *out_len) 
 int orc_lz77_cmds(const uint8_t *src, size_t n, int level, int queue_len, int *out, int max) {
   init_tables();
   queue_t q = {(int *)calloc((size_t)queue_len, sizeof(int)), 0, 0, (unsigned)queue_len};
-  lz_t *s = lz_new(level, &q, src, n);
+  lz_t *s = lz_new(level, &q, src, n, ORC_MATCHER_DE);
   int r = lz_compress(s);
   int cnt = -1;
   if (r == LZ_END) {

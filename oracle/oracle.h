@@ -8,10 +8,13 @@
  *
  * Parity pinning: inflate is pinned by the reference's own known-answer vectors
  * (tests/golden/inflate_ns.json, inflate_stream.json, transcribed from
- * test/test_ns.ml and test/test.ml) and by libz on valid streams.  Deflate is
+ * test/test_ns.ml and test/test.ml) and by libz on valid streams.  Deflate BYTES are
  * pinned only by the reference's 4 encoder KATs + 2 tree KATs
- * (tests/golden/deflate_kat.json): beyond those, deflate parity is UNPINNED
- * (no OCaml toolchain in the build image, the reference cannot be run).
+ * (tests/golden/deflate_kat.json): beyond those, deflate byte parity is UNPINNED
+ * (no OCaml toolchain in the build image, the reference cannot be run).  The LZ77
+ * DECISIONS of the matcher shared by De.Lz77 and lib/lz.ml are pinned through libz:
+ * with lib/lz.ml's hash the token stream equals libz's own (tests/test_oracle_lz.py).
+ * GZip framing (gz.c) is pinned by the reference's 5 gzip vectors (tests/golden/gzip.json).
  */
 #ifndef ORACLE_H
 #define ORACLE_H
@@ -79,6 +82,10 @@ enum { ORC_DRV_ZL = 0, ORC_DRV_HIGHER = 1, ORC_DRV_CLI = 2 };
  * under one of the reference's three drivers.  malloc'ed result. */
 uint8_t *orc_deflate_raw(const uint8_t *src, size_t n, int level, int queue_len, int driver,
                          int dynamic, size_t *out_len, uint32_t *adler);
+enum { ORC_MATCHER_DE = 0, ORC_MATCHER_LZ = 1 };
+/* the same with lib/lz.ml's match finder (Lz.state / Lz.compress, lib/lz.ml:136-573) */
+uint8_t *orc_deflate_raw_m(const uint8_t *src, size_t n, int level, int queue_len, int driver,
+                           int dynamic, int matcher, size_t *out_len, uint32_t *adler);
 /* Zl.Def.encode / Zl.Higher.compress (lib/zl.ml:509-555, 634-648) */
 uint8_t *orc_zl_deflate(const uint8_t *src, size_t n, int level, int queue_len, int dynamic,
                         size_t *out_len);

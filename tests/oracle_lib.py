@@ -49,6 +49,9 @@ class Oracle:
         lib.orc_deflate_raw.restype = ctypes.c_void_p
         lib.orc_deflate_raw.argtypes = [ctypes.c_char_p, sz, ci, ci, ci, ci, ctypes.POINTER(sz),
                                         ctypes.POINTER(ctypes.c_uint32)]
+        lib.orc_deflate_raw_m.restype = ctypes.c_void_p
+        lib.orc_deflate_raw_m.argtypes = [ctypes.c_char_p, sz, ci, ci, ci, ci, ci, ctypes.POINTER(sz),
+                                          ctypes.POINTER(ctypes.c_uint32)]
         lib.orc_zl_deflate.restype = ctypes.c_void_p
         lib.orc_zl_deflate.argtypes = [ctypes.c_char_p, sz, ci, ci, ci, ctypes.POINTER(sz)]
         lib.orc_free.argtypes = [ctypes.c_void_p]
@@ -126,11 +129,12 @@ class Oracle:
         self.lib.orc_free(p)
         return out
 
-    def deflate_raw(self, data, level=6, queue=4096, driver=0, dynamic=True):
-        """De.Lz77 + De.Def under one of the reference's drivers -> (raw DEFLATE, adler32 of input)"""
+    def deflate_raw(self, data, level=6, queue=4096, driver=0, dynamic=True, matcher=0):
+        """De.Lz77 (matcher 0) or lib/lz.ml's Lz (matcher 1) + De.Def under one of the reference's
+        drivers -> (raw DEFLATE, adler32 of input)"""
         n, a = ctypes.c_size_t(), ctypes.c_uint32()
-        p = self.lib.orc_deflate_raw(bytes(data), len(data), level, queue, driver, int(dynamic),
-                                     ctypes.byref(n), ctypes.byref(a))
+        p = self.lib.orc_deflate_raw_m(bytes(data), len(data), level, queue, driver, int(dynamic), matcher,
+                                       ctypes.byref(n), ctypes.byref(a))
         assert p
         return self._take(p, n.value), a.value
 

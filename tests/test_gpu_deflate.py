@@ -98,6 +98,26 @@ def test_order_free_head_reconstruction(oracle):
         assert st == 0 and out == oracle.deflate_raw(b, 6)[0]
 
 
+def test_lz_matcher_equals_oracle(oracle):
+    """lib/lz.ml's match finder; the oracle's variant is pinned to libz's own
+    decisions (tests/test_oracle_lz.py), the GPU must produce the oracle's bytes."""
+    import decompress_amd
+    e = decompress_amd.Engine(0)
+    e.set_matcher(1)
+    data = _datasets()
+    names = list(data)
+    for driver in (0, 1, 2):
+        for level in ((4,) if driver == 1 else (0, 3, 4, 6, 9)):
+            for q in (16, 4096):
+                wants = [oracle.deflate_raw(data[k], level, q, driver, matcher=1) for k in names]
+                res = e.deflate_many([data[k] for k in names], level=level, queue=q, driver=driver,
+                                     caps=[len(w[0]) + 3 for w in wants])
+                for k, (st, out, adler), (want, wadler) in zip(names, res, wants):
+                    assert st == 0 and out == want, (k, driver, level, q, len(out), len(want))
+    from decompress_amd import lz
+    assert lz.compress(data["text"], level=6) == oracle.deflate_raw(data["text"], 6, matcher=1)[0]
+
+
 def test_output_too_small(eng):
     from decompress_amd import workloads
     b = workloads.ascii_uniform(1, 10000)
