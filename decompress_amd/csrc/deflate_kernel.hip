@@ -106,8 +106,7 @@ struct DS {
   uint8_t dist_lo[256], dist_hi[256];
   // look-ahead ring of decision-independent matcher inputs, indexed by position & (RING-1)
   uint32_t hh[1024];     // hash_head(p): chain candidate 1
-  uint8_t flg[1024];     // chain pre-walk of p: FL_PASS a candidate shares p's first 3 bytes, FL_ENDED the
-                         // chain left the reach of p within the walked links
+  uint8_t flg[1024];     // look-ahead verdict of p (FL_*)
   uint8_t byt[1024];     // the byte at p (pending literal of the next position)
   uint32_t gmin[64];     // per hash group of one look-ahead step: head value before the step
   uint32_t ctl[5];       // [0] machine strstart, [1] machine state (1 = finished), [2] prepared_end, [3] action,
@@ -127,8 +126,11 @@ struct DS {
   } w;
 };
 constexpr uint32_t RING = 1024;
-enum { FL_PASS = 1, FL_ENDED = 2 };
-constexpr int WALK = 6;  // chain links pre-walked per position
+// look-ahead verdict of a position: FL_ENDED no candidate of its chain shares 3 bytes with it
+// (longest_match cannot improve on any prev_length), FL_MATCH the whole longest_match was run
+// ahead and its result is in the match ring, 0 the matcher has to look for itself
+enum { FL_ENDED = 2, FL_MATCH = 4 };
+constexpr int KSPEC = 128;  // chain links walked ahead per position at most (min(max_chain, KSPEC))
 constexpr int PG = 8;    // look-ahead steps (of 64 positions) prepared together
 
 __device__ __forceinline__ int distance_code(const DS *s, int d1) {
@@ -485,6 +487,7 @@ struct Ws {
   uint32_t *head;  // [HASH_SIZE] absolute position + 0 = NIL (position 0 can never match, like the reference)
   uint32_t *prev;  // [WSIZE]
   int *queue;      // [qcap]
+  uint32_t *mring; // [2][RING] longest_match run ahead: (length << 16) | distance, full / quartered chain
 };
 __device__ __forceinline__ uint32_t g_ld(const uint32_t *p) { return __builtin_nontemporal_load(p); }
 __device__ __forceinline__ int g_ldi(const int *p) { return __builtin_nontemporal_load(p); }
@@ -781,6 +784,20 @@ __device__ void enc_write_wave(DS *s, uint32_t lane) {
   }
 }
 
+// length of the common prefix of a and b, at most MAX_MATCH: what longest_match's compare loop
+// arrives at (lib/de.ml:4139-4155; its 4-byte steps land exactly on str_end).  Reads a[0..259].
+__device__ __forceinline__ uint32_t lcp258(const uint8_t *a, const uint8_t *b) {
+#pragma clang loop unroll(disable)
+  for (uint32_t k = 0; k < 256; k += 4) {
+    uint32_t x, y;
+    __builtin_memcpy(&x, a + k, 4);
+    __builtin_memcpy(&y, b + k, 4);
+    if (x != y) return k + ((uint32_t)__builtin_ctz(x ^ y) >> 3);
+  }
+  if (a[256] != b[256]) return 256;
+  return a[257] != b[257] ? 257 : 258;
+}
+
 // ---------------------------------------------------------------------------
 // De.Lz77, lib/de.ml:4013-4515, in absolute positions.
 struct Lz {
@@ -908,16 +925,25 @@ __device__ __forceinline__ bool lz_deflate(DS *s, Enc *e, Lz *z, const Ws *ws) {
   if (hash_head > z->base && z->prev_length < z->max_lazy && z->strstart - hash_head <= (uint32_t)MAX_DIST) {
     int ml;
     bool fast = false;
-    if (z->prev_length == 2 && z->strstart < z->prepared_end && z->lookahead >= MIN_LOOKAHEAD) {
-      // pre-walked chain: with best_len = 2 a candidate is examined further only when its first
-      // 3 bytes match (lib/de.ml:4133-4137); if no pre-walked candidate does and the chain ends
-      // within them, longest_match returns prev_length unchanged
-      // a candidate the real walk would visit is among the pre-walked ones (the pre-walk's reach
-      // bound p - MAX_DIST is never above the real limit)
-      fast = s->flg[z->strstart & (RING - 1)] == FL_ENDED;
+    ml = z->prev_length;
+    if (z->strstart < z->prepared_end && z->lookahead >= MIN_LOOKAHEAD) {
+      // the wave has run this position's chain ahead (kernel main loop): FL_ENDED — no candidate
+      // shares 3 bytes, nothing can beat prev_length; FL_MATCH — the best candidate of the full
+      // and of the quartered chain (lib/de.ml:4117-4119) are in the match ring.  With prev_length
+      // as the bar, longest_match returns that candidate iff it is strictly longer.
+      const uint32_t r = z->strstart & (RING - 1);
+      const uint32_t f = s->flg[r];
+      if (f == FL_ENDED) fast = true;
+      else if (f == FL_MATCH) {
+        const uint32_t m = g_ld(ws->mring + (z->prev_length >= z->good_length ? RING : 0) + r);
+        if ((int)(m >> 16) > z->prev_length) {
+          ml = (int)(m >> 16);
+          z->match_start = z->strstart - (m & 0xffff);
+        }
+        fast = true;
+      }
     }
-    if (fast) ml = z->prev_length;
-    else ml = longest_match(z, ws, hash_head);
+    if (!fast) ml = longest_match(z, ws, hash_head);
     if (ml <= 5 && ml == MIN_MATCH && z->strstart - z->match_start > (uint32_t)TOO_FAR) z->match_length = MIN_MATCH - 1;
     else z->match_length = ml;
   }
@@ -1028,7 +1054,7 @@ struct Run {  // the two state machines of one stream (lane 0's registers)
   int mode;    // tree mode asked for (TM_*)
 };
 
-__device__ void stream_begin(Run *r, const Ws *ws, const uint8_t *in, uint32_t n, uint8_t *out, uint32_t cap,
+__device__ __forceinline__ void stream_begin(Run *r, const Ws *ws, const uint8_t *in, uint32_t n, uint8_t *out, uint32_t cap,
                              int level, int qcap, int driver, int matcher) {
   Enc &e = r->e;
   e.kind = KIND_FIXED;
@@ -1174,7 +1200,7 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
     const uint64_t *__restrict__ out_off, const uint64_t *__restrict__ out_cap,
     uint64_t *__restrict__ out_len, int32_t *__restrict__ status, uint32_t *__restrict__ checksum,
     uint32_t *__restrict__ ws_head, uint32_t *__restrict__ ws_prev, int *__restrict__ ws_queue,
-    uint64_t *__restrict__ dbg, int test_flags, const uint8_t *__restrict__ gz_hdr, uint32_t gz_hdr_len,
+    uint32_t *__restrict__ ws_mring, uint64_t *__restrict__ dbg, int test_flags, const uint8_t *__restrict__ gz_hdr, uint32_t gz_hdr_len,
     const uint32_t *__restrict__ gz_crc, int matcher) {
   __shared__ DS ds;
   // optional phase profile of stream 0 (md_set_option "profile"): [0] setup [1] look-ahead [2] bulk
@@ -1195,7 +1221,8 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
   uint8_t *dst = out + out_off[sid];
   uint64_t cap64 = out_cap[sid];
   uint32_t cap = cap64 > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)cap64;
-  Ws ws{ws_head + (size_t)sid * HASH_SIZE, ws_prev + (size_t)sid * WSIZE, ws_queue + (size_t)sid * qcap};
+  Ws ws{ws_head + (size_t)sid * HASH_SIZE, ws_prev + (size_t)sid * WSIZE, ws_queue + (size_t)sid * qcap,
+        ws_mring + (size_t)sid * 2 * RING};
 
   // ---- cooperative setup: NIL heads, histograms, code tables, Adler-32 of the input
   for (uint32_t i = lane; i < (uint32_t)HASH_SIZE; i += kWave) ws.head[i] = 0;
@@ -1273,6 +1300,8 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
     for (int i = 0; i < 8; i++) ds.tp[i] = 0;
   }
   const uint32_t eff_level = driver == DRV_HIGHER ? 4 : (matcher == MD_MATCHER_LZ && level < 4) ? 4 : level;
+  const uint32_t max_chain = c_levels[eff_level][0], nice = c_levels[eff_level][3];
+  const uint32_t qlimit = max_chain >> 2, kspec = max_chain < (uint32_t)KSPEC ? max_chain : (uint32_t)KSPEC;
   const uint32_t p_end = matcher == MD_MATCHER_LZ ? (slen >= 3 ? slen - 2 : 0)
                                                   : (eff_level != 0 && slen >= 4) ? slen - 3 : 0;
   __syncthreads();
@@ -1382,9 +1411,25 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
         fl[g] = 0;
       }
       __syncthreads();
-      // pre-walk: stop at the first candidate sharing 3 bytes (the matcher will look for real) or
-      // when the chain leaves the reach of the position
-      for (int lv = 0; lv < WALK; lv++) {
+      // longest_match (lib/de.ml:4110-4174) run ahead for every position, one chain per lane, the
+      // chains of the PG steps in flight together.  The bar is prev_length = 2 and the chain is the
+      // full one; the best candidate after max_chain >> 2 links is kept as well (the matcher walks
+      // the quartered chain when prev_length >= good_length).  A candidate counts when it shares
+      // the first 3 bytes (the 16-bit pre-filters of the reference can only skip candidates that
+      // would not win); the walk ends at the first candidate of nice_length, after max_chain
+      // links, or where the chain leaves the reach of the position.  The window limit is
+      // pos - MAX_DIST whatever the window base: before the first slide the base is 0, after a
+      // slide strstart - base >= MAX_DIST.
+      uint32_t cnt[PG], best[PG], bdist[PG], bestq[PG], bdistq[PG];
+#pragma unroll
+      for (int g = 0; g < PG; g++) {
+        cnt[g] = 0;
+        best[g] = MIN_MATCH - 1;
+        bdist[g] = 0;
+        bestq[g] = MIN_MATCH - 1;
+        bdistq[g] = 0;
+      }
+      for (uint32_t lv = 0; lv < kspec; lv++) {
         bool act[PG];
         bool any = false;
 #pragma unroll
@@ -1404,7 +1449,7 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
           v[g] = 0;
           nx[g] = 0;
           if (act[g]) {
-            __builtin_memcpy(&v[g], src + cw[g], 4);  // candidate < pos <= n - 4
+            __builtin_memcpy(&v[g], src + cw[g], 4);  // candidate < pos <= n - 3
             // link of the candidate: still in the ring if the matcher has not published it yet
             nx[g] = cw[g] >= ss ? ds.hh[cw[g] & (RING - 1)] : g_ld(ws.prev + (cw[g] & WMASK));
           }
@@ -1412,7 +1457,33 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
 #pragma unroll
         for (int g = 0; g < PG; g++) {
           if (act[g]) {
-            if (((v[g] ^ w4[g]) & 0xffffffu) == 0) fl[g] = FL_PASS;
+            const uint32_t pos = pe + g * kWave + lane;
+            if (((v[g] ^ w4[g]) & 0xffffffu) == 0) {
+              if (pos + MIN_LOOKAHEAD > slen) fl[g] = 8;  // too close to the end to compare ahead: the matcher's job
+              else {
+                // scan_end pre-filter (lib/de.ml:4133-4134): a candidate that differs at the end of
+                // the best match so far cannot be longer
+                uint32_t len = 0;
+                bool look = true;
+                if (best[g] >= (uint32_t)MIN_MATCH) {
+                  uint16_t x, y;
+                  __builtin_memcpy(&x, src + pos + best[g] - 1, 2);
+                  __builtin_memcpy(&y, src + cw[g] + best[g] - 1, 2);
+                  look = x == y;
+                }
+                if (look) len = lcp258(src + pos, src + cw[g]);
+                if (len > best[g]) {
+                  best[g] = len;
+                  bdist[g] = pos - cw[g];
+                  if (len >= nice) fl[g] = FL_MATCH;
+                }
+              }
+            }
+            cnt[g]++;
+            if (cnt[g] == qlimit) {
+              bestq[g] = best[g];
+              bdistq[g] = bdist[g];
+            }
             cw[g] = nx[g];
           }
         }
@@ -1423,12 +1494,25 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
           const uint32_t pos = pe + g * kWave + lane;
           const uint32_t lower = pos > (uint32_t)MAX_DIST ? pos - MAX_DIST : 0;
           uint32_t f = fl[g];
-          if (f == 0 && !(cw[g] > lower) &&
-              !(cw[g] == c1[g] && cw[g] != 0 && pos - cw[g] <= (uint32_t)MAX_DIST))
-            f = FL_ENDED;
-          ds.flg[pos & (RING - 1)] = (uint8_t)f;
+          if (f == 0) {
+            // chain exhausted (or never entered), or max_chain links walked: the verdict is final
+            const bool entered = cnt[g] != 0;
+            const bool more = entered ? cw[g] > lower : (cw[g] != 0 && pos - cw[g] <= (uint32_t)MAX_DIST);
+            if (!more || cnt[g] >= max_chain) f = best[g] >= (uint32_t)MIN_MATCH ? FL_MATCH : FL_ENDED;
+          }
+          if (f == FL_MATCH) {
+            if (cnt[g] < qlimit) {
+              bestq[g] = best[g];
+              bdistq[g] = bdist[g];
+            }
+            const uint32_t r = pos & (RING - 1);
+            ws.mring[r] = (best[g] << 16) | bdist[g];
+            ws.mring[RING + r] = (bestq[g] << 16) | bdistq[g];
+          }
+          ds.flg[pos & (RING - 1)] = (uint8_t)(f == FL_MATCH || f == FL_ENDED ? f : 0);
         }
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the match ring has landed before lane 0 reads it
       pe = pe + nb * kWave < p_end ? pe + nb * kWave : p_end;
       pc[0] += nb;
     }
@@ -1612,7 +1696,8 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
 }  // namespace md
 
 extern "C" size_t md_deflate_ws_bytes(uint32_t n, int qcap) {
-  return (size_t)n * ((size_t)md::defl::HASH_SIZE * 4 + (size_t)md::defl::WSIZE * 4 + (size_t)qcap * 4);
+  return (size_t)n * ((size_t)md::defl::HASH_SIZE * 4 + (size_t)md::defl::WSIZE * 4 + (size_t)qcap * 4 +
+                      (size_t)md::defl::RING * 8);
 }
 
 extern "C" int md_launch_deflate(int format, int level, int qcap, int driver, int dynamic, uint32_t n,
@@ -1625,8 +1710,9 @@ extern "C" int md_launch_deflate(int format, int level, int qcap, int driver, in
   uint32_t *head = (uint32_t *)ws;
   uint32_t *prev = head + (size_t)n * md::defl::HASH_SIZE;
   int *queue = (int *)(prev + (size_t)n * md::defl::WSIZE);
+  uint32_t *mring = (uint32_t *)(queue + (size_t)n * qcap);
   hipLaunchKernelGGL(md::defl::deflate_kernel, dim3(n), dim3(md::defl::kWave), 0, stream, format, level,
                      qcap, driver, dynamic, n, in, in_off, in_len, out, out_off, out_cap, out_len, status,
-                     checksum, head, prev, queue, dbg, test_flags, gz_hdr, gz_hdr_len, gz_crc, matcher);
+                     checksum, head, prev, queue, mring, dbg, test_flags, gz_hdr, gz_hdr_len, gz_crc, matcher);
   return (int)hipGetLastError();
 }
