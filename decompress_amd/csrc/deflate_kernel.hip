@@ -961,7 +961,9 @@ __device__ __forceinline__ bool lz_deflate(DS *s, Enc *e, Lz *z, const Ws *ws) {
     z->strstart++;
     return flush;
   } else if (z->match_available) {
-    bool flush = emit_literal(s, e, (int)W(z, z->strstart - 1));
+    // the pending literal: from the look-ahead ring when the position was prepared (no HBM round trip)
+    const uint32_t lp = z->strstart - 1;
+    bool flush = emit_literal(s, e, lp < z->prepared_end ? (int)s->byt[lp & (RING - 1)] : (int)W(z, lp));
     z->strstart++;
     z->lookahead--;
     return flush;
@@ -1024,8 +1026,11 @@ __device__ __forceinline__ int lz_compress(DS *s, Enc *e, Lz *z, const Ws *ws) {
     if (z->level != 0 && z->prepared_end < z->p_end && z->strstart + 260 > z->prepared_end) return LZ_NEED;
     // literal-run state (previous position had no match, its literal is pending): the wave can
     // take the following no-match positions 64 at a time — hand over after one step
+    // (only when the next two positions are such positions: on match-rich input the hand-over
+    // would cost more than the literal)
     if (z->level != 0 && z->steps > 0 && z->match_available && z->match_length == MIN_MATCH - 1 &&
-        z->lookahead > MIN_LOOKAHEAD && z->strstart < z->prepared_end && e->qc - (e->qw - e->qr) >= 3)
+        z->lookahead > MIN_LOOKAHEAD && z->strstart + 1 < z->prepared_end && e->qc - (e->qw - e->qr) >= 3 &&
+        s->flg[z->strstart & (RING - 1)] == FL_ENDED && s->flg[(z->strstart + 1) & (RING - 1)] == FL_ENDED)
       return LZ_NEED;
     z->steps++;
     z->n_steps++;
