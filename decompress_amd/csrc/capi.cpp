@@ -118,6 +118,7 @@ const char *md_status_string(int s) {
   case MD_INVALID_GZIP_HEADER: return "Invalid GZip header";
   case MD_INVALID_GZIP_HEADER_CHECKSUM: return "Invalid GZip header checksum";
   case MD_INVALID_SIZE: return "Invalid input size";
+  case MD_QUEUE_FULL: return "Queue.Full";
   case MD_E_INVALID_ARGUMENT: return "Invalid argument";
   case MD_E_NO_DEVICE: return "No gfx950 device";
   case MD_E_HIP: return "HIP runtime error";

@@ -1055,6 +1055,7 @@ struct Run {  // the two state machines of one stream (lane 0's registers)
   Lz z;
   bool first;
   int phase;
+  bool qfull;  // the reference would have raised Queue.Full
   int ol, oc;  // end-of-block code of the block that was open when new trees were asked for
   int mode;    // tree mode asked for (TM_*)
 };
@@ -1101,6 +1102,7 @@ __device__ __forceinline__ void stream_begin(Run *r, const Ws *ws, const uint8_t
   z.n_steps = z.n_lm = z.n_chain = 0;
   z.p_end = matcher == MD_MATCHER_LZ ? (n >= 3 ? n - 2 : 0) : (z.level != 0 && n >= 4) ? n - 3 : 0;
   r->first = true;
+  r->qfull = false;
   r->phase = PH_LZ;
 }
 
@@ -1139,7 +1141,13 @@ __device__ __forceinline__ int stream_step(DS *s, const Ws *ws, Run *r, int driv
       // new trees have replaced the old ones in DS)
       lit_code(s, &e, 256, &r->ol, &r->oc);
       if (res == LZ_END) {
-        if (driver == DRV_CLI) e.q[e.qw++ & (e.qc - 1)] = Q_EOB;  // bin/decompress.ml:67
+        if (driver == DRV_CLI) {  // bin/decompress.ml:67
+          if (e.qc - (e.qw - e.qr) == 0) {  // Queue.push_exn raises Queue.Full, lib/de.ml:2214-2217
+            r->qfull = true;
+            return ACT_DONE;
+          }
+          e.q[e.qw++ & (e.qc - 1)] = Q_EOB;
+        }
         else if (z.matcher == MD_MATCHER_LZ &&
                  !(e.qw != e.qr && g_ldi(e.q + ((e.qw - 1) & (e.qc - 1))) == Q_EOB))
           e.q[e.qw++ & (e.qc - 1)] = Q_EOB;  // Lz leaves the end-of-block command to its driver
@@ -1665,6 +1673,7 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
   if (lane == 0) {
     uint32_t body = room ? run.e.o_pos : 0;
     int st = !room || run.e.overflow ? MD_UNEXPECTED_END_OF_OUTPUT : MD_OK;
+    if (room && run.qfull) st = MD_QUEUE_FULL;
     uint32_t total = hdr + body;
     if (format == MD_FORMAT_ZLIB && st == MD_OK) {
       if (cap - total < 4) st = MD_UNEXPECTED_END_OF_OUTPUT;

@@ -17,6 +17,7 @@ STATUS_NAMES = {
     5: "Invalid_complement_of_length", 6: "Invalid_distance",
     7: "Invalid_distance_code", 8: "Invalid_header", 9: "Invalid_checksum",
     10: "Invalid GZip header", 11: "Invalid GZip header checksum", 12: "Invalid input size",
+    13: "Queue.Full",
 }
 
 

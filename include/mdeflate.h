@@ -45,7 +45,10 @@ enum {
   /* Gz.Inf's `Malformed strings, lib/gz.ml:284-296 */
   MD_INVALID_GZIP_HEADER = 10,          /* "Invalid GZip header" */
   MD_INVALID_GZIP_HEADER_CHECKSUM = 11, /* "Invalid GZip header checksum" */
-  MD_INVALID_SIZE = 12                  /* "Invalid input size (expect:.., inflated:..)" */
+  MD_INVALID_SIZE = 12,                 /* "Invalid input size (expect:.., inflated:..)" */
+  /* deflate: the reference raises exception De.Queue.Full (lib/de.ml:2211-2217) — only the CLI
+   * driver can, when its unconditional end-of-block push (bin/decompress.ml:67) meets a full queue */
+  MD_QUEUE_FULL = 13
 };
 
 /* Call-level errors (negative): misuse raises Invalid_argument in the

@@ -893,7 +893,17 @@ uint8_t *orc_deflate_raw_m(const uint8_t *src, size_t n, int level, int queue_le
         rc = enc_encode(&e, V_BLOCK, b);
       }
     } else {
-      if (driver == DRV_CLI) q_push(&q, Q_EOB); /* bin/decompress.ml:67: extra EOB */
+      if (driver == DRV_CLI) { /* bin/decompress.ml:67: extra EOB */
+        if (q_available(&q) == 0) { /* Queue.push_exn raises Queue.Full (lib/de.ml:2211, :2231-2236) */
+          free(q.buf);
+          free(s);
+          free(b);
+          free(o.p);
+          *out_len = 0;
+          return NULL;
+        }
+        q_push(&q, Q_EOB);
+      }
       else if (matcher && !q_end_with_eob(&q)) q_push(&q, Q_EOB);
       make_block(driver, dynamic, 1, s, b);
       rc = enc_encode(&e, V_BLOCK, b);

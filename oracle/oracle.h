@@ -41,7 +41,8 @@ enum {
   /* Gz.Inf's `Malformed strings (lib/gz.ml:284-296) */
   ORC_INVALID_GZIP_HEADER = 10,          /* "Invalid GZip header" */
   ORC_INVALID_GZIP_HEADER_CHECKSUM = 11, /* "Invalid GZip header checksum" */
-  ORC_INVALID_SIZE = 12                  /* "Invalid input size (expect:.., inflated:..)" */
+  ORC_INVALID_SIZE = 12,                 /* "Invalid input size (expect:.., inflated:..)" */
+  ORC_QUEUE_FULL = 13                    /* deflate: exception De.Queue.Full (lib/de.ml:2211) */
 };
 
 /* Checkseum.Adler32 (external dep, RFC1950 §8.2); call sites lib/de.ml:453-455 */
@@ -79,7 +80,9 @@ int orc_gz_inflate(const uint8_t *src, size_t n, uint8_t *dst, size_t dst_cap, s
 /* ---- deflate (oracle/de_deflate.c) ---- */
 enum { ORC_DRV_ZL = 0, ORC_DRV_HIGHER = 1, ORC_DRV_CLI = 2 };
 /* Raw DEFLATE body of De.Lz77 (lib/de.ml:4013-4515) + De.Def (lib/de.ml:2354-3038)
- * under one of the reference's three drivers.  malloc'ed result. */
+ * under one of the reference's three drivers.  malloc'ed result; NULL when
+ * the reference would raise De.Queue.Full (the CLI driver's extra end-of-block push into a
+ * full queue, bin/decompress.ml:67). */
 uint8_t *orc_deflate_raw(const uint8_t *src, size_t n, int level, int queue_len, int driver,
                          int dynamic, size_t *out_len, uint32_t *adler);
 enum { ORC_MATCHER_DE = 0, ORC_MATCHER_LZ = 1 };

@@ -135,7 +135,8 @@ class Oracle:
         n, a = ctypes.c_size_t(), ctypes.c_uint32()
         p = self.lib.orc_deflate_raw_m(bytes(data), len(data), level, queue, driver, int(dynamic), matcher,
                                        ctypes.byref(n), ctypes.byref(a))
-        assert p
+        if not p:
+            return None, a.value  # the reference would raise De.Queue.Full
         return self._take(p, n.value), a.value
 
     def zl_deflate(self, data, level=6, queue=4096, dynamic=True):

@@ -56,8 +56,11 @@ def test_bytes_equal_oracle(eng, oracle, driver):
         for q in (16, 4096):
             wants = [oracle.deflate_raw(data[k], level, q, driver) for k in names]
             res = eng.deflate_many([data[k] for k in names], level=level, queue=q, driver=driver,
-                                   caps=[len(w[0]) + 3 for w in wants])
+                                   caps=[len(w[0]) + 3 if w[0] is not None else 64 for w in wants])
             for k, (st, out, adler), (want, wadler) in zip(names, res, wants):
+                if want is None:  # De.Queue.Full in the reference (test_cli_driver_queue_full)
+                    assert (st, out) == (13, b""), (k, level, q)
+                    continue
                 assert st == 0, (k, level, q)
                 assert out == want, (k, level, q, len(out), len(want))
                 assert adler == wadler == zlib.adler32(data[k])
@@ -111,11 +114,24 @@ def test_lz_matcher_equals_oracle(oracle):
             for q in (16, 4096):
                 wants = [oracle.deflate_raw(data[k], level, q, driver, matcher=1) for k in names]
                 res = e.deflate_many([data[k] for k in names], level=level, queue=q, driver=driver,
-                                     caps=[len(w[0]) + 3 for w in wants])
+                                     caps=[len(w[0]) + 3 if w[0] is not None else 64 for w in wants])
                 for k, (st, out, adler), (want, wadler) in zip(names, res, wants):
+                    if want is None:
+                        assert (st, out) == (13, b""), (k, driver, level, q)
+                        continue
                     assert st == 0 and out == want, (k, driver, level, q, len(out), len(want))
     from decompress_amd import lz
     assert lz.compress(data["text"], level=6) == oracle.deflate_raw(data["text"], 6, matcher=1)[0]
+
+
+def test_cli_driver_queue_full(eng, oracle):
+    """bin/decompress.ml:67 pushes an end-of-block command unconditionally at `End; when the final
+    literal has just filled the queue, De.Queue.push_exn raises Queue.Full (lib/de.ml:2214-2217)"""
+    assert oracle.deflate_raw(b"geg", 6, 4, 2)[0] is None
+    st, out, _ = eng.deflate_many([b"geg"], level=6, queue=4, driver=2)[0]
+    assert (st, out) == (13, b"")
+    st, out, _ = eng.deflate_many([b"geg"], level=6, queue=8, driver=2)[0]
+    assert st == 0 and zlib.decompress(out, -15) == b"geg"
 
 
 def test_output_too_small(eng):

@@ -1,0 +1,123 @@
+"""Differential fuzzing of the HIP path against the oracle, in the spirit of the reference's
+fuzz/fuzz.ml + fuzz/fuzz_ns.ml (random bytes must never crash the decoder, anything the
+encoder emits must decode back): thousands of garbage / corrupted streams in one batch, every
+status, count and output byte compared with the oracle.  Needs an MI355X: `pytest -m gpu`."""
+import random
+import zlib
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import decompress_amd
+    return decompress_amd.Engine(0)
+
+
+def _plain(rng, n):
+    kind = rng.randrange(4)
+    if kind == 0:
+        return bytes(rng.getrandbits(8) for _ in range(n))
+    if kind == 1:
+        words = [bytes(rng.choice(b"abcdefgh ") for _ in range(rng.randrange(1, 9))) for _ in range(30)]
+        out = bytearray()
+        while len(out) < n:
+            out += rng.choice(words)
+        return bytes(out[:n])
+    if kind == 2:
+        return bytes([rng.randrange(4)]) * n
+    return bytes(rng.choice(b"01") for _ in range(n))
+
+
+def _corrupt(rng, z):
+    b = bytearray(z)
+    for _ in range(rng.randrange(1, 4)):
+        how = rng.randrange(5)
+        if not b:
+            break
+        i = rng.randrange(len(b))
+        if how == 0:
+            b[i] ^= 1 << rng.randrange(8)
+        elif how == 1:
+            b[i] = rng.getrandbits(8)
+        elif how == 2:
+            del b[i:i + rng.randrange(1, 5)]
+        elif how == 3:
+            b[i:i] = bytes(rng.getrandbits(8) for _ in range(rng.randrange(1, 5)))
+        else:
+            del b[i:]
+    return bytes(b)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_inflate_garbage_and_corruption(eng, oracle, seed):
+    rng = random.Random(seed)
+    srcs, caps = [], []
+    for _ in range(700):  # pure garbage: mostly invalid block kinds / dictionaries / distances
+        n = rng.choice((0, 1, 2, 3, 5, 8, 13, 40, 200, 1500))
+        g = bytearray(rng.getrandbits(8) for _ in range(n))
+        if g and rng.random() < 0.7:
+            g[0] = (g[0] & 0xf8) | rng.choice((1, 3, 5, 4, 2, 0))  # steer BFINAL/BTYPE
+        srcs.append(bytes(g)); caps.append(rng.choice((0, 7, 300, 5000)))
+    for _ in range(500):  # corrupted valid streams of every block kind
+        data = _plain(rng, rng.choice((0, 1, 50, 700, 5000, 40000)))
+        strat = rng.choice((zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE))
+        co = zlib.compressobj(rng.choice((0, 1, 6, 9)), zlib.DEFLATED, -15, rng.choice((1, 8, 9)), strat)
+        z = co.compress(data) + co.flush()
+        srcs.append(_corrupt(rng, z) if rng.random() < 0.85 else z)
+        caps.append(max(0, len(data) + rng.choice((-3, -1, 0, 0, 1, 100))))
+    res = eng.inflate_many(srcs, caps)
+    seen = set()
+    for k, (src, cap, (st, used, out, _)) in enumerate(zip(srcs, caps, res)):
+        ost, oused, oout = oracle.de_inflate(src, cap)
+        assert (st, used) == (ost, oused), (seed, k, len(src), cap, st, ost, used, oused)
+        assert out == oout, (seed, k)
+        seen.add(st)
+    assert seen >= {0, 1, 2, 3, 4, 5, 6, 7}  # every De.Inf.Ns error variant was exercised
+
+
+def test_zlib_and_gzip_frames_corrupted(eng, oracle):
+    import decompress_amd
+    rng = random.Random(77)
+    zs, gs, caps = [], [], []
+    for _ in range(300):
+        data = _plain(rng, rng.choice((0, 10, 3000, 30000)))
+        z = zlib.compress(data, rng.choice((1, 6, 9)))
+        g = oracle.gz_deflate(data, level=rng.choice((1, 4, 6)), name=b"n" if rng.random() < 0.5 else None,
+                              comment=b"c" if rng.random() < 0.3 else None, hcrc=rng.random() < 0.5)
+        zs.append(_corrupt(rng, z) if rng.random() < 0.8 else z)
+        gs.append(_corrupt(rng, g) if rng.random() < 0.8 else g)
+        caps.append(len(data) + rng.choice((0, 0, 5, -1 if data else 0)))
+    for fmt, srcs, ref in ((decompress_amd.FORMAT_ZLIB, zs, oracle.zl_inflate),
+                           (decompress_amd.FORMAT_GZIP, gs, lambda s, c: oracle.gz_inflate(s, c)[:3])):
+        res = eng.inflate_many(srcs, caps, fmt)
+        for k, (src, cap, (st, used, out, _)) in enumerate(zip(srcs, caps, res)):
+            ost, oused, oout = ref(src, cap)
+            assert (st, used) == (ost, oused), (fmt, k, st, ost, used, oused)
+            if st in (0, 9, 12):
+                assert out == oout
+
+
+@pytest.mark.parametrize("seed", [5, 6])
+def test_deflate_random_parameters(oracle, seed):
+    """random data kinds x level x queue x driver x matcher: the oracle's bytes, and they decode"""
+    import decompress_amd
+    rng = random.Random(seed)
+    for matcher in (0, 1):
+        e = decompress_amd.Engine(0)
+        e.set_matcher(matcher)
+        for _ in range(6):
+            level, q, driver = rng.randrange(10), rng.choice((4, 16, 256, 4096, 16384)), rng.randrange(3)
+            dyn = rng.random() < 0.8
+            bufs = [_plain(rng, rng.choice((0, 1, 2, 3, 4, 5, 100, 263, 5000, 33000, 70000))) for _ in range(10)]
+            wants = [oracle.deflate_raw(b, level, q, driver, dyn, matcher)[0] for b in bufs]
+            res = e.deflate_many(bufs, level=level, queue=q, driver=driver, dynamic=dyn,
+                                 caps=[len(w) + 1 if w is not None else 64 for w in wants])
+            for b, w, (st, out, adler) in zip(bufs, wants, res):
+                if w is None:  # De.Queue.Full in the reference (CLI driver's extra EOB into a full queue)
+                    assert st == 13 and out == b""
+                    continue
+                assert st == 0 and out == w, (seed, matcher, level, q, driver, dyn, len(b))
+                assert zlib.decompress(out, -15) == b and adler == zlib.adler32(b)

@@ -118,3 +118,10 @@ def test_drivers_differ(oracle):
     assert len({bytes(v) for v in outs.values()}) == 3
     for v in outs.values():
         assert zlib.decompress(v, -15) == data
+
+
+def test_cli_driver_queue_full(oracle):
+    """the CLI driver's extra end-of-block push into a full queue: De.Queue.Full in the reference"""
+    assert oracle.deflate_raw(b"geg", 6, 4, 2)[0] is None
+    assert oracle.deflate_raw(b"geg", 6, 8, 2)[0] is not None
+    assert oracle.deflate_raw(b"geg", 6, 4, 0)[0] is not None
