@@ -468,6 +468,10 @@ const char *orc_status_string(int s) {
   case ORC_INVALID_GZIP_HEADER: return "Invalid GZip header";
   case ORC_INVALID_GZIP_HEADER_CHECKSUM: return "Invalid GZip header checksum";
   case ORC_INVALID_SIZE: return "Invalid input size";
+  case ORC_QUEUE_FULL: return "Queue.Full";
+  case ORC_LZO_INVALID_INPUT: return "Invalid input";
+  case ORC_LZO_NO_DICTIONARY: return "No dictionary at offset 0 available";
+  case ORC_LZO_OUT_OF_BOUND: return "Input is malformed or output is not large enough";
   default: return "?";
   }
 }

@@ -42,7 +42,11 @@ enum {
   ORC_INVALID_GZIP_HEADER = 10,          /* "Invalid GZip header" */
   ORC_INVALID_GZIP_HEADER_CHECKSUM = 11, /* "Invalid GZip header checksum" */
   ORC_INVALID_SIZE = 12,                 /* "Invalid input size (expect:.., inflated:..)" */
-  ORC_QUEUE_FULL = 13                    /* deflate: exception De.Queue.Full (lib/de.ml:2211) */
+  ORC_QUEUE_FULL = 13,                   /* deflate: exception De.Queue.Full (lib/de.ml:2211) */
+  /* Lzo.error (lib/lzo.ml:4-12) */
+  ORC_LZO_INVALID_INPUT = 14, /* `Malformed "Invalid input" (count, lib/lzo.ml:236) */
+  ORC_LZO_NO_DICTIONARY = 15, /* `Malformed "No dictionary at offset 0 available" (lib/lzo.ml:376) */
+  ORC_LZO_OUT_OF_BOUND = 16   /* `Invalid_argument "Input is malformed or output is not large enough" (lib/lzo.ml:401-402) */
 };
 
 /* Checkseum.Adler32 (external dep, RFC1950 §8.2); call sites lib/de.ml:453-455 */
@@ -96,6 +100,12 @@ uint8_t *orc_zl_deflate(const uint8_t *src, size_t n, int level, int queue_len, 
 uint8_t *orc_gz_deflate(const uint8_t *src, size_t n, int level, int queue_len, uint32_t mtime, int os,
                         int hcrc, int ascii, const char *name, const char *comment, size_t *out_len);
 void orc_free(void *p);
+
+/* ---- LZO1X (oracle/lzo.c) ---- */
+/* Lzo.uncompress input output (lib/lzo.ml:395-403); a failing stream leaves *written = 0 */
+int orc_lzo_uncompress(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, size_t *written);
+/* Lzo.compress in_data out_data wrkmem (lib/lzo.ml:642-660) */
+int orc_lzo_compress(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, size_t *out_len);
 /* De.T.make (lib/de.ml:2013-2068) on a histogram (mutated in place) */
 int orc_tree_make(int length, int max_length, int *freqs, int nfreqs, int *lengths, int *codes);
 /* test/test.ml `encode` / `encode_dynamic`: a command list in one last block */

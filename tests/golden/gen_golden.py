@@ -357,8 +357,36 @@ def gen_gzip():
     print("gzip.json", len(cases))
 
 
+def gen_lzo():
+    """test/test.ml:2033-2065: the one LZO known-answer vector (`expect` / `input` string lists)."""
+    text = open(os.path.join(REF, "test.ml"), encoding="latin-1").read()
+    m = re.search(r"let test_lzo_0 \(\) =", text)
+    line = text.count("\n", 0, m.start()) + 1
+
+    def strings(name):
+        lst = text.index("[", text.index("let %s" % name, m.start()))
+        end = text.index("] in", lst)
+        i, parts = lst + 1, []
+        while True:
+            i = skip_ws_comments(text, i)
+            if i >= end:
+                break
+            if text[i] == ";":
+                i += 1
+                continue
+            b, i = parse_ocaml_string(text, i)
+            parts.append(b)
+        return b"".join(parts)
+    cases = [{"name": "lzo_0_random", "src": strings("input").hex(), "out": strings("expect").hex(), "status": 0,
+              "ref": "test/test.ml:%d" % line}]
+    with open(os.path.join(OUT, "lzo.json"), "w") as f:
+        json.dump(cases, f, indent=1)
+    print("lzo.json", len(cases))
+
+
 def main():
     gen_gzip()
+    gen_lzo()
     if not os.path.isdir(REF):
         sys.exit("reference tree not present; fixtures are already committed")
     ns = gen_ns()

@@ -33,6 +33,37 @@ def load():
     return _LIB
 
 
+class MiniLzo:
+    """oracle/_ref/libminilzo.so — the reference's own LZO oracle (test/minilzo-2.10), built from the
+    reference tree by oracle/Makefile.  TEST INFRASTRUCTURE ONLY."""
+
+    def __init__(self, path):
+        self.lib = ctypes.CDLL(path)
+        sz = ctypes.c_size_t
+        for fn in ("lzo1x_1_compress", "lzo1x_decompress_safe"):
+            f = getattr(self.lib, fn)
+            f.restype = ctypes.c_int
+            f.argtypes = [ctypes.c_char_p, sz, ctypes.c_char_p, ctypes.POINTER(sz), ctypes.c_void_p]
+
+    def compress(self, data):
+        dst = ctypes.create_string_buffer(len(data) + len(data) // 16 + 64 + 3)
+        n = ctypes.c_size_t(len(dst))
+        wrk = ctypes.create_string_buffer(16384 * 8)
+        assert self.lib.lzo1x_1_compress(bytes(data), len(data), dst, ctypes.byref(n), wrk) == 0
+        return dst.raw[: n.value]
+
+    def decompress(self, data, cap):
+        dst = ctypes.create_string_buffer(max(cap, 1))
+        n = ctypes.c_size_t(cap)
+        rc = self.lib.lzo1x_decompress_safe(bytes(data), len(data), dst, ctypes.byref(n), None)
+        return rc, dst.raw[: n.value]
+
+
+def load_minilzo():
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle", "_ref", "libminilzo.so")
+    return MiniLzo(path) if os.path.exists(path) else None
+
+
 class Oracle:
     def __init__(self, lib):
         self.lib = lib
@@ -76,6 +107,27 @@ class Oracle:
                                        ctypes.c_char_p, ctypes.POINTER(sz)]
         lib.orc_status_string.restype = ctypes.c_char_p
         lib.orc_status_string.argtypes = [ci]
+
+    def lzo_uncompress(self, src, cap):
+        """Lzo.uncompress -> (status, bytes)"""
+        self.lib.orc_lzo_uncompress.restype = ctypes.c_int
+        self.lib.orc_lzo_uncompress.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t,
+                                                ctypes.POINTER(ctypes.c_size_t)]
+        dst = ctypes.create_string_buffer(max(cap, 1))
+        w = ctypes.c_size_t()
+        rc = self.lib.orc_lzo_uncompress(bytes(src), len(src), dst, cap, ctypes.byref(w))
+        return rc, dst.raw[: w.value]
+
+    def lzo_compress(self, src, cap=None):
+        """Lzo.compress -> (status, bytes)"""
+        self.lib.orc_lzo_compress.restype = ctypes.c_int
+        self.lib.orc_lzo_compress.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t,
+                                              ctypes.POINTER(ctypes.c_size_t)]
+        cap = len(src) + len(src) // 16 + 64 + 3 if cap is None else cap
+        dst = ctypes.create_string_buffer(max(cap, 1))
+        w = ctypes.c_size_t()
+        rc = self.lib.orc_lzo_compress(bytes(src), len(src), dst, cap, ctypes.byref(w))
+        return rc, dst.raw[: w.value]
 
     def gz_inflate(self, src, cap):
         """Gz.Inf over a whole buffer -> (status, consumed, bytes, meta dict)."""
