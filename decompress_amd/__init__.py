@@ -8,6 +8,6 @@ include/mdeflate.h.  All compute runs in hand-written HIP kernels
 from . import _lib  # noqa: F401
 from .engine import (Engine, Error, STATUS_NAMES, FORMAT_DEFLATE, FORMAT_ZLIB, FORMAT_GZIP,  # noqa: F401
                      DRIVER_ZL, DRIVER_HIGHER, DRIVER_CLI)
-from . import de, zl, gz, lz  # noqa: F401
+from . import de, zl, gz, lz, lzo  # noqa: F401
 
 __all__ = ["Engine", "Error", "de", "zl", "gz", "STATUS_NAMES", "FORMAT_DEFLATE", "FORMAT_ZLIB", "FORMAT_GZIP"]

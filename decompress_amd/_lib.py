@@ -49,6 +49,10 @@ SYMBOLS = [
      [c_vp, c_vp, c_sz, c_vp, c_sz, ctypes.POINTER(c_sz), ctypes.POINTER(c_sz), c_vp]),
     ("md_crc32_batch_device", ctypes.c_int, [c_vp, c_sz, c_vp, c_vp, c_vp, c_vp]),
     ("md_deflate_set_matcher", ctypes.c_int, [c_vp, ctypes.c_int]),
+    ("md_lzo_uncompress_batch_device", ctypes.c_int, [c_vp, c_sz] + [c_vp] * 8),
+    ("md_lzo_compress_batch_device", ctypes.c_int, [c_vp, c_sz] + [c_vp] * 8),
+    ("md_lzo_uncompress", ctypes.c_int, [c_vp, c_vp, c_sz, c_vp, c_sz, ctypes.POINTER(c_sz)]),
+    ("md_lzo_compress", ctypes.c_int, [c_vp, c_vp, c_sz, c_vp, c_sz, ctypes.POINTER(c_sz)]),
 ]
 
 

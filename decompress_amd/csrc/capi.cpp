@@ -46,6 +46,13 @@ extern "C" int md_launch_gz_finish(uint32_t n, const uint8_t *in, const uint64_t
                                    const uint64_t *out_off, uint64_t *out_len, uint64_t *consumed, int32_t *status,
                                    uint32_t *checksum, hipStream_t stream);
 
+extern "C" int md_launch_lzo_uncompress(uint32_t n, const uint8_t *in, const uint64_t *in_off, const uint64_t *in_len,
+                                        uint8_t *out, const uint64_t *out_off, const uint64_t *out_cap,
+                                        uint64_t *out_len, int32_t *status, hipStream_t stream);
+extern "C" int md_launch_lzo_compress(uint32_t n, const uint8_t *in, const uint64_t *in_off, const uint64_t *in_len,
+                                      uint8_t *out, const uint64_t *out_off, const uint64_t *out_cap,
+                                      uint64_t *out_len, int32_t *status, hipStream_t stream);
+
 struct md_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -119,6 +126,9 @@ const char *md_status_string(int s) {
   case MD_INVALID_GZIP_HEADER_CHECKSUM: return "Invalid GZip header checksum";
   case MD_INVALID_SIZE: return "Invalid input size";
   case MD_QUEUE_FULL: return "Queue.Full";
+  case MD_LZO_INVALID_INPUT: return "Invalid input";
+  case MD_LZO_NO_DICTIONARY: return "No dictionary at offset 0 available";
+  case MD_LZO_OUT_OF_BOUND: return "Input is malformed or output is not large enough";
   case MD_E_INVALID_ARGUMENT: return "Invalid argument";
   case MD_E_NO_DEVICE: return "No gfx950 device";
   case MD_E_HIP: return "HIP runtime error";
@@ -656,6 +666,68 @@ int md_gz_higher_uncompress(md_ctx *ctx, const uint8_t *src, size_t src_len, uin
     if (st == MD_OK) gz_meta_of(src, src_len, meta);
   }
   return st;
+}
+
+static int lzo_batch_device(md_ctx *ctx, bool compress, size_t n, const uint8_t *d_in, const uint64_t *d_in_off,
+                            const uint64_t *d_in_len, uint8_t *d_out, const uint64_t *d_out_off,
+                            const uint64_t *d_out_cap, uint64_t *d_out_len, int32_t *d_status) {
+  if (!ctx) return MD_E_INVALID_ARGUMENT;
+  if (n == 0) return MD_OK;
+  if (n > 0x7fffffffull) return fail(ctx, MD_E_INVALID_ARGUMENT, "too many streams in one batch");
+  if (!d_in_off || !d_in_len || !d_out_off || !d_out_cap || !d_out_len || !d_status)
+    return fail(ctx, MD_E_INVALID_ARGUMENT, "null descriptor array");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int e = compress ? md_launch_lzo_compress((uint32_t)n, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap,
+                                                  d_out_len, d_status, ctx->stream)
+                         : md_launch_lzo_uncompress((uint32_t)n, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap,
+                                                    d_out_len, d_status, ctx->stream);
+  if (e != 0) return fail(ctx, MD_E_HIP, "lzo kernel launch", (hipError_t)e);
+  return MD_OK;
+}
+
+int md_lzo_uncompress_batch_device(md_ctx *ctx, size_t n, const uint8_t *d_in, const uint64_t *d_in_off,
+                                   const uint64_t *d_in_len, uint8_t *d_out, const uint64_t *d_out_off,
+                                   const uint64_t *d_out_cap, uint64_t *d_out_len, int32_t *d_status) {
+  return lzo_batch_device(ctx, false, n, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap, d_out_len, d_status);
+}
+int md_lzo_compress_batch_device(md_ctx *ctx, size_t n, const uint8_t *d_in, const uint64_t *d_in_off,
+                                 const uint64_t *d_in_len, uint8_t *d_out, const uint64_t *d_out_off,
+                                 const uint64_t *d_out_cap, uint64_t *d_out_len, int32_t *d_status) {
+  return lzo_batch_device(ctx, true, n, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap, d_out_len, d_status);
+}
+
+static int lzo_one(md_ctx *ctx, bool compress, const uint8_t *src, size_t src_len, uint8_t *dst, size_t dst_cap,
+                   size_t *written) {
+  if (!ctx || !written || (!src && src_len) || (!dst && dst_cap)) return MD_E_INVALID_ARGUMENT;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  DevBuf din, dout, ddesc;
+  // compress over-copies up to 16 bytes past a short literal run: the reference's buffers need that room too
+  if (din.alloc(src_len + 16) != hipSuccess || dout.alloc(dst_cap + 16) != hipSuccess || ddesc.alloc(6 * 8) != hipSuccess)
+    return fail(ctx, MD_E_OUT_OF_MEMORY, "hipMalloc");
+  uint64_t h[5] = {0, src_len, 0, dst_cap, 0};
+  uint64_t *d64 = (uint64_t *)ddesc.p;
+  hipStream_t st = ctx->stream;
+  HIP_TRY(ctx, hipMemcpyAsync(din.p, src, src_len, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(d64, h, sizeof h, hipMemcpyHostToDevice, st));
+  int rc = lzo_batch_device(ctx, compress, 1, (const uint8_t *)din.p, d64, d64 + 1, (uint8_t *)dout.p, d64 + 2, d64 + 3,
+                            d64 + 4, (int32_t *)(d64 + 5));
+  if (rc != MD_OK) return rc;
+  uint64_t out_len = 0;
+  int32_t status = 0;
+  HIP_TRY(ctx, hipMemcpyAsync(&out_len, d64 + 4, 8, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipMemcpyAsync(&status, d64 + 5, 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  if (status == MD_OK && out_len) HIP_TRY(ctx, hipMemcpy(dst, dout.p, (size_t)out_len, hipMemcpyDeviceToHost));
+  *written = (size_t)out_len;
+  return status;
+}
+int md_lzo_uncompress(md_ctx *ctx, const uint8_t *src, size_t src_len, uint8_t *dst, size_t dst_cap,
+                      size_t *written) {
+  return lzo_one(ctx, false, src, src_len, dst, dst_cap, written);
+}
+int md_lzo_compress(md_ctx *ctx, const uint8_t *src, size_t src_len, uint8_t *dst, size_t dst_cap,
+                    size_t *written) {
+  return lzo_one(ctx, true, src, src_len, dst, dst_cap, written);
 }
 
 }  // extern "C"

@@ -1,0 +1,453 @@
+// lzo_kernels.hip — batched LZO1X for gfx950: the reference's Lzo.uncompress / Lzo.compress
+// (lib/lzo.ml), one independent stream per wavefront.
+//
+//   lzo_uncompress_kernel   The instruction stream of LZO is byte-serial, so its interpreter
+//       (`run` over `fiber`, lib/lzo.ml:246-393) is wave-uniform: every lane follows the same
+//       instruction, the opcode bytes come from a 256-byte window of the input held in registers
+//       (one dword per lane, v_readlane to pick a byte).  The work of an instruction is
+//       lane-parallel: a literal run is a coalesced copy input -> output, a match is a copy inside
+//       the output where lane k takes byte k — source byte `o_pos - off + (k mod off)` is always
+//       older than the instruction, whatever the overlap.
+//   lzo_compress_kernel     lzo1x-1 (lib/lzo.ml:578-660): the probe loop is serial by construction
+//       (what is inserted in the dictionary depends on where the previous match ended), so it runs
+//       wave-uniformly with the 16 K-entry u16 dictionary of the current 48 KiB chunk in LDS; match
+//       extension compares 8 bytes per lane (512 per step), literal runs and the trailer are
+//       coalesced copies.
+// Semantics, error cases and quirks are those of the reference as restated in oracle/lzo.c
+// (the decoder state after a literal run behaves as 3, the EOI guard on every instruction, the
+// `< 238` first-byte form, the match extension that stops 20 bytes before the end of a chunk).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mdeflate.h"
+
+namespace md {
+namespace lzo {
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint8_t ld_nt8(const uint8_t *p) { return __builtin_nontemporal_load(p); }
+
+// 256-byte window of the input in registers: lane l holds bytes [wbase + 4l, wbase + 4l + 4)
+struct Win {
+  const uint8_t *src;
+  uint32_t n, lane;
+  uint32_t wbase;  // multiple of 4
+  uint32_t w;
+  __device__ __forceinline__ void fill(uint32_t pos) {
+    wbase = pos & ~3u;
+    const uint32_t a = wbase + 4 * lane;
+    uint32_t v = 0;
+    if (a + 4 <= n) __builtin_memcpy(&v, src + a, 4);
+    else
+      for (uint32_t k = 0; a + k < n; k++) v |= (uint32_t)src[a + k] << (8 * k);
+    w = v;
+  }
+  // byte at pos < n (wave-uniform)
+  __device__ __forceinline__ uint32_t byte(uint32_t pos) {
+    if (pos - wbase >= 256u) fill(pos);
+    const uint32_t d = pos - wbase;
+    return ((uint32_t)__builtin_amdgcn_readlane((int)w, (int)(d >> 2)) >> (8 * (d & 3))) & 0xff;
+  }
+};
+
+struct Dec {
+  Win in;
+  uint8_t *dst;
+  uint32_t cap, i_pos, o_pos, lane;
+  int state;
+};
+
+// transmit (lib/lzo.ml:188-192) with blit's bounds (:81-89)
+__device__ __forceinline__ int transmit(Dec &d, uint32_t len) {
+  if (d.i_pos > d.in.n || len > d.in.n - d.i_pos || len > d.cap - d.o_pos) return MD_LZO_OUT_OF_BOUND;
+  for (uint32_t k = d.lane; k < len; k += kWave) d.dst[d.o_pos + k] = d.in.src[d.i_pos + k];
+  d.i_pos += len;
+  d.o_pos += len;
+  return MD_OK;
+}
+// copy (lib/lzo.ml:194-197): byte-serial LZ77 semantics, all bytes at once
+__device__ __forceinline__ int copy(Dec &d, uint32_t off, uint32_t len) {
+  if (off > d.o_pos || len > d.cap - d.o_pos) return MD_LZO_OUT_OF_BOUND;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // earlier instructions' bytes have landed
+  const uint8_t *s = d.dst + (d.o_pos - off);
+  for (uint32_t k = d.lane; k < len; k += kWave) d.dst[d.o_pos + k] = ld_nt8(s + (off >= len ? k : k % off));
+  d.o_pos += len;
+  return MD_OK;
+}
+// count (lib/lzo.ml:218-236)
+__device__ __forceinline__ int count(Dec &d, uint32_t *out) {
+  uint32_t idx = d.i_pos, res = 0;
+  const uint32_t max = d.in.n;
+  while (idx < max && d.in.byte(idx) == 0) {  // the reference's 4-byte then 1-byte scans count the same zeros
+    idx++;
+    res++;
+  }
+  if (idx < max) {
+    d.i_pos = idx + 1;
+    *out = res * 255 + d.in.byte(idx);
+    return MD_OK;
+  }
+  return MD_LZO_INVALID_INPUT;
+}
+
+#define LZ_EOI() \
+  if (d.i_pos >= d.in.n) return MD_UNEXPECTED_END_OF_INPUT;
+#define LZ_TRY(e)             \
+  {                           \
+    const int rc_ = (e);      \
+    if (rc_) return rc_;      \
+  }
+
+__device__ int uncompress_stream(Dec &d) {
+  LZ_EOI()
+  uint32_t chr = d.in.byte(0);
+  if (chr == 16) return MD_LZO_NO_DICTIONARY;
+  if (chr >= 18) {  // the first byte, lib/lzo.ml:372-393
+    d.i_pos = 1;
+    d.state = 0;
+    LZ_EOI()
+    LZ_TRY(transmit(d, chr - 17))
+  }
+  for (;;) {  // fiber, lib/lzo.ml:315-369
+    LZ_EOI()
+    chr = d.in.byte(d.i_pos++);
+    const int st = d.state & 3;  // -1 land 3 = 3
+    uint32_t len, off, cnt;
+    int nstate;
+    if (chr < 16 && st == 0) {
+      if (chr == 0) {
+        LZ_EOI()
+        LZ_TRY(count(d, &cnt))
+        len = 3 + 15 + cnt;
+      } else len = chr + 3;
+      d.state = -1;
+      LZ_EOI()
+      LZ_TRY(transmit(d, len))
+      continue;
+    }
+    if (chr < 16) {
+      LZ_EOI()
+      const uint32_t h = d.in.byte(d.i_pos++);
+      off = (h << 2) + (chr >> 2) + 1;
+      len = 0;
+      nstate = (int)(chr & 3);
+    } else if (chr < 32) {
+      len = chr & 7;
+      if (len == 0) {
+        LZ_EOI()
+        LZ_TRY(count(d, &cnt))
+        len = 7 + cnt;
+      }
+      LZ_EOI()
+      if (d.i_pos + 2 > d.in.n) return MD_LZO_OUT_OF_BOUND;
+      const uint32_t s = d.in.byte(d.i_pos) | (d.in.byte(d.i_pos + 1) << 8);
+      d.i_pos += 2;
+      off = 16384 + (((chr & 8) >> 3) << 14) + (s >> 2);
+      nstate = (int)(s & 0xff);
+      if (off == 16384) break;  // end_of_lzo
+    } else if (chr < 64) {
+      len = chr & 31;
+      if (len == 0) {
+        LZ_EOI()
+        LZ_TRY(count(d, &cnt))
+        len = 31 + cnt;
+      }
+      LZ_EOI()
+      if (d.i_pos + 2 > d.in.n) return MD_LZO_OUT_OF_BOUND;
+      const uint32_t s = d.in.byte(d.i_pos) | (d.in.byte(d.i_pos + 1) << 8);
+      d.i_pos += 2;
+      nstate = (int)(s & 0xff);
+      off = (s >> 2) + 1;
+    } else {
+      nstate = (int)chr;
+      len = (chr >> 5) - 1;
+      LZ_EOI()
+      const uint32_t h = d.in.byte(d.i_pos++);
+      off = (h << 3) + ((chr >> 2) & 7) + 1;
+    }
+    // Copy (lib/lzo.ml:283-288): len + 2 bytes, then copy_done = transmit (state land 3)
+    LZ_EOI()
+    d.state = nstate;
+    LZ_TRY(copy(d, off, len + 2))
+    LZ_TRY(transmit(d, (uint32_t)(nstate & 3)))
+  }
+  return MD_OK;
+}
+
+__global__ __launch_bounds__(kWave) void lzo_uncompress_kernel(
+    uint32_t n, const uint8_t *__restrict__ in, const uint64_t *__restrict__ in_off,
+    const uint64_t *__restrict__ in_len, uint8_t *__restrict__ out, const uint64_t *__restrict__ out_off,
+    const uint64_t *__restrict__ out_cap, uint64_t *__restrict__ out_len, int32_t *__restrict__ status) {
+  const uint32_t lane = threadIdx.x, sid = blockIdx.x;
+  if (sid >= n) return;
+  Dec d;
+  d.in.src = in + in_off[sid];
+  const uint64_t l64 = in_len[sid], c64 = out_cap[sid];
+  d.in.n = l64 > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)l64;
+  d.in.lane = lane;
+  d.in.fill(0);
+  d.dst = out + out_off[sid];
+  d.cap = c64 > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)c64;
+  d.i_pos = d.o_pos = 0;
+  d.lane = lane;
+  d.state = 0;
+  const int st = uncompress_stream(d);
+  if (lane == 0) {
+    status[sid] = st;
+    out_len[sid] = st == MD_OK ? d.o_pos : 0;
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// compress
+
+struct Cmp {
+  const uint8_t *src;
+  uint32_t n;  // whole input
+  uint8_t *dst;
+  uint32_t cap, lane;
+  uint32_t op;   // output position
+  bool oob;      // Out_of_bound (lib/lzo.ml:655)
+  // the byte at op - 2 when it is the second-to-last byte of the latest match (record_literals /
+  // record_trailer OR the literal count into its two low bits, lib/lzo.ml:509, :548)
+  uint32_t patch;
+};
+__device__ __forceinline__ void c_set(Cmp &c, uint32_t pos, uint32_t b) {  // wave-uniform byte store
+  if (pos >= c.cap) c.oob = true;
+  else if (c.lane == 0) c.dst[pos] = (uint8_t)b;
+}
+// blit in_data off out_data op len (lib/lzo.ml:81-89) — `room` bytes must fit both buffers, `len`
+// of them are kept (the reference copies 4 / 16 bytes for short runs and overwrites the excess)
+__device__ __forceinline__ void c_blit(Cmp &c, uint32_t off, uint32_t len, uint32_t room) {
+  if (off > c.n || room > c.n - off || c.op > c.cap || room > c.cap - c.op) {
+    c.oob = true;
+    return;
+  }
+  for (uint32_t k = c.lane; k < len; k += kWave) c.dst[c.op + k] = c.src[off + k];
+}
+__device__ __forceinline__ void long_run(Cmp &c, uint32_t len) {  // 19+ literals: 0, 0..., rest
+  uint32_t l = len - 18;
+  c_set(c, c.op++, 0);
+  while (l > 255) {
+    l -= 255;
+    c_set(c, c.op++, 0);
+  }
+  c_set(c, c.op++, l);
+}
+// record_literals, lib/lzo.ml:502-538
+__device__ __forceinline__ void record_literals(Cmp &c, uint32_t off, uint32_t len) {
+  if (len == 0) return;
+  if (len <= 3) {
+    if (c.op < 2) c.oob = true;
+    else c_set(c, c.op - 2, c.patch | len);
+    c_blit(c, off, len, 4);
+  } else if (len <= 16) {
+    c_set(c, c.op++, len - 3);
+    c_blit(c, off, len, 16);
+  } else {
+    if (len <= 18) c_set(c, c.op++, len - 3);
+    else long_run(c, len);
+    c_blit(c, off, len, len);
+  }
+  c.op += len;
+}
+// record_match, lib/lzo.ml:443-500
+__device__ __forceinline__ void record_match(Cmp &c, uint32_t off, uint32_t len) {
+  if (len <= 8 && off <= 0x0800) {
+    off -= 1;
+    c.patch = ((len - 1) << 5) | ((off & 7) << 2);
+    c_set(c, c.op++, c.patch);
+    c_set(c, c.op++, off >> 3);
+    return;
+  }
+  uint32_t marker, maxl;
+  if (off <= 0x4000) {
+    off -= 1;
+    marker = 32;
+    maxl = 33;
+  } else {
+    off -= 0x4000;
+    marker = 16 | ((off >> 11) & 8);
+    maxl = 9;
+  }
+  if (len <= maxl) c_set(c, c.op++, marker | (len - 2));
+  else {
+    uint32_t l = len - maxl;
+    c_set(c, c.op++, marker);
+    while (l > 255) {
+      l -= 255;
+      c_set(c, c.op++, 0);
+    }
+    c_set(c, c.op++, l);
+  }
+  c.patch = (off << 2) & 0xff;
+  c_set(c, c.op++, c.patch);
+  c_set(c, c.op++, (off >> 6) & 0xff);
+}
+// record_trailer, lib/lzo.ml:540-576
+__device__ __forceinline__ void record_trailer(Cmp &c, uint32_t off, uint32_t len) {
+  if (len > 0) {
+    if (c.op == 0 && len < 238) c_set(c, c.op++, 17 + len);
+    else if (len <= 3) {
+      if (c.op < 2) c.oob = true;
+      else c_set(c, c.op - 2, c.patch | len);
+    } else if (len <= 18) c_set(c, c.op++, len - 3);
+    else long_run(c, len);
+    c_blit(c, off, len, len);
+  }
+  c.op += len;
+  c_set(c, c.op++, 16 | 1);
+  c_set(c, c.op++, 0);
+  c_set(c, c.op++, 0);
+}
+
+// One 48 KiB chunk (lib/lzo.ml:578-640).  The probe positions of a literal run are known in advance
+// (`literal: ip += 1 + ((ip - ii) >> 5)` does not look at the data), so 64 of them are probed per
+// step: lane j hashes its position, the dictionary entry it would see is the latest earlier lane of
+// the step with the same hash or else the LDS entry, and the first lane whose 4 bytes agree with its
+// reference is where the serial loop finds its match; the lanes up to it enter the dictionary in
+// order.  After a match the next probe is the match end itself (`goto next`).
+__device__ uint32_t compress_chunk(Cmp &c, uint16_t *dict, uint32_t in_pos, uint32_t in_len, uint32_t t) {
+  const uint32_t idx_end = in_len > 20 ? in_len - 20 : 0, lane = c.lane;
+  uint32_t idx1 = in_pos;
+  uint32_t first = in_pos + (t < 4 ? 4 - t : 0);
+  first += 1 + ((first - idx1) >> 5);
+  for (;;) {
+    // ---- the next probe positions of this run (wave-uniform recurrence, lane j keeps p_j)
+    uint32_t p = first, mine = 0, nvalid = 0;
+    for (uint32_t j = 0; j < (uint32_t)kWave; j++) {
+      if (p - in_pos >= idx_end) break;
+      if (lane == j) mine = p;
+      nvalid++;
+      p += 1 + ((p - idx1) >> 5);
+    }
+    if (nvalid == 0) {  // the run reaches the end of the chunk
+      idx1 -= t;
+      return in_len - (idx1 - in_pos);
+    }
+    const bool valid = lane < nvalid;
+    const uint64_t vm = nvalid == 64 ? ~0ull : ((1ull << nvalid) - 1);
+    uint32_t v = 0;
+    if (valid) __builtin_memcpy(&v, c.src + mine, 4);
+    const uint32_t index = ((uint32_t)(0x1824429du * v) >> 18) & 0x3fff;
+    // latest earlier lane of the step with the same dictionary slot
+    uint64_t same = vm;
+#pragma unroll
+    for (int bit = 0; bit < 14; bit++) {
+      const bool bset = (index >> bit) & 1;
+      const uint64_t bal = __ballot(bset);
+      same &= bset ? bal : ~bal;
+    }
+    const uint64_t below = valid ? same & ((1ull << lane) - 1) : 0;
+    const uint32_t pred = (uint32_t)__shfl((int)mine, below ? 63 - (int)__builtin_clzll(below) : 0);
+    uint32_t ref = 0, rv = 0;
+    if (valid) {
+      ref = below ? pred : dict[index] + in_pos;
+      __builtin_memcpy(&rv, c.src + ref, 4);
+    }
+    const uint64_t hit = __ballot(valid && rv == v);
+    const uint32_t stop = hit ? (uint32_t)__builtin_ctzll(hit) : nvalid - 1;
+    {  // lanes up to the stop enter the dictionary; of equal slots the last one stays
+      const uint64_t upto = stop == 63 ? ~0ull : ((2ull << stop) - 1);
+      const uint64_t later = lane == 63 ? 0 : same & upto & ~((2ull << lane) - 1);
+      if (valid && lane <= stop && later == 0) dict[index] = (uint16_t)(mine - in_pos);
+    }
+    __syncthreads();
+    if (!hit) {
+      first = p;
+      continue;
+    }
+    // ---- the match at lane `stop`
+    const uint32_t idx0 = (uint32_t)__shfl((int)mine, (int)stop);
+    const uint32_t mref = (uint32_t)__shfl((int)ref, (int)stop);
+    idx1 -= t;
+    t = 0;
+    record_literals(c, idx1, idx0 - idx1);
+    uint32_t len = 4;
+    for (;;) {  // 8 bytes per lane; the loop of lib/lzo.ml:616-621 stops at the first lane that fails
+      const uint32_t o = len + 8 * lane;
+      const bool inb = idx0 + o + 8 <= c.n;
+      uint64_t a = 0, b = 0;
+      if (inb) {
+        __builtin_memcpy(&a, c.src + idx0 + o, 8);
+        __builtin_memcpy(&b, c.src + mref + o, 8);
+      }
+      const bool go = idx0 + o - in_pos < idx_end && inb && a == b;
+      const uint64_t fm = __ballot(!go);
+      if (fm == 0) {
+        len += 8 * kWave;
+        continue;
+      }
+      const uint32_t L = (uint32_t)__builtin_ctzll(fm);
+      len += 8 * L;
+      // then the bytes of the next 8 that still agree (lib/lzo.ml:624-631; ctz 0 = 0)
+      const uint64_t x = a ^ b;
+      const uint32_t extra = (inb && x) ? (uint32_t)__builtin_ctzll(x) >> 3 : 0u;
+      if (idx0 + len - in_pos < in_len) len += (uint32_t)__shfl((int)extra, (int)L);
+      break;
+    }
+    record_match(c, idx0 - mref, len);
+    first = idx0 + len;  // `goto next`: the match end is probed as it is
+    idx1 = first;
+  }
+}
+
+__global__ __launch_bounds__(kWave) void lzo_compress_kernel(
+    uint32_t n, const uint8_t *__restrict__ in, const uint64_t *__restrict__ in_off,
+    const uint64_t *__restrict__ in_len, uint8_t *__restrict__ out, const uint64_t *__restrict__ out_off,
+    const uint64_t *__restrict__ out_cap, uint64_t *__restrict__ out_len, int32_t *__restrict__ status) {
+  __shared__ uint16_t dict[1 << 14];  // make_wrkmem, lib/lzo.ml:645-646
+  const uint32_t lane = threadIdx.x, sid = blockIdx.x;
+  if (sid >= n) return;
+  Cmp c;
+  c.src = in + in_off[sid];
+  const uint64_t l64 = in_len[sid], c64 = out_cap[sid];
+  c.n = l64 > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)l64;
+  c.dst = out + out_off[sid];
+  c.cap = c64 > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)c64;
+  c.lane = lane;
+  c.op = 0;
+  c.oob = false;
+  c.patch = 0;
+  // Lzo.compress, lib/lzo.ml:648-660
+  uint32_t idx = 0, len = c.n, t = 0;
+  while (len > 20) {
+    const uint32_t ll = len < 49152u ? len : 49152u;
+    if (((t + ll) >> 5) == 0) break;
+    for (uint32_t i = lane; i < (1u << 14); i += kWave) dict[i] = 0;
+    __syncthreads();
+    t = compress_chunk(c, dict, idx, ll, t);
+    idx += ll;
+    len -= ll;
+  }
+  t += len;
+  record_trailer(c, c.n - t, t);
+  if (lane == 0) {
+    status[sid] = c.oob ? MD_LZO_OUT_OF_BOUND : MD_OK;
+    out_len[sid] = c.oob ? 0 : c.op;
+  }
+}
+
+}  // namespace lzo
+}  // namespace md
+
+extern "C" int md_launch_lzo_uncompress(uint32_t n, const uint8_t *in, const uint64_t *in_off, const uint64_t *in_len,
+                                        uint8_t *out, const uint64_t *out_off, const uint64_t *out_cap,
+                                        uint64_t *out_len, int32_t *status, hipStream_t stream) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(md::lzo::lzo_uncompress_kernel, dim3(n), dim3(md::lzo::kWave), 0, stream, n, in, in_off, in_len,
+                     out, out_off, out_cap, out_len, status);
+  return (int)hipGetLastError();
+}
+
+extern "C" int md_launch_lzo_compress(uint32_t n, const uint8_t *in, const uint64_t *in_off, const uint64_t *in_len,
+                                      uint8_t *out, const uint64_t *out_off, const uint64_t *out_cap,
+                                      uint64_t *out_len, int32_t *status, hipStream_t stream) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(md::lzo::lzo_compress_kernel, dim3(n), dim3(md::lzo::kWave), 0, stream, n, in, in_off, in_len, out,
+                     out_off, out_cap, out_len, status);
+  return (int)hipGetLastError();
+}

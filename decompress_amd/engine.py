@@ -17,7 +17,8 @@ STATUS_NAMES = {
     5: "Invalid_complement_of_length", 6: "Invalid_distance",
     7: "Invalid_distance_code", 8: "Invalid_header", 9: "Invalid_checksum",
     10: "Invalid GZip header", 11: "Invalid GZip header checksum", 12: "Invalid input size",
-    13: "Queue.Full",
+    13: "Queue.Full", 14: "Invalid input", 15: "No dictionary at offset 0 available",
+    16: "Input is malformed or output is not large enough",
 }
 
 
@@ -57,6 +58,44 @@ class Engine:
         if rc != 0:
             raise Error("%s: %s" % (self.lib.md_status_string(rc).decode(),
                                     self.lib.md_last_error_string(self.ctx).decode()))
+
+    def lzo_batch(self, compress, d_in, in_off, in_len, d_out, out_off, out_cap, results=None):
+        """Lzo.compress / Lzo.uncompress over n device-resident buffers -> (out_len, status) CUDA tensors (async)."""
+        torch = self.torch
+        n = in_off.numel()
+        if results is None:
+            results = (torch.empty(n, dtype=torch.int64, device=self.device),
+                       torch.empty(n, dtype=torch.int32, device=self.device))
+        fn = self.lib.md_lzo_compress_batch_device if compress else self.lib.md_lzo_uncompress_batch_device
+        self._check(fn(self.ctx, n, _ptr(d_in), _ptr(in_off), _ptr(in_len), _ptr(d_out), _ptr(out_off), _ptr(out_cap),
+                       _ptr(results[0]), _ptr(results[1])))
+        return results
+
+    def lzo_many(self, compress, bufs, caps):
+        """Convenience for tests: list of bytes -> list of (status, bytes)."""
+        import numpy as np
+
+        torch = self.torch
+        n = len(bufs)
+        if n == 0:
+            return []
+        in_len = np.array([len(s) for s in bufs], dtype=np.int64)
+        in_off = np.zeros(n, dtype=np.int64)
+        np.cumsum(((in_len + 31) // 16 * 16)[:-1], out=in_off[1:])
+        cap = np.array(caps, dtype=np.int64)
+        out_off = np.zeros(n, dtype=np.int64)
+        np.cumsum(((cap + 255) // 256 * 256)[:-1], out=out_off[1:])
+        blob = np.zeros(int(in_off[-1] + in_len[-1]) + 32, dtype=np.uint8)
+        for s, o in zip(bufs, in_off):
+            blob[o:o + len(s)] = np.frombuffer(bytes(s), dtype=np.uint8)
+        dev = self.device
+        t = lambda a: torch.from_numpy(a).to(dev)
+        d_out = torch.zeros(int(out_off[-1] + cap[-1]) + 32, dtype=torch.uint8, device=dev)
+        out_len, status = self.lzo_batch(compress, t(blob), t(in_off), t(in_len), d_out, t(out_off), t(cap))
+        torch.cuda.synchronize(dev)
+        out = d_out.cpu().numpy()
+        out_len, status = out_len.cpu().numpy(), status.cpu().numpy()
+        return [(int(status[i]), out[out_off[i]:out_off[i] + out_len[i]].tobytes()) for i in range(n)]
 
     def set_matcher(self, matcher):
         """0 = De.Lz77 (default), 1 = Lz (lib/lz.ml) for every later deflate of this engine."""

@@ -48,7 +48,12 @@ enum {
   MD_INVALID_SIZE = 12,                 /* "Invalid input size (expect:.., inflated:..)" */
   /* deflate: the reference raises exception De.Queue.Full (lib/de.ml:2211-2217) — only the CLI
    * driver can, when its unconditional end-of-block push (bin/decompress.ml:67) meets a full queue */
-  MD_QUEUE_FULL = 13
+  MD_QUEUE_FULL = 13,
+  /* Lzo.error, lib/lzo.ml:4-12 (LZO entry points below) */
+  MD_LZO_INVALID_INPUT = 14, /* `Malformed "Invalid input" (count, lib/lzo.ml:236) */
+  MD_LZO_NO_DICTIONARY = 15, /* `Malformed "No dictionary at offset 0 available" (lib/lzo.ml:376) */
+  MD_LZO_OUT_OF_BOUND = 16   /* `Invalid_argument "Input is malformed or output is not large enough"
+                              * (lib/lzo.ml:401-402); compress: "lzo: output is not large enough" (:655) */
 };
 
 /* Call-level errors (negative): misuse raises Invalid_argument in the
@@ -217,6 +222,26 @@ int md_gz_higher_uncompress(md_ctx *ctx, const uint8_t *src, size_t src_len, uin
  * CRC-32 of d_data[off[i], off[i] + len[i]).  Asynchronous on the context's stream. */
 int md_crc32_batch_device(md_ctx *ctx, size_t n, const uint8_t *d_data, const uint64_t *d_off,
                           const uint64_t *d_len, uint32_t *d_crc);
+
+/* ---- LZO1X (lib/lzo.ml; SURVEY 8(f) row 3, BASELINE config 5) ---- */
+
+/* Lzo.uncompress input output (lib/lzo.ml:395-403) over n independent streams resident in HBM:
+ * status[i] = MD_OK, MD_UNEXPECTED_END_OF_INPUT or one of MD_LZO_*; out_len[i] = bytes written
+ * (0 on error).  Asynchronous on the context's stream. */
+int md_lzo_uncompress_batch_device(md_ctx *ctx, size_t n, const uint8_t *d_in, const uint64_t *d_in_off,
+                                   const uint64_t *d_in_len, uint8_t *d_out, const uint64_t *d_out_off,
+                                   const uint64_t *d_out_cap, uint64_t *d_out_len, int32_t *d_status);
+/* Lzo.compress in_data out_data wrkmem (lib/lzo.ml:642-660; the 16 K-entry wrkmem lives in LDS)
+ * over n independent buffers: status[i] = MD_OK or MD_LZO_OUT_OF_BOUND when out_cap[i] is too
+ * small (n + n/16 + 64 + 3 always suffices). */
+int md_lzo_compress_batch_device(md_ctx *ctx, size_t n, const uint8_t *d_in, const uint64_t *d_in_off,
+                                 const uint64_t *d_in_len, uint8_t *d_out, const uint64_t *d_out_off,
+                                 const uint64_t *d_out_cap, uint64_t *d_out_len, int32_t *d_status);
+/* Single-buffer mirrors (host pointers, batch of one): Lzo.uncompress / Lzo.compress. */
+int md_lzo_uncompress(md_ctx *ctx, const uint8_t *src, size_t src_len, uint8_t *dst, size_t dst_cap,
+                      size_t *written);
+int md_lzo_compress(md_ctx *ctx, const uint8_t *src, size_t src_len, uint8_t *dst, size_t dst_cap,
+                    size_t *written);
 
 #ifdef __cplusplus
 }

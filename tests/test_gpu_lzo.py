@@ -1,0 +1,90 @@
+"""LZO1X on the GPU (csrc/lzo_kernels.hip) against the oracle's restatement of lib/lzo.ml and, as the
+reference's own tests do, against minilzo (oracle/_ref).  Needs an MI355X: `pytest -m gpu`."""
+import random
+
+import pytest
+
+from tests import oracle_lib
+from tests.conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import decompress_amd
+    return decompress_amd.Engine(0)
+
+
+def _datasets():
+    from decompress_amd import workloads
+    rng = random.Random(21)
+    out = []
+    for n in (0, 1, 2, 3, 4, 5, 10, 19, 20, 21, 22, 31, 32, 33, 100, 237, 238, 239, 1000, 5000, 49151, 49152, 49153,
+              49172, 49173, 60000, 100000, 131072, 200000):
+        out += [workloads.text(n, n), workloads.ascii_uniform(n, n), bytes(rng.getrandbits(8) for _ in range(n)),
+                bytes(n), (b"abcabcabd" * (n // 9 + 1))[:n], bytes([rng.randrange(3) for _ in range(n)])]
+    return out
+
+
+def test_reference_vector(eng):
+    from decompress_amd import lzo
+    for case in load_golden("lzo.json"):
+        src = bytes.fromhex(case["src"])
+        assert lzo.uncompress(src, len(src)) == ("Ok", bytes.fromhex(case["out"]))
+
+
+def test_compress_equals_oracle_and_round_trips(eng, oracle):
+    from decompress_amd import lzo
+    data = _datasets()
+    res = eng.lzo_many(True, data, [lzo.max_compressed_length(len(d)) for d in data])
+    zs = []
+    for d, (st, z) in zip(data, res):
+        ost, oz = oracle.lzo_compress(d)
+        assert (st, z) == (ost, oz) and st == 0, len(d)
+        zs.append(z)
+    back = eng.lzo_many(False, zs, [len(d) for d in data])
+    for d, (st, out) in zip(data, back):
+        assert (st, out) == (0, d)
+    m = oracle_lib.load_minilzo()
+    if m is not None:  # cross-decompression, test/test.ml:2067-2097 / fuzz/fuzz_lzo.ml
+        mz = [m.compress(d) for d in data]
+        for d, (st, out) in zip(data, eng.lzo_many(False, mz, [len(d) for d in data])):
+            assert (st, out) == (0, d)
+        for d, z in zip(data, zs):
+            assert m.decompress(z, len(d)) == (0, d)
+
+
+def test_errors_equal_oracle(eng, oracle):
+    rng = random.Random(5)
+    d = b"hello hello hello hello hello hello hello, said the parrot; " * 60
+    z = oracle.lzo_compress(d)[1]
+    cases, caps = [], []
+    for cut in range(len(z)):
+        cases.append(z[:cut]); caps.append(len(d))
+    for _ in range(400):
+        b = bytearray(z)
+        for _ in range(rng.randrange(1, 3)):
+            b[rng.randrange(len(b))] = rng.getrandbits(8)
+        cases.append(bytes(b)); caps.append(len(d) + rng.choice((0, 0, 7, 4000)))
+    for _ in range(300):
+        n = rng.choice((1, 2, 3, 5, 9, 30, 200))
+        cases.append(bytes(rng.getrandbits(8) for _ in range(n))); caps.append(rng.choice((0, 10, 1000, 70000)))
+    for cap in (0, 1, len(d) - 1, len(d)):
+        cases.append(z); caps.append(cap)
+    res = eng.lzo_many(False, cases, caps)
+    seen = set()
+    for k, (c, cap, (st, out)) in enumerate(zip(cases, caps, res)):
+        ost, oout = oracle.lzo_uncompress(c, cap)
+        assert (st, out) == (ost, oout), (k, len(c), cap, st, ost)
+        seen.add(st)
+    assert seen >= {0, 1, 16}
+    # compress into too small a buffer: "lzo: output is not large enough"
+    for cap in (0, 3, 20, len(z) - 1, len(z)):
+        assert eng.lzo_many(True, [d], [cap])[0] == oracle.lzo_compress(d, cap=cap)
+
+
+def test_c_abi_single_buffer(eng):
+    from decompress_amd import lzo
+    d = b"Salut les copains!"  # test/test.ml:2067-2079
+    assert lzo.uncompress(lzo.compress(d), 128) == ("Ok", d)
