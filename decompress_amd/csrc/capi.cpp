@@ -51,7 +51,7 @@ extern "C" int md_launch_lzo_uncompress(uint32_t n, const uint8_t *in, const uin
                                         uint64_t *out_len, int32_t *status, hipStream_t stream);
 extern "C" int md_launch_lzo_compress(uint32_t n, const uint8_t *in, const uint64_t *in_off, const uint64_t *in_len,
                                       uint8_t *out, const uint64_t *out_off, const uint64_t *out_cap,
-                                      uint64_t *out_len, int32_t *status, hipStream_t stream);
+                                      uint64_t *out_len, int32_t *status, uint16_t *ws_dict, hipStream_t stream);
 
 struct md_ctx {
   int device = 0;
@@ -68,6 +68,8 @@ struct md_ctx {
   uint8_t gz_hdr[544] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 3};
   uint32_t gz_hdr_len = 10;
   bool gz_hdr_dirty = true;
+  void *lzo_ws = nullptr;  // Lzo.compress dictionaries
+  size_t lzo_ws_bytes = 0;
   int matcher = MD_MATCHER_DE;
   int test_flags = 0;       // deflate: bit 0 = always take the order-free head reconstruction (tests)
   uint64_t *dbg = nullptr;  // device buffer of the optional in-kernel profile (32 x u64)
@@ -203,6 +205,7 @@ void md_destroy(md_ctx *ctx) {
   if (ctx->log) hipFree(ctx->log);
   if (ctx->dbg) hipFree(ctx->dbg);
   if (ctx->gz_tmp) hipFree(ctx->gz_tmp);
+  if (ctx->lzo_ws) hipFree(ctx->lzo_ws);
   if (ctx->gz_hdr_dev) hipFree(ctx->gz_hdr_dev);
   if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -677,8 +680,21 @@ static int lzo_batch_device(md_ctx *ctx, bool compress, size_t n, const uint8_t 
   if (!d_in_off || !d_in_len || !d_out_off || !d_out_cap || !d_out_len || !d_status)
     return fail(ctx, MD_E_INVALID_ARGUMENT, "null descriptor array");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (compress) {  // Lzo's wrkmem: 16 K u16 entries per stream
+    const size_t need = n * (size_t)(1u << 15);
+    if (need > ctx->lzo_ws_bytes) {
+      if (ctx->lzo_ws) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipFree(ctx->lzo_ws));
+        ctx->lzo_ws = nullptr;
+        ctx->lzo_ws_bytes = 0;
+      }
+      if (hipMalloc(&ctx->lzo_ws, need) != hipSuccess) return fail(ctx, MD_E_OUT_OF_MEMORY, "hipMalloc(lzo wrkmem)");
+      ctx->lzo_ws_bytes = need;
+    }
+  }
   const int e = compress ? md_launch_lzo_compress((uint32_t)n, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap,
-                                                  d_out_len, d_status, ctx->stream)
+                                                  d_out_len, d_status, (uint16_t *)ctx->lzo_ws, ctx->stream)
                          : md_launch_lzo_uncompress((uint32_t)n, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap,
                                                     d_out_len, d_status, ctx->stream);
   if (e != 0) return fail(ctx, MD_E_HIP, "lzo kernel launch", (hipError_t)e);

@@ -10,7 +10,8 @@
 //       older than the instruction, whatever the overlap.
 //   lzo_compress_kernel     lzo1x-1 (lib/lzo.ml:578-660): the probe loop is serial by construction
 //       (what is inserted in the dictionary depends on where the previous match ended), so it runs
-//       wave-uniformly with the 16 K-entry u16 dictionary of the current 48 KiB chunk in LDS; match
+//       wave-uniformly with the 16 K-entry u16 dictionary of the current 48 KiB chunk in an HBM
+//       workspace (L2-resident; in LDS it would cap residency at 5 wavefronts per CU); match
 //       extension compares 8 bytes per lane (512 per step), literal runs and the trailer are
 //       coalesced copies.
 // Semantics, error cases and quirks are those of the reference as restated in oracle/lzo.c
@@ -345,7 +346,7 @@ __device__ uint32_t compress_chunk(Cmp &c, uint16_t *dict, uint32_t in_pos, uint
     const uint32_t pred = (uint32_t)__shfl((int)mine, below ? 63 - (int)__builtin_clzll(below) : 0);
     uint32_t ref = 0, rv = 0;
     if (valid) {
-      ref = below ? pred : dict[index] + in_pos;
+      ref = below ? pred : (uint32_t)__builtin_nontemporal_load(dict + index) + in_pos;
       __builtin_memcpy(&rv, c.src + ref, 4);
     }
     const uint64_t hit = __ballot(valid && rv == v);
@@ -355,7 +356,7 @@ __device__ uint32_t compress_chunk(Cmp &c, uint16_t *dict, uint32_t in_pos, uint
       const uint64_t later = lane == 63 ? 0 : same & upto & ~((2ull << lane) - 1);
       if (valid && lane <= stop && later == 0) dict[index] = (uint16_t)(mine - in_pos);
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the entries have landed before the next step reads
     if (!hit) {
       first = p;
       continue;
@@ -398,10 +399,13 @@ __device__ uint32_t compress_chunk(Cmp &c, uint16_t *dict, uint32_t in_pos, uint
 __global__ __launch_bounds__(kWave) void lzo_compress_kernel(
     uint32_t n, const uint8_t *__restrict__ in, const uint64_t *__restrict__ in_off,
     const uint64_t *__restrict__ in_len, uint8_t *__restrict__ out, const uint64_t *__restrict__ out_off,
-    const uint64_t *__restrict__ out_cap, uint64_t *__restrict__ out_len, int32_t *__restrict__ status) {
-  __shared__ uint16_t dict[1 << 14];  // make_wrkmem, lib/lzo.ml:645-646
+    const uint64_t *__restrict__ out_cap, uint64_t *__restrict__ out_len, int32_t *__restrict__ status,
+    uint16_t *__restrict__ ws_dict) {
   const uint32_t lane = threadIdx.x, sid = blockIdx.x;
   if (sid >= n) return;
+  // make_wrkmem (lib/lzo.ml:645-646): 16 K u16 entries per stream in an HBM workspace — in LDS the
+  // 32 KiB would hold residency to 5 wavefronts per CU, and the probe loop lives on occupancy
+  uint16_t *dict = ws_dict + (size_t)sid * (1u << 14);
   Cmp c;
   c.src = in + in_off[sid];
   const uint64_t l64 = in_len[sid], c64 = out_cap[sid];
@@ -417,8 +421,8 @@ __global__ __launch_bounds__(kWave) void lzo_compress_kernel(
   while (len > 20) {
     const uint32_t ll = len < 49152u ? len : 49152u;
     if (((t + ll) >> 5) == 0) break;
-    for (uint32_t i = lane; i < (1u << 14); i += kWave) dict[i] = 0;
-    __syncthreads();
+    for (uint32_t i = lane; i < (1u << 11); i += kWave) reinterpret_cast<uint4 *>(dict)[i] = make_uint4(0, 0, 0, 0);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     t = compress_chunk(c, dict, idx, ll, t);
     idx += ll;
     len -= ll;
@@ -445,9 +449,9 @@ extern "C" int md_launch_lzo_uncompress(uint32_t n, const uint8_t *in, const uin
 
 extern "C" int md_launch_lzo_compress(uint32_t n, const uint8_t *in, const uint64_t *in_off, const uint64_t *in_len,
                                       uint8_t *out, const uint64_t *out_off, const uint64_t *out_cap,
-                                      uint64_t *out_len, int32_t *status, hipStream_t stream) {
+                                      uint64_t *out_len, int32_t *status, uint16_t *ws_dict, hipStream_t stream) {
   if (n == 0) return 0;
   hipLaunchKernelGGL(md::lzo::lzo_compress_kernel, dim3(n), dim3(md::lzo::kWave), 0, stream, n, in, in_off, in_len, out,
-                     out_off, out_cap, out_len, status);
+                     out_off, out_cap, out_len, status, ws_dict);
   return (int)hipGetLastError();
 }

@@ -231,7 +231,8 @@ int md_crc32_batch_device(md_ctx *ctx, size_t n, const uint8_t *d_data, const ui
 int md_lzo_uncompress_batch_device(md_ctx *ctx, size_t n, const uint8_t *d_in, const uint64_t *d_in_off,
                                    const uint64_t *d_in_len, uint8_t *d_out, const uint64_t *d_out_off,
                                    const uint64_t *d_out_cap, uint64_t *d_out_len, int32_t *d_status);
-/* Lzo.compress in_data out_data wrkmem (lib/lzo.ml:642-660; the 16 K-entry wrkmem lives in LDS)
+/* Lzo.compress in_data out_data wrkmem (lib/lzo.ml:642-660; the 16 K-entry wrkmem is a per-stream
+ * workspace owned by the context)
  * over n independent buffers: status[i] = MD_OK or MD_LZO_OUT_OF_BOUND when out_cap[i] is too
  * small (n + n/16 + 64 + 3 always suffices). */
 int md_lzo_compress_batch_device(md_ctx *ctx, size_t n, const uint8_t *d_in, const uint64_t *d_in_off,
