@@ -395,9 +395,19 @@ int md_inflate_batch_host(md_ctx *ctx, int format, size_t n, const uint8_t *h_in
   HIP_TRY(ctx, hipMemcpyAsync(d64 + 1 * n, in_len, n * 8, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(d64 + 2 * n, out_off, n * 8, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(d64 + 3 * n, out_cap, n * 8, hipMemcpyHostToDevice, st));
+  // the host path sees the capacities: size the token log so that no stream overflows it (a round
+  // accepts ~5 KB of output; the floor of 128 records is the default of the device path)
+  const int saved_records = ctx->log_records;
+  {
+    uint64_t max_cap = 0;
+    for (size_t i = 0; i < n; i++) max_cap = out_cap[i] > max_cap ? out_cap[i] : max_cap;
+    const uint64_t want = max_cap / 3072 + 16;
+    if (want > (uint64_t)ctx->log_records) ctx->log_records = (int)(want > 65536 ? 65536 : want);
+  }
   int rc = md_inflate_batch_device(ctx, format, n, (const uint8_t *)din.p, d64, d64 + n,
                                    (uint8_t *)dout.p, d64 + 2 * n, d64 + 3 * n, d64 + 4 * n,
                                    d64 + 5 * n, dstatus, dsum);
+  ctx->log_records = saved_records;
   if (rc != MD_OK) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(h_out, dout.p, out_bytes, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipMemcpyAsync(out_len, d64 + 4 * n, n * 8, hipMemcpyDeviceToHost, st));
