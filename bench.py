@@ -63,6 +63,7 @@ def parse():
     ap.add_argument("--kernel", type=int, default=0,
                     help="1 = serial per wave, 2 = lane-parallel fused, 3 = lane-parallel split (default)")
     ap.add_argument("--variant", type=int, default=-1, help="v2 geometry")
+    ap.add_argument("--overlap", type=int, default=0, help="parts of the batch run on forked streams (1 = none, default 2)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
@@ -123,6 +124,8 @@ def main():
         eng.set_option("kernel", args.kernel)
     if args.variant >= 0:
         eng.set_option("variant", args.variant)
+    if args.overlap:
+        eng.set_option("overlap", args.overlap)
 
     n = args.streams
     nbytes = args.stream_kib * 1024

@@ -58,6 +58,11 @@ struct md_ctx {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // the split inflate path runs the second half of a batch on a side stream forked from the
+  // context's stream: the decode / resolve kernels of the two halves fill each other's gaps and tails
+  hipStream_t side[2] = {nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+  int overlap = 2;  // 1 = single stream
   int ring_log2 = 13;
   int kernel = 3;   // 1 = serial per wave, 2 = lane-parallel fused (inflate_v4.hip), 3 = lane-parallel split (default)
   int variant = 0;  // v2 geometry
@@ -181,6 +186,11 @@ md_ctx *md_create(int device, void *hip_stream) {
   }
   hipEventCreate(&ctx->ev0);
   hipEventCreate(&ctx->ev1);
+  hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming);
+  for (int k = 0; k < 2; k++) {
+    hipStreamCreateWithFlags(&ctx->side[k], hipStreamNonBlocking);
+    hipEventCreateWithFlags(&ctx->ev_join[k], hipEventDisableTiming);
+  }
   if (const char *e = getenv("MD_RING_LOG2")) {
     int v = atoi(e);
     if (v >= 12 && v <= 15) ctx->ring_log2 = v;
@@ -201,6 +211,11 @@ void md_destroy(md_ctx *ctx) {
   hipSetDevice(ctx->device);
   if (ctx->ev0) hipEventDestroy(ctx->ev0);
   if (ctx->ev1) hipEventDestroy(ctx->ev1);
+  if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
+  for (int k = 0; k < 2; k++) {
+    if (ctx->ev_join[k]) hipEventDestroy(ctx->ev_join[k]);
+    if (ctx->side[k]) hipStreamDestroy(ctx->side[k]);
+  }
   if (ctx->ws) hipFree(ctx->ws);
   if (ctx->log) hipFree(ctx->log);
   if (ctx->dbg) hipFree(ctx->dbg);
@@ -251,6 +266,10 @@ int md_set_option(md_ctx *ctx, const char *key, int value) {
       hipFree(ctx->dbg);
       ctx->dbg = nullptr;
     }
+    return MD_OK;
+  }
+  if (!strcmp(key, "overlap")) {  // 1 = run the split inflate path on the context's stream only
+    ctx->overlap = value;
     return MD_OK;
   }
   if (!strcmp(key, "deflate_test_flags")) {
@@ -336,13 +355,42 @@ int md_inflate_batch_device(md_ctx *ctx, int format, size_t n, const uint8_t *d_
       if (hipMalloc(&ctx->log, need) != hipSuccess) return fail(ctx, MD_E_OUT_OF_MEMORY, "hipMalloc(token log)");
       ctx->log_bytes = need;
     }
-    rc = md_launch_inflate_split(format, (uint32_t)n, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap,
-                                 d_out_len, d_consumed, d_status, d_checksum, (uint8_t *)ctx->log,
-                                 (uint32_t)ctx->log_records, ctx->stream);
-    // streams whose token log overflowed (status 50) are redone by the fused kernel
-    if (rc == 0)
-      rc = md_launch_inflate_v2(0, format, (uint32_t)n, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap,
-                                d_out_len, d_consumed, d_status, d_checksum, nullptr, 50, ctx->stream);
+    const bool piped = ctx->overlap >= 2 && n >= 512 && ctx->side[0];
+    const size_t rec_bytes = (size_t)ctx->log_records * md_inflate_log_record_bytes();
+    if (piped) {
+      // independent parts: the first on the context's stream, the others on side streams that fork
+      // from it and join it again — the kernels of the parts fill each other's gaps and tails
+      const size_t parts = ctx->overlap >= 3 && ctx->side[1] ? 3 : 2;
+      rc = 0;
+      HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+      for (size_t k = 1; k < parts; k++) HIP_TRY(ctx, hipStreamWaitEvent(ctx->side[k - 1], ctx->ev_fork, 0));
+      for (size_t k = 0; k < parts && rc == 0; k++) {
+        const size_t a = k * (n / parts), cnt = k + 1 == parts ? n - a : n / parts;
+        hipStream_t st = k == 0 ? ctx->stream : ctx->side[k - 1];
+        rc = md_launch_inflate_split(format, (uint32_t)cnt, d_in, d_in_off + a, d_in_len + a, d_out, d_out_off + a,
+                                     d_out_cap + a, d_out_len + a, d_consumed + a, d_status + a,
+                                     d_checksum ? d_checksum + a : nullptr, (uint8_t *)ctx->log + a * rec_bytes,
+                                     (uint32_t)ctx->log_records, st);
+        // streams whose token log overflowed (status 50) are redone by the fused kernel
+        if (rc == 0)
+          rc = md_launch_inflate_v2(0, format, (uint32_t)cnt, d_in, d_in_off + a, d_in_len + a, d_out, d_out_off + a,
+                                    d_out_cap + a, d_out_len + a, d_consumed + a, d_status + a,
+                                    d_checksum ? d_checksum + a : nullptr, nullptr, 50, st);
+      }
+      for (size_t k = 1; k < parts; k++) {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_join[k - 1], ctx->side[k - 1]));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join[k - 1], 0));
+      }
+    } else
+    {
+      rc = md_launch_inflate_split(format, (uint32_t)n, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap,
+                                   d_out_len, d_consumed, d_status, d_checksum, (uint8_t *)ctx->log,
+                                   (uint32_t)ctx->log_records, ctx->stream);
+      // streams whose token log overflowed (status 50) are redone by the fused kernel
+      if (rc == 0)
+        rc = md_launch_inflate_v2(0, format, (uint32_t)n, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap,
+                                  d_out_len, d_consumed, d_status, d_checksum, nullptr, 50, ctx->stream);
+    }
   } else if (ctx->kernel == 2)
     rc = md_launch_inflate_v2(ctx->variant, format, (uint32_t)n, d_in, d_in_off, d_in_len, d_out,
                               d_out_off, d_out_cap, d_out_len, d_consumed, d_status, d_checksum,
