@@ -11,15 +11,15 @@ inflates its own 4096 streams; value = total uncompressed MiB / s over all GPUs.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Prints ONE JSON line (rank 0).  `roofline` is for the hot path's two kernels taken
-together (md::v4::decode_kernel -> token log in HBM -> md::v4::resolve_kernel; one
-"launch" = the pair, they are about equally long): algorithmic bytes = compressed
-bytes read + uncompressed bytes written per launch, over the average launch duration
-measured with HIP events on the kernels' stream; peak = 8 TB/s HBM3E
-(MI355X_MICROARCH.md).  `traffic` = FETCH_SIZE + WRITE_SIZE of both kernels per launch
-from the committed rocprofv3 --pmc passes of this same command
-(profiles/r01_split/pmc_summary.json; raw counter bytes, see the note there), null
-when the configuration differs from the profiled one.
+Prints ONE JSON line (rank 0).  `roofline` is for the hot path's kernels taken together
+(md::v4::decode_kernel -> token log in HBM -> md::v4::resolve_kernel, for the two halves
+of the batch on two forked streams; one "launch" = those four kernels, which overlap):
+algorithmic bytes = compressed bytes read + uncompressed bytes written per launch, over
+the launch duration measured with HIP events on the context's stream, which forks and
+joins the side stream; peak = 8 TB/s HBM3E (MI355X_MICROARCH.md).  `traffic` =
+FETCH_SIZE + WRITE_SIZE of those kernels per launch from the committed rocprofv3 --pmc
+passes of this same command (profiles/r01_final/pmc_summary.json; raw counter bytes,
+see the note there), null when the configuration differs from the profiled one.
 `cpu_baseline` is the repo's C restatement of lib/de.ml (oracle/, kind "port")
 timed single-threaded on a bounded sample of the same streams.
 """
@@ -41,10 +41,10 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.
 def pmc_traffic(args, n, nbytes):
     """HBM bytes per launch from the committed PMC passes (collected by tools/profile_gpu.sh with
     this workload and the default kernels); null for any other configuration."""
-    if (args.kernel or 3) != 3 or max(args.variant, 0) != 0 or n != 4096 or nbytes != 262144:
+    if (args.kernel or 3) != 3 or max(args.variant, 0) != 0 or n != 4096 or nbytes != 262144 or args.overlap not in (0, 2):
         return None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_split", "pmc_summary.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r01_final", "pmc_summary.json")) as f:
             return int(json.load(f)["traffic_bytes_per_launch_raw"])
     except (OSError, KeyError, ValueError):
         return None
@@ -233,7 +233,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(args, n, nbytes),
-                "kernel": {1: "inflate_kernel", 2: "inflate_v4_kernel", 3: "decode_kernel + resolve_kernel"}[args.kernel or 3],
+                "kernel": {1: "inflate_kernel", 2: "inflate_v4_kernel", 3: "2 x (decode_kernel + resolve_kernel), overlapped"}[args.kernel or 3],
                 "kernel_ms": round(kernel_ms, 4),
                 "algorithmic_bytes_per_launch": algo_bytes,
             },
