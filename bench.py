@@ -126,6 +126,8 @@ def main():
         eng.set_option("variant", args.variant)
     if args.overlap:
         eng.set_option("overlap", args.overlap)
+    if os.environ.get("MD_SPLIT_PCT"):
+        eng.set_option("split_pct", int(os.environ["MD_SPLIT_PCT"]))
 
     n = args.streams
     nbytes = args.stream_kib * 1024

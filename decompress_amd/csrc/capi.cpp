@@ -63,6 +63,7 @@ struct md_ctx {
   hipStream_t side[2] = {nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
   int overlap = 2;  // 1 = single stream
+  int split_pct = 50;
   int ring_log2 = 13;
   int kernel = 3;   // 1 = serial per wave, 2 = lane-parallel fused (inflate_v4.hip), 3 = lane-parallel split (default)
   int variant = 0;  // v2 geometry
@@ -268,6 +269,11 @@ int md_set_option(md_ctx *ctx, const char *key, int value) {
     }
     return MD_OK;
   }
+  if (!strcmp(key, "split_pct")) {
+    if (value < 10 || value > 90) return fail(ctx, MD_E_INVALID_ARGUMENT, "split_pct must be 10..90");
+    ctx->split_pct = value;
+    return MD_OK;
+  }
   if (!strcmp(key, "overlap")) {  // 1 = run the split inflate path on the context's stream only
     ctx->overlap = value;
     return MD_OK;
@@ -365,7 +371,12 @@ int md_inflate_batch_device(md_ctx *ctx, int format, size_t n, const uint8_t *d_
       HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
       for (size_t k = 1; k < parts; k++) HIP_TRY(ctx, hipStreamWaitEvent(ctx->side[k - 1], ctx->ev_fork, 0));
       for (size_t k = 0; k < parts && rc == 0; k++) {
-        const size_t a = k * (n / parts), cnt = k + 1 == parts ? n - a : n / parts;
+        size_t a = k * (n / parts), cnt = k + 1 == parts ? n - a : n / parts;
+        if (parts == 2) {  // tuning knob: share of the first part in percent
+          const size_t first = n * (size_t)ctx->split_pct / 100;
+          a = k == 0 ? 0 : first;
+          cnt = k == 0 ? first : n - first;
+        }
         hipStream_t st = k == 0 ? ctx->stream : ctx->side[k - 1];
         rc = md_launch_inflate_split(format, (uint32_t)cnt, d_in, d_in_off + a, d_in_len + a, d_out, d_out_off + a,
                                      d_out_cap + a, d_out_len + a, d_consumed + a, d_status + a,
