@@ -358,7 +358,7 @@ __global__ __launch_bounds__(kWave) void resolve_kernel(
 }  // namespace v4
 }  // namespace md
 
-using SplitCfg = md::v4::Cfg<256, 40, 16, 72, 4096, 3, 6144>;
+using SplitCfg = md::v4::Cfg<256, 36, 16, 64, 4096, 5, 6144>;
 
 extern "C" size_t md_inflate_log_record_bytes(void) { return md::v4::Rec<SplitCfg>::BYTES; }
 
