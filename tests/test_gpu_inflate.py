@@ -191,3 +191,21 @@ def test_python_mirror(eng):
     assert de.Inf.Ns.inflate(b"\x06", 65536) == ("Error", "Invalid_kind_of_block")
     z = zlib.compress(b"abc" * 100)
     assert zl.Inf.Ns.inflate(z, 300) == ("Ok", (len(z), 300), b"abc" * 100)
+
+
+def test_large_streams_and_log_sizing(eng):
+    """a multi-MiB stream needs far more rounds than the default token log holds: the host entry
+    points size the log from the capacity, the device path falls back to the fused kernel"""
+    import ctypes
+    import decompress_amd
+    from decompress_amd import workloads
+    data = workloads.text(77, 6 * 1024 * 1024)
+    z = zlib.compress(data, 6)
+    dst = ctypes.create_string_buffer(len(data))
+    used, wrote = ctypes.c_size_t(), ctypes.c_size_t()
+    st = eng.lib.md_zl_inf_ns_inflate(eng.ctx, z, len(z), dst, len(data), ctypes.byref(used), ctypes.byref(wrote))
+    assert (st, used.value, wrote.value) == (0, len(z), len(data)) and dst.raw == data
+    # device path, default log (128 records): overflow -> fused redo, same result
+    res = eng.inflate_many([z, z[:len(z) // 2]], [len(data), len(data)], decompress_amd.FORMAT_ZLIB)
+    assert res[0][0] == 0 and res[0][2] == data and res[0][3] == zlib.adler32(data)
+    assert res[1][0] == 1  # Unexpected end of input
