@@ -452,6 +452,21 @@ int orc_zl_inf_ns_inflate(const uint8_t *src, size_t src_len, uint8_t *dst,
   return ORC_OK;
 }
 
+/* bench.py's cpu_baseline leg: n zlib streams of one blob inflated back to back into one scratch
+ * buffer (one call per worker thread, so that the timing is C code, not the Python binding) */
+size_t orc_zl_inf_ns_inflate_batch(const uint8_t *blob, const uint64_t *off, const uint64_t *len, size_t n,
+                                   uint8_t *scratch, size_t cap, uint64_t *total_out) {
+  size_t bad = 0;
+  uint64_t total = 0;
+  for (size_t i = 0; i < n; i++) {
+    size_t used, wrote;
+    if (orc_zl_inf_ns_inflate(blob + off[i], (size_t)len[i], scratch, cap, &used, &wrote) != ORC_OK) bad++;
+    total += wrote;
+  }
+  *total_out = total;
+  return bad;
+}
+
 /* error strings: lib/de.ml:1557-1567, lib/zl.ml:385-389 */
 const char *orc_status_string(int s) {
   switch (s) {

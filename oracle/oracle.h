@@ -61,6 +61,10 @@ int orc_de_inf_ns_inflate(const uint8_t *src, size_t src_len, uint8_t *dst,
 int orc_zl_inf_ns_inflate(const uint8_t *src, size_t src_len, uint8_t *dst,
                           size_t dst_cap, size_t *consumed, size_t *written);
 
+/* n zlib streams of one blob, back to back (bench.py's multi-threaded cpu_baseline leg) */
+size_t orc_zl_inf_ns_inflate_batch(const uint8_t *blob, const uint64_t *off, const uint64_t *len, size_t n,
+                                   uint8_t *scratch, size_t cap, uint64_t *total_out);
+
 /* De.Inf.huffman (lib/de.ml:523-638).  kind: 0 CODES, 1 LENS, 2 DISTS.
  * tbl must hold 852 (LENS), 592 (DISTS) or 128 (CODES) entries.
  * Returns 0, or -1 for Invalid_huffman.  root/maxl outputs as in the OCaml triple. */
