@@ -99,6 +99,14 @@ def cpu_baseline(streams, nbytes, budget_s):
         zlib.decompress(z)
     dz = time.perf_counter() - t1
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = ""
+    try:  # a container CPU quota below the visible CPUs is what the host really gives
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = "; cgroup cpu.max = %.1f of %d visible CPUs" % (float(q) / float(per), cores)
+            cores = max(1, min(cores, int(-(-float(q) // float(per)))))
+    except (OSError, ValueError):
+        pass
     # all cores: every thread inflates its share of the batch inside ONE C call (GIL released)
     import ctypes
     blob = b"".join(streams)
@@ -133,7 +141,7 @@ def cpu_baseline(streams, nbytes, budget_s):
         "single_core_value": round(single, 2),
         "sample": "oracle/de_inflate.c Zl.Inf.Ns: %d x the batch's %d streams on %d threads (one stream per thread); "
                   "1 thread: %d streams (%d MiB out) at %.1f MiB/s; libz 1.2.11 inflate on that sample, 1 thread: "
-                  "%.1f MiB/s" % (reps, len(streams), cores, k, done >> 20, single, done / 2**20 / dz),
+                  "%.1f MiB/s%s" % (reps, len(streams), cores, k, done >> 20, single, done / 2**20 / dz, quota),
     }
 
 
