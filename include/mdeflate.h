@@ -17,6 +17,11 @@
  *  - all sizes/offsets are bytes; descriptor arrays are structure-of-arrays.
  *  - there is NO CPU fallback: every compute entry point runs HIP kernels and
  *    returns MD_E_NO_DEVICE when no gfx950 device is usable.
+ *  - limits per stream (the kernels keep 32-bit cursors): inflate reads at most
+ *    512 MiB - 16 of compressed input (bit positions are 32-bit) and writes at most
+ *    4 GiB - 16; deflate / LZO read and write at most 4 GiB - 16.  Larger descriptors are
+ *    clamped to these bounds (a longer stream then ends in "Unexpected end of input/output").
+ *    A batch holds at most 2^31 - 1 streams.
  */
 #ifndef MDEFLATE_H
 #define MDEFLATE_H
