@@ -115,8 +115,13 @@ struct DS {
   uint8_t t_xl[32], t_bl[32], t_xd[32];
   uint16_t t_bd[32];
   uint32_t bb[104];      // bit buffer of one 64-command step (<= 15 + 64*48 bits)
+  // window of the parse step: what the look-ahead knows about positions s0 .. s0 + 79
+  uint16_t pm_lf[80], pm_df[80], pm_lq[80], pm_dq[80];  // longest_match ahead: full / quartered chain
+  uint8_t pm_k[80];      // bit 0: verdict known, bit 1: hash_head valid (lib/de.ml:4365-4369)
   struct ZS {            // matcher state the wave needs for bulk literal runs (lane 0 <-> wave)
     uint32_t strstart, lookahead, base, trivial, qw, qr, bulked;
+    // trivial: 0 = the matcher must run; 1 = literal-run state (match_available, match_length 2);
+    //          2 = fresh state (no pending literal, match_length 2: right after a match)
   } zs;
   struct WCtl {
     uint64_t hold;
@@ -1026,11 +1031,10 @@ __device__ __forceinline__ int lz_compress(DS *s, Enc *e, Lz *z, const Ws *ws) {
     if (z->level != 0 && z->prepared_end < z->p_end && z->strstart + 260 > z->prepared_end) return LZ_NEED;
     // literal-run state (previous position had no match, its literal is pending): the wave can
     // take the following no-match positions 64 at a time — hand over after one step
-    // (only when the next two positions are such positions: on match-rich input the hand-over
-    // would cost more than the literal)
-    if (z->level != 0 && z->steps > 0 && z->match_available && z->match_length == MIN_MATCH - 1 &&
-        z->lookahead > MIN_LOOKAHEAD && z->strstart + 1 < z->prepared_end && e->qc - (e->qw - e->qr) >= 3 &&
-        s->flg[z->strstart & (RING - 1)] == FL_ENDED && s->flg[(z->strstart + 1) & (RING - 1)] == FL_ENDED)
+    // (and in the fresh state after a match: the wave parses ahead from the look-ahead's verdicts)
+    if (z->level != 0 && z->steps > 0 && z->match_length == MIN_MATCH - 1 &&
+        z->lookahead > MIN_LOOKAHEAD && z->strstart + 1 < z->prepared_end && e->qc - (e->qw - e->qr) >= 8 &&
+        s->flg[z->strstart & (RING - 1)] != 0 && s->flg[(z->strstart + 1) & (RING - 1)] != 0)
       return LZ_NEED;
     z->steps++;
     z->n_steps++;
@@ -1534,7 +1538,12 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
     // ---- bulk literal run: in the literal-run state a position is trivial when its chain is
     //      empty / out of reach, or none of its pre-walked candidates passes the 3-byte filter
     //      and the chain ends within them (longest_match would return prev_length = 2)
-    if (ds.zs.trivial) {
+    if (ds.zs.trivial == 2) {  // fresh state: nothing for the literal-run step, the parse step counts from 0
+      __syncthreads();
+      if (lane == 0) ds.zs.bulked = 0;
+      __syncthreads();
+    }
+    if (ds.zs.trivial == 1) {
       const uint32_t s0 = ds.zs.strstart, la = ds.zs.lookahead, base = ds.zs.base;
       const uint32_t qw = ds.zs.qw, avail = (uint32_t)qcap - (qw - ds.zs.qr);
       uint32_t maxk = la > (uint32_t)MIN_LOOKAHEAD ? la - MIN_LOOKAHEAD + 1 : 0;
@@ -1566,6 +1575,139 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
       pc[1]++;
       pc[2] += K;
     }
+    // ---- parse step: lazy evaluation (lib/de.ml:4351-4410) of up to 64 positions from the
+    //      look-ahead's verdicts, when the literal run above stopped at a match.  Every position
+    //      evaluates, as if it were reached with prev_length 2, its own lazy chain: a match at p is
+    //      deferred while the next position's match is strictly longer (full chain below
+    //      good_length, quartered from there on, no search from max_lazy on), and is emitted when
+    //      it is not.  The path from s0 through these chains is then walked and emitted.
+    if (ds.zs.trivial && (ds.zs.trivial == 2 || ds.zs.bulked < (uint32_t)kWave)) {
+      const uint32_t s0 = ds.zs.strstart, la = ds.zs.lookahead, base = ds.zs.base;
+      uint32_t qw = ds.zs.qw;
+      const uint32_t qavail = (uint32_t)qcap - (qw - ds.zs.qr);
+      // positions that may be evaluated: prepared with room for a full match behind them
+      // (insert_string of lib/de.ml:4386-4391 stays inside the ring) and MIN_LOOKAHEAD ahead
+      uint32_t E = la >= (uint32_t)MIN_LOOKAHEAD ? s0 + la - MIN_LOOKAHEAD + 1 : s0;
+      if (pe < p_end) {
+        const uint32_t lim = pe > 260 ? pe - 260 : 0;
+        if (E > lim) E = lim;
+      } else if (E > pe) E = pe;
+      __syncthreads();
+      for (uint32_t j = lane; j < 80; j += kWave) {
+        const uint32_t q = s0 + j, r = q & (RING - 1);
+        uint32_t k = 0, lf = 2, df = 0, lq = 2, dq = 0;
+        if (q < E) {
+          const uint32_t f = ds.flg[r], c1v = ds.hh[r];
+          if (f == FL_ENDED || f == FL_MATCH) k = 1;
+          if (c1v > base && q - c1v <= (uint32_t)MAX_DIST) k |= 2;
+          if (f == FL_MATCH) {
+            const uint32_t a = g_ld(ws.mring + r), b = g_ld(ws.mring + RING + r);
+            lf = a >> 16;
+            df = a & 0xffff;
+            lq = b >> 16;
+            dq = b & 0xffff;
+          }
+        }
+        ds.pm_k[j] = (uint8_t)k;
+        ds.pm_lf[j] = (uint16_t)lf;
+        ds.pm_df[j] = (uint16_t)df;
+        ds.pm_lq[j] = (uint16_t)lq;
+        ds.pm_dq[j] = (uint16_t)dq;
+      }
+      __syncthreads();
+      // the lazy chain that starts at window position `lane`
+      uint32_t typ = 2, ck = 0, cl = 0, cd = 0;  // typ 0 literal, 1 match chain, 2 unknown
+      {
+        const uint32_t k0 = ds.pm_k[lane];
+        if (k0 & 1) {
+          uint32_t L = (k0 & 2) ? ds.pm_lf[lane] : 2u, d = ds.pm_df[lane];
+          if (L == (uint32_t)MIN_MATCH && d > (uint32_t)TOO_FAR) L = 2;  // lib/de.ml:4363-4367
+          if (L < (uint32_t)MIN_MATCH) typ = 0;
+          else {
+            uint32_t t = lane + 1;
+            typ = 1;
+            for (;;) {
+              if (t >= 80 || !(ds.pm_k[t] & 1)) {
+                typ = 2;
+                break;
+              }
+              if (L >= c_levels[eff_level][1]) break;  // prev_length >= max_lazy: no search
+              const bool quart = L >= c_levels[eff_level][2];
+              const uint32_t m = (ds.pm_k[t] & 2) ? (quart ? ds.pm_lq[t] : ds.pm_lf[t]) : 2u;
+              if (m <= L) break;
+              d = quart ? ds.pm_dq[t] : ds.pm_df[t];
+              L = m;
+              t++;
+            }
+            ck = t - 1 - lane;  // positions lane .. t-2 become literals, the match sits at t-1
+            cl = L;
+            cd = d;
+          }
+        }
+      }
+      const uint64_t special = __ballot(typ != 0);  // chain starts and unknowns
+      const uint64_t unknown = __ballot(typ == 2);
+      // ---- walk and emit (wave-uniform)
+      uint32_t cur = 0, pending = ds.zs.trivial == 1 ? 1u : 0u, cmds = 0;
+      const uint32_t cmax = qavail >= 3 ? qavail - 2 : 0;
+      bool stop = false;
+      while (!stop && cur < (uint32_t)kWave) {
+        const uint64_t rest = special >> cur;
+        const uint32_t x = rest ? cur + (uint32_t)__builtin_ctzll(rest) : (uint32_t)kWave;
+        if (x > cur) {  // literal steps cur .. x-1: the pending literal, then those of cur .. x-2
+          uint32_t nl = pending + (x - 1 - cur);
+          uint32_t xe = x;
+          if (cmds + nl > cmax) {  // queue: take what fits
+            const uint32_t fit = cmax - cmds;
+            if (fit < pending || fit == 0) break;
+            xe = cur + 1 + (fit - pending);
+            nl = fit;
+            stop = true;
+          }
+          if (lane < nl) {
+            const uint32_t q = s0 + cur - pending + lane;  // position of the literal
+            const uint32_t byte = ds.byt[q & (RING - 1)];
+            ws.queue[(qw + cmds + lane) & ((uint32_t)qcap - 1)] = (int)byte;
+            atomicAdd(&ds.lits[byte], 1);
+          }
+          cmds += nl;
+          pending = 1;
+          cur = xe;
+          if (stop) break;
+        }
+        if (cur >= (uint32_t)kWave || ((unknown >> cur) & 1)) break;
+        // the chain at cur: pending literal, ck literals, one match
+        const uint32_t k = (uint32_t)__shfl((int)ck, (int)cur), L = (uint32_t)__shfl((int)cl, (int)cur);
+        const uint32_t d = (uint32_t)__shfl((int)cd, (int)cur);
+        const uint32_t nl = pending + k;
+        if (cmds + nl + 1 > cmax) break;
+        if (lane < nl) {
+          const uint32_t q = s0 + cur - pending + lane;
+          const uint32_t byte = ds.byt[q & (RING - 1)];
+          ws.queue[(qw + cmds + lane) & ((uint32_t)qcap - 1)] = (int)byte;
+          atomicAdd(&ds.lits[byte], 1);
+        } else if (lane == nl) {  // emit_match, lib/de.ml:4236-4245
+          ws.queue[(qw + cmds + nl) & ((uint32_t)qcap - 1)] = (int)(((L - 3) << 16) | (d - 1) | Q_COPY);
+          atomicAdd(&ds.lits[257 + ds.length_code[L]], 1);
+          atomicAdd(&ds.dsts[distance_code(&ds, (int)(d - 1))], 1);
+        }
+        cmds += nl + 1;
+        pending = 0;
+        cur += k + L;  // the match at cur + k covers L positions
+      }
+      // chain links of everything that was passed (all of it is in the ring)
+      for (uint32_t q = s0 + lane; q < s0 + cur; q += kWave) ws.prev[q & WMASK] = ds.hh[q & (RING - 1)];
+      if (lane == 0 && cur > 0) {
+        ds.zs.strstart = s0 + cur;
+        ds.zs.lookahead = la - cur;
+        ds.zs.qw = qw + cmds;
+        ds.zs.trivial = pending ? 1u : 2u;
+        ds.zs.bulked += cur;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __syncthreads();
+      pc[2] += cmds;
+    }
     PROF_MARK(2)
     // would the matcher hand straight back (lz_compress's two LZ_NEED exits)?  Then don't run it:
     // its state machine is a long walk through divergent code even when it has nothing to do
@@ -1573,7 +1715,8 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
       const uint32_t la = ds.zs.lookahead, s2 = ds.zs.strstart;
       const uint32_t avail = (uint32_t)qcap - (ds.zs.qw - ds.zs.qr);
       const bool need_ring = pe < p_end && s2 + 260 > pe;
-      const bool next_bulk = la > (uint32_t)MIN_LOOKAHEAD && s2 < pe && avail >= 3;
+      const bool next_bulk = la > (uint32_t)MIN_LOOKAHEAD && s2 + 1 < pe && avail >= 8 &&
+                             ds.flg[s2 & (RING - 1)] != 0 && ds.flg[(s2 + 1) & (RING - 1)] != 0;
       if (la >= (uint32_t)MIN_LOOKAHEAD && (need_ring || next_bulk)) {
         __syncthreads();
         if (lane == 0) {
@@ -1590,6 +1733,8 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
         run.z.strstart = ds.zs.strstart;
         run.z.lookahead = (int)ds.zs.lookahead;
         run.e.qw = ds.zs.qw;
+        run.z.match_available = ds.zs.trivial == 1 ? 1 : 0;  // the parse step may have changed the state
+        run.z.match_length = MIN_MATCH - 1;
       }
       // after a bulk run that made progress the wave gets another go before the matcher steps
       run.z.steps = (ds.zs.trivial && ds.zs.bulked > 0) ? 1 : 0;
@@ -1629,9 +1774,9 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
       ds.zs.qw = run.e.qw;
       ds.zs.qr = run.e.qr;
       ds.zs.bulked = 0;
-      ds.zs.trivial = (act == ACT_PREP && run.z.level != 0 && run.z.match_available &&
-                       run.z.match_length == MIN_MATCH - 1 && run.phase == PH_LZ)
-                          ? 1u
+      ds.zs.trivial = (act == ACT_PREP && run.z.level != 0 && run.z.match_length == MIN_MATCH - 1 &&
+                       run.phase == PH_LZ)
+                          ? (run.z.match_available ? 1u : 2u)
                           : 0u;
       if (prof) pq[2] += wall_clock64() - q1;
     }
