@@ -282,7 +282,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(args, n, nbytes),
-                "kernel": {1: "inflate_kernel", 2: "inflate_v4_kernel", 3: "2 x (decode_kernel + resolve_kernel), overlapped"}[args.kernel or 3],
+                "kernel": {1: "inflate_kernel", 2: "inflate_v4_kernel", 3: "2 x (decode_kernel + resolve_kernel), overlapped", 5: "inflate_wave_kernel"}[args.kernel or 3],
                 "kernel_ms": round(kernel_ms, 4),
                 "algorithmic_bytes_per_launch": algo_bytes,
             },

@@ -29,6 +29,11 @@ extern "C" int md_launch_inflate_split(int format, uint32_t n, const uint8_t *in
                                        int32_t *status, uint32_t *checksum, uint8_t *log,
                                        uint32_t log_cap, hipStream_t stream);
 
+extern "C" int md_launch_inflate_wave(int format, uint32_t n, const uint8_t *in, const uint64_t *in_off,
+                                      const uint64_t *in_len, uint8_t *out, const uint64_t *out_off,
+                                      const uint64_t *out_cap, uint64_t *out_len, uint64_t *consumed,
+                                      int32_t *status, uint32_t *checksum, uint64_t *dbg, hipStream_t stream);
+
 extern "C" size_t md_deflate_ws_bytes(uint32_t n, int qcap);
 extern "C" int md_launch_deflate(int format, int level, int qcap, int driver, int dynamic, uint32_t n,
                                  const uint8_t *in, const uint64_t *in_off, const uint64_t *in_len,
@@ -198,7 +203,7 @@ md_ctx *md_create(int device, void *hip_stream) {
   }
   if (const char *e = getenv("MD_KERNEL")) {
     int v = atoi(e);
-    if (v >= 1 && v <= 3) ctx->kernel = v;
+    if ((v >= 1 && v <= 3) || v == 5) ctx->kernel = v;
   }
   if (const char *e = getenv("MD_VARIANT")) {
     int v = atoi(e);
@@ -255,7 +260,7 @@ int md_set_option(md_ctx *ctx, const char *key, int value) {
     return MD_OK;
   }
   if (!strcmp(key, "kernel")) {
-    if (value < 1 || value > 3) return fail(ctx, MD_E_INVALID_ARGUMENT, "kernel must be 1, 2 or 3");
+    if (value < 1 || value > 5 || value == 4) return fail(ctx, MD_E_INVALID_ARGUMENT, "kernel must be 1, 2, 3 or 5");
     ctx->kernel = value;
     return MD_OK;
   }
@@ -349,7 +354,10 @@ int md_inflate_batch_device(md_ctx *ctx, int format, size_t n, const uint8_t *d_
     return MD_OK;
   }
   int rc;
-  if (ctx->kernel == 3) {
+  if (ctx->kernel == 5) {
+    rc = md_launch_inflate_wave(format, (uint32_t)n, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap, d_out_len,
+                                d_consumed, d_status, d_checksum, ctx->dbg, ctx->stream);
+  } else if (ctx->kernel == 3) {
     size_t need = n * (size_t)ctx->log_records * md_inflate_log_record_bytes();
     if (need > ctx->log_bytes) {
       if (ctx->log) {

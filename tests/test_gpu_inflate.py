@@ -23,7 +23,7 @@ def eng():
 
 
 # every kernel geometry must be bit-exact: (kernel, option, value)
-GEOMETRIES = [(3, "log_records", 128), (3, "log_records", 6), (2, "variant", 0), (2, "variant", 1), (2, "variant", 2),
+GEOMETRIES = [(5, "log_records", 128), (3, "log_records", 128), (3, "log_records", 6), (2, "variant", 0), (2, "variant", 1), (2, "variant", 2),
               (1, "ring_log2", 12), (1, "ring_log2", 13), (1, "ring_log2", 15)]
 
 
