@@ -6,99 +6,461 @@
 //          bp + i*S until it crosses bp + (i+1)*S (only lane 0 starts on a boundary, the others
 //          are speculative).  Pass k >= 1: a lane whose left neighbour ended somewhere else than
 //          where it started walks again from there and now also counts the bytes its tokens will
-//          produce.  Huffman streams re-synchronise (p ~ 0.9 inside a 256-bit zone), so the chain
+//          produce.  Huffman streams re-synchronise (p ~ 0.9 inside a zone), so the chain
 //          start_i == end_{i-1} settles after ~3 passes; the consistent prefix of lanes is
 //          accepted.  A chain of token boundaries that starts on a known boundary IS the serial
 //          decode of the reference loop (`inflate`, lib/de.ml:1667-1712).  A walk step is one
-//          32-bit peek of the LDS input ring and one 32-bit LUT entry that carries the bits to
-//          skip and the descriptor (index width, base) of the table the NEXT step indexes, so
+//          32-bit peek of the input window in LDS and one 32-bit LUT entry that carries the bits
+//          to skip and the descriptor (index width, base) of the table the NEXT step indexes, so
 //          the step has no per-type branches or selects.
-//   decode One pass over the accepted lanes from their validated starts.  A wave prefix sum of
+//   emit   One pass over the accepted lanes from their validated starts.  A wave prefix sum of
 //          the byte counts has given every lane its output position, so literals go straight
-//          to their final place in the LDS staging buffer and matches become (gap, length,
-//          distance) records; position-dependent checks (Invalid_distance,
-//          Unexpected_end_of_output) happen here at the token, in stream order.
+//          to their final place in the LDS staging buffer and matches become (length, distance,
+//          position) records.  Anything unusual (end of block, an invalid code, a distance or
+//          length the output cannot take, a full buffer) stops the lane in front of the token;
+//          the token is then looked at again with the checks in the reference's order.
 //   copy   Matches whose source is older than the round read it from already flushed output
-//          (L2/HBM, 4 in flight per lane); matches into the round itself resolve lane-parallel
-//          in LDS with exact dependency tracking.
+//          (L2/HBM, 8 matches x 32 bytes in flight per lane); matches into the round itself wait
+//          on a bitmap of the staging bytes that are still to be produced.
 //   flush  16-byte coalesced stores, Adler-32 folded in the same pass with v_dot4_u32_u8
 //          (WInf.update / tail, lib/de.ml:453-455, 499-505).
 //
-// The window is the output buffer itself (De.Inf.Ns semantics, lib/de.ml:1534).  Block headers,
-// LUT construction (lib/de.ml:523-638, 1733-1793), stored blocks (lib/de.ml:1613-1627) and the
-// zlib frame (lib/zl.ml:400-417) run wave-uniform between rounds.  The first failing token in
-// stream order decides the status and everything before it is written (oracle/de_inflate.c).
-#include "inflate_lane.hpp"
+// The window is the output buffer itself (De.Inf.Ns semantics, lib/de.ml:1534).  Block headers
+// (lib/de.ml:1733-1793) are parsed wave-uniform on the scalar unit; the Huffman tables
+// (De.Inf.huffman, lib/de.ml:523-638) are built by all lanes from the canonical code.  Stored
+// blocks (lib/de.ml:1613-1627) and the zlib frame (lib/zl.ml:400-417) run between rounds.  The first
+// failing token in stream order decides the status and everything before it is written
+// (oracle/de_inflate.c).
+#include "inflate_util.hpp"
 
 namespace md {
-namespace v5 {
-using namespace md::v4;
+namespace wv {
+
+// ---- geometry ---------------------------------------------------------------------------------
+constexpr uint32_t S = 264;        // bits per lane zone: 8.25 dwords, so the 64 cursors start on distinct LDS banks
+constexpr uint32_t KMAX = 64;      // walk steps per lane per pass
+constexpr uint32_t PASSES = 5;     // walks after the first one
+constexpr uint32_t MMAX = 14;      // match records per lane per round
+constexpr uint32_t STAGE = 6144;   // staging bytes (one round of output)
+constexpr uint32_t WIN_WORDS = 544;  // input window: 31 + 64*S + 47 bits and the two words a peek touches
 
 // LUT entry: codelen[3:0] | xb[7:4] | val9[16:8] | next.nbits[20:17] | next.tb[31:21]
 //   codelen  bits this step consumes for the code (a LINK entry consumes the root bits, the
 //            sub-table entry behind it the rest of the code)
 //   xb       extra bits that follow the code
 //   val9     literal byte | length base (3..258) | distance symbol (0..29, 30/31 invalid) | 511 = LINK
-//   next     the table the following step indexes: lit root, distance root, a sub-table, or
+//   next     the table the following step indexes: lit root (0), distance root, a sub-table, or
 //            one of the two self-looping STOP entries (end of block / empty distance slot)
-constexpr uint32_t kDistB = 852;
-constexpr uint32_t kStopEobI = 852 + 592;
+constexpr uint32_t kLitSize = 852, kDistSize = 592;  // zlib ENOUGH (lib/de.ml:579-580)
+constexpr uint32_t kDistB = kLitSize;
+constexpr uint32_t kStopEobI = kLitSize + kDistSize;
 constexpr uint32_t kStopBadI = kStopEobI + 1;
 constexpr uint32_t kLutWords = kStopEobI + 4;
 constexpr uint32_t kLinkVal = 511;
-constexpr uint32_t kStEob = 100, kStTrunc = 101;  // lane stop reasons of the decode pass; < 100 = MD_* status
+constexpr uint32_t kStEob = 100, kStTrunc = 101;  // lane stop reasons; < 100 = MD_* status
+constexpr uint32_t kNearBit = 0x8000u;            // match record: len-3[23:16] | near[15] | dist-1[14:0]
+
+struct Smem {  // the kernel's only LDS object: it sits at LDS address 0
+  uint32_t win[WIN_WORDS];
+  uint32_t lut[kLutWords];
+  uint32_t mrec[MMAX * kWave];             // match records, [m][lane]
+  uint16_t mpos[MMAX * kWave];             // their staging positions
+  alignas(16) uint8_t stage[STAGE + 16];   // one round of output; header scratch while a header is parsed
+  uint32_t pend[STAGE / 32 + 2];           // bit per staging byte: still to be produced by a near match
+};
+struct HScratch {       // aliases Smem::stage
+  uint8_t lens[384];    // code lengths: lit/len symbols, then the distance symbols
+  uint16_t work[320];   // symbols sorted by (code length, symbol)
+  uint32_t ctr;         // sub-table allocation counter
+};
+static_assert(sizeof(Smem) <= 20480, "8 wavefronts per CU");
+static_assert(sizeof(HScratch) <= STAGE, "header scratch lives in the staging buffer");
+typedef MD_LDS Smem lds_smem;
+typedef MD_LDS HScratch lds_hscratch;
 
 __device__ __forceinline__ uint32_t mk_entry(uint32_t codelen, uint32_t xb, uint32_t val9, uint32_t nbits, uint32_t tb) {
   return codelen | (xb << 4) | (val9 << 8) | (nbits << 17) | (tb << 21);
 }
-// 16-bit builder entry -> walk entry.  `sub` = the entry sits in a sub-table (its code length includes the root bits).
-__device__ __forceinline__ uint32_t walk_lit(uint32_t e, bool sub, uint32_t lroot, uint32_t droot) {
-  if (e & kLink) return mk_entry(lroot, 0, kLinkVal, (e >> 10) & 15, e & 1023);
-  const uint32_t len = ((e >> 9) & 15) - (sub ? lroot : 0u), sym = e & 511;
-  if (sym < 256) return mk_entry(len, 0, sym, lroot, 0);
-  if (sym == 256) return mk_entry(len, 0, 0, 0, kStopEobI);
+// leaf entries; `codelen` = bits the step consumes
+__device__ __forceinline__ uint32_t lit_leaf(uint32_t sym, uint32_t codelen, uint32_t lroot, uint32_t droot) {
+  if (sym < 256) return mk_entry(codelen, 0, sym, lroot, 0);
+  if (sym == 256) return mk_entry(codelen, 0, 0, 0, kStopEobI);
   const uint32_t l = (sym - 257) & 31;  // lib/de.ml:293-311 (+3 folded in; 29,30 -> 3)
   const uint32_t xb = (l >= 8 && l < 28) ? (l - 4) >> 2 : 0;
   const uint32_t base = (l < 8 ? l : l < 28 ? (4 + (l & 3)) << xb : l == 28 ? 255 : 0) + 3;
-  return mk_entry(len, xb, base, droot, kDistB);
+  return mk_entry(codelen, xb, base, droot, kDistB);
 }
-__device__ __forceinline__ uint32_t walk_dist(uint32_t e, bool sub, uint32_t lroot, uint32_t droot) {
-  if (e == kBad) return mk_entry(0, 0, 0, 0, kStopBadI);
-  if (e & kLink) return mk_entry(droot, 0, kLinkVal, (e >> 10) & 15, kDistB + (e & 1023));
-  const uint32_t len = ((e >> 9) & 15) - (sub ? droot : 0u), dv = e & 31;
+__device__ __forceinline__ uint32_t dist_leaf(uint32_t dv, uint32_t codelen, uint32_t lroot) {
+  dv &= 31;
   const uint32_t xb = (dv >= 4 && dv < 30) ? (dv - 2) >> 1 : 0;  // lib/de.ml:313-325
-  return mk_entry(len, xb, dv, lroot, 0);
+  return mk_entry(codelen, xb, dv, lroot, 0);
+}
+// distance symbol + extra bits -> distance (lib/de.ml:321-325, +1 folded in)
+__device__ __forceinline__ uint32_t dist_value(uint32_t dv, uint32_t xb, uint32_t x) {
+  return (dv < 4 ? dv + 1 : (((dv & 1) | 2) << xb) + 1) + x;
 }
 
-template <class C>
-struct Smem {
-  uint32_t inring[C::IN_WORDS + 4];
-  uint32_t lut[kLutWords];
-  union U {
-    Scratch sc;  // packed 16-bit LUTs + construction scratch: live only while a header is parsed
-    struct T {
-      uint32_t mrec[C::MMAX * kWave];            // match records, [m][lane]
-      alignas(16) uint8_t stage[C::STAGE + 16];  // one round of output
-      uint8_t owner[C::STAGE / 32 + 8];          // producer lane of each 32-byte staging block
-    } t;
-  } u;
-};
-
-// ---------------------------------------------------------------------------
-// One token-boundary walk of this lane's zone [start, limit).  COUNT adds the bytes the tokens produce.
-// A divergent per-lane loop: finished lanes leave the exec mask, the wave leaves when it is empty.
+// ---- input window -----------------------------------------------------------------------------
+// The window holds body bytes [base, base + 4*WIN_WORDS), base a multiple of 4; zero beyond the body.
+__device__ __forceinline__ void win_load(lds_u32 *win, const uint8_t *__restrict__ body, uint32_t nbytes, uint32_t base,
+                                         uint32_t lane) {
+  {
+    const uint32_t off = base + lane * 32;
+    uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (off + 32 <= nbytes) __builtin_memcpy(w, body + off, 32);
+    else if (off < nbytes)
+      for (uint32_t k = 0; k < 32 && off + k < nbytes; k++) w[k >> 2] |= (uint32_t)body[off + k] << (8 * (k & 3));
+    lds_u32 *dst = win + lane * 8;
+#pragma unroll
+    for (int k = 0; k < 8; k++) dst[k] = w[k];
+  }
+  if (lane < WIN_WORDS - 512) {
+    const uint32_t off = base + 2048 + lane * 4;
+    uint32_t w = 0;
+    if (off + 4 <= nbytes) __builtin_memcpy(&w, body + off, 4);
+    else if (off < nbytes)
+      for (uint32_t k = 0; k < 4 && off + k < nbytes; k++) w |= (uint32_t)body[off + k] << (8 * k);
+    win[512 + lane] = w;
+  }
+}
+// 32 bits of the window starting at window-relative bit position p
+__device__ __forceinline__ uint32_t peek(const lds_u32 *win, uint32_t p) {
+  const lds_u32 *q = reinterpret_cast<const lds_u32 *>(reinterpret_cast<const lds_u8 *>(win) + ((p >> 3) & ~3u));
+  return __builtin_amdgcn_alignbit(q[1], q[0], p & 31);
+}
 __device__ __forceinline__ uint32_t lut_at(const lds_u32 *lut, uint32_t tb, uint32_t idx) {
   return *reinterpret_cast<const lds_u32 *>(reinterpret_cast<const lds_u8 *>(lut) + ((tb + idx) << 2));
 }
-template <class C, bool COUNT, class PF>
-__device__ __forceinline__ void sync_pass(const Input<C> &in, const lds_u32 *lut, uint32_t lroot, bool go,
-                                          uint32_t start, uint32_t limit, uint32_t &end, uint32_t &stop,
-                                          uint32_t &nb, PF &pf) {
+
+// wave-uniform bit cursor over the window (block headers); values live in SGPRs
+struct UBits {
+  const lds_u32 *win;
+  uint64_t buf;
+  uint32_t n;   // valid bits in buf
+  uint32_t wp;  // next window word
+  __device__ __forceinline__ void init(const lds_u32 *w, uint32_t bp) {
+    win = w;
+    wp = bp >> 5;
+    buf = ((uint64_t)uni(win[wp]) | ((uint64_t)uni(win[wp + 1]) << 32)) >> (bp & 31);
+    n = 64 - (bp & 31);
+    wp += 2;
+  }
+  __device__ __forceinline__ uint32_t pos() const { return wp * 32 - n; }
+  __device__ __forceinline__ void fill() {  // afterwards n > 32
+    if (n <= 32) {
+      buf |= (uint64_t)uni(win[wp]) << n;
+      n += 32;
+      wp++;
+    }
+  }
+  __device__ __forceinline__ uint32_t peekb(uint32_t k) const { return (uint32_t)buf & ((1u << k) - 1); }
+  __device__ __forceinline__ void drop(uint32_t k) {
+    buf >>= k;
+    n -= k;
+  }
+};
+
+// ---- Huffman tables from the canonical code ---------------------------------------------------
+// De.Inf.huffman (lib/de.ml:523-638) accepts a set of code lengths iff it is not over-subscribed and
+// is complete (or is a single 1-bit code, for the lit/len and distance alphabets), and then decodes
+// the canonical prefix code; zlib's table layout is an implementation detail except for its size
+// (documented divergence D3: more than ENOUGH entries => Invalid_dictionary).  All lanes build the
+// walk table directly: per-length counts by ballot, codes by rank, root slots by a canonical search,
+// sub-tables sized by the longest code behind each root slot (what zlib's `curr` loop computes for a
+// complete code).
+struct Canon {
+  uint32_t cnt[16];    // codes per length
+  uint32_t first[16];  // first canonical code (MSB first) per length
+  uint32_t offs[16];   // rank of the first symbol of that length in `work`
+  uint32_t max, min, root, left;
+};
+__device__ __forceinline__ uint32_t lane_rank(uint64_t m) {  // set bits of m below this lane
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+}
+template <int K>
+__device__ __forceinline__ void canon_counts(const uint32_t (&len)[K], uint32_t rootpref, Canon &c) {
+#pragma unroll
+  for (int l = 1; l < 16; l++) {
+    uint32_t n = 0;
+#pragma unroll
+    for (int k = 0; k < K; k++) n += (uint32_t)__builtin_popcountll(__ballot(len[k] == (uint32_t)l));
+    c.cnt[l] = n;
+  }
+  c.cnt[0] = 0;
+  c.max = 0;
+  c.min = 16;
+#pragma unroll
+  for (int l = 15; l >= 1; l--) {
+    if (c.cnt[l] && c.max == 0) c.max = l;
+    if (c.cnt[l]) c.min = l;
+  }
+  int left = 1;
+  bool over = false;
+  uint32_t code = 0, off = 0;
+  c.first[0] = 0;
+  c.offs[0] = 0;
+#pragma unroll
+  for (int l = 1; l < 16; l++) {
+    left = (left << 1) - (int)c.cnt[l];
+    over = over || left < 0;
+    code = (code + c.cnt[l - 1]) << 1;
+    c.first[l] = code;
+    c.offs[l] = off;
+    off += c.cnt[l];
+  }
+  c.left = over ? 0xffffffffu : (uint32_t)left;  // 0xffffffff = over-subscribed
+  uint32_t root = rootpref;
+  if (root > c.max) root = c.max;
+  if (root < c.min) root = c.min;
+  c.root = root;
+}
+
+// Builds one walk table into lut[tb0 ..).  len[k] = code length of symbol lane + 64k (0 beyond the alphabet).
+// LEAF(sym, codelen) encodes a leaf.  Returns false when the table would need more than `size` entries (D3).
+template <int K, class LEAF>
+__device__ __forceinline__ bool build_walk(const uint32_t (&len)[K], const Canon &c, lds_u32 *lut, uint32_t tb0,
+                                           uint32_t size, lds_hscratch *hs, uint32_t lane, uint32_t zero_entry, LEAF leaf) {
+  const uint32_t root = c.root, rmask = (1u << root) - 1;
+  // codes by rank inside their length class; symbols sorted by (length, symbol) for the root search
+  uint32_t rev[K];
+#pragma unroll
+  for (int k = 0; k < K; k++) rev[k] = 0;
+#pragma unroll
+  for (int l = 1; l < 16; l++) {
+    if (c.cnt[l]) {
+      uint32_t base = 0;
+#pragma unroll
+      for (int k = 0; k < K; k++) {
+        const uint64_t m = __ballot(len[k] == (uint32_t)l);
+        if (len[k] == (uint32_t)l) {
+          const uint32_t rank = base + lane_rank(m);
+          rev[k] = __brev(c.first[l] + rank) >> (32 - l);
+          hs->work[c.offs[l] + rank] = (uint16_t)(lane + 64 * k);
+        }
+        base += (uint32_t)__builtin_popcountll(m);
+      }
+    }
+  }
+  const uint32_t nroot = 1u << root;
+  for (uint32_t i = lane; i < nroot; i += kWave) lut[tb0 + i] = 0;
+  if (lane == 0) hs->ctr = 0;
+  // longest code behind each root slot that leads to a sub-table
+  if (c.max > root) {
+#pragma unroll
+    for (int k = 0; k < K; k++)
+      if (len[k] > root)
+        __hip_atomic_fetch_max(&lut[tb0 + (rev[k] & rmask)], len[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  // root slots: a link (sub-tables get their place from an LDS counter) or the leaf found by canonical search
+  for (uint32_t i = lane; i < nroot; i += kWave) {
+    const uint32_t v = lut[tb0 + i];
+    uint32_t e;
+    if (v) {
+      const uint32_t sub = v - root;
+      const uint32_t off = __hip_atomic_fetch_add(&hs->ctr, 1u << sub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      e = mk_entry(root, 0, kLinkVal, sub, (tb0 + nroot + off) & 2047);
+    } else {
+      const uint32_t cw = __brev(i) >> (32 - root);  // the root bits as an MSB-first code prefix
+      uint32_t fl = 0, ft = 0;
+#pragma unroll
+      for (int l = 15; l >= 1; l--) {  // at most one length matches in a prefix code
+        if (c.cnt[l] && (uint32_t)l <= root) {
+          const uint32_t t = (cw >> (root - l)) - c.first[l];
+          if (t < c.cnt[l]) {
+            fl = l;
+            ft = c.offs[l] + t;
+          }
+        }
+      }
+      e = fl ? leaf((uint32_t)hs->work[ft], fl) : zero_entry;
+    }
+    lut[tb0 + i] = e;
+  }
+  const uint32_t used = nroot + uni(hs->ctr);
+  if (used > size) return false;  // D3
+  // sub-table entries
+  if (c.max > root) {
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      if (len[k] > root) {
+        const uint32_t link = lut[tb0 + (rev[k] & rmask)];
+        const uint32_t sub = (link >> 17) & 15, tb = link >> 21;
+        const uint32_t e = leaf(lane + 64 * k, len[k] - root);
+        for (uint32_t j = rev[k] >> root; j < (1u << sub); j += 1u << (len[k] - root)) lut[tb + j] = e;
+      }
+    }
+  }
+  return true;
+}
+
+// the order of the code-length code lengths (lib/de.ml:225-231), 5 bits each
+constexpr uint64_t kZig0 = 16ull | 17ull << 5 | 18ull << 10 | 0ull << 15 | 8ull << 20 | 7ull << 25 | 9ull << 30 | 6ull << 35 |
+                           10ull << 40 | 5ull << 45 | 11ull << 50 | 4ull << 55;
+constexpr uint64_t kZig1 = 12ull | 3ull << 5 | 13ull << 10 | 2ull << 15 | 14ull << 20 | 1ull << 25 | 15ull << 30;
+
+// Dynamic block header (lib/de.ml:1733-1793) at window bit `bp`.  On MD_OK the walk tables are in lut,
+// *lroot_out is the index width of the lit/len root table and *bp_out the bit after the header.
+__device__ __noinline__ int dynamic_tables(lds_smem *sm, uint32_t bp, uint32_t tot, uint32_t lane, uint32_t *bp_out,
+                                           uint32_t *lroot_out) {
+  const lds_u32 *win = (const lds_u32 *)sm->win;
+  lds_hscratch *hs = reinterpret_cast<lds_hscratch *>(sm->stage);
+  UBits ub;
+  ub.init(win, bp);
+  if ((int32_t)(tot - ub.pos()) < 14) return MD_UNEXPECTED_END_OF_INPUT;
+  const uint32_t hlit = ub.peekb(5) + 257;
+  ub.drop(5);
+  const uint32_t hdist = ub.peekb(5) + 1;
+  ub.drop(5);
+  const uint32_t hclen = ub.peekb(4) + 4;
+  ub.drop(4);
+  // code-length code lengths: lane j holds the length of symbol j
+  uint32_t cl[1] = {0};
+  for (uint32_t i = 0; i < hclen; i++) {
+    ub.fill();
+    if ((int32_t)(tot - ub.pos()) < 3) return MD_UNEXPECTED_END_OF_INPUT;
+    const uint32_t v = ub.peekb(3);
+    ub.drop(3);
+    const uint32_t z = (uint32_t)((i < 12 ? kZig0 >> (5 * i) : kZig1 >> (5 * (i - 12))) & 31);
+    if (lane == z) cl[0] = v;
+  }
+  // its decode table: 128 direct entries (root 7 >= longest code), two per lane: sym | len << 8, 0xffff = unreachable
+  Canon cc;
+  canon_counts<1>(cl, 7, cc);
+  uint32_t cmaxl, t_lo, t_hi;
+  if (cc.max == 0) {  // empty_table (lib/de.ml:521): a 1-bit code for symbol 0, the other slot out of bounds (D2)
+    cmaxl = 1;
+    t_lo = lane == 0 ? (1u << 8) : 0xffffu;
+    t_hi = 0xffffu;
+  } else {
+    if (cc.left != 0) return MD_INVALID_DICTIONARY;  // over-subscribed or incomplete
+    cmaxl = cc.max;
+    // rank of each symbol inside its length class, then the table by canonical search (codes <= 7 bits)
+#pragma unroll
+    for (int l = 1; l < 8; l++) {
+      const uint64_t m = __ballot(cl[0] == (uint32_t)l);
+      if (cl[0] == (uint32_t)l) hs->work[cc.offs[l] + lane_rank(m)] = (uint16_t)lane;
+    }
+    uint32_t t[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const uint32_t i = lane + 64 * h;
+      const uint32_t cw = __brev(i & ((1u << cmaxl) - 1)) >> (32 - cmaxl);
+      uint32_t fl = 0, ft = 0;
+#pragma unroll
+      for (int l = 7; l >= 1; l--) {
+        if (cc.cnt[l] && (uint32_t)l <= cmaxl) {
+          const uint32_t x = (cw >> (cmaxl - l)) - cc.first[l];
+          if (x < cc.cnt[l]) {
+            fl = l;
+            ft = cc.offs[l] + x;
+          }
+        }
+      }
+      t[h] = fl ? ((uint32_t)hs->work[ft] | (fl << 8)) : 0xffffu;
+    }
+    t_lo = t[0];
+    t_hi = t[1];
+  }
+  // the hlit + hdist code lengths, run-length coded (lib/de.ml:1733-1769)
+  const uint32_t max_res = hlit + hdist;
+  for (uint32_t x = lane; x < 384; x += kWave) hs->lens[x] = 0;
+  uint32_t i = 0, prev = 0;
+  while (i < max_res) {
+    ub.fill();
+    if ((int32_t)(tot - ub.pos()) < (int32_t)cmaxl) return MD_UNEXPECTED_END_OF_INPUT;
+    const uint32_t idx = ub.peekb(cmaxl);
+    const uint32_t e = idx < 64 ? __builtin_amdgcn_readlane(t_lo, idx) : __builtin_amdgcn_readlane(t_hi, idx - 64);
+    if (e == 0xffffu) return MD_INVALID_DICTIONARY;
+    const uint32_t sym = e & 0xff;
+    ub.drop(e >> 8);
+    if (sym < 16) {
+      if (lane == 0) hs->lens[i] = (uint8_t)sym;
+      prev = sym;
+      i++;
+    } else {
+      const uint32_t nb = sym == 16 ? 2 : sym == 17 ? 3 : 7;
+      if (sym == 16 && i == 0) return MD_INVALID_DICTIONARY;
+      ub.fill();
+      if ((int32_t)(tot - ub.pos()) < (int32_t)nb) return MD_UNEXPECTED_END_OF_INPUT;
+      const uint32_t copy = ub.peekb(nb) + (sym == 18 ? 11 : 3);
+      ub.drop(nb);
+      const uint32_t val = sym == 16 ? prev : 0;
+      if (i + copy > max_res) return MD_INVALID_DICTIONARY;
+      if (val)
+        for (uint32_t x = lane; x < copy; x += kWave) hs->lens[i + x] = (uint8_t)val;
+      prev = val;
+      i += copy;
+    }
+  }
+  *bp_out = ub.pos();
+  if (uni(hs->lens[256]) == 0) return MD_INVALID_DICTIONARY;
+  // the two alphabets, lane-parallel
+  uint32_t ll[5], dl[1];
+#pragma unroll
+  for (int k = 0; k < 5; k++) ll[k] = lane + 64 * k < hlit ? (uint32_t)hs->lens[lane + 64 * k] : 0u;
+  dl[0] = lane < hdist ? (uint32_t)hs->lens[hlit + lane] : 0u;
+  Canon cl_, cd_;
+  canon_counts<5>(ll, 9, cl_);
+  canon_counts<1>(dl, 6, cd_);
+  // De.Inf.huffman's verdicts (lib/de.ml:549-550): over-subscribed, or incomplete unless the longest code is 1 bit
+  if (cl_.left == 0xffffffffu || (cl_.left > 0 && cl_.max != 1)) return MD_INVALID_DICTIONARY;
+  const uint32_t lroot = cl_.root;
+  uint32_t droot;
+  lds_u32 *lut = (lds_u32 *)sm->lut;
+  if (cd_.max == 0) {
+    droot = 1;
+  } else {
+    if (cd_.left == 0xffffffffu || (cd_.left > 0 && cd_.max != 1)) return MD_INVALID_DICTIONARY;
+    droot = cd_.root;
+  }
+  if (!build_walk<5>(ll, cl_, lut, 0, kLitSize, hs, lane, mk_entry(0, 0, 0, lroot, 0),
+                     [=](uint32_t sym, uint32_t codelen) { return lit_leaf(sym, codelen, lroot, droot); }))
+    return MD_INVALID_DICTIONARY;
+  if (cd_.max == 0) {  // empty_table: symbol 0 on a 1-bit code, the other slot is an error (D2)
+    if (lane == 0) {
+      lut[kDistB] = dist_leaf(0, 1, lroot);
+      lut[kDistB + 1] = mk_entry(0, 0, 0, 0, kStopBadI);
+    }
+  } else if (!build_walk<1>(dl, cd_, lut, kDistB, kDistSize, hs, lane, mk_entry(0, 0, 0, lroot, 0),
+                            [=](uint32_t sym, uint32_t codelen) { return dist_leaf(sym, codelen, lroot); }))
+    return MD_INVALID_DICTIONARY;
+  *lroot_out = lroot;
+  return MD_OK;
+}
+
+// fixed_lit / fixed_dist (lib/de.ml:821-833): 288 lit/len codes of 8/9/7/8 bits, 32 distance codes of 5 bits
+__device__ __noinline__ void fixed_tables(lds_smem *sm, uint32_t lane, uint32_t *lroot_out) {
+  lds_hscratch *hs = reinterpret_cast<lds_hscratch *>(sm->stage);
+  uint32_t ll[5], dl[1];
+#pragma unroll
+  for (int k = 0; k < 5; k++) {
+    const uint32_t n = lane + 64 * k;
+    ll[k] = n < 144 ? 8 : n < 256 ? 9 : n < 280 ? 7 : n < 288 ? 8 : 0;
+  }
+  dl[0] = lane < 32 ? 5 : 0;
+  Canon cl_, cd_;
+  canon_counts<5>(ll, 9, cl_);
+  canon_counts<1>(dl, 6, cd_);
+  const uint32_t lroot = cl_.root, droot = cd_.root;
+  lds_u32 *lut = (lds_u32 *)sm->lut;
+  build_walk<5>(ll, cl_, lut, 0, kLitSize, hs, lane, mk_entry(0, 0, 0, lroot, 0),
+                [=](uint32_t sym, uint32_t codelen) { return lit_leaf(sym, codelen, lroot, droot); });
+  build_walk<1>(dl, cd_, lut, kDistB, kDistSize, hs, lane, mk_entry(0, 0, 0, lroot, 0),
+                [=](uint32_t sym, uint32_t codelen) { return dist_leaf(sym, codelen, lroot); });
+  *lroot_out = lroot;
+}
+
+// ---- the walks ----------------------------------------------------------------------------------
+// One token-boundary walk of this lane's zone [start, limit).  COUNT adds the bytes the tokens produce.
+// A divergent per-lane loop: finished lanes leave the exec mask, the wave leaves when it is empty.
+template <bool COUNT>
+__device__ __forceinline__ void sync_pass(const lds_u32 *win, const lds_u32 *lut, uint32_t lroot, bool go, uint32_t start,
+                                          uint32_t limit, uint32_t &end, uint32_t &stop, uint32_t &nb) {
   if (go) {
     uint32_t p = start, tb = 0, nbits = lroot, cnt = 0, slot = 0;
-    // a step that starts a token (tb == 0) is taken while the zone and the slot budget last
-    while ((tb < kStopEobI) & ((tb != 0) | ((p < limit) & (slot < C::KMAX)))) {
-      const uint32_t w = in.peek(p);
+    // a step that starts a token (tb == 0) is taken while the zone and the step budget last
+    while ((tb < kStopEobI) & ((tb != 0) | ((p < limit) & (slot < KMAX)))) {
+      const uint32_t w = peek(win, p);
       const uint32_t e = lut_at(lut, tb, __builtin_amdgcn_ubfe(w, 0, nbits));
       const uint32_t codelen = e & 15, xb = (e >> 4) & 15, ntb = e >> 21;
       if (COUNT) {
@@ -116,80 +478,116 @@ __device__ __forceinline__ void sync_pass(const Input<C> &in, const lds_u32 *lut
   }
 }
 
-// The decode pass: the same walk from a validated start, producing output.
 struct LaneOut {
   uint32_t endp;   // bit after the last token taken (a token boundary)
   uint32_t stopc;  // 0 = zone done, kStEob, kStTrunc (round capacity), else MD_* status of the failing token
   uint32_t bytes;  // bytes produced (up to the failing token)
   uint32_t nm;     // match records written
 };
-template <class C, class PF>
-__device__ __forceinline__ void emit_pass(const Input<C> &in, const lds_u32 *lut, uint32_t lroot, lds_u32 *mrec,
-                                            lds_u8 *stage, uint32_t lane, uint32_t total_bits, bool go,
-                                            uint32_t start, uint32_t limit, uint32_t q0, uint32_t rb,
-                                            uint32_t R0, uint32_t cap, LaneOut &lo, PF &pf) {
+
+// The token at ptok, with every check in the oracle's order (oracle/de_inflate.c ns_inflate_block): called for
+// the lanes the emit pass stopped.  Returns the stop reason; *pend_out = bit after an end-of-block code.
+__device__ __noinline__ uint32_t slow_token(const lds_u32 *win, const lds_u32 *lut, uint32_t lroot, uint32_t ptok, uint32_t q,
+                                            uint32_t tot, uint32_t cap, uint32_t *pend_out) {
+  uint32_t p = ptok;
+  uint32_t w = peek(win, p);
+  uint32_t e = lut_at(lut, 0, __builtin_amdgcn_ubfe(w, 0, lroot));
+  if (((e >> 8) & 511) == kLinkVal) {
+    p += e & 15;
+    w = peek(win, p);
+    e = lut_at(lut, e >> 21, __builtin_amdgcn_ubfe(w, 0, (e >> 17) & 15));
+  }
+  uint32_t codelen = e & 15, xb = (e >> 4) & 15, val9 = (e >> 8) & 511, ntb = e >> 21;
+  uint32_t pn = p + codelen + xb;
+  if (pn > tot) return MD_UNEXPECTED_END_OF_INPUT;  // D1
+  if (ntb == kStopEobI) {
+    *pend_out = pn;
+    return kStEob;
+  }
+  if (ntb != kDistB) {  // literal
+    if (q >= cap) return MD_UNEXPECTED_END_OF_OUTPUT;
+    return kStTrunc;
+  }
+  const uint32_t mlen = val9 + __builtin_amdgcn_ubfe(w, codelen, xb);
+  p = pn;
+  w = peek(win, p);
+  e = lut_at(lut, kDistB, __builtin_amdgcn_ubfe(w, 0, (e >> 17) & 15));
+  if ((e >> 21) == kStopBadI) return MD_INVALID_DISTANCE_CODE;  // D2
+  if (((e >> 8) & 511) == kLinkVal) {
+    p += e & 15;
+    w = peek(win, p);
+    e = lut_at(lut, e >> 21, __builtin_amdgcn_ubfe(w, 0, (e >> 17) & 15));
+    if ((e >> 21) == kStopBadI) return MD_INVALID_DISTANCE_CODE;
+  }
+  codelen = e & 15, xb = (e >> 4) & 15, val9 = (e >> 8) & 511;
+  pn = p + codelen + xb;
+  if (pn > tot) return MD_UNEXPECTED_END_OF_INPUT;
+  if (val9 >= 30) return MD_INVALID_DISTANCE_CODE;
+  const uint32_t d = dist_value(val9, xb, __builtin_amdgcn_ubfe(w, codelen, xb));
+  const uint32_t lim = q < 32768u ? q : 32768u;
+  if (d > lim) return MD_INVALID_DISTANCE;
+  if (mlen > cap - q) return MD_UNEXPECTED_END_OF_OUTPUT;
+  return kStTrunc;  // the token is fine: the round's staging buffer or record list is full
+}
+
+// The emit pass: the same walk from a validated start, producing output.  Straight-line per step; anything
+// unusual stops the lane in front of the token (ptok) and is classified afterwards by slow_token.
+__device__ __forceinline__ void emit_pass(const lds_u32 *win, const lds_u32 *lut, uint32_t lroot, lds_u32 *mrec,
+                                          lds_u16 *mpos, lds_u8 *stage, uint32_t lane, uint32_t tot, bool go, uint32_t start,
+                                          uint32_t limit, uint32_t q0, uint32_t rb, uint32_t R0, uint32_t cap, LaneOut &lo) {
   uint32_t p = start, ptok = start, tb = 0, nbits = lroot;
-  uint32_t q = q0, gap = 0, nm = 0, mlen = 0, stopc = 0;
-  const uint32_t qlim = rb + C::STAGE - 16;  // the staging buffer holds output positions [rb, qlim)
+  uint32_t q = q0, nm = 0, mlen = 0;
+  bool stopped = false;
+  const uint32_t qlim = rb + STAGE - 16;  // the staging buffer holds output positions [rb, qlim)
+  const uint32_t qmax = cap < qlim ? cap : qlim;
   if (go) {
-  uint32_t slot = 0;
-  while ((stopc == 0) & ((tb != 0) | ((p < limit) & (slot < C::KMAX)))) {
-    ptok = tb == 0 ? p : ptok;
-    const uint32_t w = in.peek(p);
-    const uint32_t e = lut_at(lut, tb, __builtin_amdgcn_ubfe(w, 0, nbits));
-    const uint32_t codelen = e & 15, xb = (e >> 4) & 15, val9 = (e >> 8) & 511, ntb = e >> 21;
-    const uint32_t x = __builtin_amdgcn_ubfe(w, codelen, xb);
-    const uint32_t pn = p + codelen + xb;
-    const bool in_dist = tb >= kDistB, is_link = val9 == kLinkVal;
-    // oracle order: empty distance slot (D2), then end of input (D1), then distance code 30/31
-    uint32_t st = ntb == kStopBadI                       ? (uint32_t)MD_INVALID_DISTANCE_CODE
-                  : (!is_link && pn > total_bits)        ? (uint32_t)MD_UNEXPECTED_END_OF_INPUT
-                  : (in_dist && !is_link && val9 >= 30u) ? (uint32_t)MD_INVALID_DISTANCE_CODE
-                                                         : 0u;
-    if (!st && !is_link) {
-      if (in_dist) {  // the distance completes a match
-        const uint32_t d = (val9 < 4 ? val9 + 1 : (((val9 & 1) | 2) << xb) + 1) + x;
-        const uint32_t lim = q < 32768u ? q : 32768u;
-        if (d > lim) st = MD_INVALID_DISTANCE;
-        else if (mlen > cap - q) st = MD_UNEXPECTED_END_OF_OUTPUT;
-        else if (q + mlen > qlim || nm == C::MMAX) st = kStTrunc;
-        else {
-          mrec[nm * kWave + lane] = (gap << 24) | ((mlen - 3) << 16) | ((q - d + mlen > R0) ? kNear : 0u) | (d - 1);
+    uint32_t slot = 0;
+    while ((!stopped) & ((tb != 0) | ((p < limit) & (slot < KMAX)))) {
+      ptok = tb == 0 ? p : ptok;
+      const uint32_t w = peek(win, p);
+      const uint32_t e = lut_at(lut, tb, __builtin_amdgcn_ubfe(w, 0, nbits));
+      const uint32_t codelen = e & 15, xb = (e >> 4) & 15, val9 = (e >> 8) & 511, ntb = e >> 21;
+      const uint32_t x = __builtin_amdgcn_ubfe(w, codelen, xb);
+      const uint32_t pn = p + codelen + xb;
+      const bool in_dist = tb >= kDistB, to_root = ntb == 0;
+      const bool lit = to_root & !in_dist, mat = to_root & in_dist, is_len = ntb == kDistB;
+      const uint32_t d = dist_value(val9, xb, x);
+      const uint32_t lim = q < 32768u ? q : 32768u;
+      const uint32_t need = mat ? mlen : 1u;
+      const bool rare = (ntb >= kStopEobI) | ((val9 != kLinkVal) & (pn > tot)) |
+                        (mat & ((val9 >= 30u) | (d > lim) | (nm == MMAX))) | ((lit | mat) & (q + need > qmax));
+      stopped = rare;
+      if (!rare) {
+        if (lit) stage[q - rb] = (uint8_t)val9;
+        if (mat) {
+          mrec[nm * kWave + lane] = ((mlen - 3) << 16) | ((q - d + mlen > R0) ? kNearBit : 0u) | (d - 1);
+          mpos[nm * kWave + lane] = (uint16_t)(q - rb);
           nm++;
-          gap = 0;
-          q += mlen;
         }
-      } else if (ntb == kDistB) {
-        mlen = val9 + x;
-      } else if (ntb == kStopEobI) {
-        st = kStEob;
-      } else {  // literal
-        if (q >= cap) st = MD_UNEXPECTED_END_OF_OUTPUT;
-        else if (q >= qlim) st = kStTrunc;
-        else {
-          stage[q - rb] = (uint8_t)val9;
-          q++;
-          gap++;
-        }
+        mlen = is_len ? val9 + x : mlen;
+        q += lit ? 1u : mat ? need : 0u;
+        p = pn;
+        nbits = (e >> 17) & 15;
+        tb = ntb;
       }
+      slot++;
     }
-    stopc = st;
-    p = (st == 0 || st == kStEob) ? pn : p;
-    nbits = (e >> 17) & 15;
-    tb = ntb;
-    slot++;
   }
+  uint32_t stopc = 0, endp = p;
+  if (go && stopped) {
+    endp = ptok;
+    stopc = slow_token(win, lut, lroot, ptok, q, tot, cap, &endp);
   }
   if (go) {
-    lo.endp = (stopc == 0 || stopc == kStEob) ? p : ptok;
+    lo.endp = endp;
     lo.stopc = stopc;
     lo.bytes = q - q0;
     lo.nm = nm;
   }
 }
 
-// ---------------------------------------------------------------------------
-struct Sink5 {
+// ---- output -------------------------------------------------------------------------------------
+struct Sink {
   lds_u8 *stage;
   uint8_t *g;
   uint32_t cap;
@@ -210,27 +608,28 @@ struct Sink5 {
       const uint32_t hi = cpos + 16 < endp ? cpos + 16 : endp;
       if (lo < hi) {
         const lds_u32 *sp = reinterpret_cast<const lds_u32 *>(stage + (cpos - rb));  // 16-byte aligned
-        const uint32_t w[4] = {sp[0], sp[1], sp[2], sp[3]};
+        const uint32_t w0 = sp[0], w1 = sp[1], w2 = sp[2], w3 = sp[3];
+        const uint4 v = make_uint4(w0, w1, w2, w3);
         if (hi - lo == 16) {
-          const uint4 v = make_uint4(w[0], w[1], w[2], w[3]);
           __builtin_memcpy(g + cpos, &v, 16);
           if (want_adler) {
             // sum d_k and sum k*d_k over the 16 bytes
-            uint32_t t1 = __builtin_amdgcn_udot4(w[0], 0x01010101u, 0u, false);
-            t1 = __builtin_amdgcn_udot4(w[1], 0x01010101u, t1, false);
-            t1 = __builtin_amdgcn_udot4(w[2], 0x01010101u, t1, false);
-            t1 = __builtin_amdgcn_udot4(w[3], 0x01010101u, t1, false);
-            uint32_t tk = __builtin_amdgcn_udot4(w[0], 0x03020100u, 0u, false);
-            tk = __builtin_amdgcn_udot4(w[1], 0x07060504u, tk, false);
-            tk = __builtin_amdgcn_udot4(w[2], 0x0b0a0908u, tk, false);
-            tk = __builtin_amdgcn_udot4(w[3], 0x0f0e0d0cu, tk, false);
+            uint32_t t1 = __builtin_amdgcn_udot4(w0, 0x01010101u, 0u, false);
+            t1 = __builtin_amdgcn_udot4(w1, 0x01010101u, t1, false);
+            t1 = __builtin_amdgcn_udot4(w2, 0x01010101u, t1, false);
+            t1 = __builtin_amdgcn_udot4(w3, 0x01010101u, t1, false);
+            uint32_t tk = __builtin_amdgcn_udot4(w0, 0x03020100u, 0u, false);
+            tk = __builtin_amdgcn_udot4(w1, 0x07060504u, tk, false);
+            tk = __builtin_amdgcn_udot4(w2, 0x0b0a0908u, tk, false);
+            tk = __builtin_amdgcn_udot4(w3, 0x0f0e0d0cu, tk, false);
             s1 += t1;
             s2 += (endp - cpos) * t1 - tk;
           }
         } else {
           for (uint32_t x = lo; x < hi; x++) {
             const uint32_t k = x - cpos;
-            const uint32_t d = (w[k >> 2] >> (8 * (k & 3))) & 0xff;
+            const uint32_t wk = k < 4 ? w0 : k < 8 ? w1 : k < 12 ? w2 : w3;
+            const uint32_t d = (wk >> (8 * (k & 3))) & 0xff;
             g[x] = (uint8_t)d;
             s1 += d;
             s2 += (endp - x) * d;
@@ -248,103 +647,127 @@ struct Sink5 {
   }
 };
 
-// ---------------------------------------------------------------------------
-// Far and near matches of a round (records of lanes [0, nvalid) with nm records each).
-template <class C, class PF>
-__device__ __forceinline__ void copy_matches(lds_u32 *mrec, lds_u8 *owner, const Sink5 &sk, uint32_t lane,
-                                             uint32_t q0, uint32_t nm, PF &pf) {
+// Far matches (the whole source is older than this round: final in HBM/L2 once the flush of earlier rounds has
+// been waited for; d >= ml) and the heads of matches that straddle the round start.
+template <class PF>
+__device__ __forceinline__ void copy_far(const lds_u32 *mrec, const lds_u16 *mpos, const Sink &sk, uint32_t lane, uint32_t nm,
+                                         PF &pf) {
   lds_u8 *stage = sk.stage;
   const uint32_t R0 = sk.pos, rb = sk.sbase(), cap = sk.cap;
   const uint8_t *g = sk.g;
-  // (b) far matches: the whole source is older than this round — final in HBM/L2, visible once the flush
-  //     of earlier rounds has been waited for; d >= ml.  The loads of up to 4 matches per lane are in flight together.
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  {
-    uint32_t qq = q0, m = 0;
-    while (__any(m < nm)) {
-      uint64_t v0[4], v1[4];
-      uint32_t dq[4], dl[4], ds[4];
+  constexpr int B = 8;
+  for (uint32_t m0 = 0; __ballot(m0 < nm) != 0; m0 += B) {
+    uint64_t v[B][4];
+    uint32_t dq[B], dl[B], ds[B];
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        dl[u] = 0;
-        dq[u] = 0;
-        ds[u] = 0;
-        v0[u] = 0;
-        v1[u] = 0;
-        while (m < nm) {  // advance to this lane's next far record
-          const uint32_t tk = mrec[m * kWave + lane];
-          const uint32_t d = (tk & 0x7fff) + 1, ml = ((tk >> 16) & 0xff) + 3;
-          qq += tk >> 24;
-          const uint32_t cq = qq;
-          qq += ml;
-          m++;
-          if (tk & kNear) continue;
-          v0[u] = out_ld_guard(g, cq - d, ml, cap);
-          if (ml > 8) v1[u] = out_ld_guard(g, cq - d + 8, ml - 8, cap);
-          dq[u] = cq;
-          dl[u] = ml;
-          ds[u] = cq - d;
-          break;
-        }
+    for (int u = 0; u < B; u++) {
+      dl[u] = 0;
+      dq[u] = 0;
+      ds[u] = 0;
+      if (m0 + u < nm) {
+        const uint32_t tk = mrec[(m0 + u) * kWave + lane];
+        const uint32_t qs = mpos[(m0 + u) * kWave + lane];  // staging index of the destination
+        const uint32_t d = (tk & 0x7fff) + 1, ml = ((tk >> 16) & 0xff) + 3;
+        const uint32_t src = rb + qs - d;
+        // near matches that begin before the round start: their head [src, R0) is final too
+        const uint32_t n = !(tk & kNearBit) ? ml : src < R0 ? R0 - src : 0u;
+        dq[u] = qs;
+        dl[u] = n;
+        ds[u] = src;
       }
+    }
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        if (dl[u]) {
-          lds_u8 *dd = stage + (dq[u] - rb);
-          const uint32_t ml = dl[u];
-          lds_st(dd, v0[u], ml);
-          if (ml > 8) lds_st(dd + 8, v1[u], ml - 8);
-          for (uint32_t j = 16; j < ml; j += 8)  // long far match: stream the rest (rare)
-            lds_st(dd + j, out_ld_guard(g, ds[u] + j, ml - j, cap), ml - j);
-        }
+    for (int u = 0; u < B; u++) {
+#pragma unroll
+      for (int c = 0; c < 4; c++) v[u][c] = dl[u] > 8u * c ? out_ld_guard(g, ds[u] + 8 * c, dl[u] - 8 * c, cap) : 0ull;
+    }
+#pragma unroll
+    for (int u = 0; u < B; u++) {
+      if (dl[u]) {
+        lds_u8 *dd = stage + dq[u];
+        const uint32_t ml = dl[u];
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+          if (ml > 8u * c) lds_st(dd + 8 * c, v[u][c], ml - 8 * c);
+        for (uint32_t j = 32; j < ml; j += 8)  // long far match: stream the rest (rare)
+          lds_st(dd + j, out_ld_guard(g, ds[u] + j, ml - j, cap), ml - j);
       }
     }
   }
   pf.tick(P_FAR);
-  // (c) near matches: the source reaches into this round's staging buffer.  `done` is the position of this
-  //     lane's first unresolved match: everything the lane produces before it is final.  A match may run when
-  //     the first unresolved lane at or after the producer of its source is itself, or is past the source's end.
-  {
-    uint32_t m = 0, qq = q0;
-    uint32_t d = 0, ml = 0, qm = 0, ja = 0;
-    bool pending = false;
-    auto advance = [&]() {
-      pending = false;
-      while (m < nm) {
-        const uint32_t tk = mrec[m * kWave + lane];
-        d = (tk & 0x7fff) + 1;
-        ml = ((tk >> 16) & 0xff) + 3;
-        qm = qq + (tk >> 24);
-        m++;
-        qq = qm + ml;
-        if (tk & kNear) {
-          const uint32_t src = qm - d;
-          ja = src >= rb ? owner[(src - rb) >> 5] : 0;
-          pending = true;
-          break;
-        }
+}
+
+// bits [a, b) of the pending map, b > a
+__device__ __forceinline__ bool pend_any(const lds_u32 *pend, uint32_t a, uint32_t b) {
+  const uint32_t w0 = a >> 5, w1 = (b - 1) >> 5;
+  uint32_t any = 0;
+  for (uint32_t w = w0; w <= w1; w++) {
+    uint32_t m = 0xffffffffu;
+    if (w == w0) m &= 0xffffffffu << (a & 31);
+    if (w == w1) m &= 0xffffffffu >> (31 - ((b - 1) & 31));
+    any |= pend[w] & m;
+  }
+  return any != 0;
+}
+template <bool SET>
+__device__ __forceinline__ void pend_update(lds_u32 *pend, uint32_t a, uint32_t b) {
+  const uint32_t w0 = a >> 5, w1 = (b - 1) >> 5;
+  for (uint32_t w = w0; w <= w1; w++) {
+    uint32_t m = 0xffffffffu;
+    if (w == w0) m &= 0xffffffffu << (a & 31);
+    if (w == w1) m &= 0xffffffffu >> (31 - ((b - 1) & 31));
+    if (SET) __hip_atomic_fetch_or(&pend[w], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else __hip_atomic_fetch_and(&pend[w], ~m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+}
+
+// Near matches: the source reaches into this round's staging buffer.  Every near match marks its destination
+// bytes pending; a lane takes its matches in order, each as soon as no source byte is pending.  The earliest
+// unresolved match of the round never waits, so every step makes progress.
+template <class PF>
+__device__ __forceinline__ void copy_near_all(const lds_u32 *mrec, const lds_u16 *mpos, lds_u32 *pend, const Sink &sk,
+                                              uint32_t lane, uint32_t nm, bool *stuck, PF &pf) {
+  lds_u8 *stage = sk.stage;
+  const uint32_t head = sk.pos - sk.sbase();  // staging index of the round start
+  uint32_t m = 0, qs = 0, d = 0, ml = 0;
+  bool have = false;
+  auto advance = [&]() {
+    have = false;
+    while (m < nm) {
+      const uint32_t tk = mrec[m * kWave + lane];
+      qs = mpos[m * kWave + lane];
+      d = (tk & 0x7fff) + 1;
+      ml = ((tk >> 16) & 0xff) + 3;
+      m++;
+      if (tk & kNearBit) {
+        have = true;
+        break;
       }
-    };
+    }
+  };
+  advance();
+  while (have) {  // mark
+    pend_update<true>(pend, qs, qs + ml);
     advance();
-    for (;;) {
-      const uint64_t pm = __ballot(pending);
-      if (!pm) break;
-      pf.count(C_NEAR_IT);
-      const uint32_t done = pending ? qm : 0xffffffffu;
-      uint32_t f = lane;
-      if (pending) f = ja + (uint32_t)__builtin_ctzll(pm >> ja);  // bit `lane` is set: pm >> ja != 0
-      const uint32_t df = __shfl(done, f);
-      if (pending && (f >= lane || df >= qm - d + ml)) {
-        const uint32_t src = qm - d;
-        lds_u8 *dd = stage + (qm - rb);
-        if (src >= R0) {
-          copy_near(dd, stage + (src - rb), ml, d);
-        } else {
-          // straddles the round start: the first bytes come from HBM
-          const uint32_t ng = R0 - src;
-          for (uint32_t j = 0; j < ng; j++) dd[j] = (uint8_t)out_ld8(g + src + j);
-          copy_near(dd + ng, stage + (R0 - rb), ml - ng, d);
-        }
+  }
+  m = 0;
+  advance();
+  for (uint32_t guard = 0; __ballot(have) != 0; guard++) {
+    if (guard > kWave * MMAX + 8) {  // cannot happen: the earliest unresolved match is always ready
+      *stuck = true;
+      break;
+    }
+    pf.count(C_NEAR_IT);
+    if (have) {
+      // source bytes: staging [qs - d, min(qs - d + ml, qs)); the part before the round start came from HBM (copy_far)
+      const int32_t s0 = (int32_t)qs - (int32_t)d;
+      const uint32_t skip = s0 < (int32_t)head ? head - (uint32_t)s0 : 0u;  // bytes already placed
+      const uint32_t sa = (uint32_t)(s0 + (int32_t)skip), sb = d < ml ? qs : (uint32_t)s0 + ml;
+      const bool ready = sa >= sb || !pend_any(pend, sa, sb);
+      if (ready) {
+        if (skip < ml) copy_near(stage + qs + skip, stage + sa, ml - skip, d);
+        pend_update<false>(pend, qs, qs + ml);
         advance();
       }
     }
@@ -353,31 +776,36 @@ __device__ __forceinline__ void copy_matches(lds_u32 *mrec, lds_u8 *owner, const
 }
 
 // ---------------------------------------------------------------------------
-// All rounds of one Huffman block.  On return *bp_io is the bit after the EOB.
-template <class C, class PF>
-__device__ __forceinline__ int inflate_block(Smem<C> *smg, Input<C> &in, Sink5 &sk, uint32_t lroot, uint32_t lane,
-                                             uint32_t total_bits, uint32_t *bp_io, PF &pf) {
+// All rounds of one Huffman block.  bp is a bit position of the body; on return *bp_io is the bit after the EOB.
+template <class PF>
+__device__ __forceinline__ int inflate_block(lds_smem *sm, const uint8_t *__restrict__ body, uint32_t body_len, Sink &sk,
+                                             uint32_t lroot, uint32_t lane, uint32_t *bp_io, PF &pf) {
   uint32_t bp = *bp_io;
-  const lds_u32 *lut = (const lds_u32 *)smg->lut;
-  lds_u32 *mrec = (lds_u32 *)smg->u.t.mrec;
-  lds_u8 *owner = (lds_u8 *)smg->u.t.owner;
+  lds_u32 *win = (lds_u32 *)sm->win;
+  const lds_u32 *lut = (const lds_u32 *)sm->lut;
+  lds_u32 *mrec = (lds_u32 *)sm->mrec;
+  lds_u16 *mpos = (lds_u16 *)sm->mpos;
+  lds_u32 *pend = (lds_u32 *)sm->pend;
+  const uint32_t total_bits = body_len * 8;
   for (;;) {
-    in.ensure(bp >> 3);
+    const uint32_t base = (bp >> 5) << 2;  // window start (byte of the body, multiple of 4)
+    win_load(win, body, body_len, base, lane);
+    const uint32_t rbp = bp - base * 8, tot = total_bits - base * 8;  // window-relative
     pf.tick(P_ENSURE);
     pf.count(C_ROUNDS);
     pf.count(C_PASSES);
-    uint32_t start = bp + lane * C::S, end = 0, stop = 0, nb = 0;
-    const uint32_t limit = bp + (lane + 1) * C::S;
-    sync_pass<C, false>(in, lut, lroot, true, start, limit, end, stop, nb, pf);
+    uint32_t start = rbp + lane * S, end = 0, stop = 0, nb = 0;
+    const uint32_t limit = rbp + (lane + 1) * S;
+    sync_pass<false>(win, lut, lroot, true, start, limit, end, stop, nb);
     pf.tick(P_DECODE1);
     bool counted = false;
-    for (uint32_t it = 0; it < C::PASSES; it++) {
+    for (uint32_t it = 0; it < PASSES; it++) {
       const uint32_t pe = __shfl_up(end, 1), ps = __shfl_up(stop, 1);
       const bool redo = lane == 0 ? !counted : (ps == 0 && (pe != start || !counted));
-      if (!__any(redo)) break;
+      if (__ballot(redo) == 0) break;
       if (redo && lane > 0) start = pe;
       pf.count(C_PASSES);
-      sync_pass<C, true>(in, lut, lroot, redo, start, limit, end, stop, nb, pf);
+      sync_pass<true>(win, lut, lroot, redo, start, limit, end, stop, nb);
       counted = counted || redo;
     }
     pf.tick(P_DECODE2);
@@ -391,27 +819,19 @@ __device__ __forceinline__ int inflate_block(Smem<C> *smg, Input<C> &in, Sink5 &
     uint32_t mynb = lane < nvalid ? nb : 0;
     const uint32_t off = wave_excl_scan(mynb, lane);
     {  // staging capacity: keep the largest prefix of lanes that fits (a lone first lane truncates itself)
-      const uint64_t fits = __ballot((R0 - rb) + off + mynb <= C::STAGE - 16);
+      const uint64_t fits = __ballot((R0 - rb) + off + mynb <= STAGE - 16);
       const uint32_t nfit = fits == ~0ull ? 64 : (uint32_t)__builtin_ctzll(~fits);
       if (nfit < nvalid) nvalid = nfit ? nfit : 1;
     }
     const bool mine = lane < nvalid;
     if (!mine) mynb = 0;
     const uint32_t q0 = R0 + off;
-    // owner table: the lane that produces the first byte of every 32-byte staging block — a lower bound of
-    // the producer of any byte in that block
-    if (mynb) {
-      const uint32_t b0 = (q0 - rb + 31) >> 5, b1 = (q0 + mynb - 1 - rb) >> 5;
-      const uint32_t b1c = b1 < C::STAGE / 32 + 7 ? b1 : C::STAGE / 32 + 7;
-      for (uint32_t bb = b0; bb <= b1c; bb++) owner[bb] = (uint8_t)lane;
-    }
-    if (lane == 0) owner[0] = 0;
     LaneOut lo;
     lo.endp = end;
     lo.stopc = 0;
     lo.bytes = 0;
     lo.nm = 0;
-    emit_pass<C>(in, lut, lroot, mrec, sk.stage, lane, total_bits, mine, start, limit, q0, rb, R0, sk.cap, lo, pf);
+    emit_pass(win, lut, lroot, mrec, mpos, sk.stage, lane, tot, mine, start, limit, q0, rb, R0, sk.cap, lo);
     pf.tick(P_EMIT_A);
     // the first stopped lane (stream order) ends the round
     uint32_t total, lstop;
@@ -428,11 +848,15 @@ __device__ __forceinline__ int inflate_block(Smem<C> *smg, Input<C> &in, Sink5 &
         total = rdlane(off + mynb, nvalid - 1);
       }
     }
-    copy_matches<C>(mrec, owner, sk, lane, q0, lo.nm, pf);
+    copy_far(mrec, mpos, sk, lane, lo.nm, pf);
+    bool stuck = false;
+    copy_near_all(mrec, mpos, pend, sk, lane, lo.nm, &stuck, pf);
     sk.flush(total);
     pf.tick(P_ADLER);
     pf.count(C_LANES, nvalid);
-    bp = rdlane(lo.endp, nvalid - 1);
+    const uint32_t nbp = base * 8 + rdlane(lo.endp, nvalid - 1);
+    if (stuck || (nbp == bp && total == 0 && (lstop == 0 || lstop == kStTrunc))) return MD_E_HIP;  // defensive: no progress
+    bp = nbp;
     if (lstop == kStEob) break;
     if (lstop != 0 && lstop != kStTrunc) return (int)lstop;
   }
@@ -440,15 +864,15 @@ __device__ __forceinline__ int inflate_block(Smem<C> *smg, Input<C> &in, Sink5 &
   return MD_OK;
 }
 
-template <class C, bool PROF>
+template <bool PROF>
 __global__ __launch_bounds__(kWave) void inflate_wave_kernel(
     int format, uint32_t n, const uint8_t *__restrict__ in, const uint64_t *__restrict__ in_off,
     const uint64_t *__restrict__ in_len, uint8_t *out, const uint64_t *__restrict__ out_off,
     const uint64_t *__restrict__ out_cap, uint64_t *__restrict__ out_len,
     uint64_t *__restrict__ consumed, int32_t *__restrict__ status, uint32_t *__restrict__ checksum,
     uint64_t *__restrict__ dbg) {
-  __shared__ Smem<C> smem;  // static: LDS addresses fold into the instructions' offset fields
-  Smem<C> *smg = &smem;
+  __shared__ Smem smem;  // static: LDS addresses fold into the instructions' offset fields
+  lds_smem *sm = (lds_smem *)&smem;
   Prof<PROF> pf;
   pf.init();
   const uint32_t lane = threadIdx.x;
@@ -474,9 +898,10 @@ __global__ __launch_bounds__(kWave) void inflate_wave_kernel(
       }
     }
   }
+  const uint8_t *body = src + body_off;
 
-  Sink5 sk;
-  sk.stage = (lds_u8 *)smg->u.t.stage;
+  Sink sk;
+  sk.stage = (lds_u8 *)sm->stage;
   sk.g = out + out_off[sid];
   sk.cap = cap;
   sk.pos = 0;
@@ -485,33 +910,26 @@ __global__ __launch_bounds__(kWave) void inflate_wave_kernel(
   sk.b = 0;
   sk.want_adler = (checksum != nullptr) || format == MD_FORMAT_ZLIB;
 
-  Input<C> inp;
-  inp.p = src + body_off;
-  inp.nbytes = body_len;
-  inp.lane = lane;
-  inp.ring = (lds_u32 *)smg->inring;
-  inp.reset(0);
+  lds_u32 *win = (lds_u32 *)sm->win;
   const uint32_t total_bits = body_len * 8;
   uint32_t bp = 0;
-  if (lane < 4) {  // the two self-looping STOP entries (+ padding)
-    const uint32_t i = kStopEobI + (lane & 1);
-    smg->lut[kStopEobI + lane] = mk_entry(0, 0, 0, 0, i);
-  }
+  if (lane < 4) sm->lut[kStopEobI + lane] = mk_entry(0, 0, 0, 0, kStopEobI + (lane & 1));  // the self-looping STOP entries
+  for (uint32_t i = lane; i < STAGE / 32 + 2; i += kWave) sm->pend[i] = 0;
 
   if (rc == MD_OK) {
     bool last = false;
     while (!last && rc == MD_OK) {
-      inp.ensure(bp >> 3);
-      UReader<C> ur{&inp, bp, total_bits};
-      if (ur.avail() < 3) {
+      const uint32_t base = (bp >> 5) << 2;
+      win_load(win, body, body_len, base, lane);
+      const uint32_t rbp = bp - base * 8, tot = total_bits - base * 8;
+      if ((int32_t)(tot - rbp) < 3) {
         rc = MD_UNEXPECTED_END_OF_INPUT;
         break;
       }
-      last = ur.peek(1);
-      ur.drop(1);
-      uint32_t type = ur.peek(2);
-      ur.drop(2);
-      bp = ur.bp;
+      const uint32_t hdr = uni(peek(win, rbp));
+      last = hdr & 1;
+      const uint32_t type = (hdr >> 1) & 3;
+      bp += 3;
       if (type == 0) {
         // flat, lib/de.ml:1613-1627
         uint32_t p = (bp + 7) >> 3;
@@ -519,17 +937,18 @@ __global__ __launch_bounds__(kWave) void inflate_wave_kernel(
           rc = MD_UNEXPECTED_END_OF_INPUT;
           break;
         }
-        uint32_t hdr = uni(inp.peek(p * 8));
-        uint32_t len = hdr & 0xffff, nlen = hdr >> 16;
+        const uint32_t h4 = (uint32_t)body[p] | ((uint32_t)body[p + 1] << 8) | ((uint32_t)body[p + 2] << 16) |
+                            ((uint32_t)body[p + 3] << 24);
+        uint32_t len = h4 & 0xffff, nlen = h4 >> 16;
         p += 4;
         if (nlen != 0xffff - len) rc = MD_INVALID_COMPLEMENT_OF_LENGTH;
         else if (len > body_len - p) rc = MD_UNEXPECTED_END_OF_INPUT;
         else if (len > sk.cap - sk.pos) rc = MD_UNEXPECTED_END_OF_OUTPUT;
         else {
-          const uint8_t *q = inp.p + p;
+          const uint8_t *q = body + p;
           uint32_t left = len;
           while (left) {
-            const uint32_t seg = left < C::STAGE - 16 ? left : C::STAGE - 16;
+            const uint32_t seg = left < STAGE - 16 ? left : STAGE - 16;
             const uint32_t s0 = sk.pos - sk.sbase();
             for (uint32_t j = lane; j < seg; j += kWave) sk.stage[s0 + j] = q[j];
             sk.flush(seg);
@@ -538,29 +957,20 @@ __global__ __launch_bounds__(kWave) void inflate_wave_kernel(
           }
           p += len;
           bp = p * 8;
-          inp.reset(p);
         }
       } else if (type == 3) {
         rc = MD_INVALID_KIND_OF_BLOCK;
       } else {
-        Lut lit, dist;
-        if (type == 1) fixed_tables(&smg->u.sc, &lit, &dist, lane);
-        else {
-          rc = dynamic_header<C>(ur, &smg->u.sc, &lit, &dist, lane);
-          bp = ur.bp;
-        }
         uint32_t lroot = 0;
-        if (rc == MD_OK) {
-          // walk entries from the packed 16-bit ones (sub-table entries start behind the root table)
-          lroot = uni(lit.root);
-          const uint32_t droot = uni(dist.root);
-          for (uint32_t i = lane; i < 852; i += kWave)
-            smg->lut[i] = walk_lit(smg->u.sc.lit[i], i >= (1u << lroot), lroot, droot);
-          for (uint32_t i = lane; i < 592; i += kWave)
-            smg->lut[kDistB + i] = walk_dist(smg->u.sc.dist[i], i >= (1u << droot), lroot, droot);
+        if (type == 1) fixed_tables(sm, lane, &lroot);
+        else {
+          uint32_t hend = 0;
+          rc = dynamic_tables(sm, rbp + 3, tot, lane, &hend, &lroot);
+          bp = base * 8 + hend;
         }
+        lroot = uni(lroot);
         pf.tick(P_HEADER);
-        if (rc == MD_OK) rc = inflate_block<C>(smg, inp, sk, lroot, lane, total_bits, &bp, pf);
+        if (rc == MD_OK) rc = inflate_block(sm, body, body_len, sk, lroot, lane, &bp, pf);
       }
     }
   }
@@ -586,24 +996,21 @@ __global__ __launch_bounds__(kWave) void inflate_wave_kernel(
   }
 }
 
-}  // namespace v5
+}  // namespace wv
 }  // namespace md
-
-//                              S   LMAX MMAX KMAX IN_BYTES PASSES STAGE
-using WaveCfg = md::v4::Cfg<256, 40, 16, 64, 4096, 5, 6144>;
 
 extern "C" int md_launch_inflate_wave(int format, uint32_t n, const uint8_t *in, const uint64_t *in_off,
                                       const uint64_t *in_len, uint8_t *out, const uint64_t *out_off,
                                       const uint64_t *out_cap, uint64_t *out_len, uint64_t *consumed,
                                       int32_t *status, uint32_t *checksum, uint64_t *dbg, hipStream_t stream) {
   if (n == 0) return 0;
-  using namespace md::v5;
-  dim3 grid(n), block(md::kWave);
+  using namespace md::wv;
+  dim3 grid(n), block(kWave);
   if (dbg)
-    hipLaunchKernelGGL((inflate_wave_kernel<WaveCfg, true>), grid, block, 0, stream, format, n, in,
-                       in_off, in_len, out, out_off, out_cap, out_len, consumed, status, checksum, dbg);
+    hipLaunchKernelGGL((inflate_wave_kernel<true>), grid, block, 0, stream, format, n, in, in_off, in_len, out, out_off,
+                       out_cap, out_len, consumed, status, checksum, dbg);
   else
-    hipLaunchKernelGGL((inflate_wave_kernel<WaveCfg, false>), grid, block, 0, stream, format, n, in,
-                       in_off, in_len, out, out_off, out_cap, out_len, consumed, status, checksum, dbg);
+    hipLaunchKernelGGL((inflate_wave_kernel<false>), grid, block, 0, stream, format, n, in, in_off, in_len, out, out_off,
+                       out_cap, out_len, consumed, status, checksum, dbg);
   return (int)hipGetLastError();
 }

@@ -48,7 +48,7 @@ int main(int argc, char **argv) {
   // stats
   double nlit = 0, nmat = 0, litbits = 0, matbits = 0, matbytes = 0, nblocks = 0, far = 0, longcode = 0;
   double rounds = 0, passes = 0, wslots = 0, lane_slots_useful = 0, lanes_acc = 0, wslots_p[16] = {0}, act_p[16] = {0};
-  double sync_hist[64] = {0}; double outbytes = 0; double a1slots=0, redo2 = 0;
+  double sync_hist[64] = {0}; double ml_gt16=0, ml_gt32=0, ml_gt8=0, straddle=0, nearc=0, farc=0, d_lt8=0; double outbytes = 0; double a1slots=0, redo2 = 0;
   while (!last) {
     last = bitsat(p, 1); int type = bitsat(p + 1, 2); p += 3; nblocks++;
     if (type == 0) { p = (p + 7) & ~7ull; int n = bitsat(p, 16); p += 32 + 8ull * n; outbytes += n; continue; }
@@ -91,9 +91,11 @@ int main(int argc, char **argv) {
       lanes_acc += nvalid;
       for (int i = 0; i < nvalid; i++) { lane_slots_useful += sl[i]; }
       // token stats over accepted lanes (recount from truth)
-      { uint64_t q = bp; uint64_t qe = end[nvalid - 1];
+      { uint64_t q = bp; uint64_t qe = end[nvalid - 1]; double R0 = outbytes;
         while (q < qe) { int ts, tb, k, ml = 0, md = 0; int u = token(q, total, &ts, &tb, &k, &ml, &md);
-          if (k == 0) { nlit++; litbits += u; } else if (k == 1) { nmat++; matbits += u; matbytes += ml; if (md > 6144) far++; } else if (k==2) {break;}
+          if (k == 0) { nlit++; litbits += u; } else if (k == 1) { nmat++; matbits += u; matbytes += ml; if (md > 6144) far++;
+            if (ml > 8) ml_gt8++; if (ml > 16) ml_gt16++; if (ml > 32) ml_gt32++; if (md < 8) d_lt8++;
+            double src = outbytes - md; if (src + ml <= R0) farc++; else { nearc++; if (src < R0) straddle++; } } else if (k==2) {break;}
           if (ts > (k == 1 ? 2 : 1)) longcode++; outbytes += tb; q += u; } }
       if (stop[nvalid - 1] == 2) eob = 1; else if (stop[nvalid - 1]) { fprintf(stderr, "bad stream\n"); return 1; }
       bp = end[nvalid - 1];
@@ -106,6 +108,7 @@ int main(int argc, char **argv) {
          rounds, passes / rounds, wslots / rounds, a1slots / rounds, lanes_acc / rounds, lane_slots_useful / rounds,
          lane_slots_useful / 64.0 / (a1slots));
   printf("  total wave-slots %.0f ; ideal (1 pass perfect) %.0f\n", wslots, lane_slots_useful / 64);
+  printf("  matches/round %.1f: far %.1f near %.1f straddle %.2f ; ml>8 %.3f ml>16 %.3f ml>32 %.4f d<8 %.4f\n", nmat/rounds, farc/rounds, nearc/rounds, straddle/rounds, ml_gt8/nmat, ml_gt16/nmat, ml_gt32/nmat, d_lt8/nmat);
   for (int i = 0; i < 8; i++) printf("   pass %d: wave-slots %.1f active lanes %.1f\n", i, wslots_p[i] / rounds, act_p[i] / rounds);
   return 0;
 }
