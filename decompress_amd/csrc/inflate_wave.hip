@@ -453,14 +453,40 @@ __device__ __noinline__ void fixed_tables(lds_smem *sm, uint32_t lane, uint32_t 
 // ---- the walks ----------------------------------------------------------------------------------
 // One token-boundary walk of this lane's zone [start, limit).  COUNT adds the bytes the tokens produce.
 // A divergent per-lane loop: finished lanes leave the exec mask, the wave leaves when it is empty.
+// A lane's bit cursor: three consecutive window words in registers (w2 is fetched a step ahead), so the only
+// LDS access a step waits for is its table entry.
+struct Cursor {
+  uint32_t w0, w1, w2, r, wa;  // window words at byte address wa, wa + 4, wa + 8; r = bit offset in w0
+  __device__ __forceinline__ void init(const lds_u32 *win, uint32_t p) {
+    wa = (p >> 5) << 2;
+    const lds_u32 *q = reinterpret_cast<const lds_u32 *>(reinterpret_cast<const lds_u8 *>(win) + wa);
+    w0 = q[0];
+    w1 = q[1];
+    w2 = q[2];
+    r = p & 31;
+  }
+  __device__ __forceinline__ uint32_t peek() const { return __builtin_amdgcn_alignbit(w1, w0, r); }
+  __device__ __forceinline__ void skip(const lds_u32 *win, uint32_t n) {  // n < 32
+    const uint32_t r2 = r + n;
+    const bool ge = r2 >= 32;
+    w0 = ge ? w1 : w0;
+    w1 = ge ? w2 : w1;
+    wa += ge ? 4u : 0u;
+    r = r2 & 31;
+    w2 = *reinterpret_cast<const lds_u32 *>(reinterpret_cast<const lds_u8 *>(win) + wa + 8);
+  }
+};
+
 template <bool COUNT>
 __device__ __forceinline__ void sync_pass(const lds_u32 *win, const lds_u32 *lut, uint32_t lroot, bool go, uint32_t start,
                                           uint32_t limit, uint32_t &end, uint32_t &stop, uint32_t &nb) {
   if (go) {
     uint32_t p = start, tb = 0, nbits = lroot, cnt = 0, slot = 0;
+    Cursor c;
+    c.init(win, start);
     // a step that starts a token (tb == 0) is taken while the zone and the step budget last
     while ((tb < kStopEobI) & ((tb != 0) | ((p < limit) & (slot < KMAX)))) {
-      const uint32_t w = peek(win, p);
+      const uint32_t w = c.peek();
       const uint32_t e = lut_at(lut, tb, __builtin_amdgcn_ubfe(w, 0, nbits));
       const uint32_t codelen = e & 15, xb = (e >> 4) & 15, ntb = e >> 21;
       if (COUNT) {
@@ -468,6 +494,7 @@ __device__ __forceinline__ void sync_pass(const lds_u32 *win, const lds_u32 *lut
         cnt += (tb == 0 ? 1u : 0u) + (ntb == kDistB ? len1 : 0u);
       }
       p += codelen + xb;
+      c.skip(win, codelen + xb);
       nbits = (e >> 17) & 15;
       tb = ntb;
       slot++;
@@ -542,9 +569,11 @@ __device__ __forceinline__ void emit_pass(const lds_u32 *win, const lds_u32 *lut
   const uint32_t qmax = cap < qlim ? cap : qlim;
   if (go) {
     uint32_t slot = 0;
+    Cursor c;
+    c.init(win, start);
     while ((!stopped) & ((tb != 0) | ((p < limit) & (slot < KMAX)))) {
       ptok = tb == 0 ? p : ptok;
-      const uint32_t w = peek(win, p);
+      const uint32_t w = c.peek();
       const uint32_t e = lut_at(lut, tb, __builtin_amdgcn_ubfe(w, 0, nbits));
       const uint32_t codelen = e & 15, xb = (e >> 4) & 15, val9 = (e >> 8) & 511, ntb = e >> 21;
       const uint32_t x = __builtin_amdgcn_ubfe(w, codelen, xb);
@@ -567,6 +596,7 @@ __device__ __forceinline__ void emit_pass(const lds_u32 *win, const lds_u32 *lut
         mlen = is_len ? val9 + x : mlen;
         q += lit ? 1u : mat ? need : 0u;
         p = pn;
+        c.skip(win, codelen + xb);
         nbits = (e >> 17) & 15;
         tb = ntb;
       }
@@ -647,129 +677,225 @@ struct Sink {
   }
 };
 
-// Far matches (the whole source is older than this round: final in HBM/L2 once the flush of earlier rounds has
-// been waited for; d >= ml) and the heads of matches that straddle the round start.
-template <class PF>
-__device__ __forceinline__ void copy_far(const lds_u32 *mrec, const lds_u16 *mpos, const Sink &sk, uint32_t lane, uint32_t nm,
-                                         PF &pf) {
-  lds_u8 *stage = sk.stage;
-  const uint32_t R0 = sk.pos, rb = sk.sbase(), cap = sk.cap;
-  const uint8_t *g = sk.g;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  constexpr int B = 8;
-  for (uint32_t m0 = 0; __ballot(m0 < nm) != 0; m0 += B) {
-    uint64_t v[B][4];
-    uint32_t dq[B], dl[B], ds[B];
-#pragma unroll
-    for (int u = 0; u < B; u++) {
-      dl[u] = 0;
-      dq[u] = 0;
-      ds[u] = 0;
-      if (m0 + u < nm) {
-        const uint32_t tk = mrec[(m0 + u) * kWave + lane];
-        const uint32_t qs = mpos[(m0 + u) * kWave + lane];  // staging index of the destination
-        const uint32_t d = (tk & 0x7fff) + 1, ml = ((tk >> 16) & 0xff) + 3;
-        const uint32_t src = rb + qs - d;
-        // near matches that begin before the round start: their head [src, R0) is final too
-        const uint32_t n = !(tk & kNearBit) ? ml : src < R0 ? R0 - src : 0u;
-        dq[u] = qs;
-        dl[u] = n;
-        ds[u] = src;
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < B; u++) {
-#pragma unroll
-      for (int c = 0; c < 4; c++) v[u][c] = dl[u] > 8u * c ? out_ld_guard(g, ds[u] + 8 * c, dl[u] - 8 * c, cap) : 0ull;
-    }
-#pragma unroll
-    for (int u = 0; u < B; u++) {
-      if (dl[u]) {
-        lds_u8 *dd = stage + dq[u];
-        const uint32_t ml = dl[u];
-#pragma unroll
-        for (int c = 0; c < 4; c++)
-          if (ml > 8u * c) lds_st(dd + 8 * c, v[u][c], ml - 8 * c);
-        for (uint32_t j = 32; j < ml; j += 8)  // long far match: stream the rest (rare)
-          lds_st(dd + j, out_ld_guard(g, ds[u] + j, ml - j, cap), ml - j);
-      }
-    }
+// ---- the pending map: one bit per staging byte that a near match has still to produce -------------
+// masks of bits [a, a + n) in the words a >> 5 and (a >> 5) + 1; returns the end bit relative to the first word
+__device__ __forceinline__ uint32_t pend_masks(uint32_t a, uint32_t n, uint32_t &m0, uint32_t &m1) {
+  const uint32_t e = (a & 31) + n;
+  m0 = 0xffffffffu << (a & 31);
+  if (e <= 32) {
+    m0 &= 0xffffffffu >> (32 - e);
+    m1 = 0;
+  } else {
+    m1 = e >= 64 ? 0xffffffffu : ~(0xffffffffu << (e - 32));
   }
-  pf.tick(P_FAR);
+  return e;
 }
-
-// bits [a, b) of the pending map, b > a
-__device__ __forceinline__ bool pend_any(const lds_u32 *pend, uint32_t a, uint32_t b) {
-  const uint32_t w0 = a >> 5, w1 = (b - 1) >> 5;
-  uint32_t any = 0;
-  for (uint32_t w = w0; w <= w1; w++) {
-    uint32_t m = 0xffffffffu;
-    if (w == w0) m &= 0xffffffffu << (a & 31);
-    if (w == w1) m &= 0xffffffffu >> (31 - ((b - 1) & 31));
-    any |= pend[w] & m;
-  }
+__device__ __forceinline__ bool pend_any(const lds_u32 *pend, uint32_t a, uint32_t b) {  // b > a
+  uint32_t m0, m1;
+  const uint32_t w0 = a >> 5, e = pend_masks(a, b - a, m0, m1);
+  uint32_t any = (pend[w0] & m0) | (pend[w0 + 1] & m1);
+  for (uint32_t w = w0 + 2, r = e; r > 64; w++, r -= 32) any |= pend[w] & (r >= 96 ? 0xffffffffu : ~(0xffffffffu << (r - 64)));
   return any != 0;
 }
 template <bool SET>
-__device__ __forceinline__ void pend_update(lds_u32 *pend, uint32_t a, uint32_t b) {
-  const uint32_t w0 = a >> 5, w1 = (b - 1) >> 5;
-  for (uint32_t w = w0; w <= w1; w++) {
-    uint32_t m = 0xffffffffu;
-    if (w == w0) m &= 0xffffffffu << (a & 31);
-    if (w == w1) m &= 0xffffffffu >> (31 - ((b - 1) & 31));
+__device__ __forceinline__ void pend_update(lds_u32 *pend, uint32_t a, uint32_t b) {  // b > a
+  uint32_t m0, m1;
+  const uint32_t w0 = a >> 5, e = pend_masks(a, b - a, m0, m1);
+  if (SET) {
+    __hip_atomic_fetch_or(&pend[w0], m0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_or(&pend[w0 + 1], m1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  } else {
+    __hip_atomic_fetch_and(&pend[w0], ~m0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_and(&pend[w0 + 1], ~m1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  for (uint32_t w = w0 + 2, r = e; r > 64; w++, r -= 32) {
+    const uint32_t m = r >= 96 ? 0xffffffffu : ~(0xffffffffu << (r - 64));
     if (SET) __hip_atomic_fetch_or(&pend[w], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     else __hip_atomic_fetch_and(&pend[w], ~m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
 }
 
-// Near matches: the source reaches into this round's staging buffer.  Every near match marks its destination
-// bytes pending; a lane takes its matches in order, each as soon as no source byte is pending.  The earliest
-// unresolved match of the round never waits, so every step makes progress.
+// exact store of the low n (1..8) bytes of v at an arbitrary LDS address: two overlapping 4-byte (or 1 + 2-byte) stores
+__device__ __forceinline__ void lds_put(lds_u8 *p, uint64_t v, uint32_t n) {
+  const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+  if (n >= 4) {
+    const uint32_t k = n - 4;  // 0..4
+    const uint32_t t = k >= 4 ? hi : __builtin_amdgcn_alignbyte(hi, lo, k);
+    *reinterpret_cast<MD_LDS u32_u *>(p) = lo;
+    *reinterpret_cast<MD_LDS u32_u *>(p + k) = t;
+  } else {
+    *p = (uint8_t)lo;
+    if (n > 1) *reinterpret_cast<MD_LDS u16_u *>(p + n - 2) = (uint16_t)(lo >> (8 * (n - 2)));
+  }
+}
+
+// Far matches (the whole source is older than this round: final in HBM/L2 once the flush of earlier rounds has
+// been waited for; d >= ml) and the heads of matches that straddle the round start.  Near matches are marked in
+// the pending map on the way; *nearmask_out = the lane's near records.  All of a lane's records are taken in one
+// go: 2 LDS reads per record, then up to 32 bytes per record in flight, then the stores.  The loads read whole
+// 8-byte words, up to 15 bytes past a record's source: the caller makes sure that stays inside the output buffer.
 template <class PF>
-__device__ __forceinline__ void copy_near_all(const lds_u32 *mrec, const lds_u16 *mpos, lds_u32 *pend, const Sink &sk,
-                                              uint32_t lane, uint32_t nm, bool *stuck, PF &pf) {
+__device__ __forceinline__ void copy_far(const lds_u32 *mrec, const lds_u16 *mpos, lds_u32 *pend, const Sink &sk, uint32_t lane,
+                                         uint32_t nm, uint32_t *nearmask_out, PF &pf) {
   lds_u8 *stage = sk.stage;
-  const uint32_t head = sk.pos - sk.sbase();  // staging index of the round start
-  uint32_t m = 0, qs = 0, d = 0, ml = 0;
-  bool have = false;
-  auto advance = [&]() {
-    have = false;
-    while (m < nm) {
-      const uint32_t tk = mrec[m * kWave + lane];
-      qs = mpos[m * kWave + lane];
-      d = (tk & 0x7fff) + 1;
-      ml = ((tk >> 16) & 0xff) + 3;
-      m++;
-      if (tk & kNearBit) {
-        have = true;
-        break;
+  const uint32_t R0 = sk.pos, rb = sk.sbase();
+  const uint8_t *g = sk.g;
+  uint32_t tk[MMAX], qs[MMAX], n[MMAX], src[MMAX];
+#pragma unroll
+  for (int u = 0; u < (int)MMAX; u++) {
+    tk[u] = mrec[u * kWave + lane];
+    qs[u] = mpos[u * kWave + lane];
+  }
+  uint32_t nearmask = 0;
+  uint64_t longm = 0;
+#pragma unroll
+  for (int u = 0; u < (int)MMAX; u++) {
+    const bool valid = (uint32_t)u < nm;
+    const uint32_t d = (tk[u] & 0x7fff) + 1, ml = ((tk[u] >> 16) & 0xff) + 3;
+    const uint32_t s = rb + qs[u] - d;
+    const bool near = valid && (tk[u] & kNearBit);
+    const uint32_t head = s < R0 ? R0 - s : 0u;  // a near match that begins before the round start: its head is final too
+    n[u] = !valid ? 0u : near ? head : ml;
+    src[u] = n[u] ? s : 0u;
+    if (near) {
+      nearmask |= 1u << u;
+      pend_update<true>(pend, qs[u], qs[u] + ml);
+    }
+    longm |= __ballot(n[u] > 16);
+  }
+  uint64_t v0[MMAX], v1[MMAX];
+#pragma unroll
+  for (int u = 0; u < (int)MMAX; u++) {
+    v0[u] = out_ld64(g + src[u]);
+    v1[u] = out_ld64(g + src[u] + 8);
+  }
+  if (longm == 0) {
+#pragma unroll
+    for (int u = 0; u < (int)MMAX; u++) {
+      if (n[u]) {
+        lds_u8 *dd = stage + qs[u];
+        lds_put(dd, v0[u], n[u] < 8 ? n[u] : 8);
+        if (n[u] > 8) lds_put(dd + 8, v1[u], n[u] - 8);
       }
     }
-  };
-  advance();
-  while (have) {  // mark
-    pend_update<true>(pend, qs, qs + ml);
-    advance();
+  } else {
+    uint64_t v2[MMAX], v3[MMAX];
+#pragma unroll
+    for (int u = 0; u < (int)MMAX; u++) {
+      v2[u] = 0;
+      v3[u] = 0;
+      if (n[u] > 16) {
+        v2[u] = out_ld64(g + src[u] + 16);
+        v3[u] = out_ld64(g + src[u] + 24);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < (int)MMAX; u++) {
+      if (n[u]) {
+        lds_u8 *dd = stage + qs[u];
+        lds_put(dd, v0[u], n[u] < 8 ? n[u] : 8);
+        if (n[u] > 8) lds_put(dd + 8, v1[u], n[u] < 16 ? n[u] - 8 : 8);
+        if (n[u] > 16) {
+          lds_put(dd + 16, v2[u], n[u] < 24 ? n[u] - 16 : 8);
+          if (n[u] > 24) lds_put(dd + 24, v3[u], n[u] < 32 ? n[u] - 24 : 8);
+          for (uint32_t j = 32; j < n[u]; j += 8)  // very long far match: stream the rest (rare)
+            lds_put(dd + j, out_ld64(g + src[u] + j), n[u] - j < 8 ? n[u] - j : 8);
+        }
+      }
+    }
   }
-  m = 0;
-  advance();
-  for (uint32_t guard = 0; __ballot(have) != 0; guard++) {
-    if (guard > kWave * MMAX + 8) {  // cannot happen: the earliest unresolved match is always ready
+  *nearmask_out = nearmask;
+  pf.tick(P_FAR);
+}
+// the same for the last rounds of a stream, where an 8-byte load could reach past the output buffer: one record at a time
+template <class PF>
+__device__ __noinline__ void copy_far_guarded(const lds_u32 *mrec, const lds_u16 *mpos, lds_u32 *pend, lds_u8 *stage,
+                                              const uint8_t *g, uint32_t R0, uint32_t rb, uint32_t cap, uint32_t lane, uint32_t nm,
+                                              uint32_t *nearmask_out) {
+  uint32_t nearmask = 0;
+  for (uint32_t m = 0; m < nm; m++) {
+    const uint32_t tk = mrec[m * kWave + lane], qs = mpos[m * kWave + lane];
+    const uint32_t d = (tk & 0x7fff) + 1, ml = ((tk >> 16) & 0xff) + 3;
+    const uint32_t s = rb + qs - d;
+    uint32_t n = ml;
+    if (tk & kNearBit) {
+      nearmask |= 1u << m;
+      pend_update<true>(pend, qs, qs + ml);
+      n = s < R0 ? R0 - s : 0u;
+    }
+    for (uint32_t j = 0; j < n; j += 8) lds_put(stage + qs + j, out_ld_guard(g, s + j, n - j, cap), n - j < 8 ? n - j : 8);
+  }
+  *nearmask_out = nearmask;
+}
+
+// staging -> staging LZ77 copy of n bytes with forward-byte semantics (dst - src = d; overlap allowed)
+__device__ __forceinline__ void stage_copy(lds_u8 *dst, const lds_u8 *src, uint32_t n, uint32_t d) {
+  if (d >= 8) {
+    for (uint32_t j = 0; j < n; j += 8) lds_put(dst + j, lds_ld64(src + j), n - j < 8 ? n - j : 8);
+  } else {
+    // period d < 8: replicate the last d bytes into a 64-bit pattern
+    uint64_t v = lds_ld64(src);
+    const uint32_t sh = 8 * d;
+    v &= (1ull << sh) - 1;
+    v |= v << sh;
+    if (2 * sh < 64) v |= v << (2 * sh);
+    if (4 * sh < 64) v |= v << (4 * sh);
+    const uint32_t adv = (0x76586880u >> (4 * d)) & 15;  // d * (8 / d): the largest multiple of the period that fits 8 bytes
+    for (uint32_t j = 0; j < n; j += adv) lds_put(dst + j, v, n - j < 8 ? n - j : 8);
+  }
+}
+
+// Near matches: the source reaches into this round's staging buffer.  A lane looks at one of its near matches per
+// step and copies it if no source byte is pending; a match that has to wait is put behind the lane's other ones, so
+// the lanes resolve their matches in dependency order rather than stream order.  The earliest unresolved match of
+// the round never waits, and every lane comes back to it, so the steps make progress.
+template <class PF>
+__device__ __forceinline__ void copy_near_all(const lds_u32 *mrec, const lds_u16 *mpos, lds_u32 *pend, const Sink &sk,
+                                              uint32_t lane, uint32_t nearmask, bool *stuck, PF &pf) {
+  lds_u8 *stage = sk.stage;
+  const uint32_t head = sk.pos - sk.sbase();  // staging index of the round start
+  uint32_t rem = nearmask, cur = 0, qs = 0, d = 0, ml = 0, sa = 0, sb = 0, skip = 0;
+  auto load = [&](uint32_t from) {  // the first remaining record at or after `from` (cyclic)
+    const uint32_t hi = rem & (0xffffffffu << from);
+    cur = (uint32_t)__builtin_ctz(hi ? hi : rem);
+    const uint32_t tk = mrec[cur * kWave + lane];
+    qs = mpos[cur * kWave + lane];
+    d = (tk & 0x7fff) + 1;
+    ml = ((tk >> 16) & 0xff) + 3;
+    // source bytes: staging [qs - d, min(qs - d + ml, qs)); the part before the round start came from HBM (copy_far)
+    const int32_t s0 = (int32_t)qs - (int32_t)d;
+    skip = s0 < (int32_t)head ? head - (uint32_t)s0 : 0u;
+    sa = (uint32_t)(s0 + (int32_t)skip);
+    sb = d < ml ? qs : (uint32_t)s0 + ml;
+  };
+  if (rem) load(0);
+  for (uint32_t guard = 0; __ballot(rem != 0) != 0; guard++) {
+    if (guard > kWave * MMAX * MMAX) {  // cannot happen
       *stuck = true;
       break;
     }
     pf.count(C_NEAR_IT);
-    if (have) {
-      // source bytes: staging [qs - d, min(qs - d + ml, qs)); the part before the round start came from HBM (copy_far)
-      const int32_t s0 = (int32_t)qs - (int32_t)d;
-      const uint32_t skip = s0 < (int32_t)head ? head - (uint32_t)s0 : 0u;  // bytes already placed
-      const uint32_t sa = (uint32_t)(s0 + (int32_t)skip), sb = d < ml ? qs : (uint32_t)s0 + ml;
+    if (rem) {
       const bool ready = sa >= sb || !pend_any(pend, sa, sb);
       if (ready) {
-        if (skip < ml) copy_near(stage + qs + skip, stage + sa, ml - skip, d);
+        const uint32_t n = ml - skip;  // skip < ml: a near match reaches into the round
+        lds_u8 *dd = stage + qs + skip;
+        const lds_u8 *ss = stage + sa;
+        if (d >= n && n <= 32) {  // the usual case: source and destination do not overlap, all loads in flight together
+          const uint64_t v0 = lds_ld64(ss), v1 = lds_ld64(ss + 8), v2 = lds_ld64(ss + 16), v3 = lds_ld64(ss + 24);
+          lds_put(dd, v0, n < 8 ? n : 8);
+          if (n > 8) lds_put(dd + 8, v1, n < 16 ? n - 8 : 8);
+          if (n > 16) {
+            lds_put(dd + 16, v2, n < 24 ? n - 16 : 8);
+            if (n > 24) lds_put(dd + 24, v3, n - 24);
+          }
+        } else {
+          stage_copy(dd, ss, n, d);
+        }
         pend_update<false>(pend, qs, qs + ml);
-        advance();
+        rem &= ~(1u << cur);
       }
+      if (rem) load(cur + 1);
     }
   }
   pf.tick(P_NEAR);
@@ -848,9 +974,16 @@ __device__ __forceinline__ int inflate_block(lds_smem *sm, const uint8_t *__rest
         total = rdlane(off + mynb, nvalid - 1);
       }
     }
-    copy_far(mrec, mpos, sk, lane, lo.nm, pf);
+    uint32_t nearmask = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // earlier rounds' flushes have landed
+    if (R0 + 40 > sk.cap) {
+      copy_far_guarded<PF>(mrec, mpos, pend, sk.stage, sk.g, R0, rb, sk.cap, lane, lo.nm, &nearmask);
+      pf.tick(P_FAR);
+    } else {
+      copy_far(mrec, mpos, pend, sk, lane, lo.nm, &nearmask, pf);
+    }
     bool stuck = false;
-    copy_near_all(mrec, mpos, pend, sk, lane, lo.nm, &stuck, pf);
+    copy_near_all(mrec, mpos, pend, sk, lane, nearmask, &stuck, pf);
     sk.flush(total);
     pf.tick(P_ADLER);
     pf.count(C_LANES, nvalid);
