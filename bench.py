@@ -1,31 +1,37 @@
 #!/usr/bin/env python3
-"""bench.py — headline benchmark: batched zlib inflate on MI355X.
+"""bench.py — headline benchmark: batched zlib inflate (and the deflate leg) on MI355X.
 
-A "step" is one pass of the hot path (Zl.Inf.Ns semantics, one stream per
-wavefront) over one batch of BASELINE.json config[1]:
+A "step" is one pass of the hot path (Zl.Inf.Ns semantics, one stream per wavefront) over one
+batch of BASELINE.json config[1]:
     4096 x 256 KiB zlib streams, dynamic Huffman (libz level 6), per GPU.
-Inputs are resident in HBM before the timed region.  Weak scaling: every rank
-inflates its own 4096 streams; value = total uncompressed MiB / s over all GPUs.
+Inputs are resident in HBM before the timed region.  Weak scaling: every rank inflates its own
+4096 streams; value = total uncompressed MiB / s over all GPUs.
 
     python bench.py --gpus 1 --steps 10 --warmup 2
+    python bench.py --gpus 8            # re-executes itself under torch.distributed.run, one rank per GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Prints ONE JSON line (rank 0).  `roofline` is for the hot path's kernels taken together
-(md::v4::decode_kernel -> token log in HBM -> md::v4::resolve_kernel, for the two halves
-of the batch on two forked streams; one "launch" = those four kernels, which overlap):
-algorithmic bytes = compressed bytes read + uncompressed bytes written per launch, over
-the launch duration measured with HIP events on the context's stream, which forks and
-joins the side stream; peak = 8 TB/s HBM3E (MI355X_MICROARCH.md).  `traffic` =
-FETCH_SIZE + WRITE_SIZE of those kernels per launch from the committed rocprofv3 --pmc
-passes of this same command (profiles/r01_final/pmc_summary.json; raw counter bytes,
-see the note there), null when the configuration differs from the profiled one.
-`cpu_baseline` is the repo's C restatement of lib/de.ml (oracle/, kind "port")
-timed single-threaded on a bounded sample of the same streams.
+Prints ONE JSON line (rank 0).
+  roofline      the hot path's one kernel, md::wv::inflate_wave_kernel: algorithmic bytes = compressed bytes
+                read + uncompressed bytes written per launch, over the launch duration
+                measured with HIP events on the stream the kernel runs on; peak = 8 TB/s HBM3E
+                (MI355X_MICROARCH.md).  `traffic` = FETCH_SIZE + WRITE_SIZE of that kernel per launch from the
+                committed rocprofv3 --pmc passes of this same command (profiles/r02_final/pmc_summary.json,
+                gfx950 correction of the guide applied), null when the configuration differs.
+  cpu_baseline  the repo's C restatement of lib/de.ml (oracle/, kind "port") on the host cores of this box,
+                bounded sample of the same streams.
+  deflate       BASELINE.json config[2] on the same GPU(s), outside the inflate timed region: 4096 x 1 MiB
+                printable-ASCII buffers, De.Lz77 + De.Def level 6, queue 4096, Zl driver — its own value,
+                ms_per_step, roofline and cpu_baseline (BASELINE's metric is "inflate+deflate").
+  ranks_seen    an all_reduce over the process group: how many ranks really took part.
+For N > 1 the per-stream results of every rank (sizes and Adler-32 from the kernel) are gathered with
+decompress_amd.shard.gather_varlen — the path's only exchange (RCCL over xGMI).
 """
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 import zlib
@@ -36,21 +42,21 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+PMC_DIR = os.path.join(ROOT, "profiles", "r02_final")
 
 
-def pmc_traffic(args, n, nbytes):
-    """HBM bytes per launch from the committed PMC passes (collected by tools/profile_gpu.sh with
-    this workload and the default kernels); null for any other configuration."""
-    if (args.kernel or 3) != 3 or max(args.variant, 0) != 0 or n != 4096 or nbytes != 262144 or args.overlap not in (0, 2):
+def pmc_traffic(name, is_default):
+    """HBM bytes per launch from the committed PMC passes (tools/profile_gpu.sh on the default workload)."""
+    if not is_default:
         return None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_final", "pmc_summary.json")) as f:
-            return int(json.load(f)["traffic_bytes_per_launch_raw"])
-    except (OSError, KeyError, ValueError):
+        with open(os.path.join(PMC_DIR, "pmc_summary.json")) as f:
+            return int(json.load(f)[name]["traffic_bytes_per_launch"])
+    except (OSError, KeyError, ValueError, TypeError):
         return None
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -59,45 +65,34 @@ def parse():
     ap.add_argument("--stream-kib", type=int, default=256)
     ap.add_argument("--unique", type=int, default=0, help="distinct streams to generate (0 = all)")
     ap.add_argument("--level", type=int, default=6)
-    ap.add_argument("--ring-log2", type=int, default=0)
-    ap.add_argument("--kernel", type=int, default=0,
-                    help="1 = serial per wave, 2 = lane-parallel fused, 3 = lane-parallel split (default)")
-    ap.add_argument("--variant", type=int, default=-1, help="v2 geometry")
-    ap.add_argument("--overlap", type=int, default=0, help="parts of the batch run on forked streams (1 = none, default 2)")
-    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the CPU baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of each CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-deflate", action="store_true", help="skip the deflate leg (config 3)")
+    ap.add_argument("--deflate-streams", type=int, default=4096)
+    ap.add_argument("--deflate-kib", type=int, default=1024)
+    ap.add_argument("--deflate-steps", type=int, default=3)
     ap.add_argument("--profile", action="store_true", help="print the in-kernel phase profile of stream 0 (stderr)")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
-def cpu_baseline(streams, nbytes, budget_s):
-    """Oracle (C port of De.Inf.Ns / Zl.Inf.Ns) on the host cores of this box, bounded sample:
-    one thread first, then one stream per thread on all cores (ctypes releases the GIL)."""
-    from concurrent.futures import ThreadPoolExecutor
-    from tests import oracle_lib
-    orc = oracle_lib.load()
+def respawn_command(args, argv, device_count):
+    """`python bench.py --gpus N` without a launcher: the command that runs N ranks of this script under
+    torch.distributed.run (None when this process is already a rank, or N <= 1).  Fails loudly when the box has
+    fewer gfx950 devices than asked for."""
+    if args.gpus <= 1 or "RANK" in os.environ:
+        return None
+    if device_count < args.gpus:
+        raise SystemExit("bench: --gpus %d but only %d gfx950 device(s) are visible" % (args.gpus, device_count))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
 
-    def one(z):
-        rc, used, out = orc.zl_inflate(z, nbytes)
-        assert rc == 0 and used == len(z) and len(out) == nbytes
-        return len(out)
 
-    done = 0
-    t0 = time.perf_counter()
-    k = 0
-    while k < len(streams):
-        done += one(streams[k])
-        k += 1
-        if time.perf_counter() - t0 > budget_s * 0.4:
-            break
-    dt = time.perf_counter() - t0
-    single = done / 2**20 / dt
-    # anchor: libz on the same sample
-    t1 = time.perf_counter()
-    for z in streams[:k]:
-        zlib.decompress(z)
-    dz = time.perf_counter() - t1
+def host_cores():
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     quota = ""
     try:  # a container CPU quota below the visible CPUs is what the host really gives
@@ -107,8 +102,33 @@ def cpu_baseline(streams, nbytes, budget_s):
             cores = max(1, min(cores, int(-(-float(q) // float(per)))))
     except (OSError, ValueError):
         pass
-    # all cores: every thread inflates its share of the batch inside ONE C call (GIL released)
+    return cores, quota
+
+
+def cpu_baseline_inflate(streams, nbytes, budget_s):
+    """Oracle (C port of De.Inf.Ns / Zl.Inf.Ns) on the host cores of this box, bounded sample:
+    one thread first, then one stream per thread on all cores (ctypes releases the GIL)."""
     import ctypes
+    from concurrent.futures import ThreadPoolExecutor
+    from tests import oracle_lib
+    orc = oracle_lib.load()
+
+    done, k = 0, 0
+    t0 = time.perf_counter()
+    while k < len(streams):
+        rc, used, out = orc.zl_inflate(streams[k], nbytes)
+        assert rc == 0 and used == len(streams[k]) and len(out) == nbytes
+        done += len(out)
+        k += 1
+        if time.perf_counter() - t0 > budget_s * 0.4:
+            break
+    single = done / 2**20 / (time.perf_counter() - t0)
+    t1 = time.perf_counter()  # anchor: libz on the same sample
+    for z in streams[:k]:
+        zlib.decompress(z)
+    dz = time.perf_counter() - t1
+    cores, quota = host_cores()
+    # all cores: every thread inflates its share of the batch inside ONE C call (GIL released)
     blob = b"".join(streams)
     offs = np.zeros(len(streams), dtype=np.uint64)
     lens = np.array([len(z) for z in streams], dtype=np.uint64)
@@ -145,11 +165,107 @@ def cpu_baseline(streams, nbytes, budget_s):
     }
 
 
+def cpu_baseline_deflate(bufs, level, budget_s):
+    """Oracle (C port of De.Lz77 + De.Def, Zl driver) on the host cores: one buffer per thread."""
+    from concurrent.futures import ThreadPoolExecutor
+    from tests import oracle_lib
+    orc = oracle_lib.load()
+    t0 = time.perf_counter()
+    orc.zl_deflate(bufs[0], level)
+    single = len(bufs[0]) / 2**20 / (time.perf_counter() - t0)
+    cores, quota = host_cores()
+    done, t1 = 0, time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cores) as ex:
+        while time.perf_counter() - t1 < budget_s * 0.6:
+            for b, _ in zip(bufs, ex.map(lambda b: orc.zl_deflate(b, level), bufs)):
+                done += len(b)
+    da = time.perf_counter() - t1
+    return {"value": round(done / 2**20 / da, 2), "unit": "MiB/s", "cores": cores, "kind": "port",
+            "single_core_value": round(single, 2),
+            "sample": "oracle/de_deflate.c Zl.Def level %d, queue 4096: %d MiB over %d sampled buffers, one buffer per "
+                      "thread on %d threads%s" % (level, done >> 20, len(bufs), cores, quota)}
+
+
+def deflate_leg(args, eng, dev, rank, world, dist, fence):
+    """BASELINE config 3: n x 1 MiB printable-ASCII buffers, level 6, queue 4096, Zl driver."""
+    import torch
+    import decompress_amd
+    n, nb = args.deflate_streams, args.deflate_kib * 1024
+    g = torch.Generator(device=dev)
+    g.manual_seed(0xC3 + rank)
+    d_in = torch.randint(0x20, 0x7f, (n * nb,), dtype=torch.uint8, device=dev, generator=g)  # uniform printable ASCII
+    cap = nb + nb // 4 + 8192
+    off = torch.arange(n, dtype=torch.int64, device=dev)
+    d_off, d_len = off * nb, torch.full((n,), nb, dtype=torch.int64, device=dev)
+    d_ooff, d_cap = off * cap, torch.full((n,), cap, dtype=torch.int64, device=dev)
+    d_out = torch.empty(n * cap, dtype=torch.uint8, device=dev)
+    res = eng.deflate_batch(decompress_amd.FORMAT_ZLIB, d_in, d_off, d_len, d_out, d_ooff, d_cap, level=6, queue=4096)
+    fence()
+    eng.timing_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.deflate_steps):
+        res = eng.deflate_batch(decompress_amd.FORMAT_ZLIB, d_in, d_off, d_len, d_out, d_ooff, d_cap, level=6, queue=4096,
+                                results=res)
+    kernel_ms = eng.timing_end() / max(1, args.deflate_steps)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    out_len, status, adler = res
+    ok = bool((status == 0).all().item())
+    comp_bytes = int(out_len.sum().item())
+    sample = []
+    if not args.no_verify:
+        from tests import oracle_lib
+        orc = oracle_lib.load()
+        for k in range(0, n, max(1, n // 8)):  # bytes equal the oracle's, and they decode (8 buffers)
+            plain = d_in[k * nb:(k + 1) * nb].cpu().numpy().tobytes()
+            got = d_out[k * cap:k * cap + int(out_len[k].item())].cpu().numpy().tobytes()
+            ok = ok and got == orc.zl_deflate(plain, 6) and zlib.decompress(got) == plain
+            ok = ok and (int(adler[k].item()) & 0xffffffff) == zlib.adler32(plain)
+            sample.append(plain)
+    if world > 1:
+        t = torch.tensor([int(ok), comp_bytes], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        ok, comp_all = int(t[0].item()) == world, int(t[1].item())
+    else:
+        comp_all = comp_bytes
+    if rank != 0:
+        return None
+    algo = n * nb + comp_bytes  # per launch: U read once + C written once
+    achieved = algo / (kernel_ms * 1e-3) / 1e9
+    is_default = (n, nb) == (4096, 1 << 20)
+    leg = {
+        "metric": "MiB/s deflate over N buffers (uncompressed bytes / wall second)",
+        "value": round(world * n * nb * args.deflate_steps / 2**20 / elapsed, 1), "unit": "MiB/s",
+        "steps": args.deflate_steps, "ms_per_step": round(elapsed / args.deflate_steps * 1e3, 3), "parity_ok": ok,
+        "config": {"workload": "C3: %d x %d KiB printable-ASCII buffers per GPU, De.Lz77 + De.Def level 6, queue 4096, "
+                               "Zl driver, dynamic blocks" % (n, args.deflate_kib),
+                   "compressed_ratio": round(comp_all / (world * n * nb), 4)},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic("deflate_kernel", is_default),
+                     "kernel": "md::deflate_kernel", "kernel_ms": round(kernel_ms, 3),
+                     "algorithmic_bytes_per_launch": algo},
+    }
+    if world == 1 and not args.no_cpu_baseline and sample:
+        leg["cpu_baseline"] = cpu_baseline_deflate(sample, 6, args.cpu_seconds)
+    return leg
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        from decompress_amd import _lib
+        cmd = respawn_command(args, sys.argv[1:], _lib.load().md_device_count())
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.execv(sys.executable, cmd)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != max(1, args.gpus):
+        sys.exit("bench: --gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
 
     import torch
     import torch.distributed as dist
@@ -162,19 +278,14 @@ def main():
     torch.cuda.set_device(dev)
 
     import decompress_amd
-    from decompress_amd import workloads
+    from decompress_amd import shard, workloads
 
     eng = decompress_amd.Engine(local_rank)
-    if args.ring_log2:
-        eng.set_option("ring_log2", args.ring_log2)
-    if args.kernel:
-        eng.set_option("kernel", args.kernel)
-    if args.variant >= 0:
-        eng.set_option("variant", args.variant)
-    if args.overlap:
-        eng.set_option("overlap", args.overlap)
-    if os.environ.get("MD_SPLIT_PCT"):
-        eng.set_option("split_pct", int(os.environ["MD_SPLIT_PCT"]))
+    ranks_seen = 1
+    if world > 1:
+        t = torch.ones(1, dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        ranks_seen = int(t.item())
 
     n = args.streams
     nbytes = args.stream_kib * 1024
@@ -236,22 +347,22 @@ def main():
     ok = ok and bool((consumed == d_in_len).all().item())
     if not args.no_verify:
         host_sum = checksum.cpu().numpy().view(np.uint32)
-        idx = list(range(0, n, max(1, n // 32)))
-        for i in idx:
+        for i in range(0, n, max(1, n // 32)):
             plain = zlib.decompress(streams[i])
             got = d_out[i * nbytes:(i + 1) * nbytes].cpu().numpy().tobytes()
             ok = ok and got == plain and int(host_sum[i]) == zlib.adler32(plain)
-    digest = int(checksum.to(torch.int64).bitwise_and(0xffffffff).sum().item())
-    if world > 1:
-        # the path's only exchange: gather per-rank result digests (RCCL all_gather)
-        from decompress_amd import shard
-        g = torch.tensor([digest, int(ok)], dtype=torch.int64, device=dev)
-        gl = shard.gather_results(dist, g, world)
-        ok = all(int(x[1].item()) for x in gl)
-        digest = sum(int(x[0].item()) for x in gl) & 0xffffffffffff
+    # the path's only exchange: every rank's per-stream results (sizes, Adler-32 from the kernel), RCCL all_gather
+    sums = checksum.to(torch.int64).bitwise_and(0xffffffff)
+    all_len = torch.cat(shard.gather_varlen(dist, out_len, world))
+    all_sum = torch.cat(shard.gather_varlen(dist, sums, world))
+    flags = shard.gather_results(dist, torch.tensor([int(ok)], dtype=torch.int64, device=dev), world)
+    ok = all(int(x.item()) for x in flags)
+    ok = ok and all_len.numel() == world * n and bool((all_len == nbytes).all().item())
+    digest = int(all_sum.sum().item()) & 0xffffffffffff
     if not ok:
         print("bench: PARITY FAILURE (status/bytes/checksum mismatch)", file=sys.stderr)
 
+    line = None
     if rank == 0:
         total_out = world * n * nbytes * args.steps
         value = total_out / 2**20 / elapsed
@@ -262,6 +373,7 @@ def main():
             "value": round(value, 1),
             "unit": "MiB/s",
             "n_gpus": world,
+            "ranks_seen": ranks_seen,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
@@ -275,20 +387,26 @@ def main():
                 "workload": "C2: %d x %d KiB zlib streams per GPU, dynamic Huffman (libz level %d), "
                             "Zl.Inf.Ns semantics, one stream per wavefront" % (n, args.stream_kib, args.level),
                 "streams_per_gpu": n, "stream_bytes": nbytes, "unique_streams": unique,
-                "compressed_ratio": round(comp_bytes / (n * nbytes), 4),
-                "kernel": args.kernel or 3, "variant": max(args.variant, 0), "gen_seconds": round(t_gen, 1),
-                "result_digest": digest,
+                "compressed_ratio": round(comp_bytes / (n * nbytes), 4), "gen_seconds": round(t_gen, 1),
+                "results_gathered": int(all_len.numel()), "result_digest": digest,
             },
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(args, n, nbytes),
-                "kernel": {1: "inflate_kernel", 2: "inflate_v4_kernel", 3: "2 x (decode_kernel + resolve_kernel), overlapped", 5: "inflate_wave_kernel"}[args.kernel or 3],
-                "kernel_ms": round(kernel_ms, 4),
+                "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "traffic": pmc_traffic("inflate_wave_kernel", (n, nbytes) == (4096, 262144)),
+                "kernel": "md::wv::inflate_wave_kernel", "kernel_ms": round(kernel_ms, 4),
                 "algorithmic_bytes_per_launch": algo_bytes,
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(streams, nbytes, args.cpu_seconds)
+            line["cpu_baseline"] = cpu_baseline_inflate(streams, nbytes, args.cpu_seconds)
+    del d_in, d_out
+    torch.cuda.empty_cache()
+    if not args.no_deflate:
+        leg = deflate_leg(args, eng, dev, rank, world, dist, fence)
+        if rank == 0:
+            line["deflate"] = leg
+    if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

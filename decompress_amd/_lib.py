@@ -12,6 +12,7 @@ SO = os.path.join(HERE, "libmdeflate.so")
 c_sz = ctypes.c_size_t
 c_u8p = ctypes.c_void_p
 c_vp = ctypes.c_void_p
+MD_STREAM_NULL = ctypes.c_void_p(-1).value  # md_create: enqueue on the legacy default stream
 
 # every symbol include/mdeflate.h declares: (name, restype, argtypes)
 SYMBOLS = [

@@ -11,24 +11,6 @@
 
 #include "mdeflate.h"
 
-extern "C" int md_launch_inflate(int ring_log2, int format, uint32_t n, const uint8_t *in,
-                                 const uint64_t *in_off, const uint64_t *in_len, uint8_t *out,
-                                 const uint64_t *out_off, const uint64_t *out_cap,
-                                 uint64_t *out_len, uint64_t *consumed, int32_t *status,
-                                 uint32_t *checksum, hipStream_t stream);
-
-extern "C" int md_launch_inflate_v2(int variant, int format, uint32_t n, const uint8_t *in,
-                                    const uint64_t *in_off, const uint64_t *in_len, uint8_t *out,
-                                    const uint64_t *out_off, const uint64_t *out_cap,
-                                    uint64_t *out_len, uint64_t *consumed, int32_t *status,
-                                    uint32_t *checksum, uint64_t *dbg, int only_status, hipStream_t stream);
-extern "C" size_t md_inflate_log_record_bytes(void);
-extern "C" int md_launch_inflate_split(int format, uint32_t n, const uint8_t *in, const uint64_t *in_off,
-                                       const uint64_t *in_len, uint8_t *out, const uint64_t *out_off,
-                                       const uint64_t *out_cap, uint64_t *out_len, uint64_t *consumed,
-                                       int32_t *status, uint32_t *checksum, uint8_t *log,
-                                       uint32_t log_cap, hipStream_t stream);
-
 extern "C" int md_launch_inflate_wave(int format, uint32_t n, const uint8_t *in, const uint64_t *in_off,
                                       const uint64_t *in_len, uint8_t *out, const uint64_t *out_off,
                                       const uint64_t *out_cap, uint64_t *out_len, uint64_t *consumed,
@@ -63,20 +45,12 @@ struct md_ctx {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  // the split inflate path runs the second half of a batch on a side stream forked from the
-  // context's stream: the decode / resolve kernels of the two halves fill each other's gaps and tails
-  hipStream_t side[2] = {nullptr, nullptr};
-  hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
-  int overlap = 2;  // 1 = single stream
-  int split_pct = 50;
-  int ring_log2 = 13;
-  int kernel = 3;   // 1 = serial per wave, 2 = lane-parallel fused (inflate_v4.hip), 3 = lane-parallel split (default)
-  int variant = 0;  // v2 geometry
   // GZip: per-stream scratch (body offsets/lengths, header status, CRCs) and the header to write
   void *gz_tmp = nullptr;
   size_t gz_tmp_bytes = 0;
   uint8_t *gz_hdr_dev = nullptr;  // device copy of gz_hdr (530 bytes max)
   uint8_t gz_hdr[544] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 3};
+  uint8_t gz_hdr_sent[544] = {0};  // what gz_hdr_dev holds
   uint32_t gz_hdr_len = 10;
   bool gz_hdr_dirty = true;
   void *lzo_ws = nullptr;  // Lzo.compress dictionaries
@@ -86,9 +60,6 @@ struct md_ctx {
   uint64_t *dbg = nullptr;  // device buffer of the optional in-kernel profile (32 x u64)
   void *ws = nullptr;       // deflate workspace (hash heads / chains / command queues)
   size_t ws_bytes = 0;
-  void *log = nullptr;      // inflate split path: per-stream token log
-  size_t log_bytes = 0;
-  int log_records = 128;    // records per stream (a stream that needs more is redone by the fused kernel)
   std::string err;
 };
 
@@ -111,6 +82,22 @@ int fail(md_ctx *ctx, int code, const char *what, hipError_t e = hipSuccess) {
     hipError_t e_ = (expr);                                  \
     if (e_ != hipSuccess) return fail(ctx, MD_E_HIP, #expr, e_); \
   } while (0)
+
+// every entry point works on the context's device and leaves the caller's current device as it found it
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = true;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+#define MD_ON_DEVICE(ctx)                 \
+  DeviceGuard guard_((ctx)->device);      \
+  if (!guard_.ok) return fail(ctx, MD_E_HIP, "hipSetDevice")
 
 bool is_gfx950(int dev) {
   hipDeviceProp_t p;
@@ -175,12 +162,15 @@ md_ctx *md_create(int device, void *hip_stream) {
   }
   md_ctx *ctx = new md_ctx();
   ctx->device = device;
-  if (hipSetDevice(device) != hipSuccess) {
+  DeviceGuard guard(device);
+  if (!guard.ok) {
     delete ctx;
     fail(nullptr, MD_E_HIP, "hipSetDevice");
     return nullptr;
   }
-  if (hip_stream) {
+  if (hip_stream == MD_STREAM_NULL) {
+    ctx->stream = nullptr;  // the device's legacy default stream: ordered with everything else enqueued on it
+  } else if (hip_stream) {
     ctx->stream = (hipStream_t)hip_stream;
   } else {
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -190,40 +180,20 @@ md_ctx *md_create(int device, void *hip_stream) {
     }
     ctx->own_stream = true;
   }
-  hipEventCreate(&ctx->ev0);
-  hipEventCreate(&ctx->ev1);
-  hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming);
-  for (int k = 0; k < 2; k++) {
-    hipStreamCreateWithFlags(&ctx->side[k], hipStreamNonBlocking);
-    hipEventCreateWithFlags(&ctx->ev_join[k], hipEventDisableTiming);
-  }
-  if (const char *e = getenv("MD_RING_LOG2")) {
-    int v = atoi(e);
-    if (v >= 12 && v <= 15) ctx->ring_log2 = v;
-  }
-  if (const char *e = getenv("MD_KERNEL")) {
-    int v = atoi(e);
-    if ((v >= 1 && v <= 3) || v == 5) ctx->kernel = v;
-  }
-  if (const char *e = getenv("MD_VARIANT")) {
-    int v = atoi(e);
-    if (v >= 0 && v <= 2) ctx->variant = v;
+  if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+    md_destroy(ctx);
+    fail(nullptr, MD_E_HIP, "hipEventCreate");
+    return nullptr;
   }
   return ctx;
 }
 
 void md_destroy(md_ctx *ctx) {
   if (!ctx) return;
-  hipSetDevice(ctx->device);
+  DeviceGuard guard(ctx->device);
   if (ctx->ev0) hipEventDestroy(ctx->ev0);
   if (ctx->ev1) hipEventDestroy(ctx->ev1);
-  if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
-  for (int k = 0; k < 2; k++) {
-    if (ctx->ev_join[k]) hipEventDestroy(ctx->ev_join[k]);
-    if (ctx->side[k]) hipStreamDestroy(ctx->side[k]);
-  }
   if (ctx->ws) hipFree(ctx->ws);
-  if (ctx->log) hipFree(ctx->log);
   if (ctx->dbg) hipFree(ctx->dbg);
   if (ctx->gz_tmp) hipFree(ctx->gz_tmp);
   if (ctx->lzo_ws) hipFree(ctx->lzo_ws);
@@ -234,18 +204,21 @@ void md_destroy(md_ctx *ctx) {
 
 int md_synchronize(md_ctx *ctx) {
   if (!ctx) return MD_E_INVALID_ARGUMENT;
+  MD_ON_DEVICE(ctx);
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return MD_OK;
 }
 
 int md_timing_begin(md_ctx *ctx) {
   if (!ctx) return MD_E_INVALID_ARGUMENT;
+  MD_ON_DEVICE(ctx);
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   return MD_OK;
 }
 
 int md_timing_end(md_ctx *ctx, float *ms) {
   if (!ctx || !ms) return MD_E_INVALID_ARGUMENT;
+  MD_ON_DEVICE(ctx);
   HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
   HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
@@ -254,16 +227,6 @@ int md_timing_end(md_ctx *ctx, float *ms) {
 
 int md_set_option(md_ctx *ctx, const char *key, int value) {
   if (!ctx || !key) return MD_E_INVALID_ARGUMENT;
-  if (!strcmp(key, "ring_log2")) {
-    if (value < 12 || value > 15) return fail(ctx, MD_E_INVALID_ARGUMENT, "ring_log2 must be 12..15");
-    ctx->ring_log2 = value;
-    return MD_OK;
-  }
-  if (!strcmp(key, "kernel")) {
-    if (value < 1 || value > 5 || value == 4) return fail(ctx, MD_E_INVALID_ARGUMENT, "kernel must be 1, 2, 3 or 5");
-    ctx->kernel = value;
-    return MD_OK;
-  }
   if (!strcmp(key, "profile")) {  // in-kernel phase profile of stream 0 (debug builds of the kernel)
     if (value && !ctx->dbg) {
       if (hipMalloc((void **)&ctx->dbg, 32 * 8) != hipSuccess) return fail(ctx, MD_E_OUT_OF_MEMORY, "hipMalloc");
@@ -274,27 +237,8 @@ int md_set_option(md_ctx *ctx, const char *key, int value) {
     }
     return MD_OK;
   }
-  if (!strcmp(key, "split_pct")) {
-    if (value < 10 || value > 90) return fail(ctx, MD_E_INVALID_ARGUMENT, "split_pct must be 10..90");
-    ctx->split_pct = value;
-    return MD_OK;
-  }
-  if (!strcmp(key, "overlap")) {  // 1 = run the split inflate path on the context's stream only
-    ctx->overlap = value;
-    return MD_OK;
-  }
   if (!strcmp(key, "deflate_test_flags")) {
     ctx->test_flags = value;
-    return MD_OK;
-  }
-  if (!strcmp(key, "log_records")) {
-    if (value < 4 || value > 65536) return fail(ctx, MD_E_INVALID_ARGUMENT, "log_records must be 4..65536");
-    ctx->log_records = value;
-    return MD_OK;
-  }
-  if (!strcmp(key, "variant")) {
-    if (value < 0 || value > 2) return fail(ctx, MD_E_INVALID_ARGUMENT, "variant must be 0..2");
-    ctx->variant = value;
     return MD_OK;
   }
   return fail(ctx, MD_E_INVALID_ARGUMENT, "unknown option");
@@ -336,7 +280,7 @@ int md_inflate_batch_device(md_ctx *ctx, int format, size_t n, const uint8_t *d_
   if (n > 0x7fffffffull) return fail(ctx, MD_E_INVALID_ARGUMENT, "too many streams in one batch");
   if (!d_in_off || !d_in_len || !d_out_off || !d_out_cap || !d_out_len || !d_consumed || !d_status)
     return fail(ctx, MD_E_INVALID_ARGUMENT, "null descriptor array");
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  MD_ON_DEVICE(ctx);
   if (format == MD_FORMAT_GZIP) {
     // Gz.Inf = header, De.Inf on the body, checksum (lib/gz.ml:463-531, :344-356)
     int rc = gz_scratch(ctx, n);
@@ -353,71 +297,8 @@ int md_inflate_batch_device(md_ctx *ctx, int format, size_t n, const uint8_t *d_
     if (e != 0) return fail(ctx, MD_E_HIP, "gz finish kernel launch", (hipError_t)e);
     return MD_OK;
   }
-  int rc;
-  if (ctx->kernel == 5) {
-    rc = md_launch_inflate_wave(format, (uint32_t)n, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap, d_out_len,
-                                d_consumed, d_status, d_checksum, ctx->dbg, ctx->stream);
-  } else if (ctx->kernel == 3) {
-    size_t need = n * (size_t)ctx->log_records * md_inflate_log_record_bytes();
-    if (need > ctx->log_bytes) {
-      if (ctx->log) {
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        HIP_TRY(ctx, hipFree(ctx->log));
-        ctx->log = nullptr;
-        ctx->log_bytes = 0;
-      }
-      if (hipMalloc(&ctx->log, need) != hipSuccess) return fail(ctx, MD_E_OUT_OF_MEMORY, "hipMalloc(token log)");
-      ctx->log_bytes = need;
-    }
-    const bool piped = ctx->overlap >= 2 && n >= 512 && ctx->side[0];
-    const size_t rec_bytes = (size_t)ctx->log_records * md_inflate_log_record_bytes();
-    if (piped) {
-      // independent parts: the first on the context's stream, the others on side streams that fork
-      // from it and join it again — the kernels of the parts fill each other's gaps and tails
-      const size_t parts = ctx->overlap >= 3 && ctx->side[1] ? 3 : 2;
-      rc = 0;
-      HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
-      for (size_t k = 1; k < parts; k++) HIP_TRY(ctx, hipStreamWaitEvent(ctx->side[k - 1], ctx->ev_fork, 0));
-      for (size_t k = 0; k < parts && rc == 0; k++) {
-        size_t a = k * (n / parts), cnt = k + 1 == parts ? n - a : n / parts;
-        if (parts == 2) {  // tuning knob: share of the first part in percent
-          const size_t first = n * (size_t)ctx->split_pct / 100;
-          a = k == 0 ? 0 : first;
-          cnt = k == 0 ? first : n - first;
-        }
-        hipStream_t st = k == 0 ? ctx->stream : ctx->side[k - 1];
-        rc = md_launch_inflate_split(format, (uint32_t)cnt, d_in, d_in_off + a, d_in_len + a, d_out, d_out_off + a,
-                                     d_out_cap + a, d_out_len + a, d_consumed + a, d_status + a,
-                                     d_checksum ? d_checksum + a : nullptr, (uint8_t *)ctx->log + a * rec_bytes,
-                                     (uint32_t)ctx->log_records, st);
-        // streams whose token log overflowed (status 50) are redone by the fused kernel
-        if (rc == 0)
-          rc = md_launch_inflate_v2(0, format, (uint32_t)cnt, d_in, d_in_off + a, d_in_len + a, d_out, d_out_off + a,
-                                    d_out_cap + a, d_out_len + a, d_consumed + a, d_status + a,
-                                    d_checksum ? d_checksum + a : nullptr, nullptr, 50, st);
-      }
-      for (size_t k = 1; k < parts; k++) {
-        HIP_TRY(ctx, hipEventRecord(ctx->ev_join[k - 1], ctx->side[k - 1]));
-        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join[k - 1], 0));
-      }
-    } else
-    {
-      rc = md_launch_inflate_split(format, (uint32_t)n, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap,
-                                   d_out_len, d_consumed, d_status, d_checksum, (uint8_t *)ctx->log,
-                                   (uint32_t)ctx->log_records, ctx->stream);
-      // streams whose token log overflowed (status 50) are redone by the fused kernel
-      if (rc == 0)
-        rc = md_launch_inflate_v2(0, format, (uint32_t)n, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap,
-                                  d_out_len, d_consumed, d_status, d_checksum, nullptr, 50, ctx->stream);
-    }
-  } else if (ctx->kernel == 2)
-    rc = md_launch_inflate_v2(ctx->variant, format, (uint32_t)n, d_in, d_in_off, d_in_len, d_out,
-                              d_out_off, d_out_cap, d_out_len, d_consumed, d_status, d_checksum,
-                              ctx->dbg, -1, ctx->stream);
-  else
-    rc = md_launch_inflate(ctx->ring_log2, format, (uint32_t)n, d_in, d_in_off, d_in_len, d_out,
-                           d_out_off, d_out_cap, d_out_len, d_consumed, d_status, d_checksum,
-                           ctx->stream);
+  int rc = md_launch_inflate_wave(format, (uint32_t)n, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap, d_out_len,
+                                  d_consumed, d_status, d_checksum, ctx->dbg, ctx->stream);
   if (rc != 0) return fail(ctx, MD_E_HIP, "inflate kernel launch", (hipError_t)rc);
   return MD_OK;
 }
@@ -444,10 +325,11 @@ int md_inflate_batch_host(md_ctx *ctx, int format, size_t n, const uint8_t *h_in
   for (size_t i = 0; i < n; i++) {
     if (in_off[i] > in_bytes || in_len[i] > in_bytes - in_off[i])
       return fail(ctx, MD_E_INVALID_ARGUMENT, "input range out of bounds");  // invalid_bounds, lib/de.ml:146
+    if (in_len[i] > MD_MAX_INFLATE_IN) return fail(ctx, MD_E_INVALID_ARGUMENT, "stream longer than MD_MAX_INFLATE_IN");
     if (out_off[i] > out_bytes || out_cap[i] > out_bytes - out_off[i])
       return fail(ctx, MD_E_INVALID_ARGUMENT, "output range out of bounds");
   }
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  MD_ON_DEVICE(ctx);
   DevBuf din, dout, ddesc;
   const size_t desc_words = 6 * n;  // in_off in_len out_off out_cap out_len consumed
   if (din.alloc(in_bytes + 8) != hipSuccess || dout.alloc(out_bytes) != hipSuccess ||
@@ -462,19 +344,9 @@ int md_inflate_batch_host(md_ctx *ctx, int format, size_t n, const uint8_t *h_in
   HIP_TRY(ctx, hipMemcpyAsync(d64 + 1 * n, in_len, n * 8, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(d64 + 2 * n, out_off, n * 8, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(d64 + 3 * n, out_cap, n * 8, hipMemcpyHostToDevice, st));
-  // the host path sees the capacities: size the token log so that no stream overflows it (a round
-  // accepts ~5 KB of output; the floor of 128 records is the default of the device path)
-  const int saved_records = ctx->log_records;
-  {
-    uint64_t max_cap = 0;
-    for (size_t i = 0; i < n; i++) max_cap = out_cap[i] > max_cap ? out_cap[i] : max_cap;
-    const uint64_t want = max_cap / 3072 + 16;
-    if (want > (uint64_t)ctx->log_records) ctx->log_records = (int)(want > 65536 ? 65536 : want);
-  }
   int rc = md_inflate_batch_device(ctx, format, n, (const uint8_t *)din.p, d64, d64 + n,
                                    (uint8_t *)dout.p, d64 + 2 * n, d64 + 3 * n, d64 + 4 * n,
                                    d64 + 5 * n, dstatus, dsum);
-  ctx->log_records = saved_records;
   if (rc != MD_OK) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(h_out, dout.p, out_bytes, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipMemcpyAsync(out_len, d64 + 4 * n, n * 8, hipMemcpyDeviceToHost, st));
@@ -544,7 +416,7 @@ int md_crc32_batch_device(md_ctx *ctx, size_t n, const uint8_t *d_data, const ui
   if (!ctx) return MD_E_INVALID_ARGUMENT;
   if (n == 0) return MD_OK;
   if (n > 0x7fffffffull || !d_off || !d_len || !d_crc) return fail(ctx, MD_E_INVALID_ARGUMENT, "bad crc32 batch");
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  MD_ON_DEVICE(ctx);
   int e = md_launch_crc32((uint32_t)n, d_data, d_off, d_len, d_crc, ctx->stream);
   if (e != 0) return fail(ctx, MD_E_HIP, "crc32 kernel launch", (hipError_t)e);
   return MD_OK;
@@ -571,7 +443,7 @@ int md_deflate_batch_device(md_ctx *ctx, int format, int level, int queue_len, i
   if (n > 0x7fffffffull) return fail(ctx, MD_E_INVALID_ARGUMENT, "too many streams in one batch");
   if (!d_in_off || !d_in_len || !d_out_off || !d_out_cap || !d_out_len || !d_status)
     return fail(ctx, MD_E_INVALID_ARGUMENT, "null descriptor array");
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  MD_ON_DEVICE(ctx);
   size_t need = md_deflate_ws_bytes((uint32_t)n, queue_len);
   if (need > ctx->ws_bytes) {
     if (ctx->ws) {
@@ -594,8 +466,12 @@ int md_deflate_batch_device(md_ctx *ctx, int format, int level, int queue_len, i
     ctx->gz_hdr[8] = level == 9 ? 2 : 0;  // xfl, lib/gz.ml:888-890
     if (ctx->gz_hdr[3] & 2) gz_hdr_crc16(ctx);
     // the stream orders this copy before the kernel; the host buffer lives in the context
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->gz_hdr_dev, ctx->gz_hdr, ctx->gz_hdr_len, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->gz_hdr_dirty || memcmp(ctx->gz_hdr_sent, ctx->gz_hdr, sizeof ctx->gz_hdr) != 0) {
+      // pageable source: the runtime stages the bytes before the call returns, the copy itself is stream-ordered
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->gz_hdr_dev, ctx->gz_hdr, sizeof ctx->gz_hdr, hipMemcpyHostToDevice, ctx->stream));
+      memcpy(ctx->gz_hdr_sent, ctx->gz_hdr, sizeof ctx->gz_hdr);
+      ctx->gz_hdr_dirty = false;
+    }
     gz_hdr = ctx->gz_hdr_dev;
     int e = md_launch_crc32((uint32_t)n, d_in, d_in_off, d_in_len, gz_crc, ctx->stream);
     if (e != 0) return fail(ctx, MD_E_HIP, "crc32 kernel launch", (hipError_t)e);
@@ -620,10 +496,11 @@ int md_deflate_batch_host(md_ctx *ctx, int format, int level, int queue_len, int
   for (size_t i = 0; i < n; i++) {
     if (in_off[i] > in_bytes || in_len[i] > in_bytes - in_off[i])
       return fail(ctx, MD_E_INVALID_ARGUMENT, "input range out of bounds");
+    if (in_len[i] > MD_MAX_STREAM) return fail(ctx, MD_E_INVALID_ARGUMENT, "stream longer than MD_MAX_STREAM");
     if (out_off[i] > out_bytes || out_cap[i] > out_bytes - out_off[i])
       return fail(ctx, MD_E_INVALID_ARGUMENT, "output range out of bounds");
   }
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  MD_ON_DEVICE(ctx);
   DevBuf din, dout, ddesc;
   if (din.alloc(in_bytes + 8) != hipSuccess || dout.alloc(out_bytes) != hipSuccess ||
       ddesc.alloc(5 * n * 8 + n * 8) != hipSuccess)
@@ -756,7 +633,7 @@ static int lzo_batch_device(md_ctx *ctx, bool compress, size_t n, const uint8_t 
   if (n > 0x7fffffffull) return fail(ctx, MD_E_INVALID_ARGUMENT, "too many streams in one batch");
   if (!d_in_off || !d_in_len || !d_out_off || !d_out_cap || !d_out_len || !d_status)
     return fail(ctx, MD_E_INVALID_ARGUMENT, "null descriptor array");
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  MD_ON_DEVICE(ctx);
   if (compress) {  // Lzo's wrkmem: 16 K u16 entries per stream
     const size_t need = n * (size_t)(1u << 15);
     if (need > ctx->lzo_ws_bytes) {
@@ -792,7 +669,7 @@ int md_lzo_compress_batch_device(md_ctx *ctx, size_t n, const uint8_t *d_in, con
 static int lzo_one(md_ctx *ctx, bool compress, const uint8_t *src, size_t src_len, uint8_t *dst, size_t dst_cap,
                    size_t *written) {
   if (!ctx || !written || (!src && src_len) || (!dst && dst_cap)) return MD_E_INVALID_ARGUMENT;
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  MD_ON_DEVICE(ctx);
   DevBuf din, dout, ddesc;
   // compress over-copies up to 16 bytes past a short literal run: the reference's buffers need that room too
   if (din.alloc(src_len + 16) != hipSuccess || dout.alloc(dst_cap + 16) != hipSuccess || ddesc.alloc(6 * 8) != hipSuccess)

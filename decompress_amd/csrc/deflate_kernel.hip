@@ -1234,10 +1234,18 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
   const uint32_t lane = threadIdx.x, sid = blockIdx.x;
   if (sid >= n) return;
   const uint8_t *src = in + in_off[sid];
+  if (in_len[sid] > MD_MAX_STREAM) {  // 32-bit cursors: the descriptor is out of range (mdeflate.h)
+    if (lane == 0) {
+      status[sid] = MD_E_INVALID_ARGUMENT;
+      out_len[sid] = 0;
+      if (checksum) checksum[sid] = 0;
+    }
+    return;
+  }
   const uint32_t slen = (uint32_t)in_len[sid];
   uint8_t *dst = out + out_off[sid];
   uint64_t cap64 = out_cap[sid];
-  uint32_t cap = cap64 > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)cap64;
+  uint32_t cap = cap64 > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)cap64;  // more room than 32-bit cursors can use
   Ws ws{ws_head + (size_t)sid * HASH_SIZE, ws_prev + (size_t)sid * WSIZE, ws_queue + (size_t)sid * qcap,
         ws_mring + (size_t)sid * 2 * RING};
 

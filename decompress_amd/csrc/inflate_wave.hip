@@ -1014,8 +1014,18 @@ __global__ __launch_bounds__(kWave) void inflate_wave_kernel(
 
   const uint8_t *src = in + in_off[sid];
   uint64_t slen64 = in_len[sid], cap64 = out_cap[sid];
-  uint32_t slen = slen64 > 0x1ffffff0ull ? 0x1ffffff0u : (uint32_t)slen64;
-  uint32_t cap = cap64 > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)cap64;
+  if (slen64 > MD_MAX_INFLATE_IN) {  // 32-bit bit positions: the descriptor is out of range (mdeflate.h)
+    if (lane == 0) {
+      out_len[sid] = 0;
+      consumed[sid] = 0;
+      status[sid] = MD_E_INVALID_ARGUMENT;
+      if (checksum) checksum[sid] = 0;
+    }
+    return;
+  }
+  const uint32_t slen = (uint32_t)slen64;
+  const bool cap_clamped = cap64 > MD_MAX_STREAM;  // more room than 32-bit cursors can use
+  const uint32_t cap = cap_clamped ? (uint32_t)MD_MAX_STREAM : (uint32_t)cap64;
 
   int rc = MD_OK;
   uint32_t body_off = 0, body_len = slen;
@@ -1115,6 +1125,7 @@ __global__ __launch_bounds__(kWave) void inflate_wave_kernel(
     if (want != adler) rc = MD_INVALID_CHECKSUM;
     used += 6;
   }
+  if (rc == MD_UNEXPECTED_END_OF_OUTPUT && cap_clamped) rc = MD_E_INVALID_ARGUMENT;  // a > 4 GiB stream
   if (lane == 0) {
     out_len[sid] = sk.pos;
     consumed[sid] = rc == MD_OK ? used : 0;

@@ -186,7 +186,14 @@ __global__ __launch_bounds__(kWave) void lzo_uncompress_kernel(
   Dec d;
   d.in.src = in + in_off[sid];
   const uint64_t l64 = in_len[sid], c64 = out_cap[sid];
-  d.in.n = l64 > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)l64;
+  if (l64 > MD_MAX_STREAM) {  // 32-bit cursors: the descriptor is out of range (mdeflate.h)
+    if (lane == 0) {
+      status[sid] = MD_E_INVALID_ARGUMENT;
+      out_len[sid] = 0;
+    }
+    return;
+  }
+  d.in.n = (uint32_t)l64;
   d.in.lane = lane;
   d.in.fill(0);
   d.dst = out + out_off[sid];
@@ -409,7 +416,14 @@ __global__ __launch_bounds__(kWave) void lzo_compress_kernel(
   Cmp c;
   c.src = in + in_off[sid];
   const uint64_t l64 = in_len[sid], c64 = out_cap[sid];
-  c.n = l64 > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)l64;
+  if (l64 > MD_MAX_STREAM) {  // 32-bit cursors: the descriptor is out of range (mdeflate.h)
+    if (lane == 0) {
+      status[sid] = MD_E_INVALID_ARGUMENT;
+      out_len[sid] = 0;
+    }
+    return;
+  }
+  c.n = (uint32_t)l64;
   c.dst = out + out_off[sid];
   c.cap = c64 > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)c64;
   c.lane = lane;

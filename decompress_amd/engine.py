@@ -31,8 +31,9 @@ def _ptr(t):
 
 
 class Engine:
-    """One engine per GPU (wraps md_ctx).  Kernels are enqueued on torch's
-    current stream of `device` unless own_stream=True."""
+    """One engine per GPU (wraps md_ctx).  Kernels are enqueued on torch's current stream of `device` — the
+    legacy default stream included (MD_STREAM_NULL), so batch calls are ordered with the torch kernels that
+    produce their inputs and consume their results — unless own_stream=True (then the caller synchronises)."""
 
     def __init__(self, device=0, own_stream=False):
         import torch
@@ -42,8 +43,12 @@ class Engine:
         if not torch.cuda.is_available():
             raise Error("decompress_amd needs a HIP device (no CPU fallback)")
         self.device = torch.device("cuda", device)
-        stream = None if own_stream else torch.cuda.current_stream(self.device).cuda_stream
-        self.ctx = self.lib.md_create(device, ctypes.c_void_p(stream) if stream else None)
+        if own_stream:
+            handle = None
+        else:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            handle = ctypes.c_void_p(stream) if stream else ctypes.c_void_p(_lib.MD_STREAM_NULL)
+        self.ctx = self.lib.md_create(device, handle)
         if not self.ctx:
             raise Error(self.lib.md_last_error_string(None).decode())
 

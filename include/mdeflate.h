@@ -18,9 +18,10 @@
  *  - there is NO CPU fallback: every compute entry point runs HIP kernels and
  *    returns MD_E_NO_DEVICE when no gfx950 device is usable.
  *  - limits per stream (the kernels keep 32-bit cursors): inflate reads at most
- *    512 MiB - 16 of compressed input (bit positions are 32-bit) and writes at most
- *    4 GiB - 16; deflate / LZO read and write at most 4 GiB - 16.  Larger descriptors are
- *    clamped to these bounds (a longer stream then ends in "Unexpected end of input/output").
+ *    MD_MAX_INFLATE_IN (512 MiB - 16: bit positions are 32-bit) of compressed input and writes at most
+ *    MD_MAX_STREAM (4 GiB - 16); deflate / LZO read and write at most MD_MAX_STREAM.  The host-pointer
+ *    entry points reject larger descriptors with MD_E_INVALID_ARGUMENT; with device descriptors the
+ *    stream's status[i] is MD_E_INVALID_ARGUMENT and nothing is read or written for it.
  *    A batch holds at most 2^31 - 1 streams.
  */
 #ifndef MDEFLATE_H
@@ -32,7 +33,9 @@
 extern "C" {
 #endif
 
-#define MD_VERSION 0x000100 /* 0.1.0 */
+#define MD_VERSION 0x000200 /* 0.2.0 */
+#define MD_MAX_INFLATE_IN 0x1ffffff0ull
+#define MD_MAX_STREAM 0xfffffff0ull
 
 /* Per-stream status: De.Inf.Ns.error (lib/de.ml:1548-1566, lib/de.mli:150-157)
  * + Zl.Inf.Ns.error (lib/zl.ml:383).  Strings: md_status_string(). */
@@ -108,11 +111,16 @@ const char *md_last_error_string(const md_ctx *ctx);
 /* Number of usable gfx950 devices (0 when none / no driver). */
 int md_device_count(void);
 
-/* One context per GPU.  `hip_stream` may be NULL (the context creates its own
- * non-blocking stream) or an existing hipStream_t to enqueue on (e.g. the
- * caller's current stream).  Replaces nothing in the reference: state objects
- * there are the window/queue bigarrays the caller allocates (lib/de.mli:93-106);
- * here they are per-wavefront LDS rings owned by the kernels. */
+/* One context per GPU.  `hip_stream`:
+ *   NULL            the context creates its own non-blocking stream (not ordered with any other stream:
+ *                   the caller synchronises, e.g. md_synchronize, before touching the buffers elsewhere);
+ *   MD_STREAM_NULL  the device's legacy default stream (hipStream_t 0): ordered with everything the caller
+ *                   enqueues there;
+ *   otherwise       an existing hipStream_t to enqueue on (e.g. the caller's current stream).
+ * Every entry point sets the context's device for the call and restores the caller's current device.
+ * Replaces nothing in the reference: state objects there are the window/queue bigarrays the caller
+ * allocates (lib/de.mli:93-106); here they are LDS buffers owned by the kernels. */
+#define MD_STREAM_NULL ((void *)(intptr_t)-1)
 md_ctx *md_create(int device, void *hip_stream);
 void md_destroy(md_ctx *ctx);
 int md_synchronize(md_ctx *ctx);

@@ -25,10 +25,6 @@ def main():
     from decompress_amd import workloads
     dev = torch.device("cuda", 0)
     eng = decompress_amd.Engine(0)
-    # the token log is sized per stream in rounds (~5 KB of output each); the default 128 records covers
-    # 256 KiB streams, the largest member here is 768 KiB — beyond the log a stream is redone by the
-    # fused kernel, which is correct but slower
-    eng.set_option("log_records", 224)
     n = args.streams
     uniq = [workloads.text(0xC4 + i, SIZES[i % 15]) for i in range(min(args.unique, n))]
     bufs = [uniq[i % len(uniq)] for i in range(n)]
