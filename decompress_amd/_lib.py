@@ -14,6 +14,21 @@ c_u8p = ctypes.c_void_p
 c_vp = ctypes.c_void_p
 MD_STREAM_NULL = ctypes.c_void_p(-1).value  # md_create: enqueue on the legacy default stream
 
+class GzHeader(ctypes.Structure):
+    """md_gz_header of include/mdeflate.h"""
+    _fields_ = [("mtime", ctypes.c_uint32), ("os", ctypes.c_int), ("hcrc", ctypes.c_int), ("ascii", ctypes.c_int),
+                ("filename", ctypes.c_char_p), ("comment", ctypes.c_char_p)]
+
+
+class DeflateParams(ctypes.Structure):
+    """md_deflate_params of include/mdeflate.h"""
+    _fields_ = [("level", ctypes.c_int), ("queue_len", ctypes.c_int), ("driver", ctypes.c_int), ("dynamic", ctypes.c_int),
+                ("matcher", ctypes.c_int), ("gz_header", ctypes.POINTER(GzHeader))]
+
+
+c_pp = ctypes.POINTER(DeflateParams)
+c_szp = ctypes.POINTER(c_sz)
+
 # every symbol include/mdeflate.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("md_version", ctypes.c_int, []),
@@ -29,11 +44,31 @@ SYMBOLS = [
      [c_vp, ctypes.c_int, c_sz] + [c_vp] * 10),
     ("md_inflate_batch_host", ctypes.c_int,
      [c_vp, ctypes.c_int, c_sz, c_vp, c_sz, c_vp, c_vp, c_vp, c_sz, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    ("md_deflate_batch_device", ctypes.c_int,
-     [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_sz] + [c_vp] * 9),
+    ("md_deflate_batch_device", ctypes.c_int, [c_vp, ctypes.c_int, c_pp, c_sz] + [c_vp] * 9),
     ("md_deflate_batch_host", ctypes.c_int,
-     [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_sz, c_vp, c_sz, c_vp, c_vp,
-      c_vp, c_sz, c_vp, c_vp, c_vp, c_vp, c_vp]),
+     [c_vp, ctypes.c_int, c_pp, c_sz, c_vp, c_sz, c_vp, c_vp, c_vp, c_sz, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    ("md_de_higher_uncompress", ctypes.c_int, [c_vp, c_vp, c_sz, c_vp, c_sz, c_szp]),
+    ("md_zl_higher_uncompress", ctypes.c_int, [c_vp, c_vp, c_sz, c_vp, c_sz, c_szp]),
+    ("md_de_lz77_compress", ctypes.c_int,
+     [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp, c_sz, c_vp, c_sz, c_szp, c_vp, c_vp]),
+    ("md_de_def_encode", ctypes.c_int, [c_vp, ctypes.c_int, c_vp, c_sz, c_vp, c_sz, c_szp]),
+    ("md_inf_decoder", c_vp, [c_vp, ctypes.c_int, c_vp, c_sz]),
+    ("md_inf_src", ctypes.c_int, [c_vp, c_vp, c_sz, c_sz]),
+    ("md_inf_decode", ctypes.c_int, [c_vp]),
+    ("md_inf_flush", None, [c_vp]),
+    ("md_inf_dst_rem", c_sz, [c_vp]),
+    ("md_inf_src_rem", c_sz, [c_vp]),
+    ("md_inf_status", ctypes.c_int, [c_vp]),
+    ("md_inf_checksum", ctypes.c_uint32, [c_vp]),
+    ("md_inf_free", None, [c_vp]),
+    ("md_def_encoder", c_vp, [c_vp, ctypes.c_int, c_pp, c_vp, c_sz]),
+    ("md_def_src", ctypes.c_int, [c_vp, c_vp, c_sz, c_sz]),
+    ("md_def_encode", ctypes.c_int, [c_vp]),
+    ("md_def_dst", None, [c_vp, c_vp, c_sz]),
+    ("md_def_dst_rem", c_sz, [c_vp]),
+    ("md_def_status", ctypes.c_int, [c_vp]),
+    ("md_def_checksum", ctypes.c_uint32, [c_vp]),
+    ("md_def_free", None, [c_vp]),
     ("md_de_higher_compress", ctypes.c_int,
      [c_vp, ctypes.c_int, c_vp, c_sz, c_vp, c_sz, ctypes.POINTER(c_sz)]),
     ("md_zl_higher_compress", ctypes.c_int,
@@ -42,14 +77,11 @@ SYMBOLS = [
      [c_vp, c_vp, c_sz, c_vp, c_sz, ctypes.POINTER(c_sz), ctypes.POINTER(c_sz)]),
     ("md_zl_inf_ns_inflate", ctypes.c_int,
      [c_vp, c_vp, c_sz, c_vp, c_sz, ctypes.POINTER(c_sz), ctypes.POINTER(c_sz)]),
-    ("md_gz_set_header", ctypes.c_int,
-     [c_vp, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p]),
     ("md_gz_higher_compress", ctypes.c_int,
-     [c_vp, ctypes.c_int, ctypes.c_int, c_vp, c_sz, c_vp, c_sz, ctypes.POINTER(c_sz)]),
+     [c_vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(GzHeader), c_vp, c_sz, c_vp, c_sz, ctypes.POINTER(c_sz)]),
     ("md_gz_higher_uncompress", ctypes.c_int,
      [c_vp, c_vp, c_sz, c_vp, c_sz, ctypes.POINTER(c_sz), ctypes.POINTER(c_sz), c_vp]),
     ("md_crc32_batch_device", ctypes.c_int, [c_vp, c_sz, c_vp, c_vp, c_vp, c_vp]),
-    ("md_deflate_set_matcher", ctypes.c_int, [c_vp, ctypes.c_int]),
     ("md_lzo_uncompress_batch_device", ctypes.c_int, [c_vp, c_sz] + [c_vp] * 8),
     ("md_lzo_compress_batch_device", ctypes.c_int, [c_vp, c_sz] + [c_vp] * 8),
     ("md_lzo_uncompress", ctypes.c_int, [c_vp, c_vp, c_sz, c_vp, c_sz, ctypes.POINTER(c_sz)]),

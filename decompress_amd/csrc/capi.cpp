@@ -22,7 +22,7 @@ extern "C" int md_launch_deflate(int format, int level, int qcap, int driver, in
                                  uint8_t *out, const uint64_t *out_off, const uint64_t *out_cap,
                                  uint64_t *out_len, int32_t *status, uint32_t *checksum, void *ws,
                                  uint64_t *dbg, int test_flags, const uint8_t *gz_hdr, uint32_t gz_hdr_len,
-                                 const uint32_t *gz_crc, int matcher, hipStream_t stream);
+                                 const uint32_t *gz_crc, int matcher, uint32_t *hist, hipStream_t stream);
 
 extern "C" int md_launch_gz_header(uint32_t n, const uint8_t *in, const uint64_t *in_off, const uint64_t *in_len,
                                    uint64_t *body_off, uint64_t *body_len, int32_t *hstatus, hipStream_t stream);
@@ -49,13 +49,10 @@ struct md_ctx {
   void *gz_tmp = nullptr;
   size_t gz_tmp_bytes = 0;
   uint8_t *gz_hdr_dev = nullptr;  // device copy of gz_hdr (530 bytes max)
-  uint8_t gz_hdr[544] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 3};
   uint8_t gz_hdr_sent[544] = {0};  // what gz_hdr_dev holds
-  uint32_t gz_hdr_len = 10;
-  bool gz_hdr_dirty = true;
+  bool gz_hdr_valid = false;
   void *lzo_ws = nullptr;  // Lzo.compress dictionaries
   size_t lzo_ws_bytes = 0;
-  int matcher = MD_MATCHER_DE;
   int test_flags = 0;       // deflate: bit 0 = always take the order-free head reconstruction (tests)
   uint64_t *dbg = nullptr;  // device buffer of the optional in-kernel profile (32 x u64)
   void *ws = nullptr;       // deflate workspace (hash heads / chains / command queues)
@@ -366,49 +363,41 @@ static uint32_t host_crc32(const uint8_t *p, size_t n) {
   }
   return c ^ 0xffffffffu;
 }
-static void gz_hdr_crc16(md_ctx *ctx) {
-  const uint32_t body = ctx->gz_hdr_len - 2;  // fixed bytes + name\0 + comment\0
-  const uint32_t c16 = (host_crc32(ctx->gz_hdr, body) & 0xffff0000u) >> 16;
-  ctx->gz_hdr[body] = (uint8_t)(c16 >> 8);
-  ctx->gz_hdr[body + 1] = (uint8_t)c16;
-}
-
-int md_gz_set_header(md_ctx *ctx, uint32_t mtime, int os, int hcrc, int ascii, const char *filename,
-                     const char *comment) {
-  if (!ctx) return MD_E_INVALID_ARGUMENT;
-  const size_t nl = filename ? strlen(filename) : 0, cl = comment ? strlen(comment) : 0;
-  if (nl > 255 || cl > 255 || os < 0 || os > 255) return fail(ctx, MD_E_INVALID_ARGUMENT, "gzip header field out of range");
-  uint8_t *h = ctx->gz_hdr;
+// The bytes Gz.Def writes in front of the body (lib/gz.ml:796-812) for the header fields of Gz.Def.encoder
+// (lib/gz.ml:859-918); returns the length, 0 when a field is out of range.
+static uint32_t gz_header_bytes(const md_gz_header *g, int level, uint8_t h[544]) {
+  static const md_gz_header dflt = {0, 3, 0, 0, nullptr, nullptr};
+  if (!g) g = &dflt;
+  const size_t nl = g->filename ? strlen(g->filename) : 0, cl = g->comment ? strlen(g->comment) : 0;
+  if (nl > 255 || cl > 255 || g->os < 0 || g->os > 255) return 0;
+  memset(h, 0, 544);
   // flg, lib/gz.ml:851-857; mtime big-endian, lib/gz.ml:801
   h[0] = 0x1f;
   h[1] = 0x8b;
   h[2] = 8;
-  h[3] = (uint8_t)((ascii ? 1 : 0) | (hcrc ? 2 : 0) | (filename ? 8 : 0) | (comment ? 16 : 0));
-  h[4] = (uint8_t)(mtime >> 24);
-  h[5] = (uint8_t)(mtime >> 16);
-  h[6] = (uint8_t)(mtime >> 8);
-  h[7] = (uint8_t)mtime;
-  h[8] = 0;
-  h[9] = (uint8_t)os;
+  h[3] = (uint8_t)((g->ascii ? 1 : 0) | (g->hcrc ? 2 : 0) | (g->filename ? 8 : 0) | (g->comment ? 16 : 0));
+  h[4] = (uint8_t)(g->mtime >> 24);
+  h[5] = (uint8_t)(g->mtime >> 16);
+  h[6] = (uint8_t)(g->mtime >> 8);
+  h[7] = (uint8_t)g->mtime;
+  h[8] = level == 9 ? 2 : 0;  // xfl, lib/gz.ml:888-890
+  h[9] = (uint8_t)g->os;
   uint32_t p = 10;
-  if (filename) {
-    memcpy(h + p, filename, nl + 1);
+  if (g->filename) {
+    memcpy(h + p, g->filename, nl + 1);
     p += (uint32_t)nl + 1;
   }
-  if (comment) {
-    memcpy(h + p, comment, cl + 1);
+  if (g->comment) {
+    memcpy(h + p, g->comment, cl + 1);
     p += (uint32_t)cl + 1;
   }
-  if (hcrc) p += 2;
-  ctx->gz_hdr_len = p;
-  return MD_OK;
-}
-
-int md_deflate_set_matcher(md_ctx *ctx, int matcher) {
-  if (!ctx) return MD_E_INVALID_ARGUMENT;
-  if (matcher != MD_MATCHER_DE && matcher != MD_MATCHER_LZ) return fail(ctx, MD_E_INVALID_ARGUMENT, "unknown matcher");
-  ctx->matcher = matcher;
-  return MD_OK;
+  if (g->hcrc) {  // the upper half of the CRC-32 of what precedes, big-endian (H10, lib/gz.ml:771-789)
+    const uint32_t c16 = (host_crc32(h, p) & 0xffff0000u) >> 16;
+    h[p] = (uint8_t)(c16 >> 8);
+    h[p + 1] = (uint8_t)c16;
+    p += 2;
+  }
+  return p;
 }
 
 int md_crc32_batch_device(md_ctx *ctx, size_t n, const uint8_t *d_data, const uint64_t *d_off,
@@ -422,28 +411,10 @@ int md_crc32_batch_device(md_ctx *ctx, size_t n, const uint8_t *d_data, const ui
   return MD_OK;
 }
 
-int md_deflate_batch_device(md_ctx *ctx, int format, int level, int queue_len, int driver,
-                            int dynamic, size_t n, const uint8_t *d_in, const uint64_t *d_in_off,
-                            const uint64_t *d_in_len, uint8_t *d_out, const uint64_t *d_out_off,
-                            const uint64_t *d_out_cap, uint64_t *d_out_len, int32_t *d_status,
-                            uint32_t *d_checksum) {
-  if (!ctx) return MD_E_INVALID_ARGUMENT;
-  if (format != MD_FORMAT_DEFLATE && format != MD_FORMAT_ZLIB && format != MD_FORMAT_GZIP)
-    return fail(ctx, MD_E_INVALID_ARGUMENT, "unknown format");
-  if (format == MD_FORMAT_GZIP) {  // Gz.Def's driver is Zl's with block_of_frequencies (lib/gz.ml:724-729)
-    driver = MD_DRIVER_ZL;
-    dynamic = 1;
-  }
-  if (level < 0 || level > 9)  // Lz77.state: "Invalid level of compression", lib/de.ml:4477
-    return fail(ctx, MD_E_INVALID_ARGUMENT, "Invalid level of compression");
-  if (queue_len < 4 || queue_len > (1 << 20) || (queue_len & (queue_len - 1)))  // lib/de.ml:2286-2288
-    return fail(ctx, MD_E_INVALID_ARGUMENT, "Length of queue MUST be a power of two");
-  if (driver < MD_DRIVER_ZL || driver > MD_DRIVER_CLI) return fail(ctx, MD_E_INVALID_ARGUMENT, "unknown driver");
-  if (n == 0) return MD_OK;
-  if (n > 0x7fffffffull) return fail(ctx, MD_E_INVALID_ARGUMENT, "too many streams in one batch");
-  if (!d_in_off || !d_in_len || !d_out_off || !d_out_cap || !d_out_len || !d_status)
-    return fail(ctx, MD_E_INVALID_ARGUMENT, "null descriptor array");
-  MD_ON_DEVICE(ctx);
+static int deflate_launch(md_ctx *ctx, int format, int level, int queue_len, int driver, int dynamic, int matcher,
+                          const md_gz_header *gz, size_t n, const uint8_t *d_in, const uint64_t *d_in_off,
+                          const uint64_t *d_in_len, uint8_t *d_out, const uint64_t *d_out_off, const uint64_t *d_out_cap,
+                          uint64_t *d_out_len, int32_t *d_status, uint32_t *d_checksum, uint32_t *d_hist) {
   size_t need = md_deflate_ws_bytes((uint32_t)n, queue_len);
   if (need > ctx->ws_bytes) {
     if (ctx->ws) {
@@ -457,34 +428,69 @@ int md_deflate_batch_device(md_ctx *ctx, int format, int level, int queue_len, i
   }
   const uint8_t *gz_hdr = nullptr;
   uint32_t *gz_crc = nullptr;
+  uint32_t gz_hdr_len = 0;
   if (format == MD_FORMAT_GZIP) {
+    uint8_t h[544];
+    gz_hdr_len = gz_header_bytes(gz, level, h);
+    if (!gz_hdr_len) return fail(ctx, MD_E_INVALID_ARGUMENT, "gzip header field out of range");
     int grc = gz_scratch(ctx, n);
     if (grc != MD_OK) return grc;
     gz_crc = (uint32_t *)((uint8_t *)ctx->gz_tmp + n * 20);
-    if (!ctx->gz_hdr_dev && hipMalloc((void **)&ctx->gz_hdr_dev, sizeof ctx->gz_hdr) != hipSuccess)
+    if (!ctx->gz_hdr_dev && hipMalloc((void **)&ctx->gz_hdr_dev, sizeof h) != hipSuccess)
       return fail(ctx, MD_E_OUT_OF_MEMORY, "hipMalloc(gzip header)");
-    ctx->gz_hdr[8] = level == 9 ? 2 : 0;  // xfl, lib/gz.ml:888-890
-    if (ctx->gz_hdr[3] & 2) gz_hdr_crc16(ctx);
-    // the stream orders this copy before the kernel; the host buffer lives in the context
-    if (ctx->gz_hdr_dirty || memcmp(ctx->gz_hdr_sent, ctx->gz_hdr, sizeof ctx->gz_hdr) != 0) {
+    if (!ctx->gz_hdr_valid || memcmp(ctx->gz_hdr_sent, h, sizeof h) != 0) {
       // pageable source: the runtime stages the bytes before the call returns, the copy itself is stream-ordered
-      HIP_TRY(ctx, hipMemcpyAsync(ctx->gz_hdr_dev, ctx->gz_hdr, sizeof ctx->gz_hdr, hipMemcpyHostToDevice, ctx->stream));
-      memcpy(ctx->gz_hdr_sent, ctx->gz_hdr, sizeof ctx->gz_hdr);
-      ctx->gz_hdr_dirty = false;
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->gz_hdr_dev, h, sizeof h, hipMemcpyHostToDevice, ctx->stream));
+      memcpy(ctx->gz_hdr_sent, h, sizeof h);
+      ctx->gz_hdr_valid = true;
     }
     gz_hdr = ctx->gz_hdr_dev;
     int e = md_launch_crc32((uint32_t)n, d_in, d_in_off, d_in_len, gz_crc, ctx->stream);
     if (e != 0) return fail(ctx, MD_E_HIP, "crc32 kernel launch", (hipError_t)e);
   }
-  int rc = md_launch_deflate(format, level, queue_len, driver, dynamic ? 1 : 0, (uint32_t)n, d_in, d_in_off,
-                             d_in_len, d_out, d_out_off, d_out_cap, d_out_len, d_status, d_checksum,
-                             ctx->ws, ctx->dbg, ctx->test_flags, gz_hdr, ctx->gz_hdr_len, gz_crc, ctx->matcher,
-                             ctx->stream);
+  int rc = md_launch_deflate(format, level, queue_len, driver, dynamic, (uint32_t)n, d_in, d_in_off, d_in_len, d_out,
+                             d_out_off, d_out_cap, d_out_len, d_status, d_checksum, ctx->ws, ctx->dbg, ctx->test_flags,
+                             gz_hdr, gz_hdr_len, gz_crc, matcher, d_hist, ctx->stream);
   if (rc != 0) return fail(ctx, MD_E_HIP, "deflate kernel launch", (hipError_t)rc);
   return MD_OK;
 }
 
-int md_deflate_batch_host(md_ctx *ctx, int format, int level, int queue_len, int driver, int dynamic,
+static int check_params(md_ctx *ctx, int format, const md_deflate_params *p, md_deflate_params *q) {
+  if (!p) return fail(ctx, MD_E_INVALID_ARGUMENT, "null md_deflate_params");
+  *q = *p;
+  if (format != MD_FORMAT_DEFLATE && format != MD_FORMAT_ZLIB && format != MD_FORMAT_GZIP)
+    return fail(ctx, MD_E_INVALID_ARGUMENT, "unknown format");
+  if (format == MD_FORMAT_GZIP) {  // Gz.Def's driver is Zl's with block_of_frequencies (lib/gz.ml:724-729)
+    q->driver = MD_DRIVER_ZL;
+    q->dynamic = 1;
+  }
+  if (q->level < 0 || q->level > 9)  // Lz77.state: "Invalid level of compression", lib/de.ml:4477
+    return fail(ctx, MD_E_INVALID_ARGUMENT, "Invalid level of compression");
+  if (q->queue_len < 4 || q->queue_len > (1 << 20) || (q->queue_len & (q->queue_len - 1)))  // lib/de.ml:2286-2288
+    return fail(ctx, MD_E_INVALID_ARGUMENT, "Length of queue MUST be a power of two");
+  if (q->driver < MD_DRIVER_ZL || q->driver > MD_DRIVER_CLI) return fail(ctx, MD_E_INVALID_ARGUMENT, "unknown driver");
+  if (q->matcher != MD_MATCHER_DE && q->matcher != MD_MATCHER_LZ) return fail(ctx, MD_E_INVALID_ARGUMENT, "unknown matcher");
+  q->dynamic = q->dynamic ? 1 : 0;
+  return MD_OK;
+}
+
+int md_deflate_batch_device(md_ctx *ctx, int format, const md_deflate_params *params, size_t n, const uint8_t *d_in,
+                            const uint64_t *d_in_off, const uint64_t *d_in_len, uint8_t *d_out, const uint64_t *d_out_off,
+                            const uint64_t *d_out_cap, uint64_t *d_out_len, int32_t *d_status, uint32_t *d_checksum) {
+  if (!ctx) return MD_E_INVALID_ARGUMENT;
+  md_deflate_params q;
+  int rc = check_params(ctx, format, params, &q);
+  if (rc != MD_OK) return rc;
+  if (n == 0) return MD_OK;
+  if (n > 0x7fffffffull) return fail(ctx, MD_E_INVALID_ARGUMENT, "too many streams in one batch");
+  if (!d_in_off || !d_in_len || !d_out_off || !d_out_cap || !d_out_len || !d_status)
+    return fail(ctx, MD_E_INVALID_ARGUMENT, "null descriptor array");
+  MD_ON_DEVICE(ctx);
+  return deflate_launch(ctx, format, q.level, q.queue_len, q.driver, q.dynamic, q.matcher, q.gz_header, n, d_in, d_in_off,
+                        d_in_len, d_out, d_out_off, d_out_cap, d_out_len, d_status, d_checksum, nullptr);
+}
+
+int md_deflate_batch_host(md_ctx *ctx, int format, const md_deflate_params *params,
                           size_t n, const uint8_t *h_in, size_t in_bytes, const uint64_t *in_off,
                           const uint64_t *in_len, uint8_t *h_out, size_t out_bytes,
                           const uint64_t *out_off, const uint64_t *out_cap, uint64_t *out_len,
@@ -514,9 +520,8 @@ int md_deflate_batch_host(md_ctx *ctx, int format, int level, int queue_len, int
   HIP_TRY(ctx, hipMemcpyAsync(d64 + 1 * n, in_len, n * 8, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(d64 + 2 * n, out_off, n * 8, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(d64 + 3 * n, out_cap, n * 8, hipMemcpyHostToDevice, st));
-  int rc = md_deflate_batch_device(ctx, format, level, queue_len, driver, dynamic, n, (const uint8_t *)din.p,
-                                   d64, d64 + n, (uint8_t *)dout.p, d64 + 2 * n, d64 + 3 * n, d64 + 4 * n,
-                                   dstatus, dsum);
+  int rc = md_deflate_batch_device(ctx, format, params, n, (const uint8_t *)din.p, d64, d64 + n, (uint8_t *)dout.p,
+                                   d64 + 2 * n, d64 + 3 * n, d64 + 4 * n, dstatus, dsum);
   if (rc != MD_OK) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(h_out, dout.p, out_bytes, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipMemcpyAsync(out_len, d64 + 4 * n, n * 8, hipMemcpyDeviceToHost, st));
@@ -526,13 +531,14 @@ int md_deflate_batch_host(md_ctx *ctx, int format, int level, int queue_len, int
   return MD_OK;
 }
 
-static int deflate_one(md_ctx *ctx, int format, int level, int queue_len, int driver, int dynamic,
+static int deflate_one(md_ctx *ctx, int format, int level, int queue_len, int driver, int dynamic, const md_gz_header *gz,
                        const uint8_t *src, size_t src_len, uint8_t *dst, size_t dst_cap, size_t *written) {
   if (!ctx || !written || (!src && src_len) || (!dst && dst_cap)) return MD_E_INVALID_ARGUMENT;
   uint64_t in_off = 0, in_len = src_len, out_off = 0, out_cap = dst_cap, out_len = 0;
   int32_t status = 0;
-  int rc = md_deflate_batch_host(ctx, format, level, queue_len, driver, dynamic, 1, src, src_len, &in_off,
-                                 &in_len, dst, dst_cap, &out_off, &out_cap, &out_len, &status, nullptr);
+  const md_deflate_params p = {level, queue_len, driver, dynamic, MD_MATCHER_DE, gz};
+  int rc = md_deflate_batch_host(ctx, format, &p, 1, src, src_len, &in_off, &in_len, dst, dst_cap, &out_off, &out_cap,
+                                 &out_len, &status, nullptr);
   if (rc != MD_OK) return rc;
   *written = (size_t)out_len;
   return status;
@@ -540,12 +546,70 @@ static int deflate_one(md_ctx *ctx, int format, int level, int queue_len, int dr
 
 int md_de_higher_compress(md_ctx *ctx, int queue_len, const uint8_t *src, size_t src_len,
                           uint8_t *dst, size_t dst_cap, size_t *written) {
-  return deflate_one(ctx, MD_FORMAT_DEFLATE, 4, queue_len, MD_DRIVER_HIGHER, 1, src, src_len, dst, dst_cap, written);
+  return deflate_one(ctx, MD_FORMAT_DEFLATE, 4, queue_len, MD_DRIVER_HIGHER, 1, nullptr, src, src_len, dst, dst_cap, written);
 }
 
 int md_zl_higher_compress(md_ctx *ctx, int level, int dynamic, int queue_len, const uint8_t *src,
                           size_t src_len, uint8_t *dst, size_t dst_cap, size_t *written) {
-  return deflate_one(ctx, MD_FORMAT_ZLIB, level, queue_len, MD_DRIVER_ZL, dynamic, src, src_len, dst, dst_cap, written);
+  return deflate_one(ctx, MD_FORMAT_ZLIB, level, queue_len, MD_DRIVER_ZL, dynamic, nullptr, src, src_len, dst, dst_cap, written);
+}
+
+// One batch-of-one launch of the deflate kernel in one of its two partial modes (drivers 3 and 4 of
+// deflate_kernel.hip): host buffers in, host buffers out.
+static int deflate_partial(md_ctx *ctx, int level, int queue_len, int driver, int dynamic, int matcher, const void *src,
+                           size_t src_len, void *dst, size_t dst_cap, size_t *out_bytes, uint32_t *hist316) {
+  MD_ON_DEVICE(ctx);
+  DevBuf din, dout, ddesc, dhist;
+  if (din.alloc(src_len + 16) != hipSuccess || dout.alloc(dst_cap + 16) != hipSuccess || ddesc.alloc(6 * 8 + 16) != hipSuccess ||
+      dhist.alloc(316 * 4) != hipSuccess)
+    return fail(ctx, MD_E_OUT_OF_MEMORY, "hipMalloc");
+  uint64_t desc[5] = {0, src_len, 0, dst_cap, 0};
+  uint64_t *d64 = (uint64_t *)ddesc.p;
+  int32_t *dstatus = (int32_t *)(d64 + 5);
+  hipStream_t st = ctx->stream;
+  if (src_len) HIP_TRY(ctx, hipMemcpyAsync(din.p, src, src_len, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(d64, desc, sizeof desc, hipMemcpyHostToDevice, st));
+  int rc = deflate_launch(ctx, MD_FORMAT_DEFLATE, level, queue_len, driver, dynamic, matcher, nullptr, 1, (const uint8_t *)din.p,
+                          d64, d64 + 1, (uint8_t *)dout.p, d64 + 2, d64 + 3, d64 + 4, dstatus, nullptr, (uint32_t *)dhist.p);
+  if (rc != MD_OK) return rc;
+  uint64_t out_len = 0;
+  int32_t status = 0;
+  HIP_TRY(ctx, hipMemcpyAsync(&out_len, d64 + 4, 8, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipMemcpyAsync(&status, dstatus, 4, hipMemcpyDeviceToHost, st));
+  if (hist316) HIP_TRY(ctx, hipMemcpyAsync(hist316, dhist.p, 316 * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  if (status == MD_OK && out_len) HIP_TRY(ctx, hipMemcpy(dst, dout.p, (size_t)out_len, hipMemcpyDeviceToHost));
+  *out_bytes = (size_t)out_len;
+  return status;
+}
+
+int md_de_lz77_compress(md_ctx *ctx, int level, int queue_len, int matcher, const uint8_t *src, size_t src_len,
+                        uint32_t *cmds, size_t cmds_cap, size_t *ncmds, uint32_t *literals, uint32_t *distances) {
+  if (!ctx || !ncmds || (!src && src_len) || (!cmds && cmds_cap)) return MD_E_INVALID_ARGUMENT;
+  if (level < 0 || level > 9) return fail(ctx, MD_E_INVALID_ARGUMENT, "Invalid level of compression");
+  if (queue_len < 4 || queue_len > (1 << 20) || (queue_len & (queue_len - 1)))
+    return fail(ctx, MD_E_INVALID_ARGUMENT, "Length of queue MUST be a power of two");
+  if (matcher != MD_MATCHER_DE && matcher != MD_MATCHER_LZ) return fail(ctx, MD_E_INVALID_ARGUMENT, "unknown matcher");
+  if (src_len > MD_MAX_STREAM || cmds_cap > MD_MAX_STREAM / 4) return fail(ctx, MD_E_INVALID_ARGUMENT, "buffer too long");
+  uint32_t hist[316];
+  size_t bytes = 0;
+  int st = deflate_partial(ctx, level, queue_len, 3, 1, matcher, src, src_len, cmds, cmds_cap * 4, &bytes, hist);
+  *ncmds = bytes / 4;
+  if (st == MD_OK) {
+    if (literals) memcpy(literals, hist, 286 * 4);
+    if (distances) memcpy(distances, hist + 286, 30 * 4);
+  }
+  return st;
+}
+
+int md_de_def_encode(md_ctx *ctx, int kind, const uint32_t *cmds, size_t ncmds, uint8_t *dst, size_t dst_cap,
+                     size_t *written) {
+  if (!ctx || !written || (!cmds && ncmds) || (!dst && dst_cap)) return MD_E_INVALID_ARGUMENT;
+  if (kind < MD_BLOCK_FLAT || kind > MD_BLOCK_DYNAMIC) return fail(ctx, MD_E_INVALID_ARGUMENT, "unknown block kind");
+  if (ncmds >= (1u << 20)) return fail(ctx, MD_E_INVALID_ARGUMENT, "more commands than the largest queue holds");
+  int queue_len = 4;
+  while ((size_t)queue_len < ncmds + 1) queue_len <<= 1;  // Queue.create: a power of two that holds them all
+  return deflate_partial(ctx, 4, queue_len, 4, kind, MD_MATCHER_DE, cmds, ncmds * 4, dst, dst_cap, written, nullptr);
 }
 
 static int inflate_one(md_ctx *ctx, int format, const uint8_t *src, size_t src_len, uint8_t *dst,
@@ -572,9 +636,20 @@ int md_zl_inf_ns_inflate(md_ctx *ctx, const uint8_t *src, size_t src_len, uint8_
   return inflate_one(ctx, MD_FORMAT_ZLIB, src, src_len, dst, dst_cap, consumed, written);
 }
 
-int md_gz_higher_compress(md_ctx *ctx, int level, int queue_len, const uint8_t *src, size_t src_len,
-                          uint8_t *dst, size_t dst_cap, size_t *written) {
-  return deflate_one(ctx, MD_FORMAT_GZIP, level, queue_len, MD_DRIVER_ZL, 1, src, src_len, dst, dst_cap, written);
+int md_gz_higher_compress(md_ctx *ctx, int level, int queue_len, const md_gz_header *header, const uint8_t *src,
+                          size_t src_len, uint8_t *dst, size_t dst_cap, size_t *written) {
+  return deflate_one(ctx, MD_FORMAT_GZIP, level, queue_len, MD_DRIVER_ZL, 1, header, src, src_len, dst, dst_cap, written);
+}
+
+// De.Higher.uncompress / Zl.Higher.uncompress (lib/de.ml:4555-4571, lib/zl.ml:650-666): the whole stream in, the
+// whole output out; the reference's `Error (`Msg s)` is md_status_string of the status returned
+int md_de_higher_uncompress(md_ctx *ctx, const uint8_t *src, size_t src_len, uint8_t *dst, size_t dst_cap, size_t *written) {
+  size_t used = 0;
+  return inflate_one(ctx, MD_FORMAT_DEFLATE, src, src_len, dst, dst_cap, &used, written);
+}
+int md_zl_higher_uncompress(md_ctx *ctx, const uint8_t *src, size_t src_len, uint8_t *dst, size_t dst_cap, size_t *written) {
+  size_t used = 0;
+  return inflate_one(ctx, MD_FORMAT_ZLIB, src, src_len, dst, dst_cap, &used, written);
 }
 
 // The accessors of a finished Gz.Inf decoder (filename / comment / os / extra, lib/gz.ml:612-633):

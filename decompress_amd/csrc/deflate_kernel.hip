@@ -61,7 +61,9 @@ __constant__ uint16_t c_levels[10][4] = {{0, 0, 0, 0},         {4, 4, 4, 8},    
                                          {4096, 258, 32, 258}};
 
 enum { KIND_FLAT = 0, KIND_FIXED = 1, KIND_DYNAMIC = 2 };
-enum { DRV_ZL = 0, DRV_HIGHER = 1, DRV_CLI = 2 };
+enum { DRV_ZL = 0, DRV_HIGHER = 1, DRV_CLI = 2,
+       DRV_LZ77 = 3,     // De.Lz77.compress alone: the queue fills are written out as commands (md_de_lz77_compress)
+       DRV_ENCODE = 4 }; // De.Def.encode alone: the input IS the command list of one last block (md_de_def_encode)
 enum { K_FIRST_ENTRY, K_ENCODE, K_BLOCK, K_FLAT_DONE };
 enum { R_OK, R_BLOCK };
 enum { V_AWAIT, V_FLUSH, V_BLOCK };
@@ -1045,6 +1047,7 @@ __device__ __forceinline__ int lz_compress(DS *s, Enc *e, Lz *z, const Ws *ws) {
 // make_block of the three drivers: the kind when it is known without trees (negated tree mode
 // otherwise: the wave builds the trees and, for TM_CHOOSE, picks the kind)
 __device__ __forceinline__ int block_plan(int driver, int dynamic, int level, int last) {
+  if (driver == DRV_ENCODE) return dynamic == 0 ? KIND_FLAT : dynamic == 1 ? KIND_FIXED : -TM_DYNAMIC;  // the caller's block kind
   if (driver == DRV_CLI) return last ? KIND_FIXED : -TM_DYNAMIC;
   if (driver == DRV_ZL && level == 0) return KIND_FLAT;
   if (driver == DRV_ZL && !dynamic) return KIND_FIXED;
@@ -1062,6 +1065,7 @@ struct Run {  // the two state machines of one stream (lane 0's registers)
   bool qfull;  // the reference would have raised Queue.Full
   int ol, oc;  // end-of-block code of the block that was open when new trees were asked for
   int mode;    // tree mode asked for (TM_*)
+  uint32_t ncmd;  // DRV_LZ77: commands written out so far
 };
 
 __device__ __forceinline__ void stream_begin(Run *r, const Ws *ws, const uint8_t *in, uint32_t n, uint8_t *out, uint32_t cap,
@@ -1107,6 +1111,7 @@ __device__ __forceinline__ void stream_begin(Run *r, const Ws *ws, const uint8_t
   z.p_end = matcher == MD_MATCHER_LZ ? (n >= 3 ? n - 2 : 0) : (z.level != 0 && n >= 4) ? n - 3 : 0;
   r->first = true;
   r->qfull = false;
+  r->ncmd = 0;
   r->phase = PH_LZ;
 }
 
@@ -1139,8 +1144,20 @@ __device__ __forceinline__ int stream_step(DS *s, const Ws *ws, Run *r, int driv
   }
   for (;;) {
     {
-      res = lz_compress(s, &e, &z, ws);
+      res = driver == DRV_ENCODE ? (int)LZ_END : lz_compress(s, &e, &z, ws);
       if (res == LZ_NEED) return ACT_PREP;
+      if (driver == DRV_LZ77) {
+        // `Flush (the queue is full) or `End: hand the queue's commands to the caller and empty it, as the
+        // caller of De.Lz77.compress does before it calls again (lib/de.mli:453-524)
+        uint32_t *co = reinterpret_cast<uint32_t *>(e.o);
+        for (; e.qr != e.qw; e.qr++) {
+          if ((r->ncmd + 1) * 4 <= e.o_cap) co[r->ncmd] = (uint32_t)g_ldi(e.q + (e.qr & (e.qc - 1)));
+          else e.overflow = true;
+          r->ncmd++;
+        }
+        if (res == LZ_END) return ACT_DONE;
+        continue;
+      }
       // the end-of-block code of the block that is open right now (force needs it after the
       // new trees have replaced the old ones in DS)
       lit_code(s, &e, 256, &r->ol, &r->oc);
@@ -1218,7 +1235,7 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
     uint64_t *__restrict__ out_len, int32_t *__restrict__ status, uint32_t *__restrict__ checksum,
     uint32_t *__restrict__ ws_head, uint32_t *__restrict__ ws_prev, int *__restrict__ ws_queue,
     uint32_t *__restrict__ ws_mring, uint64_t *__restrict__ dbg, int test_flags, const uint8_t *__restrict__ gz_hdr, uint32_t gz_hdr_len,
-    const uint32_t *__restrict__ gz_crc, int matcher) {
+    const uint32_t *__restrict__ gz_crc, int matcher, uint32_t *__restrict__ hist) {
   __shared__ DS ds;
   // optional phase profile of stream 0 (md_set_option "profile"): [0] setup [1] look-ahead [2] bulk
   // literal runs [3] matcher/driver (lane 0) [4] bit packing [5] trees, in clock ticks; [8..] event counts
@@ -1324,11 +1341,38 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
     ds.zs.bulked = 0;
     for (int i = 0; i < 8; i++) ds.tp[i] = 0;
   }
+  if (driver == DRV_ENCODE && room) {
+    // the input is a list of De.Queue commands (lib/de.ml:2245-2266) for ONE last block: load the queue and count the
+    // frequencies the way test/test.ml's `encode_dynamic` does (:84-95); nothing is left for the matcher
+    const uint32_t ncmds = slen / 4;
+    __syncthreads();
+    if (lane == 0) {
+      for (uint32_t i = 0; i < ncmds && i < (uint32_t)qcap; i++) {
+        uint32_t c;
+        __builtin_memcpy(&c, src + 4 * i, 4);
+        ws.queue[i] = (int)c;
+        if (c == (uint32_t)Q_EOB) continue;
+        if (c & Q_COPY) {
+          ds.lits[257 + ds.length_code[((c >> 16) & 0x1ff) + 3]]++;
+          ds.dsts[distance_code(&ds, (int)(c & 0xffff))]++;
+        } else ds.lits[c & 0xff]++;
+      }
+      run.e.qw = ncmds < (uint32_t)qcap ? ncmds : (uint32_t)qcap;
+      run.z.n = 0;
+      run.z.eoi = 1;
+      run.z.p_end = 0;
+      if (ncmds > (uint32_t)qcap) run.qfull = true;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+  }
+  const bool no_text = driver == DRV_ENCODE;
   const uint32_t eff_level = driver == DRV_HIGHER ? 4 : (matcher == MD_MATCHER_LZ && level < 4) ? 4 : level;
   const uint32_t max_chain = c_levels[eff_level][0], nice = c_levels[eff_level][3];
   const uint32_t qlimit = max_chain >> 2, kspec = max_chain < (uint32_t)KSPEC ? max_chain : (uint32_t)KSPEC;
-  const uint32_t p_end = matcher == MD_MATCHER_LZ ? (slen >= 3 ? slen - 2 : 0)
-                                                  : (eff_level != 0 && slen >= 4) ? slen - 3 : 0;
+  const uint32_t p_end = no_text ? 0
+                         : matcher == MD_MATCHER_LZ ? (slen >= 3 ? slen - 2 : 0)
+                                                    : (eff_level != 0 && slen >= 4) ? slen - 3 : 0;
   __syncthreads();
   PROF_MARK(0)
   for (;;) {
@@ -1823,6 +1867,19 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
     dbg[14] = run.z.n_chain;
   }
 #undef PROF_MARK
+  if (driver == DRV_LZ77) {  // the commands are out; De.Lz77.literals / distances (lib/de.mli:464-470) for the caller
+    if (hist) {
+      for (uint32_t i = lane; i < (uint32_t)L_CODES; i += kWave) hist[(size_t)sid * (L_CODES + D_CODES) + i] = (uint32_t)ds.lits[i];
+      if (lane < (uint32_t)D_CODES) hist[(size_t)sid * (L_CODES + D_CODES) + L_CODES + lane] = (uint32_t)ds.dsts[lane];
+    }
+    if (lane == 0) {
+      const bool ok = room && !run.e.overflow;
+      out_len[sid] = ok ? 4ull * run.ncmd : 0;
+      status[sid] = ok ? MD_OK : MD_UNEXPECTED_END_OF_OUTPUT;
+      if (checksum) checksum[sid] = adler;
+    }
+    return;
+  }
   if (lane == 0) {
     uint32_t body = room ? run.e.o_pos : 0;
     int st = !room || run.e.overflow ? MD_UNEXPECTED_END_OF_OUTPUT : MD_OK;
@@ -1872,7 +1929,7 @@ extern "C" int md_launch_deflate(int format, int level, int qcap, int driver, in
                                  uint8_t *out, const uint64_t *out_off, const uint64_t *out_cap,
                                  uint64_t *out_len, int32_t *status, uint32_t *checksum, void *ws,
                                  uint64_t *dbg, int test_flags, const uint8_t *gz_hdr, uint32_t gz_hdr_len,
-                                 const uint32_t *gz_crc, int matcher, hipStream_t stream) {
+                                 const uint32_t *gz_crc, int matcher, uint32_t *hist, hipStream_t stream) {
   if (n == 0) return 0;
   uint32_t *head = (uint32_t *)ws;
   uint32_t *prev = head + (size_t)n * md::defl::HASH_SIZE;
@@ -1880,6 +1937,6 @@ extern "C" int md_launch_deflate(int format, int level, int qcap, int driver, in
   uint32_t *mring = (uint32_t *)(queue + (size_t)n * qcap);
   hipLaunchKernelGGL(md::defl::deflate_kernel, dim3(n), dim3(md::defl::kWave), 0, stream, format, level,
                      qcap, driver, dynamic, n, in, in_off, in_len, out, out_off, out_cap, out_len, status,
-                     checksum, head, prev, queue, mring, dbg, test_flags, gz_hdr, gz_hdr_len, gz_crc, matcher);
+                     checksum, head, prev, queue, mring, dbg, test_flags, gz_hdr, gz_hdr_len, gz_crc, matcher, hist);
   return (int)hipGetLastError();
 }

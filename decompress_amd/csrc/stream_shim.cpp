@@ -1,0 +1,206 @@
+// stream_shim.cpp — the reference's resumable decoder / encoder state machines (`Await / `Flush / `End) above the
+// batch C ABI: SURVEY.md 8(b) export item (3).
+//
+// De.Inf.decode (lib/de.ml:1427-1474, signature lib/de.mli:82-144) and Zl.Def.encode / De.Def.encode's drivers
+// (lib/zl.ml:509-555, lib/de.mli:300-412) hand a few KiB to the codec per call; a kernel launch per 64 KiB step
+// cannot pay for itself, so the shim keeps the reference's calling protocol on the HOST — it collects the chunks
+// the caller supplies through src, runs ONE batch-of-one launch of the HIP path when the caller signals the end
+// of input (src with length 0, as in the reference), and then hands the result out through the caller's output
+// buffer in `Flush steps.  There is no CPU codec here: without a gfx950 device the launch fails and the stream
+// reports the call-level error.
+//
+// Divergence (documented): the kernels have De.Inf.Ns's whole-buffer end-of-input rule; the
+// streaming rule of lib/de.ml:941-944 (a final end-of-block code shorter than the longest code is accepted at the
+// end of the input) gives the same result on every stream a compressor emits.
+#include <stdint.h>
+#include <string.h>
+
+#include <vector>
+
+#include "mdeflate.h"
+
+struct md_inf_stream {
+  md_ctx *ctx;
+  int format;
+  uint8_t *o;
+  size_t o_len, o_pos;        // caller's output buffer (De.Inf.decoder ~o) and how much of it is filled
+  std::vector<uint8_t> in;    // everything supplied so far
+  std::vector<uint8_t> out;   // the decoded stream, once the launch has run
+  size_t served;              // bytes of `out` already handed to the caller
+  bool eoi, ran;
+  int status;                 // MD_* status of the launch
+  size_t consumed;
+  uint32_t checksum;
+};
+
+extern "C" {
+
+md_inf_stream *md_inf_decoder(md_ctx *ctx, int format, uint8_t *o, size_t o_len) {
+  if (!ctx || !o || o_len == 0) return nullptr;
+  if (format != MD_FORMAT_DEFLATE && format != MD_FORMAT_ZLIB && format != MD_FORMAT_GZIP) return nullptr;
+  md_inf_stream *s = new md_inf_stream();
+  s->ctx = ctx;
+  s->format = format;
+  s->o = o;
+  s->o_len = o_len;
+  s->o_pos = 0;
+  s->served = 0;
+  s->eoi = s->ran = false;
+  s->status = MD_OK;
+  s->consumed = 0;
+  s->checksum = 0;
+  return s;
+}
+
+void md_inf_free(md_inf_stream *s) { delete s; }
+
+int md_inf_src(md_inf_stream *s, const uint8_t *buf, size_t off, size_t len) {
+  if (!s || (!buf && len) || s->eoi) return MD_E_INVALID_ARGUMENT;
+  if (len == 0) s->eoi = true;  // De.Inf.src d buf 0 0: the end of the input
+  else s->in.insert(s->in.end(), buf + off, buf + off + len);
+  return MD_OK;
+}
+
+void md_inf_flush(md_inf_stream *s) {
+  if (s) s->o_pos = 0;
+}
+size_t md_inf_dst_rem(const md_inf_stream *s) { return s ? s->o_len - s->o_pos : 0; }
+size_t md_inf_src_rem(const md_inf_stream *s) { return s && s->ran ? s->in.size() - s->consumed : 0; }
+int md_inf_status(const md_inf_stream *s) { return s ? s->status : MD_E_INVALID_ARGUMENT; }
+uint32_t md_inf_checksum(const md_inf_stream *s) { return s ? s->checksum : 0; }
+
+static void inf_run(md_inf_stream *s) {
+  // the output size is not known: start from 4x the input and double while the codec runs out of room
+  uint64_t cap = s->in.size() * 4 + 65536;
+  for (;;) {
+    if (cap > MD_MAX_STREAM) cap = MD_MAX_STREAM;
+    s->out.resize((size_t)cap);
+    uint64_t in_off = 0, in_len = s->in.size(), out_off = 0, out_cap = cap, out_len = 0, used = 0;
+    int32_t st = 0;
+    uint32_t sum = 0;
+    static const uint8_t none = 0;
+    int rc = md_inflate_batch_host(s->ctx, s->format, 1, s->in.empty() ? &none : s->in.data(), s->in.size(), &in_off, &in_len,
+                                   s->out.data(), (size_t)cap, &out_off, &out_cap, &out_len, &used, &st, &sum);
+    if (rc != MD_OK) {
+      s->status = rc;
+      s->out.clear();
+      return;
+    }
+    if (st == MD_UNEXPECTED_END_OF_OUTPUT && cap < MD_MAX_STREAM) {
+      cap *= 2;
+      continue;
+    }
+    s->status = st;
+    s->consumed = (size_t)used;
+    s->checksum = sum;
+    s->out.resize((size_t)out_len);
+    return;
+  }
+}
+
+int md_inf_decode(md_inf_stream *s) {
+  if (!s) return MD_MALFORMED;
+  if (!s->eoi) return MD_AWAIT;
+  if (!s->ran) {
+    inf_run(s);
+    s->ran = true;
+  }
+  const size_t left = s->out.size() - s->served, room = s->o_len - s->o_pos;
+  const size_t n = left < room ? left : room;
+  if (n) memcpy(s->o + s->o_pos, s->out.data() + s->served, n);
+  s->o_pos += n;
+  s->served += n;
+  if (s->served < s->out.size() || (n && s->o_pos == s->o_len && s->status != MD_OK)) return MD_FLUSH;  // the buffer is full
+  return s->status == MD_OK ? MD_END : MD_MALFORMED;
+}
+
+// ---- the encoder side: Zl.Def.encoder / Gz.Def.encoder / De.Higher's loop with `Manual src and dst ----
+}  // extern "C"
+
+struct md_def_stream {
+  md_ctx *ctx;
+  int format;
+  md_deflate_params params;
+  md_gz_header gz;
+  std::vector<char> name, comment;
+  uint8_t *o;
+  size_t o_len, o_pos;
+  std::vector<uint8_t> in, out;
+  size_t served;
+  bool eoi, ran;
+  int status;
+  uint32_t checksum;
+};
+
+extern "C" {
+
+md_def_stream *md_def_encoder(md_ctx *ctx, int format, const md_deflate_params *params, uint8_t *o, size_t o_len) {
+  if (!ctx || !params || !o || o_len == 0) return nullptr;
+  md_def_stream *s = new md_def_stream();
+  s->ctx = ctx;
+  s->format = format;
+  s->params = *params;
+  if (params->gz_header) {  // keep our own copy of the caller's strings
+    s->gz = *params->gz_header;
+    if (s->gz.filename) {
+      s->name.assign(s->gz.filename, s->gz.filename + strlen(s->gz.filename) + 1);
+      s->gz.filename = s->name.data();
+    }
+    if (s->gz.comment) {
+      s->comment.assign(s->gz.comment, s->gz.comment + strlen(s->gz.comment) + 1);
+      s->gz.comment = s->comment.data();
+    }
+    s->params.gz_header = &s->gz;
+  }
+  s->o = o;
+  s->o_len = o_len;
+  s->o_pos = s->served = 0;
+  s->eoi = s->ran = false;
+  s->status = MD_OK;
+  s->checksum = 0;
+  return s;
+}
+void md_def_free(md_def_stream *s) { delete s; }
+int md_def_src(md_def_stream *s, const uint8_t *buf, size_t off, size_t len) {
+  if (!s || (!buf && len) || s->eoi) return MD_E_INVALID_ARGUMENT;
+  if (len == 0) s->eoi = true;
+  else s->in.insert(s->in.end(), buf + off, buf + off + len);
+  return MD_OK;
+}
+void md_def_dst(md_def_stream *s, uint8_t *o, size_t o_len) {  // Zl.Def.dst: a fresh output buffer
+  if (!s || !o || !o_len) return;
+  s->o = o;
+  s->o_len = o_len;
+  s->o_pos = 0;
+}
+size_t md_def_dst_rem(const md_def_stream *s) { return s ? s->o_len - s->o_pos : 0; }
+int md_def_status(const md_def_stream *s) { return s ? s->status : MD_E_INVALID_ARGUMENT; }
+uint32_t md_def_checksum(const md_def_stream *s) { return s ? s->checksum : 0; }
+
+int md_def_encode(md_def_stream *s) {
+  if (!s) return MD_MALFORMED;
+  if (!s->eoi) return MD_AWAIT;
+  if (!s->ran) {
+    s->ran = true;
+    const uint64_t n = s->in.size();
+    uint64_t cap = n + n / 4 + n / s->params.queue_len * 16 + 4096;  // stored blocks of a queue fill each are the worst case
+    if (cap > MD_MAX_STREAM) cap = MD_MAX_STREAM;
+    s->out.resize((size_t)cap);
+    uint64_t in_off = 0, in_len = n, out_off = 0, out_cap = cap, out_len = 0;
+    int32_t st = 0;
+    static const uint8_t none = 0;
+    int rc = md_deflate_batch_host(s->ctx, s->format, &s->params, 1, n ? s->in.data() : &none, (size_t)n, &in_off, &in_len,
+                                   s->out.data(), (size_t)cap, &out_off, &out_cap, &out_len, &st, &s->checksum);
+    s->status = rc != MD_OK ? rc : st;
+    s->out.resize(s->status == MD_OK ? (size_t)out_len : 0);
+  }
+  const size_t left = s->out.size() - s->served, room = s->o_len - s->o_pos;
+  const size_t k = left < room ? left : room;
+  if (k) memcpy(s->o + s->o_pos, s->out.data() + s->served, k);
+  s->o_pos += k;
+  s->served += k;
+  if (s->served < s->out.size()) return MD_FLUSH;
+  return s->status == MD_OK ? MD_END : MD_MALFORMED;
+}
+
+}  // extern "C"

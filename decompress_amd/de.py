@@ -1,9 +1,86 @@
-"""Mirror of the reference's `De` module surface for the hot path
-(lib/de.mli:146-173 `De.Inf.Ns`), executed on the GPU through the C ABI."""
+"""Mirror of the reference's `De` module surface for the hot path (lib/de.mli: `De.Inf`, `De.Inf.Ns`, `De.Lz77`,
+`De.Def`, `De.Higher`), executed on the GPU through the C ABI."""
+import ctypes
+
 from . import engine as _engine
+
+AWAIT, FLUSH, END, MALFORMED = 0, 1, 2, 3
+EOB = 256
+
+
+def copy_cmd(off, length):
+    """De.Queue.cmd (`Copy (off, len)), lib/de.ml:2245-2266"""
+    return 0x2000000 | ((length - 3) << 16) | (off - 1)
+
+
+class Lz77:
+    """De.Lz77 (lib/de.mli:453-524)"""
+
+    @staticmethod
+    def compress(src, level=4, queue=4096, matcher=_engine.MATCHER_DE, device=0):
+        """`De.Lz77.state ?level ~q ~w src` run to `End: (commands of every queue fill, literals[286], distances[30])"""
+        eng = _engine.default_engine(device)
+        src = bytes(src)
+        cap = len(src) + len(src) // max(1, queue - 1) + 8
+        cmds = (ctypes.c_uint32 * cap)()
+        lits, dsts, n = (ctypes.c_uint32 * 286)(), (ctypes.c_uint32 * 30)(), ctypes.c_size_t()
+        st = eng.lib.md_de_lz77_compress(eng.ctx, level, queue, matcher, src, len(src), cmds, cap, ctypes.byref(n), lits, dsts)
+        if st < 0:
+            eng._check(st)
+        if st != 0:
+            raise _engine.Error(_engine.STATUS_NAMES[st])
+        return list(cmds[:n.value]), list(lits), list(dsts)
+
+
+class Def:
+    """De.Def (lib/de.mli:300-412)"""
+    FLAT, FIXED, DYNAMIC = 0, 1, 2
+
+    @staticmethod
+    def encode(cmds, kind, device=0):
+        """the commands as ONE last block of `kind` (`Def.encode e (`Block {kind; last = true})` then `Flush);
+        Dynamic = dynamic_of_frequencies of the commands' own histogram (test/test.ml:84-95)"""
+        eng = _engine.default_engine(device)
+        arr = (ctypes.c_uint32 * max(1, len(cmds)))(*cmds)
+        cap = 8 * len(cmds) + 1024
+        dst, n = ctypes.create_string_buffer(cap), ctypes.c_size_t()
+        st = eng.lib.md_de_def_encode(eng.ctx, kind, arr, len(cmds), dst, cap, ctypes.byref(n))
+        if st < 0:
+            eng._check(st)
+        if st != 0:
+            raise _engine.Error(_engine.STATUS_NAMES[st])
+        return dst.raw[:n.value]
 
 
 class Inf:
+    @staticmethod
+    def decode_chunks(chunks, o_len=65536, fmt=_engine.FORMAT_DEFLATE, device=0):
+        """the streaming protocol of lib/de.mli:82-144 — decoder / src / decode / flush / dst_rem — driven the way
+        De.Higher.uncompress drives it: -> ("Ok" | "Malformed", bytes, [signals])"""
+        eng = _engine.default_engine(device)
+        lib = eng.lib
+        o = ctypes.create_string_buffer(o_len)
+        d = lib.md_inf_decoder(eng.ctx, fmt, o, o_len)
+        out, sigs, it = bytearray(), [], iter(chunks)
+        try:
+            while True:
+                sig = lib.md_inf_decode(d)
+                sigs.append(sig)
+                if sig == AWAIT:
+                    c = next(it, b"")
+                    lib.md_inf_src(d, bytes(c), 0, len(c))
+                elif sig == FLUSH:
+                    out += o.raw[:o_len - lib.md_inf_dst_rem(d)]
+                    lib.md_inf_flush(d)
+                else:
+                    out += o.raw[:o_len - lib.md_inf_dst_rem(d)]
+                    st = lib.md_inf_status(d)
+                    if st < 0:
+                        eng._check(st)
+                    return ("Ok" if sig == END else _engine.STATUS_NAMES[st]), bytes(out), sigs
+        finally:
+            lib.md_inf_free(d)
+
     class Ns:
         """De.Inf.Ns — whole-buffer inflate (lib/de.ml:1534-1823)."""
 
@@ -38,6 +115,11 @@ class Higher:
 
     @staticmethod
     def uncompress(src, dst_len, device=0):
-        """`De.Higher.uncompress`: Ok bytes | Error (`Msg string)."""
-        r = Inf.Ns.inflate(src, dst_len, device)
-        return r[2] if r[0] == "Ok" else r
+        """`De.Higher.uncompress ~w ~refill ~flush i o` (lib/de.ml:4555-4571): bytes | ("Error", msg)."""
+        eng = _engine.default_engine(device)
+        src = bytes(src)
+        dst, n = ctypes.create_string_buffer(max(1, dst_len)), ctypes.c_size_t()
+        st = eng.lib.md_de_higher_uncompress(eng.ctx, src, len(src), dst, dst_len, ctypes.byref(n))
+        if st < 0:
+            eng._check(st)
+        return dst.raw[:n.value] if st == 0 else ("Error", eng.lib.md_status_string(st).decode())

@@ -103,13 +103,26 @@ class Engine:
         return [(int(status[i]), out[out_off[i]:out_off[i] + out_len[i]].tobytes()) for i in range(n)]
 
     def set_matcher(self, matcher):
-        """0 = De.Lz77 (default), 1 = Lz (lib/lz.ml) for every later deflate of this engine."""
-        self._check(self.lib.md_deflate_set_matcher(self.ctx, int(matcher)))
+        """Default matcher of this Engine object's later deflate calls: 0 = De.Lz77, 1 = Lz (lib/lz.ml).  Kept on the
+        Python side — the C ABI takes the matcher per call (md_deflate_params)."""
+        if matcher not in (MATCHER_DE, MATCHER_LZ):
+            raise Error("Invalid argument: unknown matcher")
+        self._matcher = int(matcher)
 
     def gz_set_header(self, mtime=0, os=3, hcrc=False, ascii=False, filename=None, comment=None):
-        """Header fields of every later FORMAT_GZIP deflate (Gz.Def.encoder's, lib/gz.ml:859-918)."""
-        self._check(self.lib.md_gz_set_header(self.ctx, int(mtime) & 0xffffffff, int(os), int(hcrc), int(ascii),
-                                              filename, comment))
+        """Default GZip header of this Engine object's later FORMAT_GZIP deflate calls (Gz.Def.encoder's fields,
+        lib/gz.ml:859-918); passed per call through md_deflate_params.gz_header."""
+        self._gz = dict(mtime=int(mtime) & 0xffffffff, os=int(os), hcrc=int(bool(hcrc)), ascii=int(bool(ascii)),
+                        filename=filename, comment=comment)
+
+    def _params(self, level, queue, driver, dynamic, matcher=None, header=None):
+        h = header if header is not None else getattr(self, "_gz", None)
+        gz = _lib.GzHeader(**h) if h else None
+        p = _lib.DeflateParams(int(level), int(queue), int(driver), int(bool(dynamic)),
+                               int(getattr(self, "_matcher", MATCHER_DE) if matcher is None else matcher),
+                               ctypes.pointer(gz) if gz is not None else None)
+        p._keep = gz  # the struct must outlive the call
+        return p
 
     def crc32_batch(self, d_data, d_off, d_len):
         """Checkseum.Crc32 of n device-resident buffers -> uint32 tensor (device)."""
@@ -199,7 +212,7 @@ class Engine:
 
     # ------------------------------------------------------------------ deflate
     def deflate_batch(self, fmt, d_in, in_off, in_len, d_out, out_off, out_cap, level=6, queue=4096,
-                      driver=DRIVER_ZL, dynamic=True, results=None):
+                      driver=DRIVER_ZL, dynamic=True, results=None, matcher=None, header=None):
         """All arguments are CUDA tensors (uint8 data, int64 descriptors).
         Returns (out_len, status, adler32_of_input) CUDA tensors (async)."""
         torch = self.torch
@@ -209,13 +222,14 @@ class Engine:
                        torch.empty(n, dtype=torch.int32, device=self.device),
                        torch.empty(n, dtype=torch.int32, device=self.device))
         out_len, status, checksum = results
+        params = self._params(level, queue, driver, dynamic, matcher, header)
         self._check(self.lib.md_deflate_batch_device(
-            self.ctx, fmt, level, queue, driver, int(bool(dynamic)), n, _ptr(d_in), _ptr(in_off), _ptr(in_len),
+            self.ctx, fmt, ctypes.byref(params), n, _ptr(d_in), _ptr(in_off), _ptr(in_len),
             _ptr(d_out), _ptr(out_off), _ptr(out_cap), _ptr(out_len), _ptr(status), _ptr(checksum)))
         return results
 
     def deflate_many(self, bufs, fmt=FORMAT_DEFLATE, level=6, queue=4096, driver=DRIVER_ZL, dynamic=True,
-                     caps=None):
+                     caps=None, matcher=None, header=None):
         """Convenience for tests: list of bytes -> list of (status, compressed bytes, adler32 of input)."""
         import numpy as np
 
@@ -239,7 +253,7 @@ class Engine:
         d_out = torch.zeros(int(out_off[-1] + cap[-1]) + 16, dtype=torch.uint8, device=dev)
         t = lambda a: torch.from_numpy(a).to(dev)
         out_len, status, checksum = self.deflate_batch(fmt, d_in, t(in_off), t(in_len), d_out, t(out_off), t(cap),
-                                                       level, queue, driver, dynamic)
+                                                       level, queue, driver, dynamic, matcher=matcher, header=header)
         torch.cuda.synchronize(dev)
         out = d_out.cpu().numpy()
         out_len, status = out_len.cpu().numpy(), status.cpu().numpy()

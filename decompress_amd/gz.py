@@ -35,9 +35,9 @@ class Higher:
         """`Gz.Higher.compress ?level ?filename ?comment ~w ~q ~refill ~flush time cfg i o`
         (`?level` defaults to 0 upstream, lib/gz.ml:928; `cfg` = ascii / hcrc / os / mtime)."""
         eng = _engine.default_engine(device)
-        eng.gz_set_header(mtime, OS[os] if isinstance(os, str) else os, hcrc, ascii, filename, comment)
-        st, out, _ = eng.deflate_many([src], _engine.FORMAT_GZIP, level=level, queue=queue)[0]
-        eng.gz_set_header()
+        hdr = dict(mtime=int(mtime) & 0xffffffff, os=OS[os] if isinstance(os, str) else int(os), hcrc=int(bool(hcrc)),
+                   ascii=int(bool(ascii)), filename=filename, comment=comment)
+        st, out, _ = eng.deflate_many([src], _engine.FORMAT_GZIP, level=level, queue=queue, header=hdr)[0]
         if st != 0:
             raise _engine.Error(_engine.STATUS_NAMES[st])
         return out
@@ -75,8 +75,7 @@ class Def:
     @staticmethod
     def deflate_batch(bufs, level=4, queue=4096, device=0, **header):
         """n buffers at once -> [(status, gzip bytes, crc32 of the input)]"""
-        eng = _engine.default_engine(device)
-        eng.gz_set_header(**header)
-        out = eng.deflate_many(bufs, _engine.FORMAT_GZIP, level=level, queue=queue)
-        eng.gz_set_header()
-        return out
+        hdr = dict(mtime=0, os=3, hcrc=0, ascii=0, filename=None, comment=None)
+        hdr.update(header)
+        hdr["os"] = OS[hdr["os"]] if isinstance(hdr["os"], str) else int(hdr["os"])
+        return _engine.default_engine(device).deflate_many(bufs, _engine.FORMAT_GZIP, level=level, queue=queue, header=hdr)

@@ -8,11 +8,8 @@ def compress(src, level=4, queue=4096, fmt=_engine.FORMAT_DEFLATE, driver=_engin
     """`Lz.state ?level` (default 4, lib/lz.ml:525) feeding `De.Def` under `driver`; the driver pushes
     the end-of-block command at `End (`Lz.trailing` does not, lib/lz.ml:348-354)."""
     eng = _engine.default_engine(device)
-    eng.set_matcher(_engine.MATCHER_LZ)
-    try:
-        st, out, _ = eng.deflate_many([src], fmt, level=level, queue=queue, driver=driver, dynamic=dynamic)[0]
-    finally:
-        eng.set_matcher(_engine.MATCHER_DE)
+    st, out, _ = eng.deflate_many([src], fmt, level=level, queue=queue, driver=driver, dynamic=dynamic,
+                                  matcher=_engine.MATCHER_LZ)[0]
     if st != 0:
         raise _engine.Error(_engine.STATUS_NAMES[st])
     return out

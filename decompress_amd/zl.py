@@ -34,5 +34,12 @@ class Higher:
 
     @staticmethod
     def uncompress(src, dst_len, device=0):
-        r = Inf.Ns.inflate(src, dst_len, device)
-        return r[2] if r[0] == "Ok" else r
+        """`Zl.Higher.uncompress ~allocate ~refill ~flush i o` (lib/zl.ml:650-666): bytes | ("Error", msg)."""
+        import ctypes
+        eng = _engine.default_engine(device)
+        src = bytes(src)
+        dst, n = ctypes.create_string_buffer(max(1, dst_len)), ctypes.c_size_t()
+        st = eng.lib.md_zl_higher_uncompress(eng.ctx, src, len(src), dst, dst_len, ctypes.byref(n))
+        if st < 0:
+            eng._check(st)
+        return dst.raw[:n.value] if st == 0 else ("Error", eng.lib.md_status_string(st).decode())

@@ -80,7 +80,7 @@ enum {
   MD_FORMAT_GZIP = 2     /* RFC1952 as lib/gz.ml reads and writes it: Gz.Inf (lib/gz.ml:248-633),
                           * Gz.Def (lib/gz.ml:636-918).  Inflate: checksum[i] = CRC-32 of the output;
                           * the body follows De.Inf.Ns status semantics.  Deflate: header from
-                          * md_gz_set_header, body = the Zl driver's with dynamic blocks (Gz.Def's
+                          * md_deflate_params.gz_header, body = the Zl driver's with dynamic blocks (Gz.Def's
                           * make_block, lib/gz.ml:724-729), CRC-32 + ISIZE trailer; `driver` and
                           * `dynamic` are ignored, checksum[i] = CRC-32 of the input. */
 };
@@ -169,29 +169,45 @@ int md_zl_inf_ns_inflate(md_ctx *ctx, const uint8_t *src, size_t src_len,
                          uint8_t *dst, size_t dst_cap, size_t *consumed,
                          size_t *written);
 
+/* The header fields Gz.Def.encoder takes (lib/gz.ml:859-918): ?ascii ?hcrc ?filename ?comment ~mtime os.
+ * filename / comment may be NULL (absent; both must be NUL-free and < 256 bytes).  XFL follows the level
+ * (2 for level 9, else 0, lib/gz.ml:888-890).  A NULL md_gz_header* means mtime 0, os 3 (Unix), nothing else. */
+typedef struct md_gz_header {
+  uint32_t mtime;
+  int os, hcrc, ascii;
+  const char *filename, *comment;
+} md_gz_header;
+
+/* What `Zl.Def.encoder ?dynamic ~q ~w ~level` / `De.Lz77.state ?level ~q ~w` / `Lz.state` / `Gz.Def.encoder` take
+ * as arguments (lib/zl.mli, lib/de.mli:453-524, lib/lz.mli:1-19, lib/gz.ml:859): per call, nothing is kept in the
+ * context. */
+typedef struct md_deflate_params {
+  int level;     /* 0..9 (lib/de.ml:4030-4049; De.Higher ignores it: always 4, H6) */
+  int queue_len; /* De.Queue capacity, a power of two (4096 in the reference's bench / CLI) */
+  int driver;    /* MD_DRIVER_* */
+  int dynamic;   /* Zl.Def's ?dynamic: 0 -> Fixed blocks */
+  int matcher;   /* MD_MATCHER_* */
+  const md_gz_header *gz_header; /* MD_FORMAT_GZIP only; NULL = default header */
+} md_deflate_params;
+
 /* Batched deflate of n independent buffers, everything resident in HBM.
  *   stream i reads d_in[in_off[i], +in_len[i]), writes d_out[out_off[i], +out_cap[i]).
- * Per stream the output is byte-identical to the reference's De.Lz77 (lib/de.ml:4013-4515)
- * + De.Def (lib/de.ml:2354-3038) run by `driver` with a command queue of `queue_len`
- * entries (power of two; 4096 in the reference's bench/CLI) at `level` 0..9:
+ * Per stream the output is byte-identical to the reference's De.Lz77 (lib/de.ml:4013-4515; or Lz, lib/lz.ml)
+ * + De.Def (lib/de.ml:2354-3038) run by params->driver with a command queue of params->queue_len entries:
  *   MD_FORMAT_DEFLATE  the raw body,
- *   MD_FORMAT_ZLIB     Zl.Def framing: 0x78xx header + body + Adler-32 (lib/zl.ml:511-522, 494-499).
- * `dynamic` = Zl.Def's ?dynamic (false -> Fixed blocks).  Results: out_len[i], status[i]
- * (MD_OK or MD_UNEXPECTED_END_OF_OUTPUT when out_cap[i] is too small), checksum[i] =
- * Adler-32 of the input (may be NULL).  Asynchronous on the context's stream. */
-int md_deflate_batch_device(md_ctx *ctx, int format, int level, int queue_len, int driver,
-                            int dynamic, size_t n, const uint8_t *d_in, const uint64_t *d_in_off,
-                            const uint64_t *d_in_len, uint8_t *d_out, const uint64_t *d_out_off,
-                            const uint64_t *d_out_cap, uint64_t *d_out_len, int32_t *d_status,
-                            uint32_t *d_checksum);
-
-/* Match finder of every later deflate of this context: `Lz.state` instead of `De.Lz77.state`
- * (lib/lz.mli:1-19 has the same shape).  Default MD_MATCHER_DE. */
-int md_deflate_set_matcher(md_ctx *ctx, int matcher);
+ *   MD_FORMAT_ZLIB     Zl.Def framing: 0x78xx header + body + Adler-32 (lib/zl.ml:511-522, 494-499),
+ *   MD_FORMAT_GZIP     Gz.Def framing (see MD_FORMAT_GZIP).
+ * Results: out_len[i], status[i] (MD_OK, MD_UNEXPECTED_END_OF_OUTPUT when out_cap[i] is too small,
+ * MD_QUEUE_FULL), checksum[i] = Adler-32 (CRC-32 for GZip) of the input (may be NULL).  Asynchronous on the
+ * context's stream. */
+int md_deflate_batch_device(md_ctx *ctx, int format, const md_deflate_params *params, size_t n,
+                            const uint8_t *d_in, const uint64_t *d_in_off, const uint64_t *d_in_len,
+                            uint8_t *d_out, const uint64_t *d_out_off, const uint64_t *d_out_cap,
+                            uint64_t *d_out_len, int32_t *d_status, uint32_t *d_checksum);
 
 /* Same with HOST pointers (H2D, kernels, D2H, synchronise). */
-int md_deflate_batch_host(md_ctx *ctx, int format, int level, int queue_len, int driver, int dynamic,
-                          size_t n, const uint8_t *h_in, size_t in_bytes, const uint64_t *in_off,
+int md_deflate_batch_host(md_ctx *ctx, int format, const md_deflate_params *params, size_t n,
+                          const uint8_t *h_in, size_t in_bytes, const uint64_t *in_off,
                           const uint64_t *in_len, uint8_t *h_out, size_t out_bytes,
                           const uint64_t *out_off, const uint64_t *out_cap, uint64_t *out_len,
                           int32_t *status, uint32_t *checksum);
@@ -199,21 +215,65 @@ int md_deflate_batch_host(md_ctx *ctx, int format, int level, int queue_len, int
 /* Single-buffer mirrors of the reference's drivers (host pointers, batch of one):
  *   De.Higher.compress ~w ~q ~refill ~flush i o   (lib/de.mli:533-600): raw DEFLATE, level 4
  *   Zl.Higher.compress ?level ?dynamic ~w ~q ...  (lib/zl.mli, lib/zl.ml:634-648): zlib stream
+ *   De.Higher.uncompress / Zl.Higher.uncompress   (lib/de.ml:4555-4571, lib/zl.ml:650-666)
  * The reference's refill/flush callbacks become one source and one destination buffer;
- * *written is the compressed size.  Returns MD_OK / MD_UNEXPECTED_END_OF_OUTPUT / call error. */
+ * *written is the output size.  Returns MD_OK / a status (its md_status_string is the reference's
+ * `Msg) / a call error. */
 int md_de_higher_compress(md_ctx *ctx, int queue_len, const uint8_t *src, size_t src_len,
                           uint8_t *dst, size_t dst_cap, size_t *written);
 int md_zl_higher_compress(md_ctx *ctx, int level, int dynamic, int queue_len, const uint8_t *src,
                           size_t src_len, uint8_t *dst, size_t dst_cap, size_t *written);
+int md_de_higher_uncompress(md_ctx *ctx, const uint8_t *src, size_t src_len, uint8_t *dst, size_t dst_cap,
+                            size_t *written);
+int md_zl_higher_uncompress(md_ctx *ctx, const uint8_t *src, size_t src_len, uint8_t *dst, size_t dst_cap,
+                            size_t *written);
+
+/* The two halves of the encoder on their own (host pointers, batch of one), on the same HIP kernel:
+ *
+ * De.Lz77.compress (lib/de.mli:453-524; `Lz.compress` with MD_MATCHER_LZ): the match finder alone.  cmds
+ * receives the commands of every queue fill in order, in De.Queue's encoding (lib/de.ml:2245-2266: a literal is
+ * its byte, end-of-block is 256, a copy is 0x2000000 | (length - 3) << 16 | (offset - 1)); a fill ends with the
+ * end-of-block command the reference pushes when one cell is left (H1).  literals[286] / distances[30] receive
+ * De.Lz77.literals / distances, cumulative over the input (may be NULL).  MD_UNEXPECTED_END_OF_OUTPUT when
+ * cmds_cap is too small (*ncmds is then the number needed).
+ *
+ * De.Def.encode (lib/de.mli:300-412): the bit encoder alone, the way test/test.ml's `encode` uses it — the
+ * commands are ONE last block of `kind`; a Dynamic block gets its trees from the commands' own frequencies
+ * (dynamic_of_frequencies, lib/de.ml:2367-2403). */
+enum { MD_BLOCK_FLAT = 0, MD_BLOCK_FIXED = 1, MD_BLOCK_DYNAMIC = 2 };
+int md_de_lz77_compress(md_ctx *ctx, int level, int queue_len, int matcher, const uint8_t *src, size_t src_len,
+                        uint32_t *cmds, size_t cmds_cap, size_t *ncmds, uint32_t *literals, uint32_t *distances);
+int md_de_def_encode(md_ctx *ctx, int kind, const uint32_t *cmds, size_t ncmds, uint8_t *dst, size_t dst_cap,
+                     size_t *written);
+
+/* ---- the resumable state machines (host side; one launch at the end of input) ----
+ * De.Inf.decoder / decode / src / flush / dst_rem / src_rem / checksum (lib/de.mli:82-144) and the encoder loop of
+ * Zl.Def / Gz.Def / De.Higher with `Manual source and destination (lib/zl.ml:509-555): the caller supplies input
+ * with src (length 0 = end of input, as in the reference), calls decode / encode, and consumes its output buffer
+ * whenever it gets MD_FLUSH (then md_inf_flush / md_def_dst), until MD_END or MD_MALFORMED (md_*_status gives
+ * the MD_* status whose string is the reference's `Malformed message).  See csrc/stream_shim.cpp. */
+enum { MD_AWAIT = 0, MD_FLUSH = 1, MD_END = 2, MD_MALFORMED = 3 };
+typedef struct md_inf_stream md_inf_stream;
+md_inf_stream *md_inf_decoder(md_ctx *ctx, int format, uint8_t *o, size_t o_len);
+int md_inf_src(md_inf_stream *s, const uint8_t *buf, size_t off, size_t len);
+int md_inf_decode(md_inf_stream *s);
+void md_inf_flush(md_inf_stream *s);
+size_t md_inf_dst_rem(const md_inf_stream *s);
+size_t md_inf_src_rem(const md_inf_stream *s);
+int md_inf_status(const md_inf_stream *s);
+uint32_t md_inf_checksum(const md_inf_stream *s);
+void md_inf_free(md_inf_stream *s);
+typedef struct md_def_stream md_def_stream;
+md_def_stream *md_def_encoder(md_ctx *ctx, int format, const md_deflate_params *params, uint8_t *o, size_t o_len);
+int md_def_src(md_def_stream *s, const uint8_t *buf, size_t off, size_t len);
+int md_def_encode(md_def_stream *s);
+void md_def_dst(md_def_stream *s, uint8_t *o, size_t o_len);
+size_t md_def_dst_rem(const md_def_stream *s);
+int md_def_status(const md_def_stream *s);
+uint32_t md_def_checksum(const md_def_stream *s);
+void md_def_free(md_def_stream *s);
 
 /* ---- GZip (lib/gz.ml) ---- */
-
-/* The header fields Gz.Def.encoder takes (lib/gz.ml:859-918): ?ascii ?hcrc ?filename ?comment
- * ~mtime os; used by every later MD_FORMAT_GZIP deflate of this context.  filename / comment
- * may be NULL (absent; both must be NUL-free and < 256 bytes).  Default: mtime 0, os 3 (Unix),
- * nothing else.  XFL follows the level (2 for level 9, else 0, lib/gz.ml:888-890). */
-int md_gz_set_header(md_ctx *ctx, uint32_t mtime, int os, int hcrc, int ascii, const char *filename,
-                     const char *comment);
 
 /* What Gz.Inf.filename / comment / os / extra report (lib/gz.ml:612-633): offsets into src. */
 typedef struct md_gz_meta {
@@ -226,8 +286,8 @@ typedef struct md_gz_meta {
  *   Gz.Higher.compress ?level ?filename ?comment ~w ~q ... (lib/gz.ml:927-950; NB its ?level
  *   defaults to 0 there — pass the level you mean)
  *   Gz.Higher.uncompress ~refill ~flush i o            (lib/gz.ml:959-982); meta may be NULL. */
-int md_gz_higher_compress(md_ctx *ctx, int level, int queue_len, const uint8_t *src, size_t src_len,
-                          uint8_t *dst, size_t dst_cap, size_t *written);
+int md_gz_higher_compress(md_ctx *ctx, int level, int queue_len, const md_gz_header *header, const uint8_t *src,
+                          size_t src_len, uint8_t *dst, size_t dst_cap, size_t *written);
 int md_gz_higher_uncompress(md_ctx *ctx, const uint8_t *src, size_t src_len, uint8_t *dst, size_t dst_cap,
                             size_t *consumed, size_t *written, md_gz_meta *meta);
 

@@ -1010,6 +1010,31 @@ uint8_t *orc_encode_cmds(const int *cmds, int ncmds, int kind, size_t *out_len) 
   return o.p;
 }
 
+/* De.Lz77 alone (test/test.ml:798-813): the commands of every queue fill in order — what a caller of
+ * De.Lz77.compress takes out of the queue at each `Flush and at `End (lib/de.mli:453-524) — and the cumulative
+ * literals / distances histograms.  Returns the number of commands (they are stored while they fit in `max`). */
+int orc_lz77_cmds_ex(const uint8_t *src, size_t n, int level, int queue_len, int matcher, int *out, int max, int *lits286,
+                     int *dsts30) {
+  init_tables();
+  queue_t q = {(int *)calloc((size_t)queue_len, sizeof(int)), 0, 0, (unsigned)queue_len};
+  lz_t *s = lz_new(level, &q, src, n, matcher);
+  int cnt = 0;
+  for (;;) {
+    int r = lz_compress(s);
+    while (q_size(&q)) {
+      int c = q.buf[q.r++ & (q.c - 1)];
+      if (cnt < max) out[cnt] = c;
+      cnt++;
+    }
+    if (r == LZ_END) break;
+  }
+  if (lits286) memcpy(lits286, s->lits, 286 * sizeof(int));
+  if (dsts30) memcpy(dsts30, s->dsts, 30 * sizeof(int));
+  free(q.buf);
+  free(s);
+  return cnt;
+}
+
 /* De.Lz77 alone (test/test.ml:798-813): the command list of an input that fits one
  * queue fill.  Returns the number of commands (including the final End = 256), or -1
  * when the queue flushed before the end. */

@@ -21,6 +21,13 @@ def load_golden(name):
         return json.load(f)
 
 
+def golden_bytes(parts):
+    """a fixture byte string: hex, or a list of hex pieces and {"rep": byte, "count": n} runs (kept as recipes)"""
+    if isinstance(parts, str):
+        return bytes.fromhex(parts)
+    return b"".join(bytes.fromhex(x) if isinstance(x, str) else bytes([x["rep"]]) * x["count"] for x in parts)
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """ctypes handle on oracle/liboracle.so (the CPU checker; test infrastructure)."""

@@ -325,6 +325,7 @@ def gen_gzip():
         "test_empty_gzip": dict(out=b"", status=0),
         "test_empty_gzip_with_name": dict(out=b"", status=0, filename=b"test"),
         "test_foo_gzip": dict(out=b"foo", status=0, filename=b"foo"),
+        "test_multiple_flush_gzip": dict(out=b"foo", status=0, filename=b"foo"),  # test/test.ml:1726 (streaming steps)
         "test_invalid_hcrc": dict(status=11, error="Invalid GZip header checksum"),
         "test_gzip_extra": dict(out=b"foo\n", status=0, extra_key=b"lx", extra_value=b"ubuntu"),
     }
@@ -357,31 +358,180 @@ def gen_gzip():
     print("gzip.json", len(cases))
 
 
-def gen_lzo():
-    """test/test.ml:2033-2065: the one LZO known-answer vector (`expect` / `input` string lists)."""
-    text = open(os.path.join(REF, "test.ml"), encoding="latin-1").read()
-    m = re.search(r"let test_lzo_0 \(\) =", text)
-    line = text.count("\n", 0, m.start()) + 1
+# ---------------------------------------------------------------- test/test_lzo.ml
+class Rep:
+    """String.make n c with a large n: kept as a recipe, not expanded into the fixture."""
+    def __init__(self, byte, count):
+        self.byte, self.count = byte, count
 
-    def strings(name):
-        lst = text.index("[", text.index("let %s" % name, m.start()))
-        end = text.index("] in", lst)
-        i, parts = lst + 1, []
-        while True:
-            i = skip_ws_comments(text, i)
-            if i >= end:
-                break
-            if text[i] == ";":
-                i += 1
-                continue
+
+def _parts_add(parts, x):
+    for y in (x if isinstance(x, list) else [x]):
+        if isinstance(y, bytes) and parts and isinstance(parts[-1], bytes):
+            parts[-1] += y
+        else:
+            parts.append(y)
+    return parts
+
+
+def eval_str(text, i, env):
+    """Evaluates an OCaml string expression made of literals, `^`, String.make, String.concat "" <list>, parentheses
+    and names bound in env.  Returns (parts, index) with parts = [bytes | Rep]; raises ValueError on anything else."""
+    def primary(i):
+        i = skip_ws_comments(text, i)
+        if text[i] == '"':
             b, i = parse_ocaml_string(text, i)
-            parts.append(b)
-        return b"".join(parts)
-    cases = [{"name": "lzo_0_random", "src": strings("input").hex(), "out": strings("expect").hex(), "status": 0,
-              "ref": "test/test.ml:%d" % line}]
+            return [b], i
+        if text[i] == "(":
+            v, i = expr(i + 1)
+            i = skip_ws_comments(text, i)
+            if text[i] != ")":
+                raise ValueError("expected )")
+            return v, i + 1
+        if text[i] == "[":
+            i += 1
+            parts = []
+            while True:
+                i = skip_ws_comments(text, i)
+                if text[i] == "]":
+                    return parts, i + 1
+                if text[i] == ";":
+                    i += 1
+                    continue
+                v, i = expr(i)
+                _parts_add(parts, v)
+        m = re.compile(r"String\.make\s+\(?\s*([0-9+ ]+?)\s*\)?\s+'((?:\\x[0-9a-fA-F]{2})|(?:\\[0-9]{3})|.)'").match(text, i)
+        if m:
+            n = sum(int(x) for x in m.group(1).split("+"))
+            c = m.group(2)
+            byte = int(c[2:], 16) if c.startswith("\\x") else int(c[1:]) if c.startswith("\\") else ord(c)
+            return ([Rep(byte, n)] if n > 4096 else [bytes([byte]) * n]), m.end()
+        m = re.compile(r'String\.concat\s+""\s*').match(text, i)
+        if m:
+            return primary(m.end())
+        m = re.compile(r'Bstr\.string\s+(~off:\d+\s+~len:\d+\s+)?(?=")').match(text, i)
+        if m:  # Bstr.string ~off:0 ~len:n "literal": the literal (the tests always take all of it)
+            return primary(m.end())
+        m = re.compile(r"[a-z_][A-Za-z0-9_']*").match(text, i)
+        if m and m.group(0) in env:
+            return list(env[m.group(0)]), m.end()
+        raise ValueError("not a string expression at %d: %r" % (i, text[i:i + 30]))
+
+    def expr(i):
+        v, i = primary(i)
+        v = _parts_add([], v)
+        while True:
+            j = skip_ws_comments(text, i)
+            if j < len(text) and text[j] == "^":
+                w, i = primary(j + 1)
+                _parts_add(v, w)
+            else:
+                return v, i
+    return expr(i)
+
+
+def parts_json(parts):
+    out = []
+    for x in parts:
+        out.append(x.hex() if isinstance(x, bytes) else {"rep": x.byte, "count": x.count})
+    return out
+
+
+def gen_lzo():
+    """test/test_lzo.ml:32-596 — every Lzo.uncompress / uncompress_with_buffer case of the reference (inputs, expected
+    output or "an error is expected"), plus test/test.ml:2033-2065 (the same `random` vector).  Large runs
+    (String.make n c) stay recipes.  The compress-side cases (test_lzo_1, the minilzo cross-check) are properties,
+    not vectors: tests/test_oracle_lzo.py and tests/test_gpu_lzo.py run them against minilzo itself."""
+    text = open(os.path.join(REF, "test_lzo.ml"), encoding="latin-1").read()
+    genv = {}
+    for m in re.finditer(r"^let (output_lzo_\d+) =", text, re.M):
+        genv[m.group(1)], _ = eval_str(text, m.end(), {})
+    funs = [(m.group(1), m.start()) for m in re.finditer(r"^let (test_lzo_\d+) \(\) =", text, re.M)]
+    funs.append(("end", text.index("let test_minilzo")))
+    cases = []
+
+    def add(name, line, src, out=None, error=False):
+        c = {"name": name, "ref": "test/test_lzo.ml:%d" % line, "src": parts_json(src)}
+        if error:
+            c["status"] = "error"
+        else:
+            c["status"] = 0
+            c["out"] = parts_json(out)
+        cases.append(c)
+
+    for (fn, a), (_, b) in zip(funs, funs[1:]):
+        body = text[a:b]
+        if fn == "test_lzo_1":  # compress then uncompress: a property, not a vector
+            continue
+        title = re.search(r'Alcotest\.test_case\s+"([^"]*)"', body).group(1)
+        env = dict(genv)
+        expect_error = "An error is expected" in body or "Unexpected valid LZO input" in body
+        pos, k = 0, 0
+        tok = re.compile(r"\blet ([a-z_][A-Za-z0-9_']*) =|Alcotest\.\(check (res|str|string)\)\s*|Lzo\.uncompress_with_buffer\s*\(Bstr\.string ")
+        last_src = None
+        while True:
+            m = tok.search(body, pos)
+            if not m:
+                break
+            pos = m.end()
+            line = text.count("\n", 0, a + m.start()) + 1
+            if m.group(1):
+                try:
+                    env[m.group(1)], pos = eval_str(body, pos, env)
+                except (ValueError, IndexError):
+                    pass
+                continue
+            if m.group(0).startswith("Lzo.uncompress_with_buffer"):  # test_lzo_2: the input is inline
+                src, _ = eval_str(body, pos - 1, env)
+                add("%s %s" % (fn[5:], title), line, src, error=True)
+                last_src = None
+                continue
+            if m.group(2) == "res":  # (check res) "name" (Ok e | Error ...) (uncompress e)
+                nm, pos = parse_ocaml_string(body, skip_ws_comments(body, pos))
+                pos = skip_ws_comments(body, pos)
+                assert body[pos] == "("
+                j = skip_ws_comments(body, pos + 1)
+                if body.startswith("Ok", j):
+                    out, pos = eval_str(body, j + 2, env)
+                    err = False
+                else:
+                    out, err = None, True
+                    depth, pos = 1, pos + 1
+                    while depth:
+                        if body[pos] == '"':
+                            _, pos = parse_ocaml_string(body, pos)
+                            continue
+                        depth += body[pos] == "("
+                        depth -= body[pos] == ")"
+                        pos += 1
+                    pos -= 1
+                pos = skip_ws_comments(body, pos)
+                assert body[pos] == ")", body[pos:pos + 20]
+                pos = skip_ws_comments(body, pos + 1)
+                assert body[pos] == "("
+                j = skip_ws_comments(body, pos + 1)
+                assert body.startswith("uncompress", j)
+                src, pos = eval_str(body, j + len("uncompress"), env)
+                k += 1
+                add("%s %s: %s" % (fn[5:], title, nm.decode("latin-1")), line, src, out, err)
+            else:  # (check str|string) "name" a b with the decoder's result bound to a name: the other one is expected
+                nm, pos = parse_ocaml_string(body, skip_ws_comments(body, pos))
+                vals = []
+                for _ in range(2):
+                    pos = skip_ws_comments(body, pos)
+                    try:
+                        v, pos = eval_str(body, pos, {k2: v2 for k2, v2 in env.items() if k2 not in ("str", "res", "output'")})
+                        vals.append(v)
+                    except (ValueError, IndexError):
+                        pos = re.compile(r"\(Bstr\.to_string output\)|[A-Za-z_'.]+").match(body, pos).end()
+                assert len(vals) == 1, (fn, vals)
+                add("%s %s" % (fn[5:], title), line, env["input"], vals[0])
+        if expect_error and fn != "test_lzo_2":
+            add("%s %s" % (fn[5:], title), text.count("\n", 0, a) + 1, env["input"], error=True)
+    # test/test.ml:2033-2065 carries the same "random" vector as test_lzo_0
     with open(os.path.join(OUT, "lzo.json"), "w") as f:
         json.dump(cases, f, indent=1)
-    print("lzo.json", len(cases))
+    print("lzo.json", len(cases), "cases")
 
 
 def main():

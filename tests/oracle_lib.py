@@ -211,6 +211,15 @@ class Oracle:
         p = self.lib.orc_encode_cmds(arr, len(cmds), {"flat": 0, "fixed": 1, "dynamic": 2}[kind], ctypes.byref(n))
         return self._take(p, n.value)
 
+    def lz77_all(self, data, level=4, queue=4096, matcher=0):
+        """every queue fill of De.Lz77.compress (or Lz.compress) in order + literals[286] + distances[30]"""
+        cap = len(data) + len(data) // max(1, queue - 1) + 8
+        out, lits, dsts = (ctypes.c_int * cap)(), (ctypes.c_int * 286)(), (ctypes.c_int * 30)()
+        self.lib.orc_lz77_cmds_ex.restype = ctypes.c_int
+        n = self.lib.orc_lz77_cmds_ex(bytes(data), ctypes.c_size_t(len(data)), level, queue, matcher, out, cap, lits, dsts)
+        assert n <= cap
+        return [c & 0xffffffff for c in out[:n]], list(lits), list(dsts)
+
     def lz77_cmds(self, data, level=4, queue=4096):
         out = (ctypes.c_int * queue)()
         n = self.lib.orc_lz77_cmds(bytes(data), len(data), level, queue, out, queue)

@@ -141,10 +141,119 @@ def test_output_too_small(eng):
     assert st == 2  # Unexpected_end_of_output
 
 
+KAT = {c["name"]: c for c in load_golden("deflate_kat.json")}
+
+
 def test_kats_through_gpu(eng):
-    """test/test.ml:798-813: "abcde" is five literals and End -> one fixed/dynamic block."""
+    """the reference's compressed-byte KATs on the HIP path: the encoder alone (test/test.ml:507-531
+    huffman_length_extra, :1037-1055 flat) and the match finder alone (:798-813, "abcde")"""
+    from decompress_amd import de
+    c = KAT["huffman_length_extra"]
+    assert de.Def.encode(c["cmds"], de.Def.DYNAMIC) == bytes.fromhex(c["out"])
+    assert zlib.decompress(bytes.fromhex(c["out"]), -15) == bytes.fromhex(c["inflated"])
+    c = KAT["flat"]
+    assert de.Def.encode(c["cmds"], de.Def.FLAT) == bytes.fromhex(c["out"])
+    c = KAT["lz77_1"]
+    cmds, lits, dsts = de.Lz77.compress(bytes.fromhex(c["src"]), level=4)
+    assert cmds == c["cmds"]
+    assert [lits[x] for x in b"abcde"] == [1] * 5 and lits[256] == 1 and sum(dsts) == 0
     st, out, _ = eng.deflate_many([b"abcde"], level=4, driver=1)[0]
     assert st == 0 and zlib.decompress(out, -15) == b"abcde"
+
+
+@pytest.mark.parametrize("name", ["tree_0", "tree_rfc5322_corpus"])
+def test_tree_kats_through_gpu(oracle, name):
+    """test/test.ml:1169-1237: the Huffman trees of a given histogram.  A command list with exactly that histogram
+    goes through De.Def on the GPU; the block header carries the tree, so byte equality with the oracle (whose
+    T.make reproduces the KAT's lengths and codes, tests/test_oracle_deflate.py) pins the GPU's tree."""
+    from decompress_amd import de
+    c = KAT[name]
+    lb = [3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258]
+    cmds = []
+    for sym, f in enumerate(c["freqs"][:286]):
+        if sym < 256:
+            cmds += [sym] * f
+        elif sym > 256:
+            cmds += [de.copy_cmd(1, lb[sym - 257])] * f
+    cmds.append(de.EOB)
+    mc, lens, codes, _ = oracle.tree_make(c["length"], list(c["freqs"]))
+    for sym, l in c["lengths"].items():
+        assert lens[int(sym)] == l
+    assert de.Def.encode(cmds, de.Def.DYNAMIC) == oracle.encode_cmds(cmds, "dynamic")
+
+
+def test_lz77_alone_equals_oracle(eng, oracle):
+    """De.Lz77.compress / Lz.compress on their own (md_de_lz77_compress): the commands of every queue fill and the
+    two cumulative histograms equal the oracle's"""
+    from decompress_amd import de
+    data = _datasets()
+    for matcher in (0, 1):
+        for level, q in ((0, 4096), (1, 16), (4, 4096), (6, 256), (9, 4096)):
+            if matcher == 1 and level == 0:
+                continue
+            for k in ("empty", "one", "abcde", "aaaaa", "runs", "text", "ascii", "tail65300", "planted"):
+                got = de.Lz77.compress(data[k], level=level, queue=q, matcher=matcher)
+                want = oracle.lz77_all(data[k], level=level, queue=q, matcher=matcher)
+                assert got[0] == want[0], (matcher, level, q, k, len(got[0]), len(want[0]))
+                assert (got[1], got[2]) == (want[1], want[2]), (matcher, level, q, k)
+
+
+def test_def_encode_equals_oracle(eng, oracle):
+    """De.Def.encode on its own (md_de_def_encode): random command lists, the three block kinds"""
+    from decompress_amd import de
+    rng = random.Random(44)
+    for trial in range(12):
+        cmds = []
+        for _ in range(rng.choice((0, 1, 5, 300, 5000))):
+            if rng.random() < 0.6:
+                cmds.append(rng.randrange(256) if trial % 2 else rng.choice(b"etaoin shrdlu"))
+            else:
+                cmds.append(de.copy_cmd(rng.randrange(1, 32769), rng.randrange(3, 259)))
+        cmds.append(de.EOB)
+        for kind, name in ((de.Def.FIXED, "fixed"), (de.Def.DYNAMIC, "dynamic")):
+            assert de.Def.encode(cmds, kind) == oracle.encode_cmds(cmds, name), (trial, name, len(cmds))
+    lits = [rng.randrange(256) for _ in range(70000)] + [de.EOB]
+    assert de.Def.encode(lits, de.Def.FLAT) == oracle.encode_cmds(lits, "flat")
+
+
+def test_c3_stream_size(eng, oracle):
+    """BASELINE config 3 at its stream size: 8 x 1 MiB printable-ASCII buffers, level 6, queue 4096, Zl driver
+    (32 window slides, ~256 queue fills each) — bytes equal the oracle's"""
+    import decompress_amd
+    from decompress_amd import workloads
+    bufs = [workloads.ascii_uniform(0xC3 + i, 1 << 20) for i in range(8)]
+    res = eng.deflate_many(bufs, decompress_amd.FORMAT_ZLIB, level=6, queue=4096)
+    for b, (st, out, adler) in zip(bufs, res):
+        assert st == 0 and out == oracle.zl_deflate(b, 6) and adler == zlib.adler32(b)
+        assert zlib.decompress(out) == b
+
+
+def test_streaming_encoder_shim(eng, oracle):
+    """Zl.Def.encoder's protocol (`Await / `Flush / `End) above the batch ABI: md_def_*"""
+    from decompress_amd import _lib, workloads
+    lib = eng.lib
+    data = workloads.text(5, 200000)
+    params = eng._params(6, 4096, 0, True)
+    o = ctypes.create_string_buffer(4096)
+    s = lib.md_def_encoder(eng.ctx, 1, ctypes.byref(params), o, len(o))
+    out, pos, sigs = bytearray(), 0, []
+    while True:
+        sig = lib.md_def_encode(s)
+        sigs.append(sig)
+        if sig == 0:  # `Await
+            chunk = data[pos:pos + 30000]
+            pos += len(chunk)
+            assert lib.md_def_src(s, chunk, 0, len(chunk)) == 0
+        elif sig == 1:  # `Flush
+            out += o.raw[:len(o) - lib.md_def_dst_rem(s)]
+            lib.md_def_dst(s, o, len(o))
+        else:
+            out += o.raw[:len(o) - lib.md_def_dst_rem(s)]
+            break
+    assert sig == 2 and lib.md_def_status(s) == 0 and lib.md_def_checksum(s) == zlib.adler32(data)
+    lib.md_def_free(s)
+    assert bytes(out) == oracle.zl_deflate(data, 6)
+    assert sigs.count(0) == 8 and sigs.count(1) >= 10
 
 
 def test_c_abi_single(eng):
@@ -170,3 +279,8 @@ def test_python_mirror(eng):
     assert zl.Higher.uncompress(z, len(data)) == data
     r = de.Higher.compress(data)
     assert de.Higher.uncompress(r, len(data)) == data
+    # `Error (`Msg s): the reference's strings (lib/de.ml:702-730, lib/zl.ml:177-183)
+    assert de.Higher.uncompress(r[:50], len(data)) == ("Error", "Unexpected end of input")
+    assert de.Higher.uncompress(b"\x06", 10) == ("Error", "Invalid kind of block")
+    assert zl.Higher.uncompress(b"\x79\x9c" + z[2:], len(data)) == ("Error", "Invalid Zlib header")
+    assert zl.Higher.uncompress(z[:-1] + bytes([z[-1] ^ 1]), len(data)) == ("Error", "Invalid checksum")

@@ -110,6 +110,20 @@ def test_deflate_equals_oracle(eng, oracle):
     assert eng.deflate_many([bufs[3]], decompress_amd.FORMAT_GZIP, level=6, caps=[len(want) - 1])[0][0] == 2
 
 
+def test_every_os_value(eng, oracle):
+    """test/test.ml:1926-1958 (`test_gzip_os` for the 15 Gz.os constructors): 256 random bytes, level 4, header CRC —
+    the frame equals the oracle's, and the contents and the OS byte come back through Gz.Higher.uncompress"""
+    import random
+    from decompress_amd import gz
+    rng = random.Random(1926)
+    for name, os_ in gz.OS.items():
+        data = bytes(rng.getrandbits(8) for _ in range(256))
+        z = gz.Higher.compress(data, level=4, hcrc=True, os=name)
+        assert z == oracle.gz_deflate(data, level=4, hcrc=True, os=os_)
+        verdict, meta, out = gz.Higher.uncompress(z, 256)
+        assert (verdict, out, meta["os"]) == ("Ok", data, os_)
+
+
 def test_round_trip_c4_shape(eng):
     """BASELINE config 4 in small: gzip members (level 4) of text files, deflate then inflate on the GPU"""
     import decompress_amd

@@ -236,3 +236,47 @@ def test_oversize_descriptor_is_rejected(eng):
     torch.cuda.synchronize(dev)
     assert int(res[2][0].item()) == -1 and int(res[0][0].item()) == 0
     assert int(res[2][1].item()) != -1
+
+
+def test_streaming_decoder_shim(eng, oracle):
+    """De.Inf.decoder / src / decode / flush / dst_rem (lib/de.mli:82-144) above the batch ABI: chunks in,
+    `Await until the end of input, then `Flush per output buffer and `End (or `Malformed after the bytes that were
+    decoded before the error)"""
+    import decompress_amd
+    from decompress_amd import de, workloads
+    data = workloads.text(31, 300000)
+    z = zlib.compress(data, 6)
+    chunks = [z[i:i + 7000] for i in range(0, len(z), 7000)]
+    verdict, out, sigs = de.Inf.decode_chunks(chunks, o_len=65536, fmt=decompress_amd.FORMAT_ZLIB)
+    assert (verdict, out) == ("Ok", data)
+    assert sigs.count(de.AWAIT) == len(chunks) + 1 and sigs.count(de.FLUSH) == len(data) // 65536 and sigs[-1] == de.END
+    raw = z[2:-4]
+    verdict, out, sigs = de.Inf.decode_chunks([raw[:5000], raw[5000:20000]], o_len=4096)
+    ost, _, oout = oracle.de_inflate(raw[:20000], 1 << 22)
+    assert verdict == "Unexpected_end_of_input" and ost == 1 and out == oout and sigs[-1] == de.MALFORMED
+    assert de.Inf.decode_chunks([], o_len=16)[0] == "Unexpected_end_of_input"
+    assert de.Inf.decode_chunks([b"\x03\x00"], o_len=16)[:2] == ("Ok", b"")
+
+
+def test_full_batch_c2(eng):
+    """BASELINE config 2 as one batch: 4096 x 256 KiB zlib streams (512 distinct), every status, consumed count,
+    length and Adler-32 checked, 64 streams compared byte for byte"""
+    import torch
+    import decompress_amd
+    from decompress_amd import workloads
+    n, nb = 4096, 256 * 1024
+    streams = workloads.c2_streams(n, nbytes=nb, unique=512)
+    blob, in_off, in_len = workloads.pack(streams)
+    dev = eng.device
+    t = lambda a: torch.from_numpy(a).to(dev)
+    d_out = torch.empty(n * nb, dtype=torch.uint8, device=dev)
+    res = eng.inflate_batch(decompress_amd.FORMAT_ZLIB, t(blob), t(in_off), t(in_len), d_out,
+                            t(np.arange(n, dtype=np.int64) * nb), t(np.full(n, nb, dtype=np.int64)))
+    torch.cuda.synchronize(dev)
+    out_len, consumed, status, checksum = [x.cpu().numpy() for x in res]
+    assert (status == 0).all() and (out_len == nb).all() and (consumed == in_len).all()
+    plains = [zlib.decompress(z) for z in streams[:512]]
+    want = np.array([zlib.adler32(plains[i % 512]) for i in range(n)], dtype=np.uint32)
+    assert (checksum.view(np.uint32) == want).all()
+    for i in range(0, n, 64):
+        assert d_out[i * nb:(i + 1) * nb].cpu().numpy().tobytes() == plains[i % 512]

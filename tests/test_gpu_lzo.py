@@ -5,7 +5,7 @@ import random
 import pytest
 
 from tests import oracle_lib
-from tests.conftest import load_golden
+from tests.conftest import golden_bytes, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -27,11 +27,16 @@ def _datasets():
     return out
 
 
-def test_reference_vector(eng):
-    from decompress_amd import lzo
-    for case in load_golden("lzo.json"):
-        src = bytes.fromhex(case["src"])
-        assert lzo.uncompress(src, len(src)) == ("Ok", bytes.fromhex(case["out"]))
+def test_reference_vectors(eng, oracle):
+    """the 34 decoder cases of test/test_lzo.ml in one batch: expected bytes, or the oracle's error"""
+    cases = load_golden("lzo.json")
+    srcs = [golden_bytes(c["src"]) for c in cases]
+    caps = [len(golden_bytes(c["out"])) if c["status"] == 0 else 1 << 16 for c in cases]
+    for c, src, cap, (st, out) in zip(cases, srcs, caps, eng.lzo_many(False, srcs, caps)):
+        if c["status"] == 0:
+            assert (st, out) == (0, golden_bytes(c["out"])), c["name"]
+        else:
+            assert st != 0 and st == oracle.lzo_uncompress(src, cap)[0], c["name"]
 
 
 def test_compress_equals_oracle_and_round_trips(eng, oracle):

@@ -54,6 +54,18 @@ def test_generated_frames_round_trip(oracle):
         assert struct.unpack("<II", z[-8:]) == (zlib.crc32(data), len(data) & 0xffffffff)
 
 
+def test_every_os_value(oracle):
+    """test/test.ml:1926-1958 (`test_gzip_os`, run for the 15 Gz.os constructors, lib/gz.ml:214-246): 256 random
+    bytes, level 4, header CRC; the contents and the OS come back"""
+    import random
+    rng = random.Random(1926)
+    for os_ in list(range(14)) + [255]:
+        data = bytes(rng.getrandbits(8) for _ in range(256))
+        z = oracle.gz_deflate(data, level=4, hcrc=True, os=os_)
+        st, used, out, meta = oracle.gz_inflate(z, 256)
+        assert (st, used, out, meta["os"]) == (0, len(z), data, os_)
+
+
 def test_header_layout(oracle):
     z = oracle.gz_deflate(b"hello", level=4, mtime=0x01020304, os=3, name=b"f")
     assert z[:10] == bytes([0x1f, 0x8b, 8, 8, 1, 2, 3, 4, 0, 3])  # MTIME big-endian (lib/gz.ml:801)
