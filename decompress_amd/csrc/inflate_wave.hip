@@ -37,7 +37,10 @@ namespace md {
 namespace wv {
 
 // ---- geometry ---------------------------------------------------------------------------------
-constexpr uint32_t S = 264;        // bits per lane zone: 8.25 dwords, so the 64 cursors start on distinct LDS banks
+constexpr uint32_t S = 264;        // bits per lane zone at most: 8.25 dwords, so the 64 cursors start on distinct LDS banks
+constexpr uint32_t SMIN = 48;      // ... and at least: where the data expands so much that 64 full zones overflow the
+                                   // staging buffer, the zones shrink so that all 64 lanes still have work (cost then
+                                   // follows the output, not the number of zones thrown away)
 constexpr uint32_t KMAX = 64;      // walk steps per lane per pass
 constexpr uint32_t PASSES = 5;     // walks after the first one
 constexpr uint32_t MMAX = 14;      // match records per lane per round
@@ -905,7 +908,7 @@ __device__ __forceinline__ void copy_near_all(const lds_u32 *mrec, const lds_u16
 // All rounds of one Huffman block.  bp is a bit position of the body; on return *bp_io is the bit after the EOB.
 template <class PF>
 __device__ __forceinline__ int inflate_block(lds_smem *sm, const uint8_t *__restrict__ body, uint32_t body_len, Sink &sk,
-                                             uint32_t lroot, uint32_t lane, uint32_t *bp_io, PF &pf) {
+                                             uint32_t lroot, uint32_t lane, uint32_t *bp_io, uint32_t *zone_io, PF &pf) {
   uint32_t bp = *bp_io;
   lds_u32 *win = (lds_u32 *)sm->win;
   const lds_u32 *lut = (const lds_u32 *)sm->lut;
@@ -913,6 +916,7 @@ __device__ __forceinline__ int inflate_block(lds_smem *sm, const uint8_t *__rest
   lds_u16 *mpos = (lds_u16 *)sm->mpos;
   lds_u32 *pend = (lds_u32 *)sm->pend;
   const uint32_t total_bits = body_len * 8;
+  uint32_t zs = *zone_io;  // zone size of this round (wave-uniform), adapted to the expansion of the last one
   for (;;) {
     const uint32_t base = (bp >> 5) << 2;  // window start (byte of the body, multiple of 4)
     win_load(win, body, body_len, base, lane);
@@ -920,8 +924,8 @@ __device__ __forceinline__ int inflate_block(lds_smem *sm, const uint8_t *__rest
     pf.tick(P_ENSURE);
     pf.count(C_ROUNDS);
     pf.count(C_PASSES);
-    uint32_t start = rbp + lane * S, end = 0, stop = 0, nb = 0;
-    const uint32_t limit = rbp + (lane + 1) * S;
+    uint32_t start = rbp + lane * zs, end = 0, stop = 0, nb = 0;
+    const uint32_t limit = rbp + (lane + 1) * zs;
     sync_pass<false>(win, lut, lroot, true, start, limit, end, stop, nb);
     pf.tick(P_DECODE1);
     bool counted = false;
@@ -989,11 +993,17 @@ __device__ __forceinline__ int inflate_block(lds_smem *sm, const uint8_t *__rest
     pf.count(C_LANES, nvalid);
     const uint32_t nbp = base * 8 + rdlane(lo.endp, nvalid - 1);
     if (stuck || (nbp == bp && total == 0 && (lstop == 0 || lstop == kStTrunc))) return MD_E_HIP;  // defensive: no progress
+    {  // next round: 64 zones that fill about 7/8 of the staging buffer at this round's bytes-per-bit
+      const uint32_t bits = nbp - bp;
+      const uint64_t want = (uint64_t)(STAGE - STAGE / 8) * bits / ((uint64_t)kWave * (total ? total : 1u));
+      zs = want > S ? S : want < SMIN ? SMIN : (uint32_t)want;
+    }
     bp = nbp;
     if (lstop == kStEob) break;
     if (lstop != 0 && lstop != kStTrunc) return (int)lstop;
   }
   *bp_io = bp;
+  *zone_io = zs;
   return MD_OK;
 }
 
@@ -1055,7 +1065,7 @@ __global__ __launch_bounds__(kWave) void inflate_wave_kernel(
 
   lds_u32 *win = (lds_u32 *)sm->win;
   const uint32_t total_bits = body_len * 8;
-  uint32_t bp = 0;
+  uint32_t bp = 0, zone = S;
   if (lane < 4) sm->lut[kStopEobI + lane] = mk_entry(0, 0, 0, 0, kStopEobI + (lane & 1));  // the self-looping STOP entries
   for (uint32_t i = lane; i < STAGE / 32 + 2; i += kWave) sm->pend[i] = 0;
 
@@ -1113,7 +1123,7 @@ __global__ __launch_bounds__(kWave) void inflate_wave_kernel(
         }
         lroot = uni(lroot);
         pf.tick(P_HEADER);
-        if (rc == MD_OK) rc = inflate_block(sm, body, body_len, sk, lroot, lane, &bp, pf);
+        if (rc == MD_OK) rc = inflate_block(sm, body, body_len, sk, lroot, lane, &bp, &zone, pf);
       }
     }
   }

@@ -1,13 +1,17 @@
-"""Synthetic workloads of BASELINE.json's configs (seeded, no files needed).
+"""Workloads of BASELINE.json's configs as SURVEY.md 8(d) defines them (seeded; the only file is the data fixture
+tests/golden/corpus.tar.xz = the reference's test/corpus, packed by tests/golden/gen_corpus.py).
 
 C1  one 64 KiB stream of stored blocks (65535 + 1 bytes)
 C2  N x 256 KiB zlib streams, dynamic Huffman (libz level 6)      [headline]
+    plaintext i: even i = the 256 KiB of the concatenated corpus that start at offset i * 4099 (mod its length),
+    odd i = seeded Zipf-distributed word text (zlib ratio ~0.38, full range of match distances)
 C3  N x 1 MiB uniform printable-ASCII buffers (deflate input)
-
-Plaintext for C2 is Zipf-distributed word text (zlib ratio ~0.38, dynamic
-Huffman blocks, full range of match distances) — the reference's corpus does
-not travel to the GPU box, so the generator stands in for it.
+C4  the 15 corpus files, file[i mod 15], as gzip members
 """
+import io
+import lzma
+import os
+import tarfile
 import zlib
 from concurrent.futures import ProcessPoolExecutor
 
@@ -62,6 +66,41 @@ def text(seed, nbytes):
     return b[:nbytes]
 
 
+_corpus_cache = None
+
+
+def corpus():
+    """the reference's test/corpus as {name: bytes}, in name order (15 files, 3 263 944 bytes)"""
+    global _corpus_cache
+    if _corpus_cache is None:
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "corpus.tar.xz")
+        with open(path, "rb") as f:
+            tar = tarfile.open(fileobj=io.BytesIO(lzma.decompress(f.read())))
+        _corpus_cache = {m.name: tar.extractfile(m).read() for m in sorted(tar.getmembers(), key=lambda m: m.name)}
+    return _corpus_cache
+
+
+_corpus_cat = None
+
+
+def corpus_slice(i, nbytes):
+    """C2's even streams: nbytes of the concatenated corpus from offset i * 4099 (mod its length), wrapping"""
+    global _corpus_cat
+    if _corpus_cat is None:
+        _corpus_cat = b"".join(corpus().values())
+    total = len(_corpus_cat)
+    off = (i * 4099) % total
+    out = _corpus_cat[off:off + nbytes]
+    while len(out) < nbytes:
+        out += _corpus_cat[:nbytes - len(out)]
+    return out
+
+
+def c2_plain(i, nbytes, seed0=0xC2):
+    """plaintext of C2's stream i"""
+    return corpus_slice(i, nbytes) if i % 2 == 0 else text(seed0 + i, nbytes)
+
+
 def ascii_uniform(seed, nbytes):
     """C3 plaintext: bytes uniform over printable ASCII 0x20..0x7e."""
     rng = np.random.default_rng(seed)
@@ -79,16 +118,21 @@ def stored_stream(payload):
 
 
 def _c2_one(args):
+    i, nbytes, level, seed0 = args
+    return zlib.compress(c2_plain(i, nbytes, seed0), level)
+
+
+def _c2_text_one(args):
+    """round 1's C2 stand-in: every stream seeded word text"""
     seed, nbytes, level = args
-    plain = text(seed, nbytes)
-    return zlib.compress(plain, level)
+    return zlib.compress(text(seed, nbytes), level)
 
 
-def c2_streams(n, nbytes=256 * 1024, level=6, seed0=0xC2, workers=None, unique=None):
-    """n zlib streams of `nbytes` plaintext each.  `unique` < n generates that
-    many distinct streams and cycles them (seed = seed0 + i mod unique)."""
+def c2_streams(n, nbytes=256 * 1024, level=6, seed0=0xC2, workers=None, unique=None, first=0):
+    """n zlib streams of `nbytes` plaintext each: streams first .. first + n - 1 of C2.  `unique` < n generates
+    that many distinct streams and cycles them."""
     unique = n if unique is None else min(unique, n)
-    jobs = [(seed0 + i, nbytes, level) for i in range(unique)]
+    jobs = [(first + i, nbytes, level, seed0) for i in range(unique)]
     if workers == 0 or unique < 8:
         uniq = [_c2_one(j) for j in jobs]
     else:

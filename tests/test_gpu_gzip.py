@@ -124,13 +124,20 @@ def test_every_os_value(eng, oracle):
         assert (verdict, out, meta["os"]) == ("Ok", data, os_)
 
 
-def test_round_trip_c4_shape(eng):
-    """BASELINE config 4 in small: gzip members (level 4) of text files, deflate then inflate on the GPU"""
+def test_round_trip_c4_corpus(eng, oracle):
+    """BASELINE config 4 on its own data: the 15 files of the reference's test/corpus (two cycles = 30 members) as
+    gzip members, mtime 0, os Unix, no name, level 4: Gz.Def on the GPU = the oracle's bytes (and python's gzip
+    reads them), then Gz.Inf on the GPU restores the files"""
+    import gzip
     import decompress_amd
     from decompress_amd import workloads, gz
-    bufs = [workloads.text(200 + i, 21504 + 7000 * i) for i in range(12)]
+    files = list(workloads.corpus().values())
+    assert len(files) == 15 and sum(map(len, files)) == 3263944
+    bufs = files * 2
     z = gz.Def.deflate_batch(bufs, level=4)
     assert all(st == 0 for st, _, _ in z)
+    for b, (_, o, crc) in zip(files, z):
+        assert o == oracle.gz_deflate(b, level=4) and crc == zlib.crc32(b) and gzip.decompress(o) == b
     back = gz.Inf.inflate_batch([o for _, o, _ in z], [len(b) for b in bufs])
     for b, (st, used, out, crc), (_, o, _) in zip(bufs, back, z):
         assert (st, used, out, crc) == (0, len(o), b, zlib.crc32(b))

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Secondary benchmark: BASELINE config 4's per-GPU share — 4096 gzip members whose sizes cycle
-through the 15 sizes of the reference's test corpus (21 504 ... 768 771 B; the corpus itself does
-not travel, the text comes from workloads.text), level 4: Gz.Def then Gz.Inf on one MI355X.
+"""Secondary benchmark: BASELINE config 4's per-GPU share — 4096 gzip members, member i = file[i mod 15] of the
+reference's test/corpus (the data fixture tests/golden/corpus.tar.xz; 21 504 ... 768 771 B, 3 263 944 B per
+cycle), mtime 0, os Unix, no name, level 4: Gz.Def then Gz.Inf on one MI355X.
     python tools/bench_gzip.py --streams 4096
 Prints one JSON line (MiB/s of uncompressed bytes for each direction)."""
 import argparse, json, os, sys, zlib
@@ -9,16 +9,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-# sizes of test/corpus/* in the reference: 3 263 944 B per cycle
-SIZES = [21504, 24603, 38240, 46526, 49379, 93695, 102400, 111261, 125179, 152089, 246814, 377109, 426754, 513216,
-         768771]
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--streams", type=int, default=4096)
     ap.add_argument("--level", type=int, default=4)
-    ap.add_argument("--unique", type=int, default=60)
     args = ap.parse_args()
     import torch
     import decompress_amd
@@ -26,7 +20,7 @@ def main():
     dev = torch.device("cuda", 0)
     eng = decompress_amd.Engine(0)
     n = args.streams
-    uniq = [workloads.text(0xC4 + i, SIZES[i % 15]) for i in range(min(args.unique, n))]
+    uniq = list(workloads.corpus().values())
     bufs = [uniq[i % len(uniq)] for i in range(n)]
     blob, off, ln = workloads.pack(bufs)
     cap = (ln + 8192).astype(np.int64)
