@@ -14,7 +14,8 @@
 extern "C" int md_launch_inflate_wave(int format, uint32_t n, const uint8_t *in, const uint64_t *in_off,
                                       const uint64_t *in_len, uint8_t *out, const uint64_t *out_off,
                                       const uint64_t *out_cap, uint64_t *out_len, uint64_t *consumed,
-                                      int32_t *status, uint32_t *checksum, uint64_t *dbg, hipStream_t stream);
+                                      int32_t *status, uint32_t *checksum, uint64_t *dbg, uint32_t *order,
+                                      hipStream_t stream);
 
 extern "C" size_t md_deflate_ws_bytes(uint32_t n, int qcap);
 extern "C" int md_launch_deflate(int format, int level, int qcap, int driver, int dynamic, uint32_t n,
@@ -57,6 +58,8 @@ struct md_ctx {
   uint64_t *dbg = nullptr;  // device buffer of the optional in-kernel profile (32 x u64)
   void *ws = nullptr;       // deflate workspace (hash heads / chains / command queues)
   size_t ws_bytes = 0;
+  uint32_t *order = nullptr;  // inflate: launch order of a large batch (n words)
+  size_t order_words = 0;
   std::string err;
 };
 
@@ -95,6 +98,8 @@ struct DeviceGuard {
 #define MD_ON_DEVICE(ctx)                 \
   DeviceGuard guard_((ctx)->device);      \
   if (!guard_.ok) return fail(ctx, MD_E_HIP, "hipSetDevice")
+
+constexpr size_t kOrderFrom = 2049;  // 256 CUs x 8 resident wavefronts: smaller batches start all at once
 
 bool is_gfx950(int dev) {
   hipDeviceProp_t p;
@@ -191,6 +196,7 @@ void md_destroy(md_ctx *ctx) {
   if (ctx->ev0) hipEventDestroy(ctx->ev0);
   if (ctx->ev1) hipEventDestroy(ctx->ev1);
   if (ctx->ws) hipFree(ctx->ws);
+  if (ctx->order) hipFree(ctx->order);
   if (ctx->dbg) hipFree(ctx->dbg);
   if (ctx->gz_tmp) hipFree(ctx->gz_tmp);
   if (ctx->lzo_ws) hipFree(ctx->lzo_ws);
@@ -294,8 +300,24 @@ int md_inflate_batch_device(md_ctx *ctx, int format, size_t n, const uint8_t *d_
     if (e != 0) return fail(ctx, MD_E_HIP, "gz finish kernel launch", (hipError_t)e);
     return MD_OK;
   }
+  // a batch of more streams than are resident at once (8 per CU) is started longest stream first; the scratch for the
+  // order is kept and only ever grows (the one allocation a batch call can make, on its first large batch)
+  uint32_t *order = nullptr;
+  if (n >= kOrderFrom) {
+    if (n > ctx->order_words) {
+      if (ctx->order) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipFree(ctx->order));
+        ctx->order = nullptr;
+        ctx->order_words = 0;
+      }
+      if (hipMalloc((void **)&ctx->order, n * 4) != hipSuccess) return fail(ctx, MD_E_OUT_OF_MEMORY, "hipMalloc(launch order)");
+      ctx->order_words = n;
+    }
+    order = ctx->order;
+  }
   int rc = md_launch_inflate_wave(format, (uint32_t)n, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap, d_out_len,
-                                  d_consumed, d_status, d_checksum, ctx->dbg, ctx->stream);
+                                  d_consumed, d_status, d_checksum, ctx->dbg, order, ctx->stream);
   if (rc != 0) return fail(ctx, MD_E_HIP, "inflate kernel launch", (hipError_t)rc);
   return MD_OK;
 }

@@ -20,10 +20,12 @@ typedef uint64_t u64_u __attribute__((aligned(1)));
 typedef uint32_t u32_u __attribute__((aligned(1)));
 typedef uint16_t u16_u __attribute__((aligned(1)));
 
-enum { P_ENSURE = 0, P_DECODE1, P_DECODE2, P_EMIT_A, P_FAR, P_NEAR, P_ADLER, P_HEADER, P_COUNT };
-enum { C_ROUNDS = 0, C_PASSES, C_LANES, C_TOKENS, C_SLOTS, C_NEAR_IT, C_COUNT };
+enum { P_ENSURE = 0, P_DECODE1, P_DECODE2, P_EMIT_A, P_FAR, P_NEAR, P_ADLER, P_HEADER, P_NEAR_FAST, P_NEAR_SLOW, P_NEAR_UPD, P_NEAR_LOAD, P_COUNT };
+enum { C_ROUNDS = 0, C_PASSES, C_LANES, C_TOKENS, C_SLOTS, C_NEAR_IT,
+       C_END_CHAIN, C_END_FIT, C_END_RECORDS, C_END_STAGE, C_END_EOB, C_LONG_NEAR, C_COUNT };  // why rounds ended short
 template <bool ON>
 struct Prof {
+  static constexpr bool on = true;
   uint64_t t0;
   uint64_t acc[P_COUNT];
   uint32_t cnt[C_COUNT];
@@ -37,12 +39,18 @@ struct Prof {
     acc[i] += t - t0;
     t0 = t;
   }
+  __device__ __forceinline__ void tick_lds(int i) {  // after the LDS queue has drained: the phase pays for its own accesses
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    tick(i);
+  }
   __device__ __forceinline__ void count(int i, uint32_t n = 1) { cnt[i] += n; }
 };
 template <>
 struct Prof<false> {
+  static constexpr bool on = false;
   __device__ __forceinline__ void init() {}
   __device__ __forceinline__ void tick(int) {}
+  __device__ __forceinline__ void tick_lds(int) {}
   __device__ __forceinline__ void count(int, uint32_t = 1) {}
 };
 

@@ -831,20 +831,39 @@ __device__ __noinline__ void copy_far_guarded(const lds_u32 *mrec, const lds_u16
   *nearmask_out = nearmask;
 }
 
-// staging -> staging LZ77 copy of n bytes with forward-byte semantics (dst - src = d; overlap allowed)
-__device__ __forceinline__ void stage_copy(lds_u8 *dst, const lds_u8 *src, uint32_t n, uint32_t d) {
-  if (d >= 8) {
-    for (uint32_t j = 0; j < n; j += 8) lds_put(dst + j, lds_ld64(src + j), n - j < 8 ? n - j : 8);
-  } else {
-    // period d < 8: replicate the last d bytes into a 64-bit pattern
-    uint64_t v = lds_ld64(src);
+// staging -> staging LZ77 copy of n bytes with forward-byte semantics (dst - src = d; overlap allowed), by the whole
+// wave: one long or self-overlapping match at a time (dd, ss, n, d are wave-uniform).  Every destination byte j is
+// stage[ss + j mod d], and the first period [ss, ss + min(d, n)) is final when the match is ready, so the lanes are
+// independent of each other: 8 bytes per lane without overlap, one whole number of periods per lane for d < 8, 4
+// gathered bytes per lane otherwise.
+__device__ __forceinline__ void wave_copy(lds_u8 *stage, uint32_t dd, uint32_t ss, uint32_t n, uint32_t d, uint32_t lane) {
+  if (d >= n) {
+    const uint32_t j = lane * 8;
+    if (j < n) lds_put(stage + dd + j, lds_ld64(stage + ss + j), n - j < 8 ? n - j : 8);
+  } else if (d < 8) {
+    uint64_t v = lds_ld64(stage + ss);  // the same 8 bytes for every lane
     const uint32_t sh = 8 * d;
     v &= (1ull << sh) - 1;
     v |= v << sh;
     if (2 * sh < 64) v |= v << (2 * sh);
     if (4 * sh < 64) v |= v << (4 * sh);
-    const uint32_t adv = (0x76586880u >> (4 * d)) & 15;  // d * (8 / d): the largest multiple of the period that fits 8 bytes
-    for (uint32_t j = 0; j < n; j += adv) lds_put(dst + j, v, n - j < 8 ? n - j : 8);
+    const uint32_t adv = (0x76586880u >> (4 * d)) & 15;  // d * (8 / d): 5..8 bytes, 64 lanes cover 258
+    const uint32_t j = lane * adv;
+    if (j < n) lds_put(stage + dd + j, v, n - j < adv ? n - j : adv);
+  } else {
+    const float inv = 1.0f / (float)d;
+    for (uint32_t j = lane * 4; j < n; j += 4 * kWave) {
+      uint32_t r = j - (uint32_t)((float)j * inv) * d;  // j mod d, the quotient may be one off either way
+      r = (int32_t)r < 0 ? r + d : r;
+      r = r >= d ? r - d : r;
+      uint32_t w = 0;
+#pragma unroll
+      for (uint32_t k = 0; k < 4; k++) {
+        const uint32_t x = r + k >= d ? r + k - d : r + k;  // d >= 8: one wrap at most
+        w |= (uint32_t)stage[ss + x] << (8 * k);
+      }
+      lds_put(stage + dd + j, w, n - j < 4 ? n - j : 4);
+    }
   }
 }
 
@@ -878,28 +897,37 @@ __device__ __forceinline__ void copy_near_all(const lds_u32 *mrec, const lds_u16
       break;
     }
     pf.count(C_NEAR_IT);
-    if (rem) {
-      const bool ready = sa >= sb || !pend_any(pend, sa, sb);
-      if (ready) {
-        const uint32_t n = ml - skip;  // skip < ml: a near match reaches into the round
-        lds_u8 *dd = stage + qs + skip;
-        const lds_u8 *ss = stage + sa;
-        if (d >= n && n <= 32) {  // the usual case: source and destination do not overlap, all loads in flight together
-          const uint64_t v0 = lds_ld64(ss), v1 = lds_ld64(ss + 8), v2 = lds_ld64(ss + 16), v3 = lds_ld64(ss + 24);
-          lds_put(dd, v0, n < 8 ? n : 8);
-          if (n > 8) lds_put(dd + 8, v1, n < 16 ? n - 8 : 8);
-          if (n > 16) {
-            lds_put(dd + 16, v2, n < 24 ? n - 16 : 8);
-            if (n > 24) lds_put(dd + 24, v3, n - 24);
-          }
-        } else {
-          stage_copy(dd, ss, n, d);
-        }
-        pend_update<false>(pend, qs, qs + ml);
-        rem &= ~(1u << cur);
-      }
-      if (rem) load(cur + 1);
+    const bool ready = rem != 0 && (sa >= sb || !pend_any(pend, sa, sb));
+    const uint32_t n = ml - skip;  // skip < ml: a near match reaches into the round
+    const bool fast = d >= n && n <= 32;  // the usual case: source and destination do not overlap
+    if constexpr (PF::on) {
+      if (__ballot(ready && !fast)) pf.count(C_LONG_NEAR);
     }
+    pf.tick_lds(P_NEAR);
+    if (ready && fast) {  // all loads in flight together
+      lds_u8 *dd = stage + qs + skip;
+      const lds_u8 *ss = stage + sa;
+      const uint64_t v0 = lds_ld64(ss), v1 = lds_ld64(ss + 8), v2 = lds_ld64(ss + 16), v3 = lds_ld64(ss + 24);
+      lds_put(dd, v0, n < 8 ? n : 8);
+      if (n > 8) lds_put(dd + 8, v1, n < 16 ? n - 8 : 8);
+      if (n > 16) {
+        lds_put(dd + 16, v2, n < 24 ? n - 16 : 8);
+        if (n > 24) lds_put(dd + 24, v3, n - 24);
+      }
+    }
+    pf.tick_lds(P_NEAR_FAST);
+    for (uint64_t lm = __ballot(ready && !fast); lm; lm &= lm - 1) {  // long or self-overlapping: the wave takes them one by one
+      const uint32_t l = (uint32_t)__builtin_ctzll(lm);
+      wave_copy(stage, rdlane(qs + skip, l), rdlane(sa, l), rdlane(n, l), rdlane(d, l), lane);
+    }
+    pf.tick_lds(P_NEAR_SLOW);
+    if (ready) {
+      pend_update<false>(pend, qs, qs + ml);
+      rem &= ~(1u << cur);
+    }
+    pf.tick_lds(P_NEAR_UPD);
+    if (rem) load(cur + 1);
+    pf.tick_lds(P_NEAR_LOAD);
   }
   pf.tick(P_NEAR);
 }
@@ -948,10 +976,14 @@ __device__ __forceinline__ int inflate_block(lds_smem *sm, const uint8_t *__rest
     const uint32_t R0 = sk.pos, rb = sk.sbase();
     uint32_t mynb = lane < nvalid ? nb : 0;
     const uint32_t off = wave_excl_scan(mynb, lane);
+    if (nvalid < 64) pf.count(C_END_CHAIN);
     {  // staging capacity: keep the largest prefix of lanes that fits (a lone first lane truncates itself)
       const uint64_t fits = __ballot((R0 - rb) + off + mynb <= STAGE - 16);
       const uint32_t nfit = fits == ~0ull ? 64 : (uint32_t)__builtin_ctzll(~fits);
-      if (nfit < nvalid) nvalid = nfit ? nfit : 1;
+      if (nfit < nvalid) {
+        nvalid = nfit ? nfit : 1;
+        pf.count(C_END_FIT);
+      }
     }
     const bool mine = lane < nvalid;
     if (!mine) mynb = 0;
@@ -971,6 +1003,8 @@ __device__ __forceinline__ int inflate_block(lds_smem *sm, const uint8_t *__rest
         const uint32_t fl = __builtin_ctzll(fm);
         lstop = rdlane(lo.stopc, fl);
         total = rdlane(off, fl) + rdlane(lo.bytes, fl);
+        if (lstop == kStEob) pf.count(C_END_EOB);
+        else if (lstop == kStTrunc) pf.count(rdlane(lo.nm, fl) == MMAX ? C_END_RECORDS : C_END_STAGE);
         if (lane > fl) lo.nm = 0;  // later lanes are void
         nvalid = fl + 1;
       } else {
@@ -1013,14 +1047,14 @@ __global__ __launch_bounds__(kWave) void inflate_wave_kernel(
     const uint64_t *__restrict__ in_len, uint8_t *out, const uint64_t *__restrict__ out_off,
     const uint64_t *__restrict__ out_cap, uint64_t *__restrict__ out_len,
     uint64_t *__restrict__ consumed, int32_t *__restrict__ status, uint32_t *__restrict__ checksum,
-    uint64_t *__restrict__ dbg) {
+    uint64_t *__restrict__ dbg, const uint32_t *__restrict__ order) {
   __shared__ Smem smem;  // static: LDS addresses fold into the instructions' offset fields
   lds_smem *sm = (lds_smem *)&smem;
   Prof<PROF> pf;
   pf.init();
   const uint32_t lane = threadIdx.x;
-  const uint32_t sid = blockIdx.x;
-  if (sid >= n) return;
+  if (blockIdx.x >= n) return;
+  const uint32_t sid = order ? order[blockIdx.x] : blockIdx.x;  // workgroups start in index order: longest streams first
 
   const uint8_t *src = in + in_off[sid];
   uint64_t slen64 = in_len[sid], cap64 = out_cap[sid];
@@ -1150,21 +1184,65 @@ __global__ __launch_bounds__(kWave) void inflate_wave_kernel(
   }
 }
 
+// Launch order of a batch: a stream's time grows with its compressed length, and a batch of more streams than the
+// chip holds at once (8 per CU) ends when its last wavefront does.  Workgroups are started in index order, so the
+// streams are handed out longest first (256 length classes, counting sort; the order inside a class is whatever
+// the atomics give — nothing a stream computes depends on it).
+constexpr uint32_t kOrderThreads = 1024, kOrderClasses = 256;
+__global__ __launch_bounds__(kOrderThreads) void inflate_order_kernel(uint32_t n, const uint64_t *__restrict__ in_len,
+                                                                      uint32_t *__restrict__ order) {
+  __shared__ uint32_t cls[kOrderClasses];
+  __shared__ uint32_t longest;
+  const uint32_t t = threadIdx.x;
+  if (t < kOrderClasses) cls[t] = 0;
+  if (t == 0) longest = 0;
+  __syncthreads();
+  uint32_t m = 0;
+  for (uint32_t i = t; i < n; i += kOrderThreads) {
+    const uint64_t l = in_len[i];
+    const uint32_t l32 = l > MD_MAX_INFLATE_IN ? 0u : (uint32_t)l;  // rejected at once by the kernel
+    m = l32 > m ? l32 : m;
+  }
+  atomicMax(&longest, m);
+  __syncthreads();
+  const uint64_t span = (uint64_t)longest + 1;
+  auto klass = [&](uint32_t i) {
+    const uint64_t l = in_len[i];
+    const uint32_t l32 = l > MD_MAX_INFLATE_IN ? 0u : (uint32_t)l;
+    return (kOrderClasses - 1) - (uint32_t)((uint64_t)l32 * kOrderClasses / span);  // class 0 = the longest
+  };
+  for (uint32_t i = t; i < n; i += kOrderThreads) atomicAdd(&cls[klass(i)], 1u);
+  __syncthreads();
+  if (t == 0) {  // exclusive scan of 256 counters
+    uint32_t acc = 0;
+    for (uint32_t c = 0; c < kOrderClasses; c++) {
+      const uint32_t v = cls[c];
+      cls[c] = acc;
+      acc += v;
+    }
+  }
+  __syncthreads();
+  for (uint32_t i = t; i < n; i += kOrderThreads) order[atomicAdd(&cls[klass(i)], 1u)] = i;
+}
+
 }  // namespace wv
 }  // namespace md
 
+// `order` = n words of device scratch, or null for index order
 extern "C" int md_launch_inflate_wave(int format, uint32_t n, const uint8_t *in, const uint64_t *in_off,
                                       const uint64_t *in_len, uint8_t *out, const uint64_t *out_off,
                                       const uint64_t *out_cap, uint64_t *out_len, uint64_t *consumed,
-                                      int32_t *status, uint32_t *checksum, uint64_t *dbg, hipStream_t stream) {
+                                      int32_t *status, uint32_t *checksum, uint64_t *dbg, uint32_t *order,
+                                      hipStream_t stream) {
   if (n == 0) return 0;
   using namespace md::wv;
   dim3 grid(n), block(kWave);
+  if (order) hipLaunchKernelGGL(inflate_order_kernel, dim3(1), dim3(kOrderThreads), 0, stream, n, in_len, order);
   if (dbg)
     hipLaunchKernelGGL((inflate_wave_kernel<true>), grid, block, 0, stream, format, n, in, in_off, in_len, out, out_off,
-                       out_cap, out_len, consumed, status, checksum, dbg);
+                       out_cap, out_len, consumed, status, checksum, dbg, (const uint32_t *)nullptr);
   else
     hipLaunchKernelGGL((inflate_wave_kernel<false>), grid, block, 0, stream, format, n, in, in_off, in_len, out, out_off,
-                       out_cap, out_len, consumed, status, checksum, dbg);
+                       out_cap, out_len, consumed, status, checksum, dbg, (const uint32_t *)order);
   return (int)hipGetLastError();
 }

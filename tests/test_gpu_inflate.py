@@ -280,3 +280,27 @@ def test_full_batch_c2(eng):
     assert (checksum.view(np.uint32) == want).all()
     for i in range(0, n, 64):
         assert d_out[i * nb:(i + 1) * nb].cpu().numpy().tobytes() == plains[i % 512]
+
+
+def test_launch_order_of_large_batches(eng, oracle):
+    """batches of more streams than the chip holds at once are started longest first (csrc/inflate_wave.hip,
+    inflate_order_kernel): 2500 streams of very different lengths, broken and oversize-capacity ones among them,
+    every result equals the oracle's — the order changes nothing a caller can see"""
+    import decompress_amd
+    from decompress_amd import workloads
+    rng = random.Random(2500)
+    srcs, caps = [], []
+    for i in range(2500):
+        k = i % 7
+        plain = workloads.text(i, rng.randrange(0, 3000)) if k < 4 else bytes(rng.getrandbits(8) for _ in range(rng.randrange(0, 600)))
+        z = zlib.compress(plain, 1 + i % 9)
+        if k == 5:
+            z = z[:rng.randrange(0, len(z))]           # truncated
+        if k == 6 and len(z) > 8:
+            z = z[:6] + bytes([z[6] ^ 0x5a]) + z[7:]   # damaged
+        srcs.append(z)
+        caps.append(len(plain) + (8 if i % 11 else -3 if len(plain) > 3 else 0))
+    res = eng.inflate_many(srcs, caps, decompress_amd.FORMAT_ZLIB)
+    for z, cap, (st, used, out, _) in zip(srcs, caps, res):
+        ost, oused, oout = oracle.zl_inflate(z, cap)
+        assert (st, used) == (ost, oused) and (st != 0 or out == oout)
