@@ -42,7 +42,8 @@ constexpr uint32_t SMIN = 48;      // ... and at least: where the data expands s
                                    // staging buffer, the zones shrink so that all 64 lanes still have work (cost then
                                    // follows the output, not the number of zones thrown away)
 constexpr uint32_t KMAX = 64;      // walk steps per lane per pass
-constexpr uint32_t PASSES = 5;     // walks after the first one
+constexpr uint32_t PASSES = 5;     // walks after the first one: at least this many are allowed, more when the zones are small
+constexpr uint32_t PASS_BITS = 1600, PASSES_MAX = 16;  // (a walk costs in proportion to the zone size)
 constexpr uint32_t MMAX = 14;      // match records per lane per round
 constexpr uint32_t STAGE = 6144;   // staging bytes (one round of output)
 constexpr uint32_t WIN_WORDS = 544;  // input window: 31 + 64*S + 47 bits and the two words a peek touches
@@ -932,11 +933,16 @@ __device__ __forceinline__ void copy_near_all(const lds_u32 *mrec, const lds_u16
   pf.tick(P_NEAR);
 }
 
+struct Zones {  // zone size of the next round (bits, wave-uniform), carried from block to block
+  uint32_t size;        // what the round uses
+  uint32_t by_records;  // its bound from the record lists
+};
+
 // ---------------------------------------------------------------------------
 // All rounds of one Huffman block.  bp is a bit position of the body; on return *bp_io is the bit after the EOB.
 template <class PF>
 __device__ __forceinline__ int inflate_block(lds_smem *sm, const uint8_t *__restrict__ body, uint32_t body_len, Sink &sk,
-                                             uint32_t lroot, uint32_t lane, uint32_t *bp_io, uint32_t *zone_io, PF &pf) {
+                                             uint32_t lroot, uint32_t lane, uint32_t *bp_io, Zones *zone_io, PF &pf) {
   uint32_t bp = *bp_io;
   lds_u32 *win = (lds_u32 *)sm->win;
   const lds_u32 *lut = (const lds_u32 *)sm->lut;
@@ -944,7 +950,8 @@ __device__ __forceinline__ int inflate_block(lds_smem *sm, const uint8_t *__rest
   lds_u16 *mpos = (lds_u16 *)sm->mpos;
   lds_u32 *pend = (lds_u32 *)sm->pend;
   const uint32_t total_bits = body_len * 8;
-  uint32_t zs = *zone_io;  // zone size of this round (wave-uniform), adapted to the expansion of the last one
+  uint32_t zs = zone_io->size;  // zone size of this round (wave-uniform), adapted to what the last one produced
+  uint32_t zrec = zone_io->by_records;
   for (;;) {
     const uint32_t base = (bp >> 5) << 2;  // window start (byte of the body, multiple of 4)
     win_load(win, body, body_len, base, lane);
@@ -957,7 +964,8 @@ __device__ __forceinline__ int inflate_block(lds_smem *sm, const uint8_t *__rest
     sync_pass<false>(win, lut, lroot, true, start, limit, end, stop, nb);
     pf.tick(P_DECODE1);
     bool counted = false;
-    for (uint32_t it = 0; it < PASSES; it++) {
+    const uint32_t passes = zs * PASSES >= PASS_BITS ? PASSES : PASS_BITS / zs > PASSES_MAX ? PASSES_MAX : PASS_BITS / zs;
+    for (uint32_t it = 0; it < passes; it++) {
       const uint32_t pe = __shfl_up(end, 1), ps = __shfl_up(stop, 1);
       const bool redo = lane == 0 ? !counted : (ps == 0 && (pe != start || !counted));
       if (__ballot(redo) == 0) break;
@@ -1027,17 +1035,23 @@ __device__ __forceinline__ int inflate_block(lds_smem *sm, const uint8_t *__rest
     pf.count(C_LANES, nvalid);
     const uint32_t nbp = base * 8 + rdlane(lo.endp, nvalid - 1);
     if (stuck || (nbp == bp && total == 0 && (lstop == 0 || lstop == kStTrunc))) return MD_E_HIP;  // defensive: no progress
-    {  // next round: 64 zones that fill about 7/8 of the staging buffer at this round's bytes-per-bit
+    {  // next round: 64 zones that fill about 7/8 of the staging buffer at this round's bytes-per-bit ...
       const uint32_t bits = nbp - bp;
       const uint64_t want = (uint64_t)(STAGE - STAGE / 8) * bits / ((uint64_t)kWave * (total ? total : 1u));
-      zs = want > S ? S : want < SMIN ? SMIN : (uint32_t)want;
+      // ... and whose matches fit a lane's record list: a round that one lane's full list cut short shrinks the
+      // zones, a round in which no list came close lets them grow again
+      if (lstop == kStTrunc && rdlane(lo.nm, nvalid - 1) == MMAX) zrec -= zrec / 8;
+      else if (__ballot(lane < nvalid && lo.nm + 2 >= MMAX) == 0) zrec = zrec + 16 > S ? S : zrec + 16;
+      zs = want < zrec ? (uint32_t)want : zrec;
+      zs = zs < SMIN ? SMIN : zs;
     }
     bp = nbp;
     if (lstop == kStEob) break;
     if (lstop != 0 && lstop != kStTrunc) return (int)lstop;
   }
   *bp_io = bp;
-  *zone_io = zs;
+  zone_io->size = zs;
+  zone_io->by_records = zrec;
   return MD_OK;
 }
 
@@ -1099,7 +1113,8 @@ __global__ __launch_bounds__(kWave) void inflate_wave_kernel(
 
   lds_u32 *win = (lds_u32 *)sm->win;
   const uint32_t total_bits = body_len * 8;
-  uint32_t bp = 0, zone = S;
+  uint32_t bp = 0;
+  Zones zone{S, S};
   if (lane < 4) sm->lut[kStopEobI + lane] = mk_entry(0, 0, 0, 0, kStopEobI + (lane & 1));  // the self-looping STOP entries
   for (uint32_t i = lane; i < STAGE / 32 + 2; i += kWave) sm->pend[i] = 0;
 
