@@ -78,6 +78,7 @@ struct HScratch {       // aliases Smem::stage
   uint32_t ctr;         // sub-table allocation counter
 };
 static_assert(sizeof(Smem) <= 20480, "8 wavefronts per CU");
+static_assert(MMAX * kWave * 2 <= WIN_WORDS * 4, "the list of near records fits the window");
 static_assert(sizeof(HScratch) <= STAGE, "header scratch lives in the staging buffer");
 typedef MD_LDS Smem lds_smem;
 typedef MD_LDS HScratch lds_hscratch;
@@ -304,8 +305,12 @@ constexpr uint64_t kZig1 = 12ull | 3ull << 5 | 13ull << 10 | 2ull << 15 | 14ull 
 
 // Dynamic block header (lib/de.ml:1733-1793) at window bit `bp`.  On MD_OK the walk tables are in lut,
 // *lroot_out is the index width of the lit/len root table and *bp_out the bit after the header.
-__device__ __noinline__ int dynamic_tables(lds_smem *sm, uint32_t bp, uint32_t tot, uint32_t lane, uint32_t *bp_out,
-                                           uint32_t *lroot_out) {
+template <class PF>
+__device__ __noinline__ int dynamic_tables(lds_smem *sm, uint32_t bp_arg, uint32_t tot_arg, uint32_t lane, uint32_t *bp_out,
+                                           uint32_t *lroot_out, PF &pf) {
+  // arguments of a function arrive in vector registers: say that these two are wave-uniform, or the whole header
+  // parse below is compiled as divergent vector code instead of scalar code
+  const uint32_t bp = uni(bp_arg), tot = uni(tot_arg);
   const lds_u32 *win = (const lds_u32 *)sm->win;
   lds_hscratch *hs = reinterpret_cast<lds_hscratch *>(sm->stage);
   UBits ub;
@@ -397,6 +402,7 @@ __device__ __noinline__ int dynamic_tables(lds_smem *sm, uint32_t bp, uint32_t t
     }
   }
   *bp_out = ub.pos();
+  pf.tick_lds(P_HDR_LENS);
   if (uni(hs->lens[256]) == 0) return MD_INVALID_DICTIONARY;
   // the two alphabets, lane-parallel
   uint32_t ll[5], dl[1];
@@ -420,6 +426,7 @@ __device__ __noinline__ int dynamic_tables(lds_smem *sm, uint32_t bp, uint32_t t
   if (!build_walk<5>(ll, cl_, lut, 0, kLitSize, hs, lane, mk_entry(0, 0, 0, lroot, 0),
                      [=](uint32_t sym, uint32_t codelen) { return lit_leaf(sym, codelen, lroot, droot); }))
     return MD_INVALID_DICTIONARY;
+  pf.tick_lds(P_HDR_LIT);
   if (cd_.max == 0) {  // empty_table: symbol 0 on a 1-bit code, the other slot is an error (D2)
     if (lane == 0) {
       lut[kDistB] = dist_leaf(0, 1, lroot);
@@ -868,67 +875,69 @@ __device__ __forceinline__ void wave_copy(lds_u8 *stage, uint32_t dd, uint32_t s
   }
 }
 
-// Near matches: the source reaches into this round's staging buffer.  A lane looks at one of its near matches per
-// step and copies it if no source byte is pending; a match that has to wait is put behind the lane's other ones, so
-// the lanes resolve their matches in dependency order rather than stream order.  The earliest unresolved match of
-// the round never waits, and every lane comes back to it, so the steps make progress.
+// Near matches: the source reaches into this round's staging buffer.  The lanes' near records are first listed in
+// stream order (lane by lane, a lane's records in order) and then taken 64 at a time, one per lane, whatever lane
+// decoded them: the work is spread evenly however the matches fell into the zones.  Everything a record of a group
+// can depend on is an earlier group (done) or the group itself, so a group is repeated until it is done; a record is
+// copied in the pass in which none of its source bytes is pending any more.  The earliest record left in a group
+// never waits: every pass makes progress.  `list` (the index of each record in mrec/mpos) lives in the input
+// window's space, which is not needed again before the next round loads it.
 template <class PF>
-__device__ __forceinline__ void copy_near_all(const lds_u32 *mrec, const lds_u16 *mpos, lds_u32 *pend, const Sink &sk,
-                                              uint32_t lane, uint32_t nearmask, bool *stuck, PF &pf) {
+__device__ __forceinline__ void copy_near_all(const lds_u32 *mrec, const lds_u16 *mpos, lds_u32 *pend, lds_u16 *list,
+                                              const Sink &sk, uint32_t lane, uint32_t nearmask, bool *stuck, PF &pf) {
   lds_u8 *stage = sk.stage;
   const uint32_t head = sk.pos - sk.sbase();  // staging index of the round start
-  uint32_t rem = nearmask, cur = 0, qs = 0, d = 0, ml = 0, sa = 0, sb = 0, skip = 0;
-  auto load = [&](uint32_t from) {  // the first remaining record at or after `from` (cyclic)
-    const uint32_t hi = rem & (0xffffffffu << from);
-    cur = (uint32_t)__builtin_ctz(hi ? hi : rem);
-    const uint32_t tk = mrec[cur * kWave + lane];
-    qs = mpos[cur * kWave + lane];
-    d = (tk & 0x7fff) + 1;
-    ml = ((tk >> 16) & 0xff) + 3;
+  const uint32_t mine = (uint32_t)__builtin_popcount(nearmask);
+  uint32_t at = wave_excl_scan(mine, lane);
+  const uint32_t count = rdlane(at + mine, kWave - 1);
+  for (uint32_t mm = nearmask; mm; mm &= mm - 1) list[at++] = (uint16_t)((uint32_t)__builtin_ctz(mm) * kWave + lane);
+  pf.tick_lds(P_NEAR_LOAD);
+  for (uint32_t c0 = 0; c0 < count; c0 += kWave) {
+    bool todo = c0 + lane < count;
+    const uint32_t e = todo ? list[c0 + lane] : 0u;
+    const uint32_t tk = mrec[e], qs = mpos[e];
+    const uint32_t d = (tk & 0x7fff) + 1, ml = ((tk >> 16) & 0xff) + 3;
     // source bytes: staging [qs - d, min(qs - d + ml, qs)); the part before the round start came from HBM (copy_far)
     const int32_t s0 = (int32_t)qs - (int32_t)d;
-    skip = s0 < (int32_t)head ? head - (uint32_t)s0 : 0u;
-    sa = (uint32_t)(s0 + (int32_t)skip);
-    sb = d < ml ? qs : (uint32_t)s0 + ml;
-  };
-  if (rem) load(0);
-  for (uint32_t guard = 0; __ballot(rem != 0) != 0; guard++) {
-    if (guard > kWave * MMAX * MMAX) {  // cannot happen
-      *stuck = true;
-      break;
-    }
-    pf.count(C_NEAR_IT);
-    const bool ready = rem != 0 && (sa >= sb || !pend_any(pend, sa, sb));
-    const uint32_t n = ml - skip;  // skip < ml: a near match reaches into the round
+    const uint32_t skip = s0 < (int32_t)head ? head - (uint32_t)s0 : 0u;
+    const uint32_t sa = (uint32_t)(s0 + (int32_t)skip), sb = d < ml ? qs : (uint32_t)s0 + ml;
+    const uint32_t n = ml - skip;         // skip < ml: a near match reaches into the round
     const bool fast = d >= n && n <= 32;  // the usual case: source and destination do not overlap
-    if constexpr (PF::on) {
-      if (__ballot(ready && !fast)) pf.count(C_LONG_NEAR);
-    }
-    pf.tick_lds(P_NEAR);
-    if (ready && fast) {  // all loads in flight together
-      lds_u8 *dd = stage + qs + skip;
-      const lds_u8 *ss = stage + sa;
-      const uint64_t v0 = lds_ld64(ss), v1 = lds_ld64(ss + 8), v2 = lds_ld64(ss + 16), v3 = lds_ld64(ss + 24);
-      lds_put(dd, v0, n < 8 ? n : 8);
-      if (n > 8) lds_put(dd + 8, v1, n < 16 ? n - 8 : 8);
-      if (n > 16) {
-        lds_put(dd + 16, v2, n < 24 ? n - 16 : 8);
-        if (n > 24) lds_put(dd + 24, v3, n - 24);
-      }
-    }
-    pf.tick_lds(P_NEAR_FAST);
-    for (uint64_t lm = __ballot(ready && !fast); lm; lm &= lm - 1) {  // long or self-overlapping: the wave takes them one by one
-      const uint32_t l = (uint32_t)__builtin_ctzll(lm);
-      wave_copy(stage, rdlane(qs + skip, l), rdlane(sa, l), rdlane(n, l), rdlane(d, l), lane);
-    }
-    pf.tick_lds(P_NEAR_SLOW);
-    if (ready) {
-      pend_update<false>(pend, qs, qs + ml);
-      rem &= ~(1u << cur);
-    }
-    pf.tick_lds(P_NEAR_UPD);
-    if (rem) load(cur + 1);
     pf.tick_lds(P_NEAR_LOAD);
+    for (uint32_t guard = 0; __ballot(todo) != 0; guard++) {
+      if (guard > kWave) {  // cannot happen
+        *stuck = true;
+        return;
+      }
+      pf.count(C_NEAR_IT);
+      const bool ready = todo && (sa >= sb || !pend_any(pend, sa, sb));
+      if constexpr (PF::on) {
+        if (__ballot(ready && !fast)) pf.count(C_LONG_NEAR);
+      }
+      pf.tick_lds(P_NEAR);
+      if (ready && fast) {  // all loads in flight together
+        lds_u8 *dd = stage + qs + skip;
+        const lds_u8 *ss = stage + sa;
+        const uint64_t v0 = lds_ld64(ss), v1 = lds_ld64(ss + 8), v2 = lds_ld64(ss + 16), v3 = lds_ld64(ss + 24);
+        lds_put(dd, v0, n < 8 ? n : 8);
+        if (n > 8) lds_put(dd + 8, v1, n < 16 ? n - 8 : 8);
+        if (n > 16) {
+          lds_put(dd + 16, v2, n < 24 ? n - 16 : 8);
+          if (n > 24) lds_put(dd + 24, v3, n - 24);
+        }
+      }
+      pf.tick_lds(P_NEAR_FAST);
+      for (uint64_t lm = __ballot(ready && !fast); lm; lm &= lm - 1) {  // long or self-overlapping: the wave takes them one by one
+        const uint32_t l = (uint32_t)__builtin_ctzll(lm);
+        wave_copy(stage, rdlane(qs + skip, l), rdlane(sa, l), rdlane(n, l), rdlane(d, l), lane);
+      }
+      pf.tick_lds(P_NEAR_SLOW);
+      if (ready) {
+        pend_update<false>(pend, qs, qs + ml);
+        todo = false;
+      }
+      pf.tick_lds(P_NEAR_UPD);
+    }
   }
   pf.tick(P_NEAR);
 }
@@ -1029,7 +1038,7 @@ __device__ __forceinline__ int inflate_block(lds_smem *sm, const uint8_t *__rest
       copy_far(mrec, mpos, pend, sk, lane, lo.nm, &nearmask, pf);
     }
     bool stuck = false;
-    copy_near_all(mrec, mpos, pend, sk, lane, nearmask, &stuck, pf);
+    copy_near_all(mrec, mpos, pend, (lds_u16 *)sm->win, sk, lane, nearmask, &stuck, pf);
     sk.flush(total);
     pf.tick(P_ADLER);
     pf.count(C_LANES, nvalid);
@@ -1167,7 +1176,7 @@ __global__ __launch_bounds__(kWave) void inflate_wave_kernel(
         if (type == 1) fixed_tables(sm, lane, &lroot);
         else {
           uint32_t hend = 0;
-          rc = dynamic_tables(sm, rbp + 3, tot, lane, &hend, &lroot);
+          rc = dynamic_tables(sm, rbp + 3, tot, lane, &hend, &lroot, pf);
           bp = base * 8 + hend;
         }
         lroot = uni(lroot);
