@@ -20,7 +20,7 @@ typedef uint64_t u64_u __attribute__((aligned(1)));
 typedef uint32_t u32_u __attribute__((aligned(1)));
 typedef uint16_t u16_u __attribute__((aligned(1)));
 
-enum { P_ENSURE = 0, P_DECODE1, P_DECODE2, P_EMIT_A, P_FAR, P_NEAR, P_ADLER, P_HEADER, P_NEAR_FAST, P_NEAR_SLOW, P_NEAR_UPD, P_NEAR_LOAD, P_HDR_LENS, P_HDR_LIT, P_COUNT };
+enum { P_ENSURE = 0, P_DECODE1, P_DECODE2, P_EMIT_A, P_FAR, P_NEAR, P_ADLER, P_HEADER, P_NEAR_FAST, P_NEAR_SLOW, P_NEAR_UPD, P_NEAR_LOAD, P_HDR_LENS, P_HDR_LIT, P_FAR_REC, P_FAR_LOAD, P_COUNT };
 enum { C_ROUNDS = 0, C_PASSES, C_LANES, C_TOKENS, C_SLOTS, C_NEAR_IT,
        C_END_CHAIN, C_END_FIT, C_END_RECORDS, C_END_STAGE, C_END_EOB, C_LONG_NEAR, C_COUNT };  // why rounds ended short
 template <bool ON>
@@ -43,6 +43,10 @@ struct Prof {
     __builtin_amdgcn_s_waitcnt(0xc07f);
     tick(i);
   }
+  __device__ __forceinline__ void tick_all(int i) {  // after every outstanding memory access has completed
+    __builtin_amdgcn_s_waitcnt(0);
+    tick(i);
+  }
   __device__ __forceinline__ void count(int i, uint32_t n = 1) { cnt[i] += n; }
 };
 template <>
@@ -51,6 +55,7 @@ struct Prof<false> {
   __device__ __forceinline__ void init() {}
   __device__ __forceinline__ void tick(int) {}
   __device__ __forceinline__ void tick_lds(int) {}
+  __device__ __forceinline__ void tick_all(int) {}
   __device__ __forceinline__ void count(int, uint32_t = 1) {}
 };
 

@@ -44,7 +44,8 @@ constexpr uint32_t SMIN = 48;      // ... and at least: where the data expands s
 constexpr uint32_t KMAX = 64;      // walk steps per lane per pass
 constexpr uint32_t PASSES = 5;     // walks after the first one: at least this many are allowed, more when the zones are small
 constexpr uint32_t PASS_BITS = 1600, PASSES_MAX = 16;  // (a walk costs in proportion to the zone size)
-constexpr uint32_t MMAX = 14;      // match records per lane per round
+constexpr uint32_t RMAX = 896;     // match records per round, all lanes together (in stream order)
+constexpr uint32_t FG = 12;        // far-match groups of 64 records whose loads are in flight together
 constexpr uint32_t STAGE = 6144;   // staging bytes (one round of output)
 constexpr uint32_t WIN_WORDS = 544;  // input window: 31 + 64*S + 47 bits and the two words a peek touches
 
@@ -62,13 +63,14 @@ constexpr uint32_t kStopBadI = kStopEobI + 1;
 constexpr uint32_t kLutWords = kStopEobI + 4;
 constexpr uint32_t kLinkVal = 511;
 constexpr uint32_t kStEob = 100, kStTrunc = 101;  // lane stop reasons; < 100 = MD_* status
+constexpr uint32_t kCountMatch = 1u << 20;         // a walk counts bytes | matches << 20 (64 lanes: < 2^20 bytes, < 2^12 matches)
 constexpr uint32_t kNearBit = 0x8000u;            // match record: len-3[23:16] | near[15] | dist-1[14:0]
 
 struct Smem {  // the kernel's only LDS object: it sits at LDS address 0
   uint32_t win[WIN_WORDS];
   uint32_t lut[kLutWords];
-  uint32_t mrec[MMAX * kWave];             // match records, [m][lane]
-  uint16_t mpos[MMAX * kWave];             // their staging positions
+  uint32_t mrec[RMAX];                     // the round's match records in stream order
+  uint16_t mpos[RMAX];                     // their staging positions
   alignas(16) uint8_t stage[STAGE + 16];   // one round of output; header scratch while a header is parsed
   uint32_t pend[STAGE / 32 + 2];           // bit per staging byte: still to be produced by a near match
 };
@@ -78,7 +80,7 @@ struct HScratch {       // aliases Smem::stage
   uint32_t ctr;         // sub-table allocation counter
 };
 static_assert(sizeof(Smem) <= 20480, "8 wavefronts per CU");
-static_assert(MMAX * kWave * 2 <= WIN_WORDS * 4, "the list of near records fits the window");
+static_assert(RMAX * 2 <= WIN_WORDS * 4, "the list of near records fits the window");
 static_assert(sizeof(HScratch) <= STAGE, "header scratch lives in the staging buffer");
 typedef MD_LDS Smem lds_smem;
 typedef MD_LDS HScratch lds_hscratch;
@@ -500,8 +502,8 @@ __device__ __forceinline__ void sync_pass(const lds_u32 *win, const lds_u32 *lut
       const uint32_t w = c.peek();
       const uint32_t e = lut_at(lut, tb, __builtin_amdgcn_ubfe(w, 0, nbits));
       const uint32_t codelen = e & 15, xb = (e >> 4) & 15, ntb = e >> 21;
-      if (COUNT) {
-        const uint32_t len1 = ((e >> 8) & 511) + __builtin_amdgcn_ubfe(w, codelen, xb) - 1;
+      if (COUNT) {  // bytes in the low 20 bits, matches above (kCountMatch)
+        const uint32_t len1 = ((e >> 8) & 511) + __builtin_amdgcn_ubfe(w, codelen, xb) + (kCountMatch - 1);
         cnt += (tb == 0 ? 1u : 0u) + (ntb == kDistB ? len1 : 0u);
       }
       p += codelen + xb;
@@ -520,7 +522,7 @@ struct LaneOut {
   uint32_t endp;   // bit after the last token taken (a token boundary)
   uint32_t stopc;  // 0 = zone done, kStEob, kStTrunc (round capacity), else MD_* status of the failing token
   uint32_t bytes;  // bytes produced (up to the failing token)
-  uint32_t nm;     // match records written
+  uint32_t nm;     // match records written (from the lane's first record on)
 };
 
 // The token at ptok, with every check in the oracle's order (oracle/de_inflate.c ns_inflate_block): called for
@@ -565,16 +567,17 @@ __device__ __noinline__ uint32_t slow_token(const lds_u32 *win, const lds_u32 *l
   const uint32_t lim = q < 32768u ? q : 32768u;
   if (d > lim) return MD_INVALID_DISTANCE;
   if (mlen > cap - q) return MD_UNEXPECTED_END_OF_OUTPUT;
-  return kStTrunc;  // the token is fine: the round's staging buffer or record list is full
+  return kStTrunc;  // the token is fine: the round's staging buffer is full
 }
 
 // The emit pass: the same walk from a validated start, producing output.  Straight-line per step; anything
 // unusual stops the lane in front of the token (ptok) and is classified afterwards by slow_token.
 __device__ __forceinline__ void emit_pass(const lds_u32 *win, const lds_u32 *lut, uint32_t lroot, lds_u32 *mrec,
-                                          lds_u16 *mpos, lds_u8 *stage, uint32_t lane, uint32_t tot, bool go, uint32_t start,
+                                          lds_u16 *mpos, lds_u8 *stage, uint32_t rec0, uint32_t tot, bool go, uint32_t start,
                                           uint32_t limit, uint32_t q0, uint32_t rb, uint32_t R0, uint32_t cap, LaneOut &lo) {
+  // rec0 = the lane's first record: the walk before counted the matches, the lanes' records follow each other
   uint32_t p = start, ptok = start, tb = 0, nbits = lroot;
-  uint32_t q = q0, nm = 0, mlen = 0;
+  uint32_t q = q0, rec = rec0, mlen = 0;
   bool stopped = false;
   const uint32_t qlim = rb + STAGE - 16;  // the staging buffer holds output positions [rb, qlim)
   const uint32_t qmax = cap < qlim ? cap : qlim;
@@ -595,14 +598,14 @@ __device__ __forceinline__ void emit_pass(const lds_u32 *win, const lds_u32 *lut
       const uint32_t lim = q < 32768u ? q : 32768u;
       const uint32_t need = mat ? mlen : 1u;
       const bool rare = (ntb >= kStopEobI) | ((val9 != kLinkVal) & (pn > tot)) |
-                        (mat & ((val9 >= 30u) | (d > lim) | (nm == MMAX))) | ((lit | mat) & (q + need > qmax));
+                        (mat & ((val9 >= 30u) | (d > lim))) | ((lit | mat) & (q + need > qmax));
       stopped = rare;
       if (!rare) {
         if (lit) stage[q - rb] = (uint8_t)val9;
         if (mat) {
-          mrec[nm * kWave + lane] = ((mlen - 3) << 16) | ((q - d + mlen > R0) ? kNearBit : 0u) | (d - 1);
-          mpos[nm * kWave + lane] = (uint16_t)(q - rb);
-          nm++;
+          mrec[rec] = ((mlen - 3) << 16) | ((q - d + mlen > R0) ? kNearBit : 0u) | (d - 1);
+          mpos[rec] = (uint16_t)(q - rb);
+          rec++;
         }
         mlen = is_len ? val9 + x : mlen;
         q += lit ? 1u : mat ? need : 0u;
@@ -623,7 +626,7 @@ __device__ __forceinline__ void emit_pass(const lds_u32 *win, const lds_u32 *lut
     lo.endp = endp;
     lo.stopc = stopc;
     lo.bytes = q - q0;
-    lo.nm = nm;
+    lo.nm = rec - rec0;
   }
 }
 
@@ -741,67 +744,72 @@ __device__ __forceinline__ void lds_put(lds_u8 *p, uint64_t v, uint32_t n) {
 }
 
 // Far matches (the whole source is older than this round: final in HBM/L2 once the flush of earlier rounds has
-// been waited for; d >= ml) and the heads of matches that straddle the round start.  Near matches are marked in
-// the pending map on the way; *nearmask_out = the lane's near records.  All of a lane's records are taken in one
-// go: 2 LDS reads per record, then up to 32 bytes per record in flight, then the stores.  The loads read whole
-// 8-byte words, up to 15 bytes past a record's source: the caller makes sure that stays inside the output buffer.
+// been waited for; d >= ml) and the heads of matches that straddle the round start.  The round's records are taken
+// in stream order, one per lane, FG x 64 at a time: 2 LDS reads per record, then up to 32 bytes per record in flight,
+// then the stores; what a record has beyond 32 bytes is copied by the whole wave, 8 bytes per lane.  Near matches
+// are marked in the pending map on the way and listed, in stream order, for copy_near_all (*nnear_out of them).  The
+// loads read whole 8-byte words, up to 15 bytes past a record's source: the caller makes sure that stays inside
+// the output buffer.
 template <class PF>
-__device__ __forceinline__ void copy_far(const lds_u32 *mrec, const lds_u16 *mpos, lds_u32 *pend, const Sink &sk, uint32_t lane,
-                                         uint32_t nm, uint32_t *nearmask_out, PF &pf) {
+__device__ __forceinline__ void copy_far(const lds_u32 *mrec, const lds_u16 *mpos, lds_u32 *pend, lds_u16 *list, const Sink &sk,
+                                         uint32_t lane, uint32_t nrec, uint32_t *nnear_out, PF &pf) {
   lds_u8 *stage = sk.stage;
   const uint32_t R0 = sk.pos, rb = sk.sbase();
   const uint8_t *g = sk.g;
-  uint32_t tk[MMAX], qs[MMAX], n[MMAX], src[MMAX];
+  uint32_t nnear = 0;
+  for (uint32_t c0 = 0; c0 < nrec; c0 += FG * kWave) {
+    uint32_t qs[FG], n[FG], src[FG];
+    uint64_t long32 = 0, long16 = 0;
 #pragma unroll
-  for (int u = 0; u < (int)MMAX; u++) {
-    tk[u] = mrec[u * kWave + lane];
-    qs[u] = mpos[u * kWave + lane];
-  }
-  uint32_t nearmask = 0;
-  uint64_t longm = 0;
-#pragma unroll
-  for (int u = 0; u < (int)MMAX; u++) {
-    const bool valid = (uint32_t)u < nm;
-    const uint32_t d = (tk[u] & 0x7fff) + 1, ml = ((tk[u] >> 16) & 0xff) + 3;
-    const uint32_t s = rb + qs[u] - d;
-    const bool near = valid && (tk[u] & kNearBit);
-    const uint32_t head = s < R0 ? R0 - s : 0u;  // a near match that begins before the round start: its head is final too
-    n[u] = !valid ? 0u : near ? head : ml;
-    src[u] = n[u] ? s : 0u;
-    if (near) {
-      nearmask |= 1u << u;
-      pend_update<true>(pend, qs[u], qs[u] + ml);
-    }
-    longm |= __ballot(n[u] > 16);
-  }
-  uint64_t v0[MMAX], v1[MMAX];
-#pragma unroll
-  for (int u = 0; u < (int)MMAX; u++) {
-    v0[u] = out_ld64(g + src[u]);
-    v1[u] = out_ld64(g + src[u] + 8);
-  }
-  if (longm == 0) {
-#pragma unroll
-    for (int u = 0; u < (int)MMAX; u++) {
-      if (n[u]) {
-        lds_u8 *dd = stage + qs[u];
-        lds_put(dd, v0[u], n[u] < 8 ? n[u] : 8);
-        if (n[u] > 8) lds_put(dd + 8, v1[u], n[u] - 8);
+    for (int u = 0; u < (int)FG; u++) {
+      qs[u] = 0;
+      n[u] = 0;
+      src[u] = 0;
+      if (c0 + u * kWave >= nrec) continue;  // (wave-uniform)
+      const uint32_t r = c0 + u * kWave + lane;
+      const bool has = r < nrec;
+      const uint32_t tk = mrec[has ? r : 0u];
+      qs[u] = mpos[has ? r : 0u];
+      const uint32_t d = (tk & 0x7fff) + 1, ml = ((tk >> 16) & 0xff) + 3;
+      const uint32_t s = rb + qs[u] - d;
+      const bool near = has && (tk & kNearBit);
+      const uint32_t head = s < R0 ? R0 - s : 0u;  // a near match that begins before the round start: its head is final too
+      n[u] = !has ? 0u : near ? head : ml;
+      src[u] = n[u] ? s : 0u;
+      const uint64_t nb = __ballot(near);
+      if (near) {
+        list[nnear + lane_rank(nb)] = (uint16_t)r;
+        pend_update<true>(pend, qs[u], qs[u] + ml);
       }
+      nnear += (uint32_t)__builtin_popcountll(nb);
+      long16 |= __ballot(n[u] > 16);
+      long32 |= __ballot(n[u] > 32);
     }
-  } else {
-    uint64_t v2[MMAX], v3[MMAX];
+    pf.tick_all(P_FAR_REC);
+    uint64_t v0[FG], v1[FG], v2[FG], v3[FG];
 #pragma unroll
-    for (int u = 0; u < (int)MMAX; u++) {
+    for (int u = 0; u < (int)FG; u++) {
+      v0[u] = 0;
+      v1[u] = 0;
       v2[u] = 0;
       v3[u] = 0;
-      if (n[u] > 16) {
-        v2[u] = out_ld64(g + src[u] + 16);
-        v3[u] = out_ld64(g + src[u] + 24);
+      if (c0 + u * kWave >= nrec) continue;
+      v0[u] = out_ld64(g + src[u]);
+      v1[u] = out_ld64(g + src[u] + 8);
+    }
+    if (long16) {
+#pragma unroll
+      for (int u = 0; u < (int)FG; u++) {
+        if (n[u] > 16) {
+          v2[u] = out_ld64(g + src[u] + 16);
+          v3[u] = out_ld64(g + src[u] + 24);
+        }
       }
     }
+    pf.tick_all(P_FAR_LOAD);
 #pragma unroll
-    for (int u = 0; u < (int)MMAX; u++) {
+    for (int u = 0; u < (int)FG; u++) {
+      if (c0 + u * kWave >= nrec) continue;
       if (n[u]) {
         lds_u8 *dd = stage + qs[u];
         lds_put(dd, v0[u], n[u] < 8 ? n[u] : 8);
@@ -809,34 +817,48 @@ __device__ __forceinline__ void copy_far(const lds_u32 *mrec, const lds_u16 *mpo
         if (n[u] > 16) {
           lds_put(dd + 16, v2[u], n[u] < 24 ? n[u] - 16 : 8);
           if (n[u] > 24) lds_put(dd + 24, v3[u], n[u] < 32 ? n[u] - 24 : 8);
-          for (uint32_t j = 32; j < n[u]; j += 8)  // very long far match: stream the rest (rare)
-            lds_put(dd + j, out_ld64(g + src[u] + j), n[u] - j < 8 ? n[u] - j : 8);
         }
       }
     }
+    if (long32) {  // the rest of the long ones, one record at a time by the whole wave
+#pragma unroll
+      for (int u = 0; u < (int)FG; u++) {
+        for (uint64_t lm = __ballot(n[u] > 32); lm; lm &= lm - 1) {
+          const uint32_t l = (uint32_t)__builtin_ctzll(lm);
+          const uint32_t ln = rdlane(n[u], l), lsrc = rdlane(src[u], l), lqs = rdlane(qs[u], l);
+          const uint32_t j = 32 + lane * 8;
+          if (j < ln) lds_put(stage + lqs + j, out_ld64(g + lsrc + j), ln - j < 8 ? ln - j : 8);
+        }
+      }
+    }
+    pf.tick_all(P_FAR);
   }
-  *nearmask_out = nearmask;
-  pf.tick(P_FAR);
+  *nnear_out = nnear;
 }
-// the same for the last rounds of a stream, where an 8-byte load could reach past the output buffer: one record at a time
+// the same for the last rounds of a stream, where an 8-byte load could reach past the output buffer: guarded loads
 template <class PF>
-__device__ __noinline__ void copy_far_guarded(const lds_u32 *mrec, const lds_u16 *mpos, lds_u32 *pend, lds_u8 *stage,
-                                              const uint8_t *g, uint32_t R0, uint32_t rb, uint32_t cap, uint32_t lane, uint32_t nm,
-                                              uint32_t *nearmask_out) {
-  uint32_t nearmask = 0;
-  for (uint32_t m = 0; m < nm; m++) {
-    const uint32_t tk = mrec[m * kWave + lane], qs = mpos[m * kWave + lane];
+__device__ __noinline__ void copy_far_guarded(const lds_u32 *mrec, const lds_u16 *mpos, lds_u32 *pend, lds_u16 *list,
+                                              lds_u8 *stage, const uint8_t *g, uint32_t R0, uint32_t rb, uint32_t cap,
+                                              uint32_t lane, uint32_t nrec, uint32_t *nnear_out) {
+  uint32_t nnear = 0;
+  for (uint32_t c0 = 0; c0 < nrec; c0 += kWave) {
+    const uint32_t r = c0 + lane;
+    const bool has = r < nrec;
+    const uint32_t tk = mrec[has ? r : 0u], qs = mpos[has ? r : 0u];
     const uint32_t d = (tk & 0x7fff) + 1, ml = ((tk >> 16) & 0xff) + 3;
     const uint32_t s = rb + qs - d;
-    uint32_t n = ml;
-    if (tk & kNearBit) {
-      nearmask |= 1u << m;
+    const bool near = has && (tk & kNearBit);
+    uint32_t n = has ? ml : 0u;
+    const uint64_t nb = __ballot(near);
+    if (near) {
+      list[nnear + lane_rank(nb)] = (uint16_t)r;
       pend_update<true>(pend, qs, qs + ml);
       n = s < R0 ? R0 - s : 0u;
     }
+    nnear += (uint32_t)__builtin_popcountll(nb);
     for (uint32_t j = 0; j < n; j += 8) lds_put(stage + qs + j, out_ld_guard(g, s + j, n - j, cap), n - j < 8 ? n - j : 8);
   }
-  *nearmask_out = nearmask;
+  *nnear_out = nnear;
 }
 
 // staging -> staging LZ77 copy of n bytes with forward-byte semantics (dst - src = d; overlap allowed), by the whole
@@ -875,23 +897,17 @@ __device__ __forceinline__ void wave_copy(lds_u8 *stage, uint32_t dd, uint32_t s
   }
 }
 
-// Near matches: the source reaches into this round's staging buffer.  The lanes' near records are first listed in
-// stream order (lane by lane, a lane's records in order) and then taken 64 at a time, one per lane, whatever lane
-// decoded them: the work is spread evenly however the matches fell into the zones.  Everything a record of a group
-// can depend on is an earlier group (done) or the group itself, so a group is repeated until it is done; a record is
-// copied in the pass in which none of its source bytes is pending any more.  The earliest record left in a group
-// never waits: every pass makes progress.  `list` (the index of each record in mrec/mpos) lives in the input
-// window's space, which is not needed again before the next round loads it.
+// Near matches: the source reaches into this round's staging buffer.  copy_far listed them in stream order; they
+// are taken 64 at a time, one per lane, whatever lane decoded them.  Everything a record of a group can depend on is
+// an earlier group (done) or the group itself, so a group is repeated until it is done; a record is copied in the
+// pass in which none of its source bytes is pending any more.  The earliest record left in a group never waits:
+// every pass makes progress.  `list` lives in the input window's space, which is not needed again before the next
+// round loads it.
 template <class PF>
-__device__ __forceinline__ void copy_near_all(const lds_u32 *mrec, const lds_u16 *mpos, lds_u32 *pend, lds_u16 *list,
-                                              const Sink &sk, uint32_t lane, uint32_t nearmask, bool *stuck, PF &pf) {
+__device__ __forceinline__ void copy_near_all(const lds_u32 *mrec, const lds_u16 *mpos, lds_u32 *pend, const lds_u16 *list,
+                                              const Sink &sk, uint32_t lane, uint32_t count, bool *stuck, PF &pf) {
   lds_u8 *stage = sk.stage;
   const uint32_t head = sk.pos - sk.sbase();  // staging index of the round start
-  const uint32_t mine = (uint32_t)__builtin_popcount(nearmask);
-  uint32_t at = wave_excl_scan(mine, lane);
-  const uint32_t count = rdlane(at + mine, kWave - 1);
-  for (uint32_t mm = nearmask; mm; mm &= mm - 1) list[at++] = (uint16_t)((uint32_t)__builtin_ctz(mm) * kWave + lane);
-  pf.tick_lds(P_NEAR_LOAD);
   for (uint32_t c0 = 0; c0 < count; c0 += kWave) {
     bool todo = c0 + lane < count;
     const uint32_t e = todo ? list[c0 + lane] : 0u;
@@ -942,16 +958,11 @@ __device__ __forceinline__ void copy_near_all(const lds_u32 *mrec, const lds_u16
   pf.tick(P_NEAR);
 }
 
-struct Zones {  // zone size of the next round (bits, wave-uniform), carried from block to block
-  uint32_t size;        // what the round uses
-  uint32_t by_records;  // its bound from the record lists
-};
-
 // ---------------------------------------------------------------------------
 // All rounds of one Huffman block.  bp is a bit position of the body; on return *bp_io is the bit after the EOB.
 template <class PF>
 __device__ __forceinline__ int inflate_block(lds_smem *sm, const uint8_t *__restrict__ body, uint32_t body_len, Sink &sk,
-                                             uint32_t lroot, uint32_t lane, uint32_t *bp_io, Zones *zone_io, PF &pf) {
+                                             uint32_t lroot, uint32_t lane, uint32_t *bp_io, uint32_t *zone_io, PF &pf) {
   uint32_t bp = *bp_io;
   lds_u32 *win = (lds_u32 *)sm->win;
   const lds_u32 *lut = (const lds_u32 *)sm->lut;
@@ -959,8 +970,7 @@ __device__ __forceinline__ int inflate_block(lds_smem *sm, const uint8_t *__rest
   lds_u16 *mpos = (lds_u16 *)sm->mpos;
   lds_u32 *pend = (lds_u32 *)sm->pend;
   const uint32_t total_bits = body_len * 8;
-  uint32_t zs = zone_io->size;  // zone size of this round (wave-uniform), adapted to what the last one produced
-  uint32_t zrec = zone_io->by_records;
+  uint32_t zs = *zone_io;  // zone size of this round (wave-uniform), adapted to the expansion of the last one
   for (;;) {
     const uint32_t base = (bp >> 5) << 2;  // window start (byte of the body, multiple of 4)
     win_load(win, body, body_len, base, lane);
@@ -991,76 +1001,76 @@ __device__ __forceinline__ int inflate_block(lds_smem *sm, const uint8_t *__rest
       nvalid = bad ? (uint32_t)__builtin_ctzll(bad) : 64;  // lane 0 is always counted: nvalid >= 1
     }
     const uint32_t R0 = sk.pos, rb = sk.sbase();
-    uint32_t mynb = lane < nvalid ? nb : 0;
+    uint32_t mynb = lane < nvalid ? nb : 0;  // bytes | matches << 20
     const uint32_t off = wave_excl_scan(mynb, lane);
     if (nvalid < 64) pf.count(C_END_CHAIN);
-    {  // staging capacity: keep the largest prefix of lanes that fits (a lone first lane truncates itself)
-      const uint64_t fits = __ballot((R0 - rb) + off + mynb <= STAGE - 16);
+    {  // staging and record capacity: keep the largest prefix of lanes that fits (a lone first lane truncates itself;
+       // its matches always fit)
+      const uint32_t bend = ((off + mynb) & (kCountMatch - 1)), rend = (off + mynb) >> 20;
+      const uint64_t fits = __ballot((R0 - rb) + bend <= STAGE - 16 && rend <= RMAX);
       const uint32_t nfit = fits == ~0ull ? 64 : (uint32_t)__builtin_ctzll(~fits);
       if (nfit < nvalid) {
+        pf.count(rdlane(rend, nfit) > RMAX ? C_END_RECORDS : C_END_FIT);
         nvalid = nfit ? nfit : 1;
-        pf.count(C_END_FIT);
       }
     }
     const bool mine = lane < nvalid;
     if (!mine) mynb = 0;
-    const uint32_t q0 = R0 + off;
+    const uint32_t boff = off & (kCountMatch - 1), roff = off >> 20;
+    const uint32_t q0 = R0 + boff;
     LaneOut lo;
     lo.endp = end;
     lo.stopc = 0;
     lo.bytes = 0;
     lo.nm = 0;
-    emit_pass(win, lut, lroot, mrec, mpos, sk.stage, lane, tot, mine, start, limit, q0, rb, R0, sk.cap, lo);
+    emit_pass(win, lut, lroot, mrec, mpos, sk.stage, roff, tot, mine, start, limit, q0, rb, R0, sk.cap, lo);
     pf.tick(P_EMIT_A);
     // the first stopped lane (stream order) ends the round
-    uint32_t total, lstop;
+    uint32_t total, lstop, nrec;
     {
       const uint64_t fm = __ballot(mine && lo.stopc != 0);
       if (fm) {
         const uint32_t fl = __builtin_ctzll(fm);
         lstop = rdlane(lo.stopc, fl);
-        total = rdlane(off, fl) + rdlane(lo.bytes, fl);
+        total = rdlane(boff, fl) + rdlane(lo.bytes, fl);
+        nrec = rdlane(roff, fl) + rdlane(lo.nm, fl);  // later lanes are void
         if (lstop == kStEob) pf.count(C_END_EOB);
-        else if (lstop == kStTrunc) pf.count(rdlane(lo.nm, fl) == MMAX ? C_END_RECORDS : C_END_STAGE);
-        if (lane > fl) lo.nm = 0;  // later lanes are void
+        else if (lstop == kStTrunc) pf.count(C_END_STAGE);
         nvalid = fl + 1;
       } else {
         lstop = 0;
-        total = rdlane(off + mynb, nvalid - 1);
+        const uint32_t all = rdlane(off + mynb, nvalid - 1);
+        total = all & (kCountMatch - 1);
+        nrec = all >> 20;
       }
     }
-    uint32_t nearmask = 0;
+    uint32_t nnear = 0;
+    lds_u16 *list = (lds_u16 *)sm->win;  // the window is done with until the next round loads it
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // earlier rounds' flushes have landed
     if (R0 + 40 > sk.cap) {
-      copy_far_guarded<PF>(mrec, mpos, pend, sk.stage, sk.g, R0, rb, sk.cap, lane, lo.nm, &nearmask);
+      copy_far_guarded<PF>(mrec, mpos, pend, list, sk.stage, sk.g, R0, rb, sk.cap, lane, nrec, &nnear);
       pf.tick(P_FAR);
     } else {
-      copy_far(mrec, mpos, pend, sk, lane, lo.nm, &nearmask, pf);
+      copy_far(mrec, mpos, pend, list, sk, lane, nrec, &nnear, pf);
     }
     bool stuck = false;
-    copy_near_all(mrec, mpos, pend, (lds_u16 *)sm->win, sk, lane, nearmask, &stuck, pf);
+    copy_near_all(mrec, mpos, pend, list, sk, lane, nnear, &stuck, pf);
     sk.flush(total);
     pf.tick(P_ADLER);
     pf.count(C_LANES, nvalid);
     const uint32_t nbp = base * 8 + rdlane(lo.endp, nvalid - 1);
     if (stuck || (nbp == bp && total == 0 && (lstop == 0 || lstop == kStTrunc))) return MD_E_HIP;  // defensive: no progress
-    {  // next round: 64 zones that fill about 7/8 of the staging buffer at this round's bytes-per-bit ...
+    {  // next round: 64 zones that fill about 7/8 of the staging buffer at this round's bytes-per-bit
       const uint32_t bits = nbp - bp;
       const uint64_t want = (uint64_t)(STAGE - STAGE / 8) * bits / ((uint64_t)kWave * (total ? total : 1u));
-      // ... and whose matches fit a lane's record list: a round that one lane's full list cut short shrinks the
-      // zones, a round in which no list came close lets them grow again
-      if (lstop == kStTrunc && rdlane(lo.nm, nvalid - 1) == MMAX) zrec -= zrec / 8;
-      else if (__ballot(lane < nvalid && lo.nm + 2 >= MMAX) == 0) zrec = zrec + 16 > S ? S : zrec + 16;
-      zs = want < zrec ? (uint32_t)want : zrec;
-      zs = zs < SMIN ? SMIN : zs;
+      zs = want > S ? S : want < SMIN ? SMIN : (uint32_t)want;
     }
     bp = nbp;
     if (lstop == kStEob) break;
     if (lstop != 0 && lstop != kStTrunc) return (int)lstop;
   }
   *bp_io = bp;
-  zone_io->size = zs;
-  zone_io->by_records = zrec;
+  *zone_io = zs;
   return MD_OK;
 }
 
@@ -1123,7 +1133,7 @@ __global__ __launch_bounds__(kWave) void inflate_wave_kernel(
   lds_u32 *win = (lds_u32 *)sm->win;
   const uint32_t total_bits = body_len * 8;
   uint32_t bp = 0;
-  Zones zone{S, S};
+  uint32_t zone = S;
   if (lane < 4) sm->lut[kStopEobI + lane] = mk_entry(0, 0, 0, 0, kStopEobI + (lane & 1));  // the self-looping STOP entries
   for (uint32_t i = lane; i < STAGE / 32 + 2; i += kWave) sm->pend[i] = 0;
 
