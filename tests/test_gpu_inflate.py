@@ -304,3 +304,35 @@ def test_launch_order_of_large_batches(eng, oracle):
     for z, cap, (st, used, out, _) in zip(srcs, caps, res):
         ost, oused, oout = oracle.zl_inflate(z, cap)
         assert (st, used) == (ost, oused) and (st != 0 or out == oout)
+
+
+def test_match_shapes(eng):
+    """the copy phases of a round (csrc/inflate_wave.hip: copy_far, copy_near_all, wave_copy) on inputs made for
+    them: self-overlapping matches of every small period and of periods around 8, 16, 32 and 258 (the whole wave
+    copies those), long far matches, matches that straddle round starts, and text so dense in short matches that a
+    round's record pool fills before its staging buffer"""
+    import decompress_amd
+    rng = random.Random(77)
+    rb = lambda n: bytes(rng.getrandbits(8) for _ in range(n))
+    plains = []
+    for p in (1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 15, 16, 17, 24, 31, 32, 33, 40, 63, 64, 65, 100, 200, 257, 258, 259, 300):
+        unit = rb(p)
+        plains.append(rb(50) + unit * (4000 // p + 2) + rb(20) + unit * (700 // p + 1))
+    block = rb(400)
+    plains.append(block + rb(20000) + block + rb(33) + block[:300] + rb(7000) + block[100:])           # long far matches
+    plains.append(b"".join(block[i:i + 258] + rb(3) for i in range(0, 140)) * 12)                        # 258-byte matches, near and far
+    grams = [rb(3) for _ in range(40)]
+    plains.append(b"".join(rng.choice(grams) + bytes([rng.randrange(256)]) for _ in range(30000)))        # a match every 4 bytes
+    plains.append(b"".join(rng.choice(grams) for _ in range(40000)))                                      # nothing but matches
+    plains.append(bytes(200000))                                                                          # one run
+    plains.append((b"ab" * 70 + b"c") * 900)
+    srcs, caps = [], []
+    for i, pl in enumerate(plains):
+        for level in (1, 6, 9):
+            srcs.append(zlib.compress(pl, level))
+            caps.append(len(pl))
+    res = eng.inflate_many(srcs, caps, decompress_amd.FORMAT_ZLIB)
+    for k, (st, used, out, adler) in enumerate(res):
+        pl = plains[k // 3]
+        assert (st, used) == (0, len(srcs[k])), (k, st)
+        assert out == pl and adler == zlib.adler32(pl), k
