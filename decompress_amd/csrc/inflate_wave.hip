@@ -571,7 +571,11 @@ __device__ __noinline__ uint32_t slow_token(const lds_u32 *win, const lds_u32 *l
 }
 
 // The emit pass: the same walk from a validated start, producing output.  Straight-line per step; anything
-// unusual stops the lane in front of the token (ptok) and is classified afterwards by slow_token.
+// unusual stops the lane in front of the token (ptok) and is classified afterwards by slow_token.  CHECKED = false
+// leaves out the tests the caller has ruled out for the whole round: the end of the input is beyond the window, the
+// output position is past 32 KiB (no distance can reach before the start) and everything counted fits the staging
+// buffer and the output capacity.
+template <bool CHECKED>
 __device__ __forceinline__ void emit_pass(const lds_u32 *win, const lds_u32 *lut, uint32_t lroot, lds_u32 *mrec,
                                           lds_u16 *mpos, lds_u8 *stage, uint32_t rec0, uint32_t tot, bool go, uint32_t start,
                                           uint32_t limit, uint32_t q0, uint32_t rb, uint32_t R0, uint32_t cap, LaneOut &lo) {
@@ -597,8 +601,9 @@ __device__ __forceinline__ void emit_pass(const lds_u32 *win, const lds_u32 *lut
       const uint32_t d = dist_value(val9, xb, x);
       const uint32_t lim = q < 32768u ? q : 32768u;
       const uint32_t need = mat ? mlen : 1u;
-      const bool rare = (ntb >= kStopEobI) | ((val9 != kLinkVal) & (pn > tot)) |
-                        (mat & ((val9 >= 30u) | (d > lim))) | ((lit | mat) & (q + need > qmax));
+      const bool rare = CHECKED ? (ntb >= kStopEobI) | ((val9 != kLinkVal) & (pn > tot)) |
+                                      (mat & ((val9 >= 30u) | (d > lim))) | ((lit | mat) & (q + need > qmax))
+                                : (ntb >= kStopEobI) | (mat & (val9 >= 30u));
       stopped = rare;
       if (!rare) {
         if (lit) stage[q - rb] = (uint8_t)val9;
@@ -1023,7 +1028,12 @@ __device__ __forceinline__ int inflate_block(lds_smem *sm, const uint8_t *__rest
     lo.stopc = 0;
     lo.bytes = 0;
     lo.nm = 0;
-    emit_pass(win, lut, lroot, mrec, mpos, sk.stage, roff, tot, mine, start, limit, q0, rb, R0, sk.cap, lo);
+    {
+      const uint32_t all = rdlane(off + mynb, nvalid - 1) & (kCountMatch - 1);  // bytes the round will produce
+      const bool plain = tot >= rbp + kWave * zs + 64 && R0 >= 32768u && all <= sk.cap - R0 && (R0 - rb) + all <= STAGE - 16;
+      if (plain) emit_pass<false>(win, lut, lroot, mrec, mpos, sk.stage, roff, tot, mine, start, limit, q0, rb, R0, sk.cap, lo);
+      else emit_pass<true>(win, lut, lroot, mrec, mpos, sk.stage, roff, tot, mine, start, limit, q0, rb, R0, sk.cap, lo);
+    }
     pf.tick(P_EMIT_A);
     // the first stopped lane (stream order) ends the round
     uint32_t total, lstop, nrec;
