@@ -108,28 +108,42 @@ __device__ __forceinline__ uint32_t dist_value(uint32_t dv, uint32_t xb, uint32_
 }
 
 // ---- input window -----------------------------------------------------------------------------
-// The window holds body bytes [base, base + 4*WIN_WORDS), base a multiple of 4; zero beyond the body.
-__device__ __forceinline__ void win_load(lds_u32 *win, const uint8_t *__restrict__ body, uint32_t nbytes, uint32_t base,
-                                         uint32_t lane) {
-  {
-    const uint32_t off = base + lane * 32;
-    uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+// The window holds body bytes [base, base + 4*WIN_WORDS), base a multiple of 4; zero beyond the body.  A lane loads
+// 32 bytes of it (and the first lanes one more word): fetch() starts the loads into registers, put() stores them to
+// LDS.  A round fetches the window of the next one as soon as it knows where that begins, so the copy phases hide
+// the latency (the window's LDS space is in use by then: copy_near_all's list).
+struct Window {
+  uint32_t w[8], wx;
+  uint32_t base;  // of the fetched words; 0xffffffff = nothing fetched
+  __device__ __forceinline__ void fetch(const uint8_t *__restrict__ body, uint32_t nbytes, uint32_t b, uint32_t lane) {
+    base = b;
+    const uint32_t off = b + lane * 32;
+#pragma unroll
+    for (int k = 0; k < 8; k++) w[k] = 0;
     if (off + 32 <= nbytes) __builtin_memcpy(w, body + off, 32);
     else if (off < nbytes)
       for (uint32_t k = 0; k < 32 && off + k < nbytes; k++) w[k >> 2] |= (uint32_t)body[off + k] << (8 * (k & 3));
+    wx = 0;
+    if (lane < WIN_WORDS - 512) {
+      const uint32_t ox = b + 2048 + lane * 4;
+      if (ox + 4 <= nbytes) __builtin_memcpy(&wx, body + ox, 4);
+      else if (ox < nbytes)
+        for (uint32_t k = 0; k < 4 && ox + k < nbytes; k++) wx |= (uint32_t)body[ox + k] << (8 * k);
+    }
+  }
+  __device__ __forceinline__ void put(lds_u32 *win, uint32_t lane) const {
     lds_u32 *dst = win + lane * 8;
 #pragma unroll
     for (int k = 0; k < 8; k++) dst[k] = w[k];
+    if (lane < WIN_WORDS - 512) win[512 + lane] = wx;
   }
-  if (lane < WIN_WORDS - 512) {
-    const uint32_t off = base + 2048 + lane * 4;
-    uint32_t w = 0;
-    if (off + 4 <= nbytes) __builtin_memcpy(&w, body + off, 4);
-    else if (off < nbytes)
-      for (uint32_t k = 0; k < 4 && off + k < nbytes; k++) w |= (uint32_t)body[off + k] << (8 * k);
-    win[512 + lane] = w;
+  // the window at `b` in LDS, from the fetched words if they are the right ones
+  __device__ __forceinline__ void ensure(lds_u32 *win, const uint8_t *__restrict__ body, uint32_t nbytes, uint32_t b, uint32_t lane) {
+    if (base != b) fetch(body, nbytes, b, lane);
+    put(win, lane);
+    base = 0xffffffffu;
   }
-}
+};
 // 32 bits of the window starting at window-relative bit position p
 __device__ __forceinline__ uint32_t peek(const lds_u32 *win, uint32_t p) {
   const lds_u32 *q = reinterpret_cast<const lds_u32 *>(reinterpret_cast<const lds_u8 *>(win) + ((p >> 3) & ~3u));
@@ -967,7 +981,8 @@ __device__ __forceinline__ void copy_near_all(const lds_u32 *mrec, const lds_u16
 // All rounds of one Huffman block.  bp is a bit position of the body; on return *bp_io is the bit after the EOB.
 template <class PF>
 __device__ __forceinline__ int inflate_block(lds_smem *sm, const uint8_t *__restrict__ body, uint32_t body_len, Sink &sk,
-                                             uint32_t lroot, uint32_t lane, uint32_t *bp_io, uint32_t *zone_io, PF &pf) {
+                                             uint32_t lroot, uint32_t lane, uint32_t *bp_io, uint32_t *zone_io, Window &wnd,
+                                             PF &pf) {
   uint32_t bp = *bp_io;
   lds_u32 *win = (lds_u32 *)sm->win;
   const lds_u32 *lut = (const lds_u32 *)sm->lut;
@@ -978,7 +993,7 @@ __device__ __forceinline__ int inflate_block(lds_smem *sm, const uint8_t *__rest
   uint32_t zs = *zone_io;  // zone size of this round (wave-uniform), adapted to the expansion of the last one
   for (;;) {
     const uint32_t base = (bp >> 5) << 2;  // window start (byte of the body, multiple of 4)
-    win_load(win, body, body_len, base, lane);
+    wnd.ensure(win, body, body_len, base, lane);
     const uint32_t rbp = bp - base * 8, tot = total_bits - base * 8;  // window-relative
     pf.tick(P_ENSURE);
     pf.count(C_ROUNDS);
@@ -1054,6 +1069,8 @@ __device__ __forceinline__ int inflate_block(lds_smem *sm, const uint8_t *__rest
         nrec = all >> 20;
       }
     }
+    const uint32_t nbp = base * 8 + rdlane(lo.endp, nvalid - 1);
+    wnd.fetch(body, body_len, (nbp >> 5) << 2, lane);  // the next round's (or the next block header's) window: on its way
     uint32_t nnear = 0;
     lds_u16 *list = (lds_u16 *)sm->win;  // the window is done with until the next round loads it
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // earlier rounds' flushes have landed
@@ -1068,7 +1085,6 @@ __device__ __forceinline__ int inflate_block(lds_smem *sm, const uint8_t *__rest
     sk.flush(total);
     pf.tick(P_ADLER);
     pf.count(C_LANES, nvalid);
-    const uint32_t nbp = base * 8 + rdlane(lo.endp, nvalid - 1);
     if (stuck || (nbp == bp && total == 0 && (lstop == 0 || lstop == kStTrunc))) return MD_E_HIP;  // defensive: no progress
     {  // next round: 64 zones that fill about 7/8 of the staging buffer at this round's bytes-per-bit
       const uint32_t bits = nbp - bp;
@@ -1144,6 +1160,8 @@ __global__ __launch_bounds__(kWave) void inflate_wave_kernel(
   const uint32_t total_bits = body_len * 8;
   uint32_t bp = 0;
   uint32_t zone = S;
+  Window wnd;
+  wnd.base = 0xffffffffu;
   if (lane < 4) sm->lut[kStopEobI + lane] = mk_entry(0, 0, 0, 0, kStopEobI + (lane & 1));  // the self-looping STOP entries
   for (uint32_t i = lane; i < STAGE / 32 + 2; i += kWave) sm->pend[i] = 0;
 
@@ -1151,7 +1169,7 @@ __global__ __launch_bounds__(kWave) void inflate_wave_kernel(
     bool last = false;
     while (!last && rc == MD_OK) {
       const uint32_t base = (bp >> 5) << 2;
-      win_load(win, body, body_len, base, lane);
+      wnd.ensure(win, body, body_len, base, lane);
       const uint32_t rbp = bp - base * 8, tot = total_bits - base * 8;
       if ((int32_t)(tot - rbp) < 3) {
         rc = MD_UNEXPECTED_END_OF_INPUT;
@@ -1201,7 +1219,7 @@ __global__ __launch_bounds__(kWave) void inflate_wave_kernel(
         }
         lroot = uni(lroot);
         pf.tick(P_HEADER);
-        if (rc == MD_OK) rc = inflate_block(sm, body, body_len, sk, lroot, lane, &bp, &zone, pf);
+        if (rc == MD_OK) rc = inflate_block(sm, body, body_len, sk, lroot, lane, &bp, &zone, wnd, pf);
       }
     }
   }
