@@ -92,97 +92,7 @@ __device__ __forceinline__ uint64_t out_ld_guard(const uint8_t *g, uint32_t x, u
   for (uint32_t j = 0; j < n && j < 8; j++) v |= (uint64_t)out_ld8(g + x + j) << (8 * j);
   return v;
 }
-// store the low n (1..8) bytes of v
-__device__ __forceinline__ void out_st(uint8_t *p, uint64_t v, uint32_t n) {
-  if (n >= 8) {
-    *reinterpret_cast<u64_u *>(p) = v;
-    return;
-  }
-  if (n & 4) {
-    *reinterpret_cast<u32_u *>(p) = (uint32_t)v;
-    p += 4;
-    v >>= 32;
-  }
-  if (n & 2) {
-    *reinterpret_cast<u16_u *>(p) = (uint16_t)v;
-    p += 2;
-    v >>= 16;
-  }
-  if (n & 1) *p = (uint8_t)v;
-}
-// LZ77 copy of ml bytes to g[q ..) from d bytes back.  Every source byte is read
-// from [q-d, q) — final and visible — never from bytes this copy writes itself.
-// Loads of up to 32 bytes are in flight together.
-__device__ __forceinline__ void copy_match(uint8_t *g, uint32_t q, uint32_t ml, uint32_t d, uint32_t cap) {
-  const uint32_t src = q - d;
-  if (d >= 8) {
-    for (uint32_t o = 0; o < ml; o += d) {  // periodic: dst[o + j] = orig[j], j < d
-      const uint32_t n = ml - o < d ? ml - o : d;
-      for (uint32_t j = 0; j < n; j += 32) {
-        const uint32_t m = n - j;
-        uint64_t v[4];
-#pragma unroll
-        for (uint32_t u = 0; u < 4; u++) v[u] = m > 8 * u ? out_ld_guard(g, src + j + 8 * u, m - 8 * u, cap) : 0;
-#pragma unroll
-        for (uint32_t u = 0; u < 4; u++)
-          if (m > 8 * u) out_st(g + q + o + j + 8 * u, v[u], m - 8 * u);
-      }
-    }
-  } else {
-    // period d < 8: replicate the last d bytes into a 64-bit pattern
-    uint64_t v = out_ld_guard(g, src, d, cap);
-    const uint32_t sh = 8 * d;
-    v &= (1ull << sh) - 1;
-    v |= v << sh;
-    if (2 * sh < 64) v |= v << (2 * sh);
-    if (4 * sh < 64) v |= v << (4 * sh);
-    const uint32_t adv = d * (8 / d);  // largest multiple of the period that fits 8 bytes
-    uint32_t j = 0;
-    for (; j + 8 <= ml; j += adv) out_st(g + q + j, v, 8);
-    if (j < ml) out_st(g + q + j, v, ml - j);
-  }
-}
-
 __device__ __forceinline__ uint64_t lds_ld64(const lds_u8 *p) { return *reinterpret_cast<const MD_LDS u64_u *>(p); }
-__device__ __forceinline__ void lds_st64(lds_u8 *p, uint64_t v) { *reinterpret_cast<MD_LDS u64_u *>(p) = v; }
-// store the low r (< 8) bytes of v
-__device__ __forceinline__ void lds_st_tail(lds_u8 *p, uint64_t v, uint32_t r) {
-  if (r & 4) {
-    *reinterpret_cast<MD_LDS u32_u *>(p) = (uint32_t)v;
-    p += 4;
-    v >>= 32;
-  }
-  if (r & 2) {
-    *reinterpret_cast<MD_LDS u16_u *>(p) = (uint16_t)v;
-    p += 2;
-    v >>= 16;
-  }
-  if (r & 1) *p = (uint8_t)v;
-}
-__device__ __forceinline__ void lds_st(lds_u8 *p, uint64_t v, uint32_t n) {
-  if (n >= 8) lds_st64(p, v);
-  else lds_st_tail(p, v, n);
-}
-// staging -> staging LZ77 copy with forward-byte semantics (overlap allowed)
-__device__ __forceinline__ void copy_near(lds_u8 *dst, const lds_u8 *src, uint32_t ml, uint32_t d) {
-  if (d >= 8) {
-    uint32_t j = 0;
-    for (; j + 8 <= ml; j += 8) lds_st64(dst + j, lds_ld64(src + j));
-    if (j < ml) lds_st_tail(dst + j, lds_ld64(src + j), ml - j);
-  } else {
-    // period d < 8: replicate the last d bytes into a 64-bit pattern
-    uint64_t v = lds_ld64(src);
-    const uint32_t sh = 8 * d;
-    v &= (1ull << sh) - 1;
-    v |= v << sh;
-    if (2 * sh < 64) v |= v << (2 * sh);
-    if (4 * sh < 64) v |= v << (4 * sh);
-    const uint32_t adv = d * (8 / d);  // largest multiple of the period that fits 8 bytes
-    uint32_t j = 0;
-    for (; j + 8 <= ml; j += adv) lds_st64(dst + j, v);
-    if (j < ml) lds_st_tail(dst + j, v, ml - j);
-  }
-}
 
 }  // namespace wv
 }  // namespace md

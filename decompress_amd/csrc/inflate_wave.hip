@@ -1,27 +1,31 @@
 // inflate_wave.hip — batched RFC1951 inflate for gfx950 (MI355X): one stream per wavefront, one kernel.
 //
-// The 64 lanes decode 64 consecutive S-bit zones of the compressed block per round:
+// The 64 lanes decode 64 consecutive zones (48 .. S bits, re-sized every round from what the last one produced) of
+// the compressed block per round:
 //
 //   sync   Light passes that only FIND TOKEN BOUNDARIES.  Pass 0: lane i walks the tokens from bit
 //          bp + i*S until it crosses bp + (i+1)*S (only lane 0 starts on a boundary, the others
 //          are speculative).  Pass k >= 1: a lane whose left neighbour ended somewhere else than
-//          where it started walks again from there and now also counts the bytes its tokens will
-//          produce.  Huffman streams re-synchronise (p ~ 0.9 inside a zone), so the chain
-//          start_i == end_{i-1} settles after ~3 passes; the consistent prefix of lanes is
+//          where it started walks again from there and now also counts the bytes and matches its
+//          tokens will produce.  Huffman streams re-synchronise (p ~ 0.9 inside a full zone), so the
+//          chain start_i == end_{i-1} settles after ~4 passes; the consistent prefix of lanes is
 //          accepted.  A chain of token boundaries that starts on a known boundary IS the serial
 //          decode of the reference loop (`inflate`, lib/de.ml:1667-1712).  A walk step is one
 //          32-bit peek of the input window in LDS and one 32-bit LUT entry that carries the bits
 //          to skip and the descriptor (index width, base) of the table the NEXT step indexes, so
 //          the step has no per-type branches or selects.
 //   emit   One pass over the accepted lanes from their validated starts.  A wave prefix sum of
-//          the byte counts has given every lane its output position, so literals go straight
-//          to their final place in the LDS staging buffer and matches become (length, distance,
-//          position) records.  Anything unusual (end of block, an invalid code, a distance or
-//          length the output cannot take, a full buffer) stops the lane in front of the token;
-//          the token is then looked at again with the checks in the reference's order.
-//   copy   Matches whose source is older than the round read it from already flushed output
-//          (L2/HBM, 8 matches x 32 bytes in flight per lane); matches into the round itself wait
-//          on a bitmap of the staging bytes that are still to be produced.
+//          the counts has given every lane its output position and its first record, so literals
+//          go straight to their final place in the LDS staging buffer and matches become (length,
+//          distance, position) records in one pool, in stream order.  Anything unusual (end of
+//          block, an invalid code, a distance or length the output cannot take, a full buffer)
+//          stops the lane in front of the token; the token is then looked at again with the checks
+//          in the reference's order.
+//   copy   By record, 64 per step across the wave.  Matches whose source is older than the round
+//          read it from already flushed output (L2/HBM, up to 32 bytes per record, all of the
+//          round's records in flight together); matches into the round itself are listed and wait
+//          on a bitmap of the staging bytes that are still to be produced; long and self-overlapping
+//          ones are copied by the whole wave.
 //   flush  16-byte coalesced stores, Adler-32 folded in the same pass with v_dot4_u32_u8
 //          (WInf.update / tail, lib/de.ml:453-455, 499-505).
 //
