@@ -294,7 +294,7 @@ def main():
     # every rank owns different streams (seed offset by rank): weak scaling
     t_gen = time.perf_counter()
     streams = workloads.c2_streams(n, nbytes=nbytes, level=args.level, first=rank * n,
-                                   unique=unique, workers=max(1, (os.cpu_count() or 8) // max(1, world)))
+                                   unique=unique, workers=max(1, min(32, (os.cpu_count() or 8) // max(1, world))))
     t_gen = time.perf_counter() - t_gen
     assert all(((s[2] >> 1) & 3) == 2 for s in streams[:64]), "first block must be dynamic Huffman"
     blob, in_off, in_len = workloads.pack(streams, align=16)
