@@ -1420,6 +1420,12 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
           const uint32_t pos = pe + g * kWave + lane;
           const bool valid = pos < p_end;
           const uint32_t h = hv[g];
+          // A lane that shares its hash with an earlier lane of the step got back a position of this step (or of a
+          // later one: `bad`).  No such lane: every returned value is the head before the step, i.e. the answer.
+          if (__ballot(valid && ret[g] >= pe + g * kWave) == 0) {
+            c1[g] = valid ? ret[g] : 0;
+            continue;
+          }
           // lanes of this step with the same hash: intersect the ballots of the 15 hash bits
           uint64_t same = __ballot(valid);
 #pragma unroll
