@@ -367,10 +367,16 @@ int orc_de_inf_ns_inflate(const uint8_t *src, size_t src_len, uint8_t *dst,
   *consumed = 0;
   *written = 0;
   for (;;) {
-    int last, type, rc;
-    TRY(fill_bits(&d, 3));
-    TRY(pop_bits(&d, 1, &last));
-    TRY(pop_bits(&d, 2, &type));
+    int last = 0, type = 0, rc;
+    /* a failure in the 3 header bits reports what the earlier blocks wrote, like a failure inside a block
+     * (the reference returns `Error e` without counts either way; the C ABI reports the bytes produced) */
+    rc = fill_bits(&d, 3);
+    if (!rc) rc = pop_bits(&d, 1, &last);
+    if (!rc) rc = pop_bits(&d, 2, &type);
+    if (rc) {
+      *written = d.o_pos;
+      return rc;
+    }
     switch (type) {
     case 0: rc = ns_flat(&d); break;
     case 1:

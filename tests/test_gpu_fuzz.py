@@ -121,3 +121,12 @@ def test_deflate_random_parameters(oracle, seed):
                     continue
                 assert st == 0 and out == w, (seed, matcher, level, q, driver, dyn, len(b))
                 assert zlib.decompress(out, -15) == b and adler == zlib.adler32(b)
+
+
+def test_random_streams_every_field():
+    """tests/stress_inflate.py, a bounded run: random plaintexts of nine kinds (random, text, runs, periods, corpus
+    slices, n-gram soup, two-symbol, repeated halves, ASCII) compressed at random levels / memory levels /
+    strategies, some truncated or with a flipped bit, output capacities exact, generous or short, batches of 7,
+    300 and 2300 streams: status, consumed count AND the bytes written before a failure equal the oracle's"""
+    from tests import stress_inflate
+    assert stress_inflate.run(8, 20260928, verbose=False) == 0
