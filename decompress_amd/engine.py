@@ -20,6 +20,7 @@ STATUS_NAMES = {
     13: "Queue.Full", 14: "Invalid input", 15: "No dictionary at offset 0 available",
     16: "Input is malformed or output is not large enough",
 }
+STATUS_CODES = {v: k for k, v in STATUS_NAMES.items()}
 
 
 class Error(RuntimeError):
