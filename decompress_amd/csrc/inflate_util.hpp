@@ -2,6 +2,7 @@
 // copies with LZ77 forward-byte semantics, wave scans, the optional in-kernel phase profile.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 #include "mdeflate.h"

@@ -393,33 +393,45 @@ __device__ __noinline__ int dynamic_tables(lds_smem *sm, uint32_t bp_arg, uint32
   // the hlit + hdist code lengths, run-length coded (lib/de.ml:1733-1769)
   const uint32_t max_res = hlit + hdist;
   for (uint32_t x = lane; x < 384; x += kWave) hs->lens[x] = 0;
-  uint32_t i = 0, prev = 0;
-  while (i < max_res) {
-    ub.fill();
-    if ((int32_t)(tot - ub.pos()) < (int32_t)cmaxl) return MD_UNEXPECTED_END_OF_INPUT;
-    const uint32_t idx = ub.peekb(cmaxl);
-    const uint32_t e = idx < 64 ? __builtin_amdgcn_readlane(t_lo, idx) : __builtin_amdgcn_readlane(t_hi, idx - 64);
-    if (e == 0xffffu) return MD_INVALID_DICTIONARY;
-    const uint32_t sym = e & 0xff;
-    ub.drop(e >> 8);
-    if (sym < 16) {
-      if (lane == 0) hs->lens[i] = (uint8_t)sym;
-      prev = sym;
-      i++;
-    } else {
-      const uint32_t nb = sym == 16 ? 2 : sym == 17 ? 3 : 7;
-      if (sym == 16 && i == 0) return MD_INVALID_DICTIONARY;
+  // One scalar step per symbol.  With enough input left for the longest header there can be (316 symbols of 7 + 7
+  // bits) the end-of-input tests are left out of the loop.
+  auto run_lengths = [&](auto checked) -> int {
+    constexpr bool CHECK = decltype(checked)::value;
+    uint32_t i = 0, prev = 0;
+    while (i < max_res) {
       ub.fill();
-      if ((int32_t)(tot - ub.pos()) < (int32_t)nb) return MD_UNEXPECTED_END_OF_INPUT;
-      const uint32_t copy = ub.peekb(nb) + (sym == 18 ? 11 : 3);
-      ub.drop(nb);
-      const uint32_t val = sym == 16 ? prev : 0;
-      if (i + copy > max_res) return MD_INVALID_DICTIONARY;
-      if (val)
-        for (uint32_t x = lane; x < copy; x += kWave) hs->lens[i + x] = (uint8_t)val;
-      prev = val;
-      i += copy;
+      if (CHECK && (int32_t)(tot - ub.pos()) < (int32_t)cmaxl) return MD_UNEXPECTED_END_OF_INPUT;
+      const uint32_t idx = ub.peekb(cmaxl);
+      const uint32_t e_lo = __builtin_amdgcn_readlane(t_lo, idx & 63), e_hi = __builtin_amdgcn_readlane(t_hi, idx & 63);
+      const uint32_t e = idx < 64 ? e_lo : e_hi;
+      if (e == 0xffffu) return MD_INVALID_DICTIONARY;
+      const uint32_t sym = e & 0xff;
+      ub.drop(e >> 8);
+      if (sym < 16) {
+        hs->lens[i] = (uint8_t)sym;  // every lane stores the same byte: no exec-mask change on the scalar path
+        prev = sym;
+        i++;
+      } else {
+        const uint32_t nb = sym == 16 ? 2 : sym == 17 ? 3 : 7;
+        if (sym == 16 && i == 0) return MD_INVALID_DICTIONARY;
+        ub.fill();
+        if (CHECK && (int32_t)(tot - ub.pos()) < (int32_t)nb) return MD_UNEXPECTED_END_OF_INPUT;
+        const uint32_t copy = ub.peekb(nb) + (sym == 18 ? 11 : 3);
+        ub.drop(nb);
+        const uint32_t val = sym == 16 ? prev : 0;
+        if (i + copy > max_res) return MD_INVALID_DICTIONARY;
+        if (val)
+          for (uint32_t x = lane; x < copy; x += kWave) hs->lens[i + x] = (uint8_t)val;
+        prev = val;
+        i += copy;
+      }
     }
+    return MD_OK;
+  };
+  {
+    const bool plenty = (int32_t)(tot - ub.pos()) >= 316 * 14 + 64;
+    const int rc = plenty ? run_lengths(std::false_type{}) : run_lengths(std::true_type{});
+    if (rc != MD_OK) return rc;
   }
   *bp_out = ub.pos();
   pf.tick_lds(P_HDR_LENS);
