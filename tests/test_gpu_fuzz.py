@@ -130,3 +130,11 @@ def test_random_streams_every_field():
     300 and 2300 streams: status, consumed count AND the bytes written before a failure equal the oracle's"""
     from tests import stress_inflate
     assert stress_inflate.run(8, 20260928, verbose=False) == 0
+
+
+def test_random_buffers_deflate_every_byte():
+    """tests/stress_deflate.py, a bounded run: random buffers of nine kinds through Zl.Def, De.Higher, the CLI
+    driver and the Lz matcher at random levels, queue sizes and block kinds, exact-fit and one-byte-short output
+    capacities: every compressed byte and status equals the oracle's (Queue.Full included)"""
+    from tests import stress_deflate
+    assert stress_deflate.run(12, 20260928, verbose=False) == 0
