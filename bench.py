@@ -24,6 +24,11 @@ Prints ONE JSON line (rank 0).
   deflate       BASELINE.json config[2] on the same GPU(s), outside the inflate timed region: 4096 x 1 MiB
                 printable-ASCII buffers, De.Lz77 + De.Def level 6, queue 4096, Zl driver — its own value,
                 ms_per_step, roofline and cpu_baseline (BASELINE's metric is "inflate+deflate").
+  r01_workload  the same kernel on round 1's input (every stream seeded word text), N = 1 only.
+  gzip, lzo     BASELINE.json config[3] / config[4], one GPU's share each (N = 1 only, outside `value`): 4096 gzip
+                members = the reference's corpus files cycled, Gz.Def level 4 then Gz.Inf; 8192 x 128 KiB buffers
+                through Lzo.compress then Lzo.uncompress — MiB/s, ms and HBM fraction per direction, round trip
+                and oracle bytes checked.
   ranks_seen    an all_reduce over the process group: how many ranks really took part.
 For N > 1 the per-stream results of every rank (sizes and Adler-32 from the kernel) are gathered with
 decompress_amd.shard.gather_varlen — the path's only exchange (RCCL over xGMI).
@@ -69,6 +74,7 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-deflate", action="store_true", help="skip the deflate leg (config 3)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the gzip (config 4) and LZO (config 5) legs")
     ap.add_argument("--no-text-leg", action="store_true", help="skip the extra inflate measurement on round 1's workload")
     ap.add_argument("--deflate-streams", type=int, default=4096)
     ap.add_argument("--deflate-kib", type=int, default=1024)
@@ -255,6 +261,106 @@ def deflate_leg(args, eng, dev, rank, world, dist, fence):
     return leg
 
 
+def gzip_leg(args, eng, dev):
+    """BASELINE config 4's per-GPU share: 4096 gzip members = the 15 files of the reference's test/corpus cycled,
+    Gz.Def level 4 (mtime 0, OS Unix, no name) then Gz.Inf; bytes checked against the oracle on one cycle."""
+    import numpy as np
+    import torch
+    import decompress_amd
+    from decompress_amd import workloads
+    n = 4096
+    uniq = list(workloads.corpus().values())
+    bufs = [uniq[i % len(uniq)] for i in range(n)]
+    blob, off, ln = workloads.pack(bufs)
+    cap = (ln + 8192).astype(np.int64)
+    ooff = np.zeros(n, dtype=np.int64)
+    np.cumsum(((cap + 255) // 256 * 256)[:-1], out=ooff[1:])
+    t = lambda a: torch.from_numpy(a).to(dev)
+    d_in, d_off, d_len = t(blob), t(off), t(ln)
+    d_z = torch.empty(int(ooff[-1] + cap[-1]), dtype=torch.uint8, device=dev)
+    d_zoff, d_zcap = t(ooff), t(cap)
+    hdr = dict(mtime=0, os=3, hcrc=0, ascii=0, filename=None, comment=None)
+    res = eng.deflate_batch(decompress_amd.FORMAT_GZIP, d_in, d_off, d_len, d_z, d_zoff, d_zcap, level=4, header=hdr)
+    torch.cuda.synchronize(dev)
+    eng.timing_begin()
+    res = eng.deflate_batch(decompress_amd.FORMAT_GZIP, d_in, d_off, d_len, d_z, d_zoff, d_zcap, level=4, header=hdr, results=res)
+    ms_def = eng.timing_end()
+    z_len, z_status, _ = res
+    ok = bool((z_status == 0).all().item())
+    d_back = torch.zeros(int(blob.size) + 64, dtype=torch.uint8, device=dev)
+    r = eng.inflate_batch(decompress_amd.FORMAT_GZIP, d_z, d_zoff, z_len.to(torch.int64), d_back, d_off, d_len)
+    torch.cuda.synchronize(dev)
+    eng.timing_begin()
+    for _ in range(3):
+        r = eng.inflate_batch(decompress_amd.FORMAT_GZIP, d_z, d_zoff, z_len.to(torch.int64), d_back, d_off, d_len, results=r)
+    ms_inf = eng.timing_end() / 3
+    out_len, consumed, status, crc = r
+    ok = ok and bool((status == 0).all().item()) and bool((out_len == d_len).all().item())
+    ok = ok and bool(torch.equal(d_back[:blob.size], d_in[:blob.size]))
+    if not args.no_verify:
+        from tests import oracle_lib
+        orc = oracle_lib.load()
+        zl = z_len.cpu().numpy()
+        for k in range(0, len(uniq), 4):  # 4 of the 15 files: the member's bytes equal the oracle's
+            got = d_z[int(ooff[k]):int(ooff[k]) + int(zl[k])].cpu().numpy().tobytes()
+            ok = ok and got == orc.gz_deflate(bufs[k], level=4)
+    total, comp = float(ln.sum()), float(z_len.sum().item())
+    return {"workload": "C4: 4096 gzip members = the reference's 15 corpus files cycled (%d B), Gz.Def level 4 / Gz.Inf" % int(total),
+            "deflate": {"value": round(total / 2**20 / (ms_def * 1e-3), 1), "unit": "MiB/s", "ms": round(ms_def, 2),
+                        "frac": round((total + comp) / (ms_def * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+            "inflate": {"value": round(total / 2**20 / (ms_inf * 1e-3), 1), "unit": "MiB/s", "ms": round(ms_inf, 3),
+                        "frac": round((total + comp) / (ms_inf * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+            "compressed_ratio": round(comp / total, 4), "parity_ok": ok}
+
+
+def lzo_leg(args, eng, dev):
+    """BASELINE config 5: 8192 x 128 KiB buffers (half word text, half printable-ASCII noise; 128 distinct),
+    Lzo.compress then Lzo.uncompress; bytes checked against the oracle on a sample."""
+    import numpy as np
+    import torch
+    from decompress_amd import workloads, lzo
+    n, nb = 8192, 128 * 1024
+    uniq = [(workloads.text if i % 2 == 0 else workloads.ascii_uniform)(0xC5 + i, nb) for i in range(128)]
+    bufs = [uniq[i % len(uniq)] for i in range(n)]
+    blob, off, ln = workloads.pack(bufs, align=32)
+    cap = np.full(n, lzo.max_compressed_length(nb), dtype=np.int64)
+    zoff = np.arange(n, dtype=np.int64) * ((int(cap[0]) + 255) // 256 * 256)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    d_in, d_off, d_len = t(blob), t(off), t(ln)
+    d_z = torch.empty(int(zoff[-1] + cap[-1]) + 64, dtype=torch.uint8, device=dev)
+    d_zoff, d_zcap = t(zoff), t(cap)
+    res = eng.lzo_batch(True, d_in, d_off, d_len, d_z, d_zoff, d_zcap)
+    torch.cuda.synchronize(dev)
+    eng.timing_begin()
+    res = eng.lzo_batch(True, d_in, d_off, d_len, d_z, d_zoff, d_zcap, results=res)
+    ms_c = eng.timing_end()
+    z_len, z_st = res
+    ok = bool((z_st == 0).all().item())
+    d_back = torch.zeros(int(blob.size) + 64, dtype=torch.uint8, device=dev)
+    r = eng.lzo_batch(False, d_z, d_zoff, z_len, d_back, d_off, d_len)
+    torch.cuda.synchronize(dev)
+    eng.timing_begin()
+    for _ in range(3):
+        r = eng.lzo_batch(False, d_z, d_zoff, z_len, d_back, d_off, d_len, results=r)
+    ms_d = eng.timing_end() / 3
+    ok = ok and bool((r[1] == 0).all().item()) and bool((r[0] == d_len).all().item())
+    ok = ok and bool(torch.equal(d_back[:blob.size], d_in[:blob.size]))
+    if not args.no_verify:
+        from tests import oracle_lib
+        orc = oracle_lib.load()
+        zl = z_len.cpu().numpy()
+        for k in range(0, len(uniq), 16):
+            got = d_z[int(zoff[k]):int(zoff[k]) + int(zl[k])].cpu().numpy().tobytes()
+            ok = ok and got == orc.lzo_compress(bufs[k])[1]
+    total, comp = float(ln.sum()), float(z_len.sum().item())
+    return {"workload": "C5: 8192 x 128 KiB buffers (half word text, half printable ASCII), Lzo.compress / Lzo.uncompress",
+            "compress": {"value": round(total / 2**20 / (ms_c * 1e-3), 1), "unit": "MiB/s", "ms": round(ms_c, 2),
+                         "frac": round((total + comp) / (ms_c * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+            "uncompress": {"value": round(total / 2**20 / (ms_d * 1e-3), 1), "unit": "MiB/s", "ms": round(ms_d, 3),
+                           "frac": round((total + comp) / (ms_d * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+            "compressed_ratio": round(comp / total, 4), "parity_ok": ok}
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -425,6 +531,11 @@ def main():
         leg = deflate_leg(args, eng, dev, rank, world, dist, fence)
         if rank == 0:
             line["deflate"] = leg
+    if world == 1 and not args.no_secondary:  # configs 4 and 5, one GPU's share each (not part of `value`)
+        torch.cuda.empty_cache()
+        line["gzip"] = gzip_leg(args, eng, dev)
+        torch.cuda.empty_cache()
+        line["lzo"] = lzo_leg(args, eng, dev)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
