@@ -636,7 +636,7 @@ __device__ __forceinline__ void emit_pass(const lds_u32 *win, const lds_u32 *lut
                                 : (ntb >= kStopEobI) | (mat & (val9 >= 30u));
       stopped = rare;
       if (!rare) {
-        if (lit) stage[q - rb] = (uint8_t)val9;
+        stage[lit ? q - rb : STAGE + 15] = (uint8_t)val9;  // (a slack byte when the step is not a literal: no branch)
         if (mat) {
           mrec[rec] = ((mlen - 3) << 16) | ((q - d + mlen > R0) ? kNearBit : 0u) | (d - 1);
           mpos[rec] = (uint16_t)(q - rb);
