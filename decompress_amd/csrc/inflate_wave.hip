@@ -57,7 +57,7 @@ constexpr uint32_t WIN_WORDS = 544;  // input window: 31 + 64*S + 47 bits and th
 //   codelen  bits this step consumes for the code (a LINK entry consumes the root bits, the
 //            sub-table entry behind it the rest of the code)
 //   xb       extra bits that follow the code
-//   val9     literal byte | length base (3..258) | distance symbol (0..29, 30/31 invalid) | 511 = LINK
+//   val9     literal byte | length base (3..258) | distance base m, base = (m << xb) + 1 (500 = invalid symbol) | 511 = LINK
 //   next     the table the following step indexes: lit root (0), distance root, a sub-table, or
 //            one of the two self-looping STOP entries (end of block / empty distance slot)
 constexpr uint32_t kLitSize = 852, kDistSize = 592;  // zlib ENOUGH (lib/de.ml:579-580)
@@ -101,15 +101,17 @@ __device__ __forceinline__ uint32_t lit_leaf(uint32_t sym, uint32_t codelen, uin
   const uint32_t base = (l < 8 ? l : l < 28 ? (4 + (l & 3)) << xb : l == 28 ? 255 : 0) + 3;
   return mk_entry(codelen, xb, base, droot, kDistB);
 }
+// a distance leaf carries the base of its symbol as `m`, base = (m << xb) + 1: m = the symbol itself for 0..3, 2 or 3
+// for 4..29 (lib/de.ml:313-325); the invalid symbols 30 and 31 carry kBadDist (any value >= 30 that is not LINK)
+constexpr uint32_t kBadDist = 500;
 __device__ __forceinline__ uint32_t dist_leaf(uint32_t dv, uint32_t codelen, uint32_t lroot) {
   dv &= 31;
-  const uint32_t xb = (dv >= 4 && dv < 30) ? (dv - 2) >> 1 : 0;  // lib/de.ml:313-325
-  return mk_entry(codelen, xb, dv, lroot, 0);
+  const uint32_t xb = (dv >= 4 && dv < 30) ? (dv - 2) >> 1 : 0;
+  const uint32_t m = dv < 4 ? dv : dv < 30 ? ((dv & 1) | 2) : kBadDist;
+  return mk_entry(codelen, xb, m, lroot, 0);
 }
-// distance symbol + extra bits -> distance (lib/de.ml:321-325, +1 folded in)
-__device__ __forceinline__ uint32_t dist_value(uint32_t dv, uint32_t xb, uint32_t x) {
-  return (dv < 4 ? dv + 1 : (((dv & 1) | 2) << xb) + 1) + x;
-}
+// leaf value + extra bits -> distance (lib/de.ml:321-325, +1 folded in)
+__device__ __forceinline__ uint32_t dist_value(uint32_t m, uint32_t xb, uint32_t x) { return (m << xb) + 1 + x; }
 
 // ---- input window -----------------------------------------------------------------------------
 // The window holds body bytes [base, base + 4*WIN_WORDS), base a multiple of 4; zero beyond the body.  A lane loads
