@@ -336,3 +336,32 @@ def test_match_shapes(eng):
         pl = plains[k // 3]
         assert (st, used) == (0, len(srcs[k])), (k, st)
         assert out == pl and adler == zlib.adler32(pl), k
+
+
+def test_two_contexts_in_two_threads(oracle):
+    """two contexts with their own HIP streams, driven from two host threads at once (large batches, so the launch
+    order scratch of each context is in use): every result is its own — no state is shared between handles"""
+    import threading
+    import decompress_amd
+    from decompress_amd import workloads
+    plains = [[workloads.text(1000 * t + i, 3000 + 37 * i) for i in range(2200)] for t in range(2)]
+    srcs = [[zlib.compress(p, 6) for p in ps] for ps in plains]
+    out, errs = [None, None], []
+
+    def work(t):
+        try:
+            eng = decompress_amd.Engine(0, own_stream=True)
+            for _ in range(3):
+                out[t] = eng.inflate_many(srcs[t], [len(p) for p in plains[t]], decompress_amd.FORMAT_ZLIB)
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errs, errs
+    for t in range(2):
+        for p, z, (st, used, o, adler) in zip(plains[t], srcs[t], out[t]):
+            assert (st, used, o, adler) == (0, len(z), p, zlib.adler32(p))
