@@ -23,7 +23,8 @@ class GzHeader(ctypes.Structure):
 class DeflateParams(ctypes.Structure):
     """md_deflate_params of include/mdeflate.h"""
     _fields_ = [("level", ctypes.c_int), ("queue_len", ctypes.c_int), ("driver", ctypes.c_int), ("dynamic", ctypes.c_int),
-                ("matcher", ctypes.c_int), ("gz_header", ctypes.POINTER(GzHeader))]
+                ("matcher", ctypes.c_int), ("gz_header", ctypes.POINTER(GzHeader)), ("wbits", ctypes.c_int),
+                ("total_in_bytes", ctypes.c_size_t)]
 
 
 c_pp = ctypes.POINTER(DeflateParams)

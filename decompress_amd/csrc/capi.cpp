@@ -17,12 +17,26 @@ extern "C" int md_launch_inflate_wave(int format, uint32_t n, const uint8_t *in,
                                       int32_t *status, uint32_t *checksum, uint64_t *dbg, uint32_t *order,
                                       hipStream_t stream);
 
-extern "C" size_t md_deflate_ws_bytes(uint32_t n, int qcap);
+// deflate: the front workspace (deflate_common.hpp) is opaque here
+struct md_front {
+  const void *p_end, *slot, *chunk0, *tail, *flags;
+  void *link, *flg, *m, *mq;
+};
+extern "C" size_t md_deflate_queue_bytes(uint32_t n, int qcap);
+extern "C" size_t md_front_small_bytes(uint32_t n);
+extern "C" size_t md_front_big_bytes(uint64_t positions);
+extern "C" void md_front_carve(void *small_ws, void *big_ws, uint32_t n, uint64_t positions, md_front *f);
+extern "C" int md_launch_deflate_plan(uint32_t n, const uint64_t *in_len, int driver, int matcher, int level,
+                                      uint64_t cap_positions, uint32_t cap_chunks, const md_front *f, hipStream_t stream);
+extern "C" int md_launch_deflate_front(uint32_t n, uint32_t nchunks_max, const uint8_t *in, const uint64_t *in_off,
+                                       const uint64_t *in_len, int matcher, uint32_t max_chain, uint32_t nice,
+                                       const md_front *f, hipStream_t stream);
+extern "C" void md_deflate_level_params(int driver, int matcher, int level, uint32_t *max_chain, uint32_t *nice);
 extern "C" int md_launch_deflate(int format, int level, int qcap, int driver, int dynamic, uint32_t n,
                                  const uint8_t *in, const uint64_t *in_off, const uint64_t *in_len,
                                  uint8_t *out, const uint64_t *out_off, const uint64_t *out_cap,
-                                 uint64_t *out_len, int32_t *status, uint32_t *checksum, void *ws,
-                                 uint64_t *dbg, int test_flags, const uint8_t *gz_hdr, uint32_t gz_hdr_len,
+                                 uint64_t *out_len, int32_t *status, uint32_t *checksum, const md_front *fr, void *queue_ws,
+                                 uint64_t *dbg, const uint8_t *gz_hdr, uint32_t gz_hdr_len,
                                  const uint32_t *gz_crc, int matcher, uint32_t *hist, hipStream_t stream);
 
 extern "C" int md_launch_gz_header(uint32_t n, const uint8_t *in, const uint64_t *in_off, const uint64_t *in_len,
@@ -54,10 +68,12 @@ struct md_ctx {
   bool gz_hdr_valid = false;
   void *lzo_ws = nullptr;  // Lzo.compress dictionaries
   size_t lzo_ws_bytes = 0;
-  int test_flags = 0;       // deflate: bit 0 = always take the order-free head reconstruction (tests)
+  int test_flags = 0;       // (kept for callers of md_set_option "deflate_test_flags": no effect since 0.3)
   uint64_t *dbg = nullptr;  // device buffer of the optional in-kernel profile (32 x u64)
-  void *ws = nullptr;       // deflate workspace (hash heads / chains / command queues)
-  size_t ws_bytes = 0;
+  // deflate workspaces, grow-only: command queues (n x queue_len), the per-stream part of the front workspace
+  // (slots, chunk starts: n-sized) and its per-position part (hash-chain links, look-ahead verdicts: 11 bytes per input byte)
+  void *ws = nullptr, *fsmall = nullptr, *fbig = nullptr;
+  size_t ws_bytes = 0, fsmall_bytes = 0, fbig_bytes = 0;
   uint32_t *order = nullptr;  // inflate: launch order of a large batch (n words)
   size_t order_words = 0;
   std::string err;
@@ -196,6 +212,8 @@ void md_destroy(md_ctx *ctx) {
   if (ctx->ev0) hipEventDestroy(ctx->ev0);
   if (ctx->ev1) hipEventDestroy(ctx->ev1);
   if (ctx->ws) hipFree(ctx->ws);
+  if (ctx->fsmall) hipFree(ctx->fsmall);
+  if (ctx->fbig) hipFree(ctx->fbig);
   if (ctx->order) hipFree(ctx->order);
   if (ctx->dbg) hipFree(ctx->dbg);
   if (ctx->gz_tmp) hipFree(ctx->gz_tmp);
@@ -433,20 +451,60 @@ int md_crc32_batch_device(md_ctx *ctx, size_t n, const uint8_t *d_data, const ui
   return MD_OK;
 }
 
+// a grow-only device buffer of the context
+static int grow(md_ctx *ctx, void **buf, size_t *have, size_t need, const char *what) {
+  if (need <= *have) return MD_OK;
+  if (*buf) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipFree(*buf));
+    *buf = nullptr;
+    *have = 0;
+  }
+  if (hipMalloc(buf, need) != hipSuccess) return fail(ctx, MD_E_OUT_OF_MEMORY, what);
+  *have = need;
+  return MD_OK;
+}
+
+// total_in: an upper bound of the sum of in_len when the caller knows one (md_deflate_params.total_in_bytes), else 0:
+// the front workspace is then sized from the totals the plan kernel computes, which costs one 16-byte read-back
+// (a synchronisation with the context's stream).
 static int deflate_launch(md_ctx *ctx, int format, int level, int queue_len, int driver, int dynamic, int matcher,
                           const md_gz_header *gz, size_t n, const uint8_t *d_in, const uint64_t *d_in_off,
                           const uint64_t *d_in_len, uint8_t *d_out, const uint64_t *d_out_off, const uint64_t *d_out_cap,
-                          uint64_t *d_out_len, int32_t *d_status, uint32_t *d_checksum, uint32_t *d_hist) {
-  size_t need = md_deflate_ws_bytes((uint32_t)n, queue_len);
-  if (need > ctx->ws_bytes) {
-    if (ctx->ws) {
-      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-      HIP_TRY(ctx, hipFree(ctx->ws));
-      ctx->ws = nullptr;
-      ctx->ws_bytes = 0;
-    }
-    if (hipMalloc(&ctx->ws, need) != hipSuccess) return fail(ctx, MD_E_OUT_OF_MEMORY, "hipMalloc(deflate workspace)");
-    ctx->ws_bytes = need;
+                          uint64_t *d_out_len, int32_t *d_status, uint32_t *d_checksum, uint32_t *d_hist, size_t total_in) {
+  int grc_ = grow(ctx, &ctx->ws, &ctx->ws_bytes, md_deflate_queue_bytes((uint32_t)n, queue_len), "hipMalloc(deflate command queues)");
+  if (grc_ != MD_OK) return grc_;
+  grc_ = grow(ctx, &ctx->fsmall, &ctx->fsmall_bytes, md_front_small_bytes((uint32_t)n), "hipMalloc(deflate plan)");
+  if (grc_ != MD_OK) return grc_;
+  md_front fr;
+  uint64_t positions = 0;
+  uint32_t chunks = 0;
+  uint32_t max_chain = 0, nice = 0;
+  md_deflate_level_params(driver, matcher, level, &max_chain, &nice);
+  const bool matcher_runs = max_chain != 0 && driver != 4;  // level 0 copies; De.Def.encode has no text
+  if (matcher_runs && total_in != 0) {
+    // slot <= len + 64 + 255 positions and <= len / 256 + 1 chunks per stream
+    positions = (uint64_t)total_in + 319ull * n;
+    const uint64_t c64 = (uint64_t)total_in / 256 + n;
+    if (c64 > 0x7fffffffull) return fail(ctx, MD_E_INVALID_ARGUMENT, "batch too large for one launch");
+    chunks = (uint32_t)c64;
+    grc_ = grow(ctx, &ctx->fbig, &ctx->fbig_bytes, md_front_big_bytes(positions), "hipMalloc(deflate front workspace)");
+    if (grc_ != MD_OK) return grc_;
+  }
+  md_front_carve(ctx->fsmall, ctx->fbig, (uint32_t)n, positions, &fr);
+  int prc = md_launch_deflate_plan((uint32_t)n, d_in_len, driver, matcher, level, positions, chunks, &fr, ctx->stream);
+  if (prc != 0) return fail(ctx, MD_E_HIP, "deflate plan kernel launch", (hipError_t)prc);
+  if (matcher_runs && total_in == 0) {
+    uint64_t tot_pos = 0;
+    uint32_t tot_chunks = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&tot_pos, (const uint64_t *)fr.slot + n, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(&tot_chunks, (const uint32_t *)fr.chunk0 + n, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    positions = tot_pos;
+    chunks = tot_chunks;
+    grc_ = grow(ctx, &ctx->fbig, &ctx->fbig_bytes, md_front_big_bytes(positions), "hipMalloc(deflate front workspace)");
+    if (grc_ != MD_OK) return grc_;
+    md_front_carve(ctx->fsmall, ctx->fbig, (uint32_t)n, positions, &fr);
   }
   const uint8_t *gz_hdr = nullptr;
   uint32_t *gz_crc = nullptr;
@@ -470,8 +528,12 @@ static int deflate_launch(md_ctx *ctx, int format, int level, int queue_len, int
     int e = md_launch_crc32((uint32_t)n, d_in, d_in_off, d_in_len, gz_crc, ctx->stream);
     if (e != 0) return fail(ctx, MD_E_HIP, "crc32 kernel launch", (hipError_t)e);
   }
+  if (matcher_runs && chunks != 0) {
+    int frc = md_launch_deflate_front((uint32_t)n, chunks, d_in, d_in_off, d_in_len, matcher, max_chain, nice, &fr, ctx->stream);
+    if (frc != 0) return fail(ctx, MD_E_HIP, "deflate front kernel launch", (hipError_t)frc);
+  }
   int rc = md_launch_deflate(format, level, queue_len, driver, dynamic, (uint32_t)n, d_in, d_in_off, d_in_len, d_out,
-                             d_out_off, d_out_cap, d_out_len, d_status, d_checksum, ctx->ws, ctx->dbg, ctx->test_flags,
+                             d_out_off, d_out_cap, d_out_len, d_status, d_checksum, &fr, ctx->ws, ctx->dbg,
                              gz_hdr, gz_hdr_len, gz_crc, matcher, d_hist, ctx->stream);
   if (rc != 0) return fail(ctx, MD_E_HIP, "deflate kernel launch", (hipError_t)rc);
   return MD_OK;
@@ -493,7 +555,16 @@ static int check_params(md_ctx *ctx, int format, const md_deflate_params *p, md_
   if (q->driver < MD_DRIVER_ZL || q->driver > MD_DRIVER_CLI) return fail(ctx, MD_E_INVALID_ARGUMENT, "unknown driver");
   if (q->matcher != MD_MATCHER_DE && q->matcher != MD_MATCHER_LZ) return fail(ctx, MD_E_INVALID_ARGUMENT, "unknown matcher");
   q->dynamic = q->dynamic ? 1 : 0;
+  if (q->wbits != 0 && q->wbits != 15)  // De.Lz77.state ~w: only make_window ~bits:15 (lib/de.ml:4462-4464, :4513)
+    return fail(ctx, MD_E_INVALID_ARGUMENT, "only 32 KiB windows (wbits 15) are implemented");
   return MD_OK;
+}
+
+// what md_def_encoder checks before it keeps the parameters (stream_shim.cpp); not part of the public header
+int md_validate_deflate_params(md_ctx *ctx, int format, const md_deflate_params *params) {
+  if (!ctx) return MD_E_INVALID_ARGUMENT;
+  md_deflate_params q;
+  return check_params(ctx, format, params, &q);
 }
 
 int md_deflate_batch_device(md_ctx *ctx, int format, const md_deflate_params *params, size_t n, const uint8_t *d_in,
@@ -509,7 +580,7 @@ int md_deflate_batch_device(md_ctx *ctx, int format, const md_deflate_params *pa
     return fail(ctx, MD_E_INVALID_ARGUMENT, "null descriptor array");
   MD_ON_DEVICE(ctx);
   return deflate_launch(ctx, format, q.level, q.queue_len, q.driver, q.dynamic, q.matcher, q.gz_header, n, d_in, d_in_off,
-                        d_in_len, d_out, d_out_off, d_out_cap, d_out_len, d_status, d_checksum, nullptr);
+                        d_in_len, d_out, d_out_off, d_out_cap, d_out_len, d_status, d_checksum, nullptr, q.total_in_bytes);
 }
 
 int md_deflate_batch_host(md_ctx *ctx, int format, const md_deflate_params *params,
@@ -519,7 +590,7 @@ int md_deflate_batch_host(md_ctx *ctx, int format, const md_deflate_params *para
                           int32_t *status, uint32_t *checksum) {
   if (!ctx) return MD_E_INVALID_ARGUMENT;
   if (n == 0) return MD_OK;
-  if (!in_off || !in_len || !out_off || !out_cap || !out_len || !status)
+  if (!params || !in_off || !in_len || !out_off || !out_cap || !out_len || !status)
     return fail(ctx, MD_E_INVALID_ARGUMENT, "null descriptor array");
   for (size_t i = 0; i < n; i++) {
     if (in_off[i] > in_bytes || in_len[i] > in_bytes - in_off[i])
@@ -542,7 +613,11 @@ int md_deflate_batch_host(md_ctx *ctx, int format, const md_deflate_params *para
   HIP_TRY(ctx, hipMemcpyAsync(d64 + 1 * n, in_len, n * 8, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(d64 + 2 * n, out_off, n * 8, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(d64 + 3 * n, out_cap, n * 8, hipMemcpyHostToDevice, st));
-  int rc = md_deflate_batch_device(ctx, format, params, n, (const uint8_t *)din.p, d64, d64 + n, (uint8_t *)dout.p,
+  md_deflate_params hp = *params;
+  hp.total_in_bytes = 0;
+  for (size_t i = 0; i < n; i++) hp.total_in_bytes += (size_t)in_len[i];
+  if (hp.total_in_bytes == 0) hp.total_in_bytes = 1;  // all empty: still no read-back
+  int rc = md_deflate_batch_device(ctx, format, &hp, n, (const uint8_t *)din.p, d64, d64 + n, (uint8_t *)dout.p,
                                    d64 + 2 * n, d64 + 3 * n, d64 + 4 * n, dstatus, dsum);
   if (rc != MD_OK) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(h_out, dout.p, out_bytes, hipMemcpyDeviceToHost, st));
@@ -558,7 +633,7 @@ static int deflate_one(md_ctx *ctx, int format, int level, int queue_len, int dr
   if (!ctx || !written || (!src && src_len) || (!dst && dst_cap)) return MD_E_INVALID_ARGUMENT;
   uint64_t in_off = 0, in_len = src_len, out_off = 0, out_cap = dst_cap, out_len = 0;
   int32_t status = 0;
-  const md_deflate_params p = {level, queue_len, driver, dynamic, MD_MATCHER_DE, gz};
+  const md_deflate_params p = {level, queue_len, driver, dynamic, MD_MATCHER_DE, gz, 0, 0};
   int rc = md_deflate_batch_host(ctx, format, &p, 1, src, src_len, &in_off, &in_len, dst, dst_cap, &out_off, &out_cap,
                                  &out_len, &status, nullptr);
   if (rc != MD_OK) return rc;
@@ -592,7 +667,8 @@ static int deflate_partial(md_ctx *ctx, int level, int queue_len, int driver, in
   if (src_len) HIP_TRY(ctx, hipMemcpyAsync(din.p, src, src_len, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(d64, desc, sizeof desc, hipMemcpyHostToDevice, st));
   int rc = deflate_launch(ctx, MD_FORMAT_DEFLATE, level, queue_len, driver, dynamic, matcher, nullptr, 1, (const uint8_t *)din.p,
-                          d64, d64 + 1, (uint8_t *)dout.p, d64 + 2, d64 + 3, d64 + 4, dstatus, nullptr, (uint32_t *)dhist.p);
+                          d64, d64 + 1, (uint8_t *)dout.p, d64 + 2, d64 + 3, d64 + 4, dstatus, nullptr, (uint32_t *)dhist.p,
+                          src_len ? src_len : 1);
   if (rc != MD_OK) return rc;
   uint64_t out_len = 0;
   int32_t status = 0;
@@ -629,6 +705,11 @@ int md_de_def_encode(md_ctx *ctx, int kind, const uint32_t *cmds, size_t ncmds, 
   if (!ctx || !written || (!cmds && ncmds) || (!dst && dst_cap)) return MD_E_INVALID_ARGUMENT;
   if (kind < MD_BLOCK_FLAT || kind > MD_BLOCK_DYNAMIC) return fail(ctx, MD_E_INVALID_ARGUMENT, "unknown block kind");
   if (ncmds >= (1u << 20)) return fail(ctx, MD_E_INVALID_ARGUMENT, "more commands than the largest queue holds");
+  for (size_t i = 0; i < ncmds; i++) {  // De.Queue's encodings only (lib/de.ml:2245-2266): the kernel indexes tables with the fields
+    const uint32_t c = cmds[i];
+    const bool ok = (c & 0x2000000u) ? ((c & ~0x2ffffffu) == 0 && ((c >> 16) & 0x1ff) <= 255 && (c & 0xffff) <= 32767) : c <= 256;
+    if (!ok) return fail(ctx, MD_E_INVALID_ARGUMENT, "not a De.Queue command");
+  }
   int queue_len = 4;
   while ((size_t)queue_len < ncmds + 1) queue_len <<= 1;  // Queue.create: a power of two that holds them all
   return deflate_partial(ctx, 4, queue_len, 4, kind, MD_MATCHER_DE, cmds, ncmds * 4, dst, dst_cap, written, nullptr);

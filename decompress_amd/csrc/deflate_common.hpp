@@ -1,0 +1,87 @@
+// deflate_common.hpp — what the three kernels of the deflate path share (gfx950).
+//
+//   deflate_plan_kernel   per-stream slots of the position-indexed workspace (a scan over the batch)
+//   deflate_link_kernel   hash chains: link[p] = distance to the latest earlier position with the hash of p
+//                         (insert_string, lib/de.ml:4220-4226; head table in LDS, one workgroup per stream)
+//   deflate_match_kernel  longest_match (lib/de.ml:4110-4174) for EVERY position, every position independent
+//   deflate_kernel        the sequential part: lazy evaluation, De.Queue, De.T, De.Def, the drivers
+//
+// In deflate_slow every position p < p_end is inserted into the hash chains exactly once and in order, whatever
+// the matcher decides, so the chain structure is a pure function of the input: the first two kernels compute it
+// (and what longest_match would find at each position) for the whole batch at full occupancy, the third one only
+// takes the decisions.  See DESIGN.md 4.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mdeflate.h"
+
+namespace md {
+namespace defl {
+
+constexpr int kWave = 64;
+constexpr int MIN_MATCH = 3, MAX_MATCH = 258, MIN_LOOKAHEAD = MAX_MATCH + MIN_MATCH + 1;
+constexpr int HASH_BITS = 15, HASH_SIZE = 1 << HASH_BITS, TOO_FAR = 4096;
+constexpr int WSIZE = 1 << 15, WMASK = WSIZE - 1, MAX_DIST = WSIZE - MIN_LOOKAHEAD;
+
+// look-ahead verdict of a position (flg[]): FL_ENDED no candidate of its chain shares 3 bytes with it (longest_match
+// cannot improve on any prev_length), FL_MATCH the whole longest_match was run ahead and its result is in m[] / mq[]
+// (full / quartered chain, (length << 16) | distance), 0 the matcher has to look for itself
+enum { FL_ENDED = 2, FL_MATCH = 4 };
+constexpr int KSPEC = 128;  // chain links walked ahead per position at most (min(max_chain, KSPEC))
+constexpr int PGM = 4;      // steps of 64 positions one wavefront of the match kernel keeps in flight
+constexpr uint32_t kChunk = PGM * kWave;
+
+// Position-indexed workspace of a batch.  Stream i owns positions [slot[i], slot[i + 1]) of link / flg / m / mq.
+struct Front {
+  const uint32_t *p_end;   // [n]     positions < p_end[i] are inserted ahead (and have a verdict)
+  const uint64_t *slot;    // [n + 1]
+  const uint32_t *chunk0;  // [n + 1] first kChunk-position chunk of stream i in the match kernel's grid
+  const uint32_t *tail;    // [2 n]   hash head of position len - 3 (De matcher): 4th byte 0 / the byte 32 KiB earlier (H7)
+  const uint32_t *flags;   // [1]     bit 0: the batch needs more workspace than the caller's size hint allowed
+  uint16_t *link;          // distance to the previous position with the same hash, 0 = none within 32767
+  uint8_t *flg;            // FL_*
+  uint32_t *m, *mq;        // longest_match ahead over the full / quartered chain, valid where flg == FL_MATCH
+};
+
+// hash of the string at a, from its little-endian first 4 bytes:
+//   De.Lz77  hash4, lib/de.ml:4067-4071: 4 bytes multiplied by 0x9e3779b1, top 15 bits;
+//   Lz       update_hash (lib/lz.ml:153-155, shift 5, 15 bits) rolled over 3 bytes by fill_window's
+//            priming (lib/lz.ml:399-401) + insert_string (lib/lz.ml:297-304) — every string that is
+//            inserted at all is inserted right after its predecessor, so the rolled state is this
+//            pure function of the 3 bytes.
+__device__ __forceinline__ uint32_t hash_of(int matcher, uint32_t w4) {
+  if (matcher == MD_MATCHER_LZ)
+    return (((w4 & 0xff) << 10) ^ (((w4 >> 8) & 0xff) << 5) ^ ((w4 >> 16) & 0xff)) & (HASH_SIZE - 1);
+  return (uint32_t)(w4 * 0x9e3779b1u) >> (32 - HASH_BITS);
+}
+// positions < p_end are inserted whatever the matcher decides: the last ones are not (lookahead < MIN_MATCH), and
+// De's hash of position len - 3 reads a byte beyond the data (H7): that one is left to the sequential kernel
+__device__ __forceinline__ uint32_t stream_p_end(int matcher, uint32_t eff_level, uint32_t len) {
+  if (matcher == MD_MATCHER_LZ) return len >= 3 ? len - 2 : 0;
+  return (eff_level != 0 && len >= 4) ? len - 3 : 0;
+}
+__device__ __forceinline__ uint32_t effective_level(int driver, int matcher, int level) {
+  if (driver == 1 /* DRV_HIGHER */) return 4;               // H6: De.Higher.compress has no ?level
+  if (matcher == MD_MATCHER_LZ && level < 4) return 4;      // Lz.state: 0..4 are _4 (lib/lz.ml:535)
+  return (uint32_t)level;
+}
+
+__device__ __forceinline__ uint64_t lanes_below(uint32_t lane) { return (1ull << lane) - 1; }
+
+// length of the common prefix of a and b, at most MAX_MATCH: what longest_match's compare loop
+// arrives at (lib/de.ml:4139-4155; its 4-byte steps land exactly on str_end).  Reads a[0..259].
+__device__ __forceinline__ uint32_t lcp258(const uint8_t *a, const uint8_t *b) {
+#pragma clang loop unroll(disable)
+  for (uint32_t k = 0; k < 256; k += 4) {
+    uint32_t x, y;
+    __builtin_memcpy(&x, a + k, 4);
+    __builtin_memcpy(&y, b + k, 4);
+    if (x != y) return k + ((uint32_t)__builtin_ctz(x ^ y) >> 3);
+  }
+  if (a[256] != b[256]) return 256;
+  return a[257] != b[257] ? 257 : 258;
+}
+
+}  // namespace defl
+}  // namespace md

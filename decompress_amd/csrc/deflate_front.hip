@@ -1,0 +1,378 @@
+// deflate_front.hip — the decision-independent half of De.Lz77 (lib/de.ml:4013-4515) for gfx950 (MI355X).
+//
+// deflate_slow inserts every position p < p_end into the hash chains exactly once and in order, whatever the lazy
+// matcher decides (lib/de.ml:4351-4410: insert at strstart, then every position a match covers), so
+//   hash_head(p)  = the latest earlier position with the hash of p           (insert_string, lib/de.ml:4220-4226)
+//   prev[c]       = hash_head(c) for every candidate c still in reach        (the chain links)
+// are pure functions of the input.  Two kernels compute them for the whole batch before the sequential kernel runs:
+//
+//   deflate_link_kernel   one workgroup per stream, the 32 K-entry head table in LDS (128 KiB): 8 x 64 positions per
+//                         group, one LDS atomic-max per position returning the old head, equal hashes inside a step
+//                         matched by ballots.  Output link[p] = p - hash_head(p) as 16 bits (0 = none in reach):
+//                         the only HBM traffic is the input read once and 2 bytes per position written once.
+//   deflate_match_kernel  longest_match (lib/de.ml:4110-4174) run for every position as if reached with
+//                         prev_length = 2 (full and quartered chain), positions independent of each other: the grid
+//                         is all 256-position chunks of the batch, XCD-contiguous so that the 32 KiB window of a
+//                         stream region stays in one L2.  Output flg[p] (FL_*) and m[p] / mq[p].
+//
+// Neither kernel takes a decision: the lazy evaluation, the queue, the trees and the bit encoder read these
+// arrays in deflate_kernel.hip.  Before this split the same work sat inside the sequential kernel with the head
+// table in HBM (one atomic and ~3 dependent HBM round trips per position): 66x the algorithmic traffic.
+#include "deflate_common.hpp"
+
+namespace md {
+namespace defl {
+
+constexpr int PGL = 8;  // steps of 64 positions whose LDS atomics are in flight together (link kernel)
+
+// ---- per-stream slots ---------------------------------------------------------------------------
+constexpr uint32_t kPlanThreads = 1024;
+__device__ __forceinline__ uint64_t slot_positions(uint32_t p_end, uint32_t len) {
+  return p_end ? (((uint64_t)len + 64 + (kChunk - 1)) / kChunk) * kChunk : 0;  // reads a little past p_end stay inside
+}
+__global__ __launch_bounds__(kPlanThreads) void deflate_plan_kernel(uint32_t n, const uint64_t *__restrict__ in_len, int driver,
+                                                                    int matcher, int level, uint64_t cap_positions,
+                                                                    uint32_t cap_chunks, uint32_t *__restrict__ p_end,
+                                                                    uint64_t *__restrict__ slot, uint32_t *__restrict__ chunk0,
+                                                                    uint32_t *__restrict__ flags) {
+  __shared__ uint64_t spos[kPlanThreads];
+  __shared__ uint32_t schk[kPlanThreads];
+  const uint32_t t = threadIdx.x;
+  const uint32_t per = (n + kPlanThreads - 1) / kPlanThreads;
+  const uint32_t lo = t * per < n ? t * per : n, hi = lo + per < n ? lo + per : n;
+  const uint32_t eff = effective_level(driver, matcher, level);
+  const bool no_text = driver == 4;  // DRV_ENCODE: the input is a command list
+  uint64_t pos = 0;
+  uint32_t chk = 0;
+  for (uint32_t i = lo; i < hi; i++) {
+    const uint64_t l64 = in_len[i];
+    const uint32_t len = l64 > MD_MAX_STREAM ? 0u : (uint32_t)l64;
+    const uint32_t pe = no_text ? 0u : stream_p_end(matcher, eff, len);
+    p_end[i] = pe;
+    pos += slot_positions(pe, len);
+    chk += (pe + kChunk - 1) / kChunk;
+  }
+  spos[t] = pos;
+  schk[t] = chk;
+  __syncthreads();
+  if (t == 0) {
+    uint64_t a = 0;
+    uint32_t c = 0;
+    for (uint32_t k = 0; k < kPlanThreads; k++) {
+      const uint64_t v = spos[k];
+      const uint32_t w = schk[k];
+      spos[k] = a;
+      schk[k] = c;
+      a += v;
+      c += w;
+    }
+    slot[n] = a;
+    chunk0[n] = c;
+    // the caller sized the workspace from md_deflate_params.total_in_bytes: a batch that needs more is refused
+    flags[0] = (cap_positions != 0 && (a > cap_positions || c > cap_chunks)) ? 1u : 0u;
+  }
+  __syncthreads();
+  pos = spos[t];
+  chk = schk[t];
+  for (uint32_t i = lo; i < hi; i++) {
+    const uint64_t l64 = in_len[i];
+    const uint32_t len = l64 > MD_MAX_STREAM ? 0u : (uint32_t)l64;
+    const uint32_t pe = p_end[i];
+    slot[i] = pos;
+    chunk0[i] = chk;
+    pos += slot_positions(pe, len);
+    chk += (pe + kChunk - 1) / kChunk;
+  }
+}
+
+// ---- hash chains ----------------------------------------------------------------------------------
+// head[h] <- max(pos), one LDS atomic per position, the steps of a group issued back to back (a wavefront's LDS
+// operations execute in order).  The values a set of equal hashes gets back are >= the head before the set and one of
+// them is exactly that value: a lane that shares its hash with another lane of its step is recognised by a returned
+// position inside the step, and such steps sort themselves out by ballots (the predecessor of a lane is the nearest
+// lower lane with its hash, else the smallest value the set got back).
+__global__ __launch_bounds__(kWave) void deflate_link_kernel(uint32_t n, const uint8_t *__restrict__ in,
+                                                             const uint64_t *__restrict__ in_off,
+                                                             const uint64_t *__restrict__ in_len,
+                                                             const uint32_t *__restrict__ p_end_a,
+                                                             const uint64_t *__restrict__ slot, uint16_t *__restrict__ link,
+                                                             uint32_t *__restrict__ tail, const uint32_t *__restrict__ flags,
+                                                             int matcher) {
+  __shared__ uint32_t head[HASH_SIZE];  // absolute position, 0 = NIL (position 0 can never match, like the reference)
+  __shared__ uint32_t gmin[kWave];
+  const uint32_t lane = threadIdx.x, sid = blockIdx.x;
+  if (sid >= n || flags[0]) return;
+  const uint32_t p_end = p_end_a[sid];
+  const uint64_t l64 = in_len[sid];
+  const uint32_t slen = l64 > MD_MAX_STREAM ? 0u : (uint32_t)l64;
+  const uint8_t *src = in + in_off[sid];
+  uint16_t *lk = link + slot[sid];
+  {
+    uint4 *h4 = reinterpret_cast<uint4 *>(head);
+    for (uint32_t i = lane; i < (uint32_t)HASH_SIZE / 4; i += kWave) h4[i] = make_uint4(0, 0, 0, 0);
+  }
+  __syncthreads();
+  for (uint32_t pe = 0; pe < p_end; pe += PGL * kWave) {
+    uint32_t w4[PGL], hv[PGL], ret[PGL];
+#pragma unroll
+    for (int g = 0; g < PGL; g++) {
+      const uint32_t pos = pe + g * kWave + lane;
+      w4[g] = 0;
+      if (pos < p_end) {
+        if (pos + 4 <= slen) __builtin_memcpy(&w4[g], src + pos, 4);
+        else w4[g] = (uint32_t)src[pos] | ((uint32_t)src[pos + 1] << 8) | ((uint32_t)src[pos + 2] << 16);  // Lz's last string
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < PGL; g++) {
+      const uint32_t pos = pe + g * kWave + lane;
+      hv[g] = hash_of(matcher, w4[g]);
+      ret[g] = pos < p_end ? atomicMax(&head[hv[g]], pos) : 0xffffffffu;
+    }
+#pragma unroll
+    for (int g = 0; g < PGL; g++) {
+      const uint32_t s0 = pe + g * kWave;
+      if (s0 >= p_end) break;  // uniform
+      const uint32_t pos = s0 + lane;
+      const bool valid = pos < p_end;
+      uint32_t c1;
+      if (__ballot(valid && ret[g] >= s0) == 0) {
+        c1 = valid ? ret[g] : 0;  // no two lanes share a hash: every returned value is the head before the step
+      } else {
+        const uint32_t h = hv[g];
+        uint64_t same = __ballot(valid);
+#pragma unroll
+        for (int bit = 0; bit < HASH_BITS; bit++) {
+          const bool mine = (h >> bit) & 1;
+          const uint64_t bal = __ballot(mine);
+          same &= mine ? bal : ~bal;
+        }
+        const uint64_t below = same & lanes_below(lane);
+        const uint32_t first = valid ? (uint32_t)__builtin_ctzll(same) : lane;
+        gmin[lane] = 0xffffffffu;
+        __syncthreads();
+        if (valid) atomicMin(&gmin[first], ret[g]);
+        __syncthreads();
+        c1 = !valid ? 0u : below ? s0 + 63u - (uint32_t)__builtin_clzll(below) : gmin[lane];
+        __syncthreads();
+      }
+      if (valid) {
+        const uint32_t d = pos - c1;
+        lk[pos] = (uint16_t)((c1 != 0 && d <= 32767u) ? d : 0u);
+      }
+    }
+  }
+  __syncthreads();
+  // De's position len - 3 (lookahead 3): hash4 reads a 4th byte beyond the data (H7) — zero before the first slide of
+  // the reference's 64 KiB buffer, the byte 32 KiB earlier after it.  Which one depends on the matcher's trajectory:
+  // both heads are handed over.
+  if (lane < 2) {
+    uint32_t res = 0;
+    if (matcher == MD_MATCHER_DE && slen >= 3) {
+      const uint32_t p = slen - 3;
+      const uint32_t b3 = (lane == 1 && slen >= (uint32_t)WSIZE) ? src[slen - WSIZE] : 0u;
+      const uint32_t w = (uint32_t)src[p] | ((uint32_t)src[p + 1] << 8) | ((uint32_t)src[p + 2] << 16) | (b3 << 24);
+      res = head[hash_of(matcher, w)];
+    }
+    tail[2 * sid + lane] = res;
+  }
+}
+
+// ---- longest_match ahead --------------------------------------------------------------------------
+// One chain per lane, PGM steps of 64 positions per wavefront in flight together.  The bar is prev_length = 2 and the
+// chain is the full one; the best candidate after max_chain >> 2 links is kept as well (the matcher walks the
+// quartered chain when prev_length >= good_length, lib/de.ml:4117-4119).  A candidate counts when it shares the first
+// 3 bytes (the 16-bit pre-filters of the reference can only skip candidates that would not win); the walk ends at the
+// first candidate of nice_length, after max_chain links, or where the chain leaves the reach of the position.  The
+// window limit is pos - MAX_DIST whatever the window base: before the first slide the base is 0, after a slide
+// strstart - base >= MAX_DIST.  The head candidate is admitted at distance == MAX_DIST, links only below it
+// (lib/de.ml:4367-4369 vs :4165).
+__global__ __launch_bounds__(kWave) void deflate_match_kernel(uint32_t n, uint32_t nchunks_max, const uint8_t *__restrict__ in,
+                                                              const uint64_t *__restrict__ in_off,
+                                                              const uint64_t *__restrict__ in_len,
+                                                              const uint32_t *__restrict__ p_end_a,
+                                                              const uint64_t *__restrict__ slot,
+                                                              const uint32_t *__restrict__ chunk0,
+                                                              const uint16_t *__restrict__ link, uint8_t *__restrict__ flg,
+                                                              uint32_t *__restrict__ m, uint32_t *__restrict__ mq,
+                                                              const uint32_t *__restrict__ flags, uint32_t max_chain,
+                                                              uint32_t nice) {
+  const uint32_t lane = threadIdx.x;
+  if (flags[0]) return;
+  // workgroup b runs on XCD b % 8: give every XCD one contiguous eighth of the chunks, so that the chunks that share
+  // a 32 KiB window (and its 64 KiB of links) meet in the same L2
+  const uint32_t per = (nchunks_max + 7) / 8;
+  const uint32_t c = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if ((blockIdx.x >> 3) >= per || c >= chunk0[n]) return;
+  uint32_t lo = 0, hi = n;  // the stream of chunk c: the last i with chunk0[i] <= c
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (chunk0[mid] <= c) lo = mid;
+    else hi = mid;
+  }
+  const uint32_t sid = lo;
+  const uint32_t p_end = p_end_a[sid];
+  const uint32_t pe = (c - chunk0[sid]) * kChunk;
+  if (pe >= p_end) return;
+  const uint32_t slen = (uint32_t)in_len[sid];
+  const uint8_t *src = in + in_off[sid];
+  const uint64_t so = slot[sid];
+  const uint16_t *lk = link + so;
+  const uint32_t qlimit = max_chain >> 2, kspec = max_chain < (uint32_t)KSPEC ? max_chain : (uint32_t)KSPEC;
+
+  uint32_t w4[PGM], cw[PGM], fl[PGM], cnt[PGM], best[PGM], bdist[PGM], bestq[PGM], bdistq[PGM];
+#pragma unroll
+  for (int g = 0; g < PGM; g++) {
+    const uint32_t pos = pe + g * kWave + lane;
+    w4[g] = 0;
+    cw[g] = 0;
+    if (pos < p_end) {
+      if (pos + 4 <= slen) __builtin_memcpy(&w4[g], src + pos, 4);
+      else w4[g] = (uint32_t)src[pos] | ((uint32_t)src[pos + 1] << 8) | ((uint32_t)src[pos + 2] << 16);
+      const uint32_t l = lk[pos];
+      cw[g] = l ? pos - l : 0u;
+    }
+    fl[g] = 0;
+    cnt[g] = 0;
+    best[g] = MIN_MATCH - 1;
+    bdist[g] = 0;
+    bestq[g] = MIN_MATCH - 1;
+    bdistq[g] = 0;
+  }
+  for (uint32_t lv = 0; lv < kspec; lv++) {
+    bool act[PGM];
+    bool any = false;
+#pragma unroll
+    for (int g = 0; g < PGM; g++) {
+      const uint32_t pos = pe + g * kWave + lane;
+      const uint32_t lower = pos > (uint32_t)MAX_DIST ? pos - MAX_DIST : 0;
+      act[g] = pos < p_end && fl[g] == 0 && (lv == 0 ? (cw[g] != 0 && pos - cw[g] <= (uint32_t)MAX_DIST) : cw[g] > lower);
+      any = any || act[g];
+    }
+    if (__ballot(any) == 0) break;
+    uint32_t v[PGM], nx[PGM];
+#pragma unroll
+    for (int g = 0; g < PGM; g++) {
+      v[g] = 0;
+      nx[g] = 0;
+      if (act[g]) {
+        __builtin_memcpy(&v[g], src + cw[g], 4);  // candidate < pos <= len - 3
+        const uint32_t l = lk[cw[g]];
+        nx[g] = l ? cw[g] - l : 0u;
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < PGM; g++) {
+      if (act[g]) {
+        const uint32_t pos = pe + g * kWave + lane;
+        if (((v[g] ^ w4[g]) & 0xffffffu) == 0) {
+          if (pos + MIN_LOOKAHEAD > slen) fl[g] = 8;  // too close to the end to compare ahead: the matcher's job
+          else {
+            // scan_end pre-filter (lib/de.ml:4133-4134): a candidate that differs at the end of the best match so
+            // far cannot be longer
+            uint32_t len = 0;
+            bool look = true;
+            if (best[g] >= (uint32_t)MIN_MATCH) {
+              uint16_t x, y;
+              __builtin_memcpy(&x, src + pos + best[g] - 1, 2);
+              __builtin_memcpy(&y, src + cw[g] + best[g] - 1, 2);
+              look = x == y;
+            }
+            if (look) len = lcp258(src + pos, src + cw[g]);
+            if (len > best[g]) {
+              best[g] = len;
+              bdist[g] = pos - cw[g];
+              if (len >= nice) fl[g] = FL_MATCH;
+            }
+          }
+        }
+        cnt[g]++;
+        if (cnt[g] == qlimit) {
+          bestq[g] = best[g];
+          bdistq[g] = bdist[g];
+        }
+        cw[g] = nx[g];
+      }
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < PGM; g++) {
+    const uint32_t pos = pe + g * kWave + lane;
+    if (pos < p_end) {
+      const uint32_t lower = pos > (uint32_t)MAX_DIST ? pos - MAX_DIST : 0;
+      uint32_t f = fl[g];
+      if (f == 0) {
+        // chain exhausted (or never entered), or max_chain links walked: the verdict is final
+        const bool entered = cnt[g] != 0;
+        const bool more = entered ? cw[g] > lower : (cw[g] != 0 && pos - cw[g] <= (uint32_t)MAX_DIST);
+        if (!more || cnt[g] >= max_chain) f = best[g] >= (uint32_t)MIN_MATCH ? FL_MATCH : FL_ENDED;
+      }
+      if (f == FL_MATCH) {
+        if (cnt[g] < qlimit) {
+          bestq[g] = best[g];
+          bdistq[g] = bdist[g];
+        }
+        m[so + pos] = (best[g] << 16) | bdist[g];
+        mq[so + pos] = (bestq[g] << 16) | bdistq[g];
+      }
+      flg[so + pos] = (uint8_t)(f == FL_MATCH || f == FL_ENDED ? f : 0);
+    }
+  }
+}
+
+}  // namespace defl
+}  // namespace md
+
+// The front workspace: a small part sized by the number of streams (slots, chunk starts, p_end, tails, flags) and a
+// large one sized by the slot positions of the batch (link, flg, m, mq).
+static inline size_t up256(size_t b) { return (b + 255) & ~(size_t)255; }
+extern "C" size_t md_front_small_bytes(uint32_t n) {
+  const size_t k = n;
+  return up256((k + 1) * 8) + up256((k + 1) * 4) + up256(k * 4) + up256(k * 8) + 256;
+}
+extern "C" size_t md_front_big_bytes(uint64_t positions) {
+  const size_t np = (size_t)positions;
+  return up256(np * 2) + up256(np) + 2 * up256(np * 4);
+}
+static inline uint8_t *bump(uint8_t *&p, size_t bytes) {
+  uint8_t *r = p;
+  p += up256(bytes);
+  return r;
+}
+extern "C" void md_front_carve(void *small_ws, void *big_ws, uint32_t n, uint64_t positions, md::defl::Front *f) {
+  uint8_t *p = (uint8_t *)small_ws;
+  const size_t np = (size_t)positions, k = n;
+  f->slot = (const uint64_t *)bump(p, (k + 1) * 8);
+  f->chunk0 = (const uint32_t *)bump(p, (k + 1) * 4);
+  f->p_end = (const uint32_t *)bump(p, k * 4);
+  f->tail = (const uint32_t *)bump(p, k * 8);
+  f->flags = (const uint32_t *)bump(p, 4);
+  p = (uint8_t *)big_ws;
+  f->link = (uint16_t *)bump(p, np * 2);
+  f->flg = (uint8_t *)bump(p, np);
+  f->m = (uint32_t *)bump(p, np * 4);
+  f->mq = (uint32_t *)bump(p, np * 4);
+}
+
+// slot[] / chunk0[] / p_end[] of the batch (slot[n], chunk0[n] = totals); cap_* = what the big part was sized for
+// (0 = it will be sized from the totals afterwards)
+extern "C" int md_launch_deflate_plan(uint32_t n, const uint64_t *in_len, int driver, int matcher, int level,
+                                      uint64_t cap_positions, uint32_t cap_chunks, const md::defl::Front *f, hipStream_t stream) {
+  hipLaunchKernelGGL(md::defl::deflate_plan_kernel, dim3(1), dim3(md::defl::kPlanThreads), 0, stream, n, in_len, driver, matcher,
+                     level, cap_positions, cap_chunks, (uint32_t *)f->p_end, (uint64_t *)f->slot, (uint32_t *)f->chunk0,
+                     (uint32_t *)f->flags);
+  return (int)hipGetLastError();
+}
+// link[] / tail[], then flg[] / m[] / mq[]: nchunks_max >= chunk0[n]
+extern "C" int md_launch_deflate_front(uint32_t n, uint32_t nchunks_max, const uint8_t *in, const uint64_t *in_off,
+                                       const uint64_t *in_len, int matcher, uint32_t max_chain, uint32_t nice,
+                                       const md::defl::Front *f, hipStream_t stream) {
+  using namespace md::defl;
+  if (n == 0 || nchunks_max == 0) return 0;
+  hipLaunchKernelGGL(deflate_link_kernel, dim3(n), dim3(kWave), 0, stream, n, in, in_off, in_len, f->p_end, f->slot, f->link,
+                     (uint32_t *)f->tail, f->flags, matcher);
+  const uint32_t per = (nchunks_max + 7) / 8;
+  hipLaunchKernelGGL(deflate_match_kernel, dim3(per * 8), dim3(kWave), 0, stream, n, nchunks_max, in, in_off, in_len, f->p_end,
+                     f->slot, f->chunk0, f->link, f->flg, f->m, f->mq, f->flags, max_chain, nice);
+  return (int)hipGetLastError();
+}

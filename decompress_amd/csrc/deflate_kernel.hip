@@ -1,4 +1,4 @@
-// deflate_kernel.hip — batched RFC1951 deflate for gfx950 (MI355X).
+// deflate_kernel.hip — batched RFC1951 deflate for gfx950 (MI355X): the sequential kernel.
 //
 // Bit-exact with the reference's streaming compressor:
 //   De.Lz77 (zlib deflate_slow, 4-byte multiplicative hash)      lib/de.ml:4013-4515
@@ -12,33 +12,23 @@
 //
 // Layout: one independent stream per wavefront.  The lazy matcher and the driver
 // of a stream are sequential state machines (every decision depends on the
-// previous one): lane 0 runs them.  What does NOT depend on decisions is done by
-// the whole wave: in deflate_slow every position p <= n-4 is inserted into the hash
-// chains exactly once and in order, so hash_head(p) — the latest earlier position
-// with the same hash4 — is a pure function of the input.  The wave computes it 8 x 64
-// positions per group (coalesced hash, atomic-max head update returning the old
-// head, equal hashes matched by ballots) into an LDS ring, pre-walks 6 chain links
-// per position (3-byte pre-filter of longest_match, lib/de.ml:4133-4137), takes
-// literal runs 64 positions at a time, builds the Huffman trees (all but zlib's
-// heap merge loop) and packs the bits of a queue fill 64 commands per step.
-// Hash heads / chains (abs positions, 2 x 128 KiB) and the command queue live in
-// a per-stream HBM workspace; histograms, heap and code tables live in LDS.
+// previous one): lane 0 runs them.  What does NOT depend on decisions has been computed
+// for the whole batch by deflate_front.hip before this kernel starts: link[p] (the hash
+// chains: hash_head(p) and every chain link are pure functions of the input) and, per
+// position, what longest_match finds there (flg / m / mq).  This kernel streams those
+// arrays into an LDS ring, takes literal runs 64 positions at a time, parses the lazy
+// evaluation from the verdicts, builds the Huffman trees (all but zlib's heap merge loop)
+// and packs the bits of a queue fill 64 commands per step.  The command queue lives in a
+// per-stream HBM workspace; histograms, heap and code tables live in LDS.
 // The window is the input buffer itself: w[rel] = in[base + rel]; bytes the
 // reference reads beyond the data (H7) follow its 64 KiB sliding buffer exactly
 // (zero before the first slide, the byte 32 KiB earlier after it).  See DESIGN.md 4.
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-
-#include "mdeflate.h"
+#include "deflate_common.hpp"
 
 namespace md {
 namespace defl {
 
-constexpr int kWave = 64;
 constexpr int MAX_BITS = 15, L_CODES = 286, D_CODES = 30, BL_CODES = 19, HEAP_SIZE = 2 * L_CODES + 1;
-constexpr int MIN_MATCH = 3, MAX_MATCH = 258, MIN_LOOKAHEAD = MAX_MATCH + MIN_MATCH + 1;
-constexpr int HASH_BITS = 15, HASH_SIZE = 1 << HASH_BITS, TOO_FAR = 4096;
-constexpr int WSIZE = 1 << 15, WMASK = WSIZE - 1, MAX_DIST = WSIZE - MIN_LOOKAHEAD;
 constexpr int Q_EOB = 256, Q_COPY = 0x2000000;
 
 __constant__ uint8_t c_zigzag[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
@@ -133,12 +123,7 @@ struct DS {
   } w;
 };
 constexpr uint32_t RING = 1024;
-// look-ahead verdict of a position: FL_ENDED no candidate of its chain shares 3 bytes with it
-// (longest_match cannot improve on any prev_length), FL_MATCH the whole longest_match was run
-// ahead and its result is in the match ring, 0 the matcher has to look for itself
-enum { FL_ENDED = 2, FL_MATCH = 4 };
-constexpr int KSPEC = 128;  // chain links walked ahead per position at most (min(max_chain, KSPEC))
-constexpr int PG = 8;    // look-ahead steps (of 64 positions) prepared together
+constexpr int PG = 8;    // steps of 64 positions loaded into the ring together
 
 __device__ __forceinline__ int distance_code(const DS *s, int d1) {
   return d1 < 256 ? s->dist_lo[d1] : s->dist_hi[d1 >> 7];
@@ -183,7 +168,6 @@ __device__ void heap_down(DS *s, int hlen, int k) {  // pqdownheap, lib/de.ml:18
   }
   s->hk[k] = v;
 }
-__device__ __forceinline__ uint64_t lanes_below(uint32_t lane) { return (1ull << lane) - 1; }
 __device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -491,12 +475,18 @@ __device__ void trees_wave(DS *s, int mode, uint32_t lane) {
 // ---------------------------------------------------------------------------
 // workspace in HBM, per stream
 struct Ws {
-  uint32_t *head;  // [HASH_SIZE] absolute position + 0 = NIL (position 0 can never match, like the reference)
-  uint32_t *prev;  // [WSIZE]
-  int *queue;      // [qcap]
-  uint32_t *mring; // [2][RING] longest_match run ahead: (length << 16) | distance, full / quartered chain
+  const uint16_t *link;   // [slot] link[p] = p - hash_head(p), 0 = NIL / out of reach (deflate_link_kernel)
+  const uint8_t *flg;     // [slot] look-ahead verdict FL_* of p (deflate_match_kernel)
+  const uint32_t *m, *mq; // [slot] longest_match run ahead: (length << 16) | distance, full / quartered chain
+  int *queue;             // [qcap]
+  uint32_t tail0, tail1;  // hash head of position len - 3 when its 4th byte is 0 / the byte 32 KiB earlier (H7)
 };
 __device__ __forceinline__ uint32_t g_ld(const uint32_t *p) { return __builtin_nontemporal_load(p); }
+// hash_head(p) = the position p's chain link points at (absolute; 0 = NIL, like the reference's position 0)
+__device__ __forceinline__ uint32_t link_at(const Ws *ws, uint32_t p) {
+  const uint32_t l = __builtin_nontemporal_load(ws->link + p);
+  return l ? p - l : 0u;
+}
 __device__ __forceinline__ int g_ldi(const int *p) { return __builtin_nontemporal_load(p); }
 
 struct Enc {  // De.Def.encoder, lib/de.ml:2465-2478
@@ -791,20 +781,6 @@ __device__ void enc_write_wave(DS *s, uint32_t lane) {
   }
 }
 
-// length of the common prefix of a and b, at most MAX_MATCH: what longest_match's compare loop
-// arrives at (lib/de.ml:4139-4155; its 4-byte steps land exactly on str_end).  Reads a[0..259].
-__device__ __forceinline__ uint32_t lcp258(const uint8_t *a, const uint8_t *b) {
-#pragma clang loop unroll(disable)
-  for (uint32_t k = 0; k < 256; k += 4) {
-    uint32_t x, y;
-    __builtin_memcpy(&x, a + k, 4);
-    __builtin_memcpy(&y, b + k, 4);
-    if (x != y) return k + ((uint32_t)__builtin_ctz(x ^ y) >> 3);
-  }
-  if (a[256] != b[256]) return 256;
-  return a[257] != b[257] ? 257 : 258;
-}
-
 // ---------------------------------------------------------------------------
 // De.Lz77, lib/de.ml:4013-4515, in absolute positions.
 struct Lz {
@@ -845,29 +821,12 @@ __device__ __forceinline__ uint32_t W32(const Lz *z, uint32_t a) {
   }
   return W(z, a) | (W(z, a + 1) << 8) | (W(z, a + 2) << 16) | (W(z, a + 3) << 24);
 }
-// hash of the string at a, from its little-endian first 4 bytes:
-//   De.Lz77  hash4, lib/de.ml:4067-4071: 4 bytes multiplied by 0x9e3779b1, top 15 bits;
-//   Lz       update_hash (lib/lz.ml:153-155, shift 5, 15 bits) rolled over 3 bytes by fill_window's
-//            priming (lib/lz.ml:399-401) + insert_string (lib/lz.ml:297-304) — every string that is
-//            inserted at all is inserted right after its predecessor, so the rolled state is this
-//            pure function of the 3 bytes.
-__device__ __forceinline__ uint32_t hash_of(int matcher, uint32_t w4) {
-  if (matcher == MD_MATCHER_LZ)
-    return (((w4 & 0xff) << 10) ^ (((w4 >> 8) & 0xff) << 5) ^ ((w4 >> 16) & 0xff)) & (HASH_SIZE - 1);
-  return (uint32_t)(w4 * 0x9e3779b1u) >> (32 - HASH_BITS);
-}
-__device__ __forceinline__ unsigned hash4(const Lz *z, uint32_t a) { return hash_of(z->matcher, W32(z, a)); }
+// insert_string, lib/de.ml:4220-4226: the chains were built ahead (deflate_link_kernel), inserting is looking up
 __device__ uint32_t insert_string(const DS *s, const Lz *z, const Ws *ws, uint32_t str) {
-  if (str < z->prepared_end) {  // precomputed by the wave; the chain link is published now, in order
-    uint32_t res = s->hh[str & (RING - 1)];
-    ws->prev[str & WMASK] = res;
-    return res;
-  }
-  unsigned h = hash4(z, str);
-  uint32_t res = g_ld(ws->head + h);
-  ws->prev[str & WMASK] = res;
-  ws->head[h] = str;
-  return res;
+  if (str < z->prepared_end) return s->hh[str & (RING - 1)];
+  if (str < z->p_end) return link_at(ws, str);
+  // De's last string (position len - 3, lookahead 3): its hash reads one byte beyond the data (H7)
+  return W(z, str + 3) == 0 ? ws->tail0 : ws->tail1;
 }
 // longest_match, lib/de.ml:4110-4174
 __device__ int longest_match(Lz *z, const Ws *ws, uint32_t cur_match) {
@@ -897,7 +856,7 @@ __device__ int longest_match(Lz *z, const Ws *ws, uint32_t cur_match) {
         scan_end = W16(z, ss + best_len - 1);
       }
     }
-    cur_match = g_ld(ws->prev + (cur_match & WMASK));
+    cur_match = link_at(ws, cur_match);
     z->n_chain++;
     chain_length--;
     if (!(cur_match > limit && chain_length != 0)) break;
@@ -942,7 +901,7 @@ __device__ __forceinline__ bool lz_deflate(DS *s, Enc *e, Lz *z, const Ws *ws) {
       const uint32_t f = s->flg[r];
       if (f == FL_ENDED) fast = true;
       else if (f == FL_MATCH) {
-        const uint32_t m = g_ld(ws->mring + (z->prev_length >= z->good_length ? RING : 0) + r);
+        const uint32_t m = g_ld((z->prev_length >= z->good_length ? ws->mq : ws->m) + z->strstart);
         if ((int)(m >> 16) > z->prev_length) {
           ml = (int)(m >> 16);
           z->match_start = z->strstart - (m & 0xffff);
@@ -1233,8 +1192,7 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
     const uint64_t *__restrict__ in_off, const uint64_t *__restrict__ in_len, uint8_t *__restrict__ out,
     const uint64_t *__restrict__ out_off, const uint64_t *__restrict__ out_cap,
     uint64_t *__restrict__ out_len, int32_t *__restrict__ status, uint32_t *__restrict__ checksum,
-    uint32_t *__restrict__ ws_head, uint32_t *__restrict__ ws_prev, int *__restrict__ ws_queue,
-    uint32_t *__restrict__ ws_mring, uint64_t *__restrict__ dbg, int test_flags, const uint8_t *__restrict__ gz_hdr, uint32_t gz_hdr_len,
+    Front fr, int *__restrict__ ws_queue, uint64_t *__restrict__ dbg, const uint8_t *__restrict__ gz_hdr, uint32_t gz_hdr_len,
     const uint32_t *__restrict__ gz_crc, int matcher, uint32_t *__restrict__ hist) {
   __shared__ DS ds;
   // optional phase profile of stream 0 (md_set_option "profile"): [0] setup [1] look-ahead [2] bulk
@@ -1251,7 +1209,8 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
   const uint32_t lane = threadIdx.x, sid = blockIdx.x;
   if (sid >= n) return;
   const uint8_t *src = in + in_off[sid];
-  if (in_len[sid] > MD_MAX_STREAM) {  // 32-bit cursors: the descriptor is out of range (mdeflate.h)
+  if (in_len[sid] > MD_MAX_STREAM || fr.flags[0]) {  // 32-bit cursors: the descriptor is out of range (mdeflate.h);
+                                                       // or the batch is larger than md_deflate_params.total_in_bytes said
     if (lane == 0) {
       status[sid] = MD_E_INVALID_ARGUMENT;
       out_len[sid] = 0;
@@ -1263,11 +1222,10 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
   uint8_t *dst = out + out_off[sid];
   uint64_t cap64 = out_cap[sid];
   uint32_t cap = cap64 > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)cap64;  // more room than 32-bit cursors can use
-  Ws ws{ws_head + (size_t)sid * HASH_SIZE, ws_prev + (size_t)sid * WSIZE, ws_queue + (size_t)sid * qcap,
-        ws_mring + (size_t)sid * 2 * RING};
+  const uint64_t so = fr.slot[sid];
+  Ws ws{fr.link + so, fr.flg + so, fr.m + so, fr.mq + so, ws_queue + (size_t)sid * qcap, fr.tail[2 * sid], fr.tail[2 * sid + 1]};
 
-  // ---- cooperative setup: NIL heads, histograms, code tables, Adler-32 of the input
-  for (uint32_t i = lane; i < (uint32_t)HASH_SIZE; i += kWave) ws.head[i] = 0;
+  // ---- cooperative setup: histograms, code tables, Adler-32 of the input
   for (uint32_t i = lane; i < (uint32_t)HEAP_SIZE; i += kWave) ds.lits[i] = i == 256 ? 1 : 0;  // make_literals
   if (lane < 2 * D_CODES + 1) ds.dsts[lane] = 0;
   for (uint32_t len = lane; len < 259; len += kWave) {  // _length, lib/de.ml:240-256
@@ -1368,8 +1326,6 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
   }
   const bool no_text = driver == DRV_ENCODE;
   const uint32_t eff_level = driver == DRV_HIGHER ? 4 : (matcher == MD_MATCHER_LZ && level < 4) ? 4 : level;
-  const uint32_t max_chain = c_levels[eff_level][0], nice = c_levels[eff_level][3];
-  const uint32_t qlimit = max_chain >> 2, kspec = max_chain < (uint32_t)KSPEC ? max_chain : (uint32_t)KSPEC;
   const uint32_t p_end = no_text ? 0
                          : matcher == MD_MATCHER_LZ ? (slen >= 3 ? slen - 2 : 0)
                                                     : (eff_level != 0 && slen >= 4) ? slen - 3 : 0;
@@ -1379,8 +1335,8 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
     if (ds.ctl[1]) break;
     const uint32_t ss = ds.ctl[0];
     uint32_t pe = ds.ctl[2];
-    // ---- the wave runs ahead of the matcher: hash heads + pre-walked chains, PG steps of 64
-    //      positions at a time so that the chain walks of the steps overlap in flight
+    // ---- the ring runs ahead of the matcher: hash heads, verdicts and bytes of the next positions, PG steps of 64
+    //      positions per load (all of it was computed for the whole batch by deflate_front.hip)
     for (;;) {
       uint32_t nb = 0;
       if (pe < p_end) {
@@ -1392,202 +1348,28 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
         if (nb < (uint32_t)PG && nb != left && pe >= ss + 324) nb = 0;
       }
       if (nb == 0) break;
-      uint32_t w4[PG], c1[PG], cw[PG], fl[PG], hv[PG], ret[PG];
+      uint32_t lk[PG], fv[PG], bv[PG];
 #pragma unroll
       for (int g = 0; g < PG; g++) {
         const uint32_t pos = pe + g * kWave + lane;
-        w4[g] = 0;
+        lk[g] = 0;
+        fv[g] = 0;
+        bv[g] = 0;
         if ((uint32_t)g < nb && pos < p_end) {
-          if (pos + 4 <= slen) __builtin_memcpy(&w4[g], src + pos, 4);
-          else w4[g] = (uint32_t)src[pos] | ((uint32_t)src[pos + 1] << 8) | ((uint32_t)src[pos + 2] << 16);  // Lz's last string
-        }
-      }
-      // head[h] <- max(pos), one atomic per position, all steps of the group in flight together.
-      // The returned values of a set of equal hashes are >= the head before the set, and one of them
-      // is exactly that value.  Steps are expected to reach a head in program order (same wave,
-      // same address); `bad` catches a step overtaken by a later one and the group is then redone
-      // from the raw (hash, returned value) pairs, which does not depend on any order.
-#pragma unroll
-      for (int g = 0; g < PG; g++) {
-        const uint32_t pos = pe + g * kWave + lane;
-        hv[g] = hash_of(matcher, w4[g]);
-        ret[g] = ((uint32_t)g < nb && pos < p_end) ? atomicMax(ws.head + hv[g], pos) : 0xffffffffu;
-      }
-      bool bad = (test_flags & 1) != 0;
-#pragma unroll
-      for (int g = 0; g < PG; g++) {
-        if ((uint32_t)g < nb) {  // uniform
-          const uint32_t pos = pe + g * kWave + lane;
-          const bool valid = pos < p_end;
-          const uint32_t h = hv[g];
-          // A lane that shares its hash with an earlier lane of the step got back a position of this step (or of a
-          // later one: `bad`).  No such lane: every returned value is the head before the step, i.e. the answer.
-          if (__ballot(valid && ret[g] >= pe + g * kWave) == 0) {
-            c1[g] = valid ? ret[g] : 0;
-            continue;
-          }
-          // lanes of this step with the same hash: intersect the ballots of the 15 hash bits
-          uint64_t same = __ballot(valid);
-#pragma unroll
-          for (int bit = 0; bit < HASH_BITS; bit++) {
-            const bool mine = (h >> bit) & 1;
-            const uint64_t bal = __ballot(mine);
-            same &= mine ? bal : ~bal;
-          }
-          const uint64_t below = same & lanes_below(lane);
-          const bool found = valid && below != 0;
-          const uint32_t pred = below ? 63u - (uint32_t)__builtin_clzll(below) : 0u;
-          const uint32_t first = valid ? (uint32_t)__builtin_ctzll(same) : lane;
-          ds.gmin[lane] = 0xffffffffu;
-          __syncthreads();
-          if (valid) atomicMin(&ds.gmin[first], ret[g]);
-          __syncthreads();
-          if (valid && ret[g] >= pe + (g + 1) * kWave) bad = true;  // a later step got there first
-          c1[g] = valid ? (found ? pe + g * kWave + pred : ds.gmin[lane]) : 0;
-          __syncthreads();
-        } else c1[g] = 0;
-      }
-      if (__ballot(bad)) {
-        // order-free reconstruction: predecessor = nearest earlier position of the group with the
-        // same hash, else the smallest value any of them got back (the head before the group)
-        uint16_t *rh = (uint16_t *)ds.hk;             // [PG * 64] hashes (tree scratch is idle here)
-        uint32_t *rr = (uint32_t *)(ds.hk + 128);     // [PG * 64] returned values
-#pragma unroll
-        for (int g = 0; g < PG; g++) {
-          const uint32_t pos = pe + g * kWave + lane;
-          const bool valid = (uint32_t)g < nb && pos < p_end;
-          rh[g * kWave + lane] = valid ? (uint16_t)hv[g] : (uint16_t)0xffff;
-          rr[g * kWave + lane] = ret[g];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int g = 0; g < PG; g++) {
-          const uint32_t me = g * kWave + lane;
-          uint32_t vmin = 0xffffffffu, pred = 0xffffffffu;
-          for (uint32_t k = 0; k < nb * kWave; k++) {
-            if (rh[k] == hv[g]) {
-              if (rr[k] < vmin) vmin = rr[k];
-              if (k < me) pred = k;
-            }
-          }
-          const uint32_t pos = pe + me;
-          if ((uint32_t)g < nb) c1[g] = pos < p_end ? (pred != 0xffffffffu ? pe + pred : vmin) : 0;
-        }
-        __syncthreads();
-      }
-#pragma unroll
-      for (int g = 0; g < PG; g++) {
-        if ((uint32_t)g < nb) {
-          const uint32_t r = (pe + g * kWave + lane) & (RING - 1);
-          ds.hh[r] = c1[g];
-          ds.byt[r] = (uint8_t)w4[g];
-        }
-        cw[g] = c1[g];
-        fl[g] = 0;
-      }
-      __syncthreads();
-      // longest_match (lib/de.ml:4110-4174) run ahead for every position, one chain per lane, the
-      // chains of the PG steps in flight together.  The bar is prev_length = 2 and the chain is the
-      // full one; the best candidate after max_chain >> 2 links is kept as well (the matcher walks
-      // the quartered chain when prev_length >= good_length).  A candidate counts when it shares
-      // the first 3 bytes (the 16-bit pre-filters of the reference can only skip candidates that
-      // would not win); the walk ends at the first candidate of nice_length, after max_chain
-      // links, or where the chain leaves the reach of the position.  The window limit is
-      // pos - MAX_DIST whatever the window base: before the first slide the base is 0, after a
-      // slide strstart - base >= MAX_DIST.
-      uint32_t cnt[PG], best[PG], bdist[PG], bestq[PG], bdistq[PG];
-#pragma unroll
-      for (int g = 0; g < PG; g++) {
-        cnt[g] = 0;
-        best[g] = MIN_MATCH - 1;
-        bdist[g] = 0;
-        bestq[g] = MIN_MATCH - 1;
-        bdistq[g] = 0;
-      }
-      for (uint32_t lv = 0; lv < kspec; lv++) {
-        bool act[PG];
-        bool any = false;
-#pragma unroll
-        for (int g = 0; g < PG; g++) {
-          const uint32_t pos = pe + g * kWave + lane;
-          const uint32_t lower = pos > (uint32_t)MAX_DIST ? pos - MAX_DIST : 0;
-          // the head candidate is admitted at distance == MAX_DIST, links only above the limit
-          // (lib/de.ml:4367-4369 vs :4165)
-          act[g] = (uint32_t)g < nb && fl[g] == 0 &&
-                   (lv == 0 ? (cw[g] != 0 && pos - cw[g] <= (uint32_t)MAX_DIST) : cw[g] > lower);
-          any = any || act[g];
-        }
-        if (__ballot(any) == 0) break;
-        uint32_t v[PG], nx[PG];
-#pragma unroll
-        for (int g = 0; g < PG; g++) {
-          v[g] = 0;
-          nx[g] = 0;
-          if (act[g]) {
-            __builtin_memcpy(&v[g], src + cw[g], 4);  // candidate < pos <= n - 3
-            // link of the candidate: still in the ring if the matcher has not published it yet
-            nx[g] = cw[g] >= ss ? ds.hh[cw[g] & (RING - 1)] : g_ld(ws.prev + (cw[g] & WMASK));
-          }
-        }
-#pragma unroll
-        for (int g = 0; g < PG; g++) {
-          if (act[g]) {
-            const uint32_t pos = pe + g * kWave + lane;
-            if (((v[g] ^ w4[g]) & 0xffffffu) == 0) {
-              if (pos + MIN_LOOKAHEAD > slen) fl[g] = 8;  // too close to the end to compare ahead: the matcher's job
-              else {
-                // scan_end pre-filter (lib/de.ml:4133-4134): a candidate that differs at the end of
-                // the best match so far cannot be longer
-                uint32_t len = 0;
-                bool look = true;
-                if (best[g] >= (uint32_t)MIN_MATCH) {
-                  uint16_t x, y;
-                  __builtin_memcpy(&x, src + pos + best[g] - 1, 2);
-                  __builtin_memcpy(&y, src + cw[g] + best[g] - 1, 2);
-                  look = x == y;
-                }
-                if (look) len = lcp258(src + pos, src + cw[g]);
-                if (len > best[g]) {
-                  best[g] = len;
-                  bdist[g] = pos - cw[g];
-                  if (len >= nice) fl[g] = FL_MATCH;
-                }
-              }
-            }
-            cnt[g]++;
-            if (cnt[g] == qlimit) {
-              bestq[g] = best[g];
-              bdistq[g] = bdist[g];
-            }
-            cw[g] = nx[g];
-          }
+          lk[g] = __builtin_nontemporal_load(ws.link + pos);
+          fv[g] = __builtin_nontemporal_load(ws.flg + pos);
+          bv[g] = src[pos];
         }
       }
 #pragma unroll
       for (int g = 0; g < PG; g++) {
         if ((uint32_t)g < nb) {
-          const uint32_t pos = pe + g * kWave + lane;
-          const uint32_t lower = pos > (uint32_t)MAX_DIST ? pos - MAX_DIST : 0;
-          uint32_t f = fl[g];
-          if (f == 0) {
-            // chain exhausted (or never entered), or max_chain links walked: the verdict is final
-            const bool entered = cnt[g] != 0;
-            const bool more = entered ? cw[g] > lower : (cw[g] != 0 && pos - cw[g] <= (uint32_t)MAX_DIST);
-            if (!more || cnt[g] >= max_chain) f = best[g] >= (uint32_t)MIN_MATCH ? FL_MATCH : FL_ENDED;
-          }
-          if (f == FL_MATCH) {
-            if (cnt[g] < qlimit) {
-              bestq[g] = best[g];
-              bdistq[g] = bdist[g];
-            }
-            const uint32_t r = pos & (RING - 1);
-            ws.mring[r] = (best[g] << 16) | bdist[g];
-            ws.mring[RING + r] = (bestq[g] << 16) | bdistq[g];
-          }
-          ds.flg[pos & (RING - 1)] = (uint8_t)(f == FL_MATCH || f == FL_ENDED ? f : 0);
+          const uint32_t pos = pe + g * kWave + lane, r = pos & (RING - 1);
+          ds.hh[r] = lk[g] ? pos - lk[g] : 0u;
+          ds.flg[r] = (uint8_t)fv[g];
+          ds.byt[r] = (uint8_t)bv[g];
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the match ring has landed before lane 0 reads it
       pe = pe + nb * kWave < p_end ? pe + nb * kWave : p_end;
       pc[0] += nb;
     }
@@ -1620,7 +1402,6 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
         const uint32_t byte = ds.byt[(p - 1) & (RING - 1)];  // the pending literal of the previous position
         ws.queue[(qw + lane) & ((uint32_t)qcap - 1)] = (int)byte;
         atomicAdd(&ds.lits[byte], 1);
-        ws.prev[p & WMASK] = hhv;  // the chain link of p is published in order
       }
       if (lane == 0) {
         ds.zs.strstart = s0 + K;
@@ -1659,7 +1440,7 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
           if (f == FL_ENDED || f == FL_MATCH) k = 1;
           if (c1v > base && q - c1v <= (uint32_t)MAX_DIST) k |= 2;
           if (f == FL_MATCH) {
-            const uint32_t a = g_ld(ws.mring + r), b = g_ld(ws.mring + RING + r);
+            const uint32_t a = g_ld(ws.m + q), b = g_ld(ws.mq + q);
             lf = a >> 16;
             df = a & 0xffff;
             lq = b >> 16;
@@ -1753,8 +1534,6 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
         pending = 0;
         cur += k + L;  // the match at cur + k covers L positions
       }
-      // chain links of everything that was passed (all of it is in the ring)
-      for (uint32_t q = s0 + lane; q < s0 + cur; q += kWave) ws.prev[q & WMASK] = ds.hh[q & (RING - 1)];
       if (lane == 0 && cur > 0) {
         ds.zs.strstart = s0 + cur;
         ds.zs.lookahead = la - cur;
@@ -1880,7 +1659,7 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
     }
     if (lane == 0) {
       const bool ok = room && !run.e.overflow;
-      out_len[sid] = ok ? 4ull * run.ncmd : 0;
+      out_len[sid] = room ? 4ull * run.ncmd : 0;  // on overflow: the size the caller needs (mdeflate.h)
       status[sid] = ok ? MD_OK : MD_UNEXPECTED_END_OF_OUTPUT;
       if (checksum) checksum[sid] = adler;
     }
@@ -1925,24 +1704,26 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
 }  // namespace defl
 }  // namespace md
 
-extern "C" size_t md_deflate_ws_bytes(uint32_t n, int qcap) {
-  return (size_t)n * ((size_t)md::defl::HASH_SIZE * 4 + (size_t)md::defl::WSIZE * 4 + (size_t)qcap * 4 +
-                      (size_t)md::defl::RING * 8);
-}
+extern "C" size_t md_deflate_queue_bytes(uint32_t n, int qcap) { return (size_t)n * (size_t)qcap * 4; }
 
+// fr: the front workspace of this batch, filled by md_launch_deflate_plan + md_launch_deflate_front
 extern "C" int md_launch_deflate(int format, int level, int qcap, int driver, int dynamic, uint32_t n,
                                  const uint8_t *in, const uint64_t *in_off, const uint64_t *in_len,
                                  uint8_t *out, const uint64_t *out_off, const uint64_t *out_cap,
-                                 uint64_t *out_len, int32_t *status, uint32_t *checksum, void *ws,
-                                 uint64_t *dbg, int test_flags, const uint8_t *gz_hdr, uint32_t gz_hdr_len,
+                                 uint64_t *out_len, int32_t *status, uint32_t *checksum, const md::defl::Front *fr,
+                                 void *queue_ws, uint64_t *dbg, const uint8_t *gz_hdr, uint32_t gz_hdr_len,
                                  const uint32_t *gz_crc, int matcher, uint32_t *hist, hipStream_t stream) {
   if (n == 0) return 0;
-  uint32_t *head = (uint32_t *)ws;
-  uint32_t *prev = head + (size_t)n * md::defl::HASH_SIZE;
-  int *queue = (int *)(prev + (size_t)n * md::defl::WSIZE);
-  uint32_t *mring = (uint32_t *)(queue + (size_t)n * qcap);
   hipLaunchKernelGGL(md::defl::deflate_kernel, dim3(n), dim3(md::defl::kWave), 0, stream, format, level,
                      qcap, driver, dynamic, n, in, in_off, in_len, out, out_off, out_cap, out_len, status,
-                     checksum, head, prev, queue, mring, dbg, test_flags, gz_hdr, gz_hdr_len, gz_crc, matcher, hist);
+                     checksum, *fr, (int *)queue_ws, dbg, gz_hdr, gz_hdr_len, gz_crc, matcher, hist);
   return (int)hipGetLastError();
+}
+
+// max_chain / nice_length of the level the matcher runs at (lib/de.ml:4030-4049) for the front kernels
+extern "C" void md_deflate_level_params(int driver, int matcher, int level, uint32_t *max_chain, uint32_t *nice) {
+  static const uint16_t lv[10][2] = {{0, 0}, {4, 8}, {8, 16}, {32, 32}, {16, 16}, {32, 32}, {128, 128}, {256, 128}, {1024, 258}, {4096, 258}};
+  int eff = driver == 1 ? 4 : (matcher == MD_MATCHER_LZ && level < 4) ? 4 : level;
+  *max_chain = lv[eff][0];
+  *nice = lv[eff][1];
 }

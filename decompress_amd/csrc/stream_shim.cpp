@@ -134,8 +134,13 @@ struct md_def_stream {
 
 extern "C" {
 
+extern "C" int md_validate_deflate_params(md_ctx *ctx, int format, const md_deflate_params *params);
+
 md_def_stream *md_def_encoder(md_ctx *ctx, int format, const md_deflate_params *params, uint8_t *o, size_t o_len) {
   if (!ctx || !params || !o || o_len == 0) return nullptr;
+  // format, level, queue (a power of two >= 4), driver, matcher, window: refused here (md_last_error_string says
+  // why), not at the end of the input — Zl.Def.encoder raises Invalid_argument at construction too (lib/de.ml:2286-2288)
+  if (md_validate_deflate_params(ctx, format, params) != MD_OK) return nullptr;
   md_def_stream *s = new md_def_stream();
   s->ctx = ctx;
   s->format = format;

@@ -116,12 +116,12 @@ class Engine:
         self._gz = dict(mtime=int(mtime) & 0xffffffff, os=int(os), hcrc=int(bool(hcrc)), ascii=int(bool(ascii)),
                         filename=filename, comment=comment)
 
-    def _params(self, level, queue, driver, dynamic, matcher=None, header=None):
+    def _params(self, level, queue, driver, dynamic, matcher=None, header=None, total_in=0):
         h = header if header is not None else getattr(self, "_gz", None)
         gz = _lib.GzHeader(**h) if h else None
         p = _lib.DeflateParams(int(level), int(queue), int(driver), int(bool(dynamic)),
                                int(getattr(self, "_matcher", MATCHER_DE) if matcher is None else matcher),
-                               ctypes.pointer(gz) if gz is not None else None)
+                               ctypes.pointer(gz) if gz is not None else None, 0, int(total_in))
         p._keep = gz  # the struct must outlive the call
         return p
 
@@ -213,9 +213,10 @@ class Engine:
 
     # ------------------------------------------------------------------ deflate
     def deflate_batch(self, fmt, d_in, in_off, in_len, d_out, out_off, out_cap, level=6, queue=4096,
-                      driver=DRIVER_ZL, dynamic=True, results=None, matcher=None, header=None):
+                      driver=DRIVER_ZL, dynamic=True, results=None, matcher=None, header=None, total_in=0):
         """All arguments are CUDA tensors (uint8 data, int64 descriptors).
-        Returns (out_len, status, adler32_of_input) CUDA tensors (async)."""
+        Returns (out_len, status, adler32_of_input) CUDA tensors (async).  total_in: an upper bound of in_len.sum()
+        when the caller knows it (md_deflate_params.total_in_bytes); 0 makes the engine read the sum back first."""
         torch = self.torch
         n = in_off.numel()
         if results is None:
@@ -223,7 +224,7 @@ class Engine:
                        torch.empty(n, dtype=torch.int32, device=self.device),
                        torch.empty(n, dtype=torch.int32, device=self.device))
         out_len, status, checksum = results
-        params = self._params(level, queue, driver, dynamic, matcher, header)
+        params = self._params(level, queue, driver, dynamic, matcher, header, total_in)
         self._check(self.lib.md_deflate_batch_device(
             self.ctx, fmt, ctypes.byref(params), n, _ptr(d_in), _ptr(in_off), _ptr(in_len),
             _ptr(d_out), _ptr(out_off), _ptr(out_cap), _ptr(out_len), _ptr(status), _ptr(checksum)))
@@ -254,7 +255,8 @@ class Engine:
         d_out = torch.zeros(int(out_off[-1] + cap[-1]) + 16, dtype=torch.uint8, device=dev)
         t = lambda a: torch.from_numpy(a).to(dev)
         out_len, status, checksum = self.deflate_batch(fmt, d_in, t(in_off), t(in_len), d_out, t(out_off), t(cap),
-                                                       level, queue, driver, dynamic, matcher=matcher, header=header)
+                                                       level, queue, driver, dynamic, matcher=matcher, header=header,
+                                                       total_in=max(1, int(in_len.sum())))
         torch.cuda.synchronize(dev)
         out = d_out.cpu().numpy()
         out_len, status = out_len.cpu().numpy(), status.cpu().numpy()

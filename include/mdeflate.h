@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MD_VERSION 0x000200 /* 0.2.0 */
+#define MD_VERSION 0x000300 /* 0.3.0 */
 #define MD_MAX_INFLATE_IN 0x1ffffff0ull
 #define MD_MAX_STREAM 0xfffffff0ull
 
@@ -188,6 +188,14 @@ typedef struct md_deflate_params {
   int dynamic;   /* Zl.Def's ?dynamic: 0 -> Fixed blocks */
   int matcher;   /* MD_MATCHER_* */
   const md_gz_header *gz_header; /* MD_FORMAT_GZIP only; NULL = default header */
+  int wbits;     /* log2 of the sliding window `De.Lz77.state ~w` derives from its window buffer (lib/de.ml:4462-4464):
+                  * 0 or 15 = De.make_window ~bits:15, the only size the reference's callers use and the only one
+                  * the kernels implement; anything else is MD_E_INVALID_ARGUMENT */
+  size_t total_in_bytes; /* batch calls with device descriptors: an upper bound of the sum of in_len[i], or 0 when the
+                  * caller does not know it.  The engine sizes a per-position workspace (11 bytes per input byte:
+                  * hash-chain links and look-ahead verdicts) from it; with 0 it reads the sum back from the device first,
+                  * i.e. the call waits for the work already enqueued on the context's stream.  A batch whose descriptors
+                  * add up to more than the hint gets status[i] = MD_E_INVALID_ARGUMENT for every stream. */
 } md_deflate_params;
 
 /* Batched deflate of n independent buffers, everything resident in HBM.

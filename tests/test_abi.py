@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_builds_and_loads():
     build.build()
     lib = _lib.load()
-    assert lib.md_version() == 0x000200
+    assert lib.md_version() == 0x000300
 
 
 def test_header_symbols_exported():

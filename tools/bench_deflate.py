@@ -32,12 +32,13 @@ def main():
     d_in, d_off, d_len = t(blob), t(off), t(ln)
     d_out = torch.empty(int(cap.sum()), dtype=torch.uint8, device=dev)
     d_ooff, d_cap = t(ooff), t(cap)
-    res = eng.deflate_batch(decompress_amd.FORMAT_ZLIB, d_in, d_off, d_len, d_out, d_ooff, d_cap, level=args.level)
+    total_in = n * nb
+    res = eng.deflate_batch(decompress_amd.FORMAT_ZLIB, d_in, d_off, d_len, d_out, d_ooff, d_cap, level=args.level, total_in=total_in)
     torch.cuda.synchronize()
     eng.timing_begin()
     for _ in range(args.steps):
         res = eng.deflate_batch(decompress_amd.FORMAT_ZLIB, d_in, d_off, d_len, d_out, d_ooff, d_cap,
-                                level=args.level, results=res)
+                                level=args.level, results=res, total_in=total_in)
     ms = eng.timing_end() / args.steps
     out_len, status, _ = res
     ok = bool((status == 0).all().item())
