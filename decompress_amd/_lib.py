@@ -53,6 +53,7 @@ SYMBOLS = [
     ("md_de_lz77_compress", ctypes.c_int,
      [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp, c_sz, c_vp, c_sz, c_szp, c_vp, c_vp]),
     ("md_de_def_encode", ctypes.c_int, [c_vp, ctypes.c_int, c_vp, c_sz, c_vp, c_sz, c_szp]),
+    ("md_de_def_run", ctypes.c_int, [c_vp, ctypes.c_int, c_vp, c_sz, c_vp, c_sz, c_szp, c_vp, c_sz, c_szp]),
     ("md_inf_decoder", c_vp, [c_vp, ctypes.c_int, c_vp, c_sz]),
     ("md_inf_src", ctypes.c_int, [c_vp, c_vp, c_sz, c_sz]),
     ("md_inf_decode", ctypes.c_int, [c_vp]),

@@ -481,7 +481,7 @@ static int deflate_launch(md_ctx *ctx, int format, int level, int queue_len, int
   uint32_t chunks = 0;
   uint32_t max_chain = 0, nice = 0;
   md_deflate_level_params(driver, matcher, level, &max_chain, &nice);
-  const bool matcher_runs = max_chain != 0 && driver != 4;  // level 0 copies; De.Def.encode has no text
+  const bool matcher_runs = max_chain != 0 && driver < 4;  // level 0 copies; De.Def.encode has no text
   if (matcher_runs && total_in != 0) {
     // slot <= len + 64 + 255 positions and <= len / 256 + 1 chunks per stream
     positions = (uint64_t)total_in + 319ull * n;
@@ -713,6 +713,23 @@ int md_de_def_encode(md_ctx *ctx, int kind, const uint32_t *cmds, size_t ncmds, 
   int queue_len = 4;
   while ((size_t)queue_len < ncmds + 1) queue_len <<= 1;  // Queue.create: a power of two that holds them all
   return deflate_partial(ctx, 4, queue_len, 4, kind, MD_MATCHER_DE, cmds, ncmds * 4, dst, dst_cap, written, nullptr);
+}
+
+int md_de_def_run(md_ctx *ctx, int queue_len, const uint32_t *ops, size_t nops, uint8_t *dst, size_t dst_cap, size_t *written,
+                  uint8_t *results, size_t results_cap, size_t *nresults) {
+  if (!ctx || !written || (!ops && nops) || (!dst && dst_cap) || (!results && results_cap)) return MD_E_INVALID_ARGUMENT;
+  if (queue_len < 4 || queue_len > (1 << 20) || (queue_len & (queue_len - 1)))
+    return fail(ctx, MD_E_INVALID_ARGUMENT, "Length of queue MUST be a power of two");
+  if (nops > MD_MAX_STREAM / 4) return fail(ctx, MD_E_INVALID_ARGUMENT, "operation list too long");
+  uint32_t res[316];
+  memset(res, 0, sizeof res);
+  int st = deflate_partial(ctx, 4, queue_len, 5, 0, MD_MATCHER_DE, ops, nops * 4, dst, dst_cap, written, res);
+  if (st < 0 && st != MD_E_INVALID_ARGUMENT) return st;
+  const size_t n = res[0];
+  if (nresults) *nresults = n;
+  for (size_t i = 0; i < n && i < results_cap && i < 315; i++) results[i] = (uint8_t)res[1 + i];
+  if (st == MD_E_INVALID_ARGUMENT) return fail(ctx, st, "not a De.Def operation list");
+  return st;
 }
 
 static int inflate_one(md_ctx *ctx, int format, const uint8_t *src, size_t src_len, uint8_t *dst,

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(kPlanThreads) void deflate_plan_kernel(uint32_t n, 
   const uint32_t per = (n + kPlanThreads - 1) / kPlanThreads;
   const uint32_t lo = t * per < n ? t * per : n, hi = lo + per < n ? lo + per : n;
   const uint32_t eff = effective_level(driver, matcher, level);
-  const bool no_text = driver == 4;  // DRV_ENCODE: the input is a command list
+  const bool no_text = driver >= 4;  // DRV_ENCODE / DRV_SCRIPT: the input is a list of commands / operations
   uint64_t pos = 0;
   uint32_t chk = 0;
   for (uint32_t i = lo; i < hi; i++) {
@@ -112,17 +112,30 @@ __global__ __launch_bounds__(kWave) void deflate_link_kernel(uint32_t n, const u
     for (uint32_t i = lane; i < (uint32_t)HASH_SIZE / 4; i += kWave) h4[i] = make_uint4(0, 0, 0, 0);
   }
   __syncthreads();
+  // the input of group k + 2 is requested before group k is worked on: one wavefront per CU has nothing else to hide
+  // the HBM latency of its loads behind
+  auto load_group = [&](uint32_t pe, uint32_t (&w)[PGL]) {
+#pragma unroll
+    for (int g = 0; g < PGL; g++) {
+      const uint32_t pos = pe + g * kWave + lane;
+      w[g] = 0;
+      if (pos < p_end) {
+        if (pos + 4 <= slen) __builtin_memcpy(&w[g], src + pos, 4);
+        else w[g] = (uint32_t)src[pos] | ((uint32_t)src[pos + 1] << 8) | ((uint32_t)src[pos + 2] << 16);  // Lz's last string
+      }
+    }
+  };
+  uint32_t wa[PGL], wb[PGL];
+  load_group(0, wa);
+  load_group(PGL * kWave, wb);
   for (uint32_t pe = 0; pe < p_end; pe += PGL * kWave) {
     uint32_t w4[PGL], hv[PGL], ret[PGL];
 #pragma unroll
     for (int g = 0; g < PGL; g++) {
-      const uint32_t pos = pe + g * kWave + lane;
-      w4[g] = 0;
-      if (pos < p_end) {
-        if (pos + 4 <= slen) __builtin_memcpy(&w4[g], src + pos, 4);
-        else w4[g] = (uint32_t)src[pos] | ((uint32_t)src[pos + 1] << 8) | ((uint32_t)src[pos + 2] << 16);  // Lz's last string
-      }
+      w4[g] = wa[g];
+      wa[g] = wb[g];
     }
+    load_group(pe + 2 * PGL * kWave, wb);
 #pragma unroll
     for (int g = 0; g < PGL; g++) {
       const uint32_t pos = pe + g * kWave + lane;

@@ -53,7 +53,11 @@ __constant__ uint16_t c_levels[10][4] = {{0, 0, 0, 0},         {4, 4, 4, 8},    
 enum { KIND_FLAT = 0, KIND_FIXED = 1, KIND_DYNAMIC = 2 };
 enum { DRV_ZL = 0, DRV_HIGHER = 1, DRV_CLI = 2,
        DRV_LZ77 = 3,     // De.Lz77.compress alone: the queue fills are written out as commands (md_de_lz77_compress)
-       DRV_ENCODE = 4 }; // De.Def.encode alone: the input IS the command list of one last block (md_de_def_encode)
+       DRV_ENCODE = 4,   // De.Def.encode alone: the input IS the command list of one last block (md_de_def_encode)
+       DRV_SCRIPT = 5 }; // De.Def.encode driven step by step: the input is a list of operations (md_de_def_run)
+// operations of DRV_SCRIPT, 32-bit words (mdeflate.h MD_OP_*)
+enum { OP_FILL = 1, OP_BLOCK = 2, OP_FLUSH = 3, OP_SUCC_LITERAL = 4, OP_SUCC_LENGTH = 5, OP_SUCC_DISTANCE = 6, OP_NEW_FREQS = 7,
+       OP_QUEUE_RESET = 8 };
 enum { K_FIRST_ENTRY, K_ENCODE, K_BLOCK, K_FLAT_DONE };
 enum { R_OK, R_BLOCK };
 enum { V_AWAIT, V_FLUSH, V_BLOCK };
@@ -77,39 +81,29 @@ __device__ __forceinline__ TreeRef tref(TreeT<N> *t) {
   return TreeRef{t->lengths, t->codes, t->clen, &t->max_code};
 }
 
-// LDS scratch of one stream
+constexpr uint32_t RING = 1024;
+constexpr int PG = 8;    // steps of 64 positions loaded into the ring together
+
+// LDS of one stream: 9.6 KiB, so that 16 streams share a CU (4 096 streams = one generation on 256 CUs).  What is
+// live only while the trees of a block are built (heap, parent links, lengths) shares its space with what is live
+// only while the matcher runs (the ring of look-ahead inputs, the parse window): building trees kills the ring, and
+// it is loaded again from the front workspace before the matcher goes on (`ring_dead`).
 struct DS {
-  int lits[HEAP_SIZE];   // live literal/length histogram (make_literals, lib/de.ml:2333), mutated by T.make
-  int dsts[2 * D_CODES + 1];
-  int blf[2 * BL_CODES + 1];
-  alignas(16) uint64_t hk[L_CODES + 2];  // T.make's heap as keys (freq << 32 | depth << 16 | node), 1-based
-  uint16_t heap[HEAP_SIZE];              // its sorted tail: nodes in the order they left the heap
-  uint16_t dads[HEAP_SIZE];
-  uint16_t tlen[HEAP_SIZE];  // tree_lengths of the tree being built (leaves and internal nodes)
-  int bl_count[MAX_BITS + 1];
+  int lits[L_CODES];     // live literal/length histogram (make_literals, lib/de.ml:2333), mutated by T.make's pkzip rule
+  int dsts[D_CODES];
+  int blf[BL_CODES];
   TreeT<L_CODES> lt;           // trees of the CURRENT block (e.blk)
   TreeT<D_CODES> dt;
   TreeT<BL_CODES> bt;
   int kind_result;             // block kind chosen by trees_wave
   uint32_t tp[8];              // profile of trees_wave (ticks), only when profiling
-  uint16_t symbols[L_CODES + D_CODES + 8];  // (len << 8) | code of the code-length stream
   int nsymbols, h_lit, h_dst, h_len;
-  uint8_t length_code[259];
-  uint8_t dist_lo[256], dist_hi[256];
-  // look-ahead ring of decision-independent matcher inputs, indexed by position & (RING-1)
-  uint32_t hh[1024];     // hash_head(p): chain candidate 1
-  uint8_t flg[1024];     // look-ahead verdict of p (FL_*)
-  uint8_t byt[1024];     // the byte at p (pending literal of the next position)
-  uint32_t gmin[64];     // per hash group of one look-ahead step: head value before the step
   uint32_t ctl[5];       // [0] machine strstart, [1] machine state (1 = finished), [2] prepared_end, [3] action,
                          // [4] tree mode of ACT_TREES
+  uint32_t ring_dead;    // the ring's space was used by the tree builder: load it again from strstart - 1 on
   // wave-parallel bit packing of one queue fill (enc_write_wave)
   uint8_t t_xl[32], t_bl[32], t_xd[32];
   uint16_t t_bd[32];
-  uint32_t bb[104];      // bit buffer of one 64-command step (<= 15 + 64*48 bits)
-  // window of the parse step: what the look-ahead knows about positions s0 .. s0 + 79
-  uint16_t pm_lf[80], pm_df[80], pm_lq[80], pm_dq[80];  // longest_match ahead: full / quartered chain
-  uint8_t pm_k[80];      // bit 0: verdict known, bit 1: hash_head valid (lib/de.ml:4365-4369)
   struct ZS {            // matcher state the wave needs for bulk literal runs (lane 0 <-> wave)
     uint32_t strstart, lookahead, base, trivial, qw, qr, bulked;
     // trivial: 0 = the matcher must run; 1 = literal-run state (match_available, match_length 2);
@@ -121,14 +115,48 @@ struct DS {
     uint8_t *o;
     int *q;
   } w;
+  union alignas(16) {
+    struct {  // while trees are built (T.make)
+      alignas(16) uint64_t hk[L_CODES + 2];  // the heap as keys (freq << 32 | depth << 16 | node), 1-based
+      uint16_t heap[HEAP_SIZE];              // its sorted tail: nodes in the order they left the heap
+      uint16_t dads[HEAP_SIZE];
+      uint16_t tlen[HEAP_SIZE];  // tree_lengths of the tree being built (leaves and internal nodes)
+      int bl_count[MAX_BITS + 1];
+    };
+    // from the end of trees_wave to the header's bit packing: (len << 8) | code of the code-length stream, over the
+    // heap (dead by then)
+    uint16_t symbols[L_CODES + D_CODES + 8];
+    struct {  // while the matcher runs
+      // ring of decision-independent matcher inputs, indexed by position & (RING-1)
+      uint16_t hl[RING];     // link[p] = p - hash_head(p), 0 = none
+      uint8_t flg[RING];     // look-ahead verdict of p (FL_*)
+      uint8_t byt[RING];     // the byte at p (pending literal of the next position)
+      // window of the parse step: what the look-ahead knows about positions s0 .. s0 + 79
+      uint16_t pm_lf[80], pm_df[80], pm_lq[80], pm_dq[80];  // longest_match ahead: full / quartered chain
+      uint8_t pm_k[80];      // bit 0: verdict known, bit 1: hash_head valid (lib/de.ml:4365-4369)
+      // bit buffer of one 64-command packing step (<= 15 + 64*48 bits): behind the ring (a queue fill is packed
+      // while the ring is alive) and behind `symbols` (a header is packed from them)
+      uint32_t bb[104];
+    };
+  };
 };
-constexpr uint32_t RING = 1024;
-constexpr int PG = 8;    // steps of 64 positions loaded into the ring together
+static_assert(sizeof(DS) <= 10240 - 320, "16 streams per CU (with the lane-0 state next to it)");
 
-__device__ __forceinline__ int distance_code(const DS *s, int d1) {
-  return d1 < 256 ? s->dist_lo[d1] : s->dist_hi[d1 >> 7];
+// _length (lib/de.ml:240-256) of a match length 3..258 and _distance (lib/de.ml:258-291) of distance - 1, by arithmetic:
+// beyond the first codes a code is two bits (one bit) under the leading one of the value
+__device__ __forceinline__ int length_code_of(int len) {
+  const int l = len - 3;
+  if (l < 8) return l;
+  if (l == 255) return 28;
+  const int k = 31 - __builtin_clz((unsigned)l);
+  return 4 * (k - 1) + ((l >> (k - 2)) & 3);
 }
-__device__ void static_lit(int sym, int *len, int *code) {  // lib/de.ml:373-409
+__device__ __forceinline__ int distance_code(const DS *, int d1) {
+  if (d1 < 4) return d1;
+  const int k = 31 - __builtin_clz((unsigned)d1);
+  return 2 * k + ((d1 >> (k - 1)) & 1);
+}
+__device__ __forceinline__ void static_lit(int sym, int *len, int *code) {  // lib/de.ml:373-409
   int l, c;
   if (sym < 144) { l = 8; c = 0x30 + sym; }
   else if (sym < 256) { l = 9; c = 0x190 + (sym - 144); }
@@ -228,7 +256,6 @@ __device__ void tree_make_wave(DS *s, int length, int max_length, int *f, TreeRe
       s->heap[--hm] = (uint16_t)mi;
       const uint32_t fs = (uint32_t)(n >> 32) + (uint32_t)(m >> 32);
       const uint32_t dn = ((uint32_t)n >> 16), dm = ((uint32_t)m >> 16);
-      f[node] = (int)fs;
       s->dads[ni] = s->dads[mi] = (uint16_t)node;
       s->hk[1] = hkey(fs, (dn >= dm ? dn : dm) + 1, (uint32_t)node);
       node++;
@@ -426,7 +453,7 @@ __device__ void trees_wave(DS *s, int mode, uint32_t lane) {
   tree_make_wave<TPROF>(s, L_CODES, MAX_BITS, s->lits, tref(&s->lt), lane);
   tree_make_wave<TPROF>(s, D_CODES, MAX_BITS, s->dsts, tref(&s->dt), lane);
   uint64_t t_prev = TPROF ? wall_clock64() : 0;
-  if (lane < 2 * BL_CODES + 1) s->blf[lane] = 0;
+  if (lane < BL_CODES) s->blf[lane] = 0;
   __syncthreads();
   tree_rle_wave(s, tref(&s->lt), 0, false, lane);
   tree_rle_wave(s, tref(&s->dt), 0, false, lane);
@@ -505,7 +532,7 @@ __device__ __forceinline__ void out_byte(Enc *e, unsigned b) {
   else e->overflow = true;
   e->o_pos++;
 }
-__device__ void put_bits(Enc *e, unsigned v, int n) {
+__device__ __forceinline__ void put_bits(Enc *e, unsigned v, int n) {
   e->hold |= (uint64_t)v << e->bits;
   e->bits += n;
   while (e->bits >= 16) {
@@ -515,7 +542,7 @@ __device__ void put_bits(Enc *e, unsigned v, int n) {
     e->bits -= 16;
   }
 }
-__device__ void align_bits(Enc *e) {
+__device__ __forceinline__ void align_bits(Enc *e) {
   if (e->bits > 8) {
     out_byte(e, (unsigned)e->hold & 0xff);
     out_byte(e, (unsigned)(e->hold >> 8) & 0xff);
@@ -523,13 +550,13 @@ __device__ void align_bits(Enc *e) {
   e->hold = 0;
   e->bits = 0;
 }
-__device__ void lit_code(const DS *s, const Enc *e, int sym, int *len, int *code) {
+__device__ __forceinline__ void lit_code(const DS *s, const Enc *e, int sym, int *len, int *code) {
   if (e->kind == KIND_DYNAMIC) {
     *len = s->lt.clen[sym];
     *code = s->lt.codes[sym];
   } else static_lit(sym, len, code);
 }
-__device__ void dst_code(const DS *s, const Enc *e, int sym, int *len, int *code) {
+__device__ __forceinline__ void dst_code(const DS *s, const Enc *e, int sym, int *len, int *code) {
   if (e->kind == KIND_DYNAMIC) {
     *len = s->dt.clen[sym];
     *code = s->dt.codes[sym];
@@ -538,18 +565,18 @@ __device__ void dst_code(const DS *s, const Enc *e, int sym, int *len, int *code
     *code = (int)(__brev((unsigned)sym) >> 27);
   }
 }
-__device__ bool cmd_exists(const DS *s, const Enc *e, int cmd) {  // Def.exists, lib/de.ml:2451-2463
+__device__ __forceinline__ bool cmd_exists(const DS *s, const Enc *e, int cmd) {  // Def.exists, lib/de.ml:2451-2463
   if (e->kind != KIND_DYNAMIC || cmd == Q_EOB) return true;
   if (!(cmd & Q_COPY)) return s->lt.clen[cmd & 0xff] > 0;
   int off = cmd & 0xffff, len = (cmd >> 16) & 0x1ff;
-  return s->lt.clen[257 + s->length_code[len + 3]] > 0 && s->dt.clen[distance_code(s, off)] > 0;
+  return s->lt.clen[257 + length_code_of(len + 3)] > 0 && s->dt.clen[distance_code(s, off)] > 0;
 }
-__device__ void emit_eob(const DS *s, Enc *e) {
+__device__ __forceinline__ void emit_eob(const DS *s, Enc *e) {
   int l, c;
   lit_code(s, e, 256, &l, &c);
   put_bits(e, (unsigned)c, l);
 }
-__device__ void emit_header(const DS *s, Enc *e) {  // lib/de.ml:2566-2633
+__device__ __forceinline__ void emit_header(const DS *s, Enc *e) {  // lib/de.ml:2566-2633
   put_bits(e, e->last ? 1 : 0, 1);
   if (e->kind == KIND_FIXED) put_bits(e, 1, 2);
   else if (e->kind == KIND_DYNAMIC) {
@@ -568,7 +595,7 @@ __device__ void emit_header(const DS *s, Enc *e) {  // lib/de.ml:2566-2633
     e->flat = 0;
   }
 }
-__device__ int enc_write_flat(Enc *e) {  // lib/de.ml:2927-2962
+__device__ __forceinline__ int enc_write_flat(Enc *e) {  // lib/de.ml:2927-2962
   while (e->qw != e->qr && e->flat < e->fmax) {
     int cmd = g_ldi(e->q + (e->qr++ & (e->qc - 1)));
     if (cmd != Q_EOB) {
@@ -582,7 +609,7 @@ __device__ int enc_write_flat(Enc *e) {  // lib/de.ml:2927-2962
   }
   return R_OK;
 }
-__device__ void flat_len(Enc *e) {
+__device__ __forceinline__ void flat_len(Enc *e) {
   if (e->qw != e->qr && g_ldi(e->q + ((e->qw - 1) & (e->qc - 1))) == Q_EOB) e->qw--;
   unsigned len = e->qw - e->qr;
   e->fmax = len < 0xffff ? (int)len : 0xffff;
@@ -716,7 +743,7 @@ __device__ void enc_write_wave(DS *s, uint32_t lane) {
     const bool is_eob = act && cmd == Q_EOB;
     const bool is_copy = act && (cmd & Q_COPY) != 0;
     const int off = cmd & 0xffff, ml = (cmd >> 16) & 0x1ff;
-    const int lcode = is_copy ? s->length_code[ml + 3] : 0;
+    const int lcode = is_copy ? length_code_of(ml + 3) : 0;
     const int dcode = is_copy ? distance_code(s, off) : 0;
     bool ex = true;  // Def.exists, lib/de.ml:2451-2463
     if (act && kind == KIND_DYNAMIC && !is_eob)
@@ -822,14 +849,17 @@ __device__ __forceinline__ uint32_t W32(const Lz *z, uint32_t a) {
   return W(z, a) | (W(z, a + 1) << 8) | (W(z, a + 2) << 16) | (W(z, a + 3) << 24);
 }
 // insert_string, lib/de.ml:4220-4226: the chains were built ahead (deflate_link_kernel), inserting is looking up
-__device__ uint32_t insert_string(const DS *s, const Lz *z, const Ws *ws, uint32_t str) {
-  if (str < z->prepared_end) return s->hh[str & (RING - 1)];
+__device__ __forceinline__ uint32_t insert_string(const DS *s, const Lz *z, const Ws *ws, uint32_t str) {
+  if (str < z->prepared_end) {
+    const uint32_t l = s->hl[str & (RING - 1)];
+    return l ? str - l : 0u;
+  }
   if (str < z->p_end) return link_at(ws, str);
   // De's last string (position len - 3, lookahead 3): its hash reads one byte beyond the data (H7)
   return W(z, str + 3) == 0 ? ws->tail0 : ws->tail1;
 }
 // longest_match, lib/de.ml:4110-4174
-__device__ int longest_match(Lz *z, const Ws *ws, uint32_t cur_match) {
+__device__ __forceinline__ int longest_match(Lz *z, const Ws *ws, uint32_t cur_match) {
   const uint32_t ss = z->strstart;
   const uint32_t str_end = ss + (MAX_MATCH - 1);
   const uint32_t rel = ss - z->base;
@@ -863,7 +893,7 @@ __device__ int longest_match(Lz *z, const Ws *ws, uint32_t cur_match) {
   }
   return best_len <= z->lookahead ? best_len : z->lookahead;
 }
-__device__ bool q_push_auto(DS *s, Enc *e, int v) {  // emit_*: push + auto EOB when one cell is left
+__device__ __forceinline__ bool q_push_auto(DS *s, Enc *e, int v) {  // emit_*: push + auto EOB when one cell is left
   e->q[e->qw++ & (e->qc - 1)] = v;
   if (e->qc - (e->qw - e->qr) == 1) {
     e->q[e->qw++ & (e->qc - 1)] = Q_EOB;
@@ -871,12 +901,12 @@ __device__ bool q_push_auto(DS *s, Enc *e, int v) {  // emit_*: push + auto EOB 
   }
   return false;
 }
-__device__ bool emit_match(DS *s, Enc *e, int off, int len) {
-  s->lits[257 + s->length_code[len]]++;
+__device__ __forceinline__ bool emit_match(DS *s, Enc *e, int off, int len) {
+  s->lits[257 + length_code_of(len)]++;
   s->dsts[distance_code(s, off - 1)]++;
   return q_push_auto(s, e, ((len - 3) << 16) | (off - 1) | Q_COPY);
 }
-__device__ bool emit_literal(DS *s, Enc *e, int chr) {
+__device__ __forceinline__ bool emit_literal(DS *s, Enc *e, int chr) {
   s->lits[chr]++;
   return q_push_auto(s, e, chr);
 }
@@ -939,7 +969,7 @@ __device__ __forceinline__ bool lz_deflate(DS *s, Enc *e, Lz *z, const Ws *ws) {
   z->lookahead--;
   return false;
 }
-__device__ bool lz_copy(DS *s, Enc *e, Lz *z) {  // level 0, lib/de.ml:4412-4423
+__device__ __forceinline__ bool lz_copy(DS *s, Enc *e, Lz *z) {  // level 0, lib/de.ml:4412-4423
   bool flush = (e->qc - (e->qw - e->qr)) <= 1;
   while (!flush && z->lookahead > 0) {
     flush = emit_literal(s, e, (int)W(z, z->strstart));
@@ -1014,7 +1044,7 @@ __device__ __forceinline__ int block_plan(int driver, int dynamic, int level, in
 }
 
 enum { ACT_PREP = 0, ACT_WRITE = 1, ACT_DONE = 2, ACT_TREES = 3 };
-enum { PH_LZ = 0, PH_FLUSH = 1, PH_END = 2, PH_TREES = 3, PH_TREES_END = 4 };
+enum { PH_LZ = 0, PH_FLUSH = 1, PH_END = 2, PH_TREES = 3, PH_TREES_END = 4, PH_SC_TREES = 5, PH_SC_WRITE = 6 };
 
 struct Run {  // the two state machines of one stream (lane 0's registers)
   Enc e;
@@ -1025,6 +1055,9 @@ struct Run {  // the two state machines of one stream (lane 0's registers)
   int ol, oc;  // end-of-block code of the block that was open when new trees were asked for
   int mode;    // tree mode asked for (TM_*)
   uint32_t ncmd;  // DRV_LZ77: commands written out so far
+  uint32_t sc_pos, sc_nrc;  // DRV_SCRIPT: next operation word, results reported so far
+  int sc_last;
+  bool sc_bad;              // DRV_SCRIPT: a malformed operation list
 };
 
 __device__ __forceinline__ void stream_begin(Run *r, const Ws *ws, const uint8_t *in, uint32_t n, uint8_t *out, uint32_t cap,
@@ -1071,7 +1104,115 @@ __device__ __forceinline__ void stream_begin(Run *r, const Ws *ws, const uint8_t
   r->first = true;
   r->qfull = false;
   r->ncmd = 0;
+  r->sc_pos = r->sc_nrc = 0;
+  r->sc_last = 0;
+  r->sc_bad = false;
   r->phase = PH_LZ;
+}
+
+// DRV_SCRIPT: De.Def.encode (lib/de.ml:2965-3038) driven the way the reference's tests drive it
+// (test/test_ns.ml:388-615): the caller fills the queue, counts frequencies (succ_literal / succ_length /
+// succ_distance, lib/de.ml:2339-2351) and passes `Block {kind; last} / `Flush; every encode answers `Ok (0) or
+// `Block (1) into res[1..], res[0] = their number.  A Dynamic block is dynamic_of_frequencies of the live
+// histograms at that moment (and mutates them, H2).
+__device__ __forceinline__ int script_step(DS *s, Run *r, uint32_t *res, uint32_t res_cap) {
+  Enc &e = r->e;
+  const uint8_t *ops = r->z.in;
+  const uint32_t nops = r->z.n / 4;
+  auto word = [&](uint32_t i) {
+    uint32_t v;
+    __builtin_memcpy(&v, ops + 4 * (size_t)i, 4);
+    return v;
+  };
+  int rc;
+  if (r->phase == PH_SC_TREES) {
+    rc = enc_begin(s, &e, V_BLOCK, KIND_DYNAMIC, r->sc_last, r->ol, r->oc);
+    goto have_rc;
+  }
+  if (r->phase == PH_SC_WRITE) {  // a command loop just finished: take its result
+    e.hold = s->w.hold;
+    e.bits = (int)s->w.bits;
+    e.o_pos = s->w.o_pos;
+    e.qr = s->w.qr;
+    e.overflow = e.overflow || s->w.overflow;
+    e.k = (int)s->w.k;
+    rc = (int)s->w.rc;
+    goto record;
+  }
+  for (;;) {
+    if (r->sc_pos >= nops) return ACT_DONE;
+    {
+      const uint32_t op = word(r->sc_pos++);
+      const uint32_t left = nops - r->sc_pos;
+      switch (op) {
+      case OP_FILL: {
+        if (left < 1 || word(r->sc_pos) > left - 1) goto bad;
+        const uint32_t n = word(r->sc_pos++);
+        for (uint32_t i = 0; i < n; i++) {
+          if (e.qc - (e.qw - e.qr) == 0) {  // Queue.push_exn: Queue.Full, lib/de.ml:2214-2217
+            r->qfull = true;
+            return ACT_DONE;
+          }
+          const uint32_t c = word(r->sc_pos++);
+          const bool ok = (c & Q_COPY) ? ((c & ~0x2ffffffu) == 0 && ((c >> 16) & 0x1ff) <= 255 && (c & 0xffff) <= 32767) : c <= 256;
+          if (!ok) goto bad;
+          e.q[e.qw++ & (e.qc - 1)] = (int)c;
+        }
+        continue;
+      }
+      case OP_SUCC_LITERAL:
+        if (left < 1 || word(r->sc_pos) > 255) goto bad;
+        s->lits[word(r->sc_pos++)]++;
+        continue;
+      case OP_SUCC_LENGTH:
+        if (left < 1 || word(r->sc_pos) < 3 || word(r->sc_pos) > 258) goto bad;
+        s->lits[257 + length_code_of((int)word(r->sc_pos++))]++;
+        continue;
+      case OP_SUCC_DISTANCE:
+        if (left < 1 || word(r->sc_pos) < 1 || word(r->sc_pos) > 32768) goto bad;
+        s->dsts[distance_code(s, (int)word(r->sc_pos++) - 1)]++;
+        continue;
+      case OP_NEW_FREQS:  // make_literals () / make_distances (), lib/de.ml:2333-2346
+        for (int i = 0; i < L_CODES; i++) s->lits[i] = i == 256 ? 1 : 0;
+        for (int i = 0; i < D_CODES; i++) s->dsts[i] = 0;
+        continue;
+      case OP_QUEUE_RESET:
+        e.qw = e.qr = 0;
+        continue;
+      case OP_FLUSH:
+        lit_code(s, &e, 256, &r->ol, &r->oc);
+        rc = enc_begin(s, &e, V_FLUSH, 0, 0, r->ol, r->oc);
+        break;
+      case OP_BLOCK: {
+        if (left < 2 || word(r->sc_pos) > 2) goto bad;
+        const int kind = (int)word(r->sc_pos++), last = word(r->sc_pos++) ? 1 : 0;
+        lit_code(s, &e, 256, &r->ol, &r->oc);
+        if (kind == KIND_DYNAMIC) {
+          r->sc_last = last;
+          r->mode = TM_DYNAMIC;
+          r->phase = PH_SC_TREES;
+          return ACT_TREES;
+        }
+        rc = enc_begin(s, &e, V_BLOCK, kind, last, r->ol, r->oc);
+        break;
+      }
+      default:
+        goto bad;
+      }
+    }
+  have_rc:
+    if (rc == W_PENDING) {
+      r->phase = PH_SC_WRITE;
+      return ACT_WRITE;
+    }
+  record:
+    r->phase = PH_LZ;
+    r->sc_nrc++;
+    if (res && r->sc_nrc < res_cap) res[r->sc_nrc] = rc == R_BLOCK ? 1u : 0u;
+  }
+bad:
+  r->sc_bad = true;
+  return ACT_DONE;
 }
 
 // Lane 0: runs the matcher and the encoder's serial parts until the wave has to do something:
@@ -1187,6 +1328,7 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
   return v;
 }
 
+template <bool PROF>
 __global__ __launch_bounds__(kWave) void deflate_kernel(
     int format, int level, int qcap, int driver, int dynamic, uint32_t n, const uint8_t *__restrict__ in,
     const uint64_t *__restrict__ in_off, const uint64_t *__restrict__ in_len, uint8_t *__restrict__ out,
@@ -1197,7 +1339,7 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
   __shared__ DS ds;
   // optional phase profile of stream 0 (md_set_option "profile"): [0] setup [1] look-ahead [2] bulk
   // literal runs [3] matcher/driver (lane 0) [4] bit packing [5] trees, in clock ticks; [8..] event counts
-  const bool prof = dbg != nullptr && blockIdx.x == 0;
+  const bool prof = PROF && dbg != nullptr && blockIdx.x == 0;
   uint64_t pt[6] = {0, 0, 0, 0, 0, 0}, pc[4] = {0, 0, 0, 0}, pa[4] = {0, 0, 0, 0}, pn[4] = {0, 0, 0, 0}, pmax = 0, pq[3] = {0, 0, 0};
   uint64_t t_prev = prof ? wall_clock64() : 0;
 #define PROF_MARK(i)                      \
@@ -1226,24 +1368,8 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
   Ws ws{fr.link + so, fr.flg + so, fr.m + so, fr.mq + so, ws_queue + (size_t)sid * qcap, fr.tail[2 * sid], fr.tail[2 * sid + 1]};
 
   // ---- cooperative setup: histograms, code tables, Adler-32 of the input
-  for (uint32_t i = lane; i < (uint32_t)HEAP_SIZE; i += kWave) ds.lits[i] = i == 256 ? 1 : 0;  // make_literals
-  if (lane < 2 * D_CODES + 1) ds.dsts[lane] = 0;
-  for (uint32_t len = lane; len < 259; len += kWave) {  // _length, lib/de.ml:240-256
-    int c = 0;
-    if (len >= 3) {
-      int l = (int)len - 3;
-      if (l == 255) c = 28;
-      else for (c = 27; c > 0 && c_base_length[c] > l; c--) {}
-    }
-    ds.length_code[len] = (uint8_t)c;
-  }
-  for (uint32_t d = lane; d < 256; d += kWave) {  // _distance, lib/de.ml:258-291
-    int c;
-    for (c = 29; c > 0 && (int)c_base_dist[c] > (int)d; c--) {}
-    ds.dist_lo[d] = (uint8_t)c;
-    for (c = 29; c > 0 && (int)c_base_dist[c] > (int)(d << 7); c--) {}
-    ds.dist_hi[d] = (uint8_t)c;
-  }
+  for (uint32_t i = lane; i < (uint32_t)L_CODES; i += kWave) ds.lits[i] = i == 256 ? 1 : 0;  // make_literals
+  if (lane < D_CODES) ds.dsts[lane] = 0;
   if (lane < 32) {
     ds.t_xl[lane] = c_extra_lbits[lane];
     ds.t_bl[lane] = c_base_length[lane];
@@ -1288,13 +1414,17 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
     for (uint32_t i = lane; i < gz_hdr_len && i < cap; i += kWave) dst[i] = gz_hdr[i];
     hdr = gz_hdr_len;
   }
-  Run run;
+  // the two state machines of the stream: lane 0's, kept in LDS — as registers they cost every lane of the wave ~100
+  // VGPRs (a value only lane 0 uses still takes a whole vector register) and with them half of the occupancy
+  __shared__ Run run;
   const bool room = cap >= hdr;
   if (lane == 0) {
     if (room) stream_begin(&run, &ws, src, slen, dst + hdr, cap - hdr, level, qcap, driver, matcher);
     ds.ctl[0] = 0;
     ds.ctl[1] = room ? 0 : 1;
     ds.ctl[2] = 0;
+    ds.ctl[3] = ACT_PREP;
+    ds.ring_dead = 0;
     ds.zs.trivial = 0;
     ds.zs.bulked = 0;
     for (int i = 0; i < 8; i++) ds.tp[i] = 0;
@@ -1311,7 +1441,7 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
         ws.queue[i] = (int)c;
         if (c == (uint32_t)Q_EOB) continue;
         if (c & Q_COPY) {
-          ds.lits[257 + ds.length_code[((c >> 16) & 0x1ff) + 3]]++;
+          ds.lits[257 + length_code_of((int)((c >> 16) & 0x1ff) + 3)]++;
           ds.dsts[distance_code(&ds, (int)(c & 0xffff))]++;
         } else ds.lits[c & 0xff]++;
       }
@@ -1324,7 +1454,7 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
   }
-  const bool no_text = driver == DRV_ENCODE;
+  const bool no_text = driver == DRV_ENCODE || driver == DRV_SCRIPT;
   const uint32_t eff_level = driver == DRV_HIGHER ? 4 : (matcher == MD_MATCHER_LZ && level < 4) ? 4 : level;
   const uint32_t p_end = no_text ? 0
                          : matcher == MD_MATCHER_LZ ? (slen >= 3 ? slen - 2 : 0)
@@ -1335,11 +1465,20 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
     if (ds.ctl[1]) break;
     const uint32_t ss = ds.ctl[0];
     uint32_t pe = ds.ctl[2];
+    // the tree builder used the ring's space, and the code-length symbols of the header it made sit there until the
+    // command loop that follows ACT_TREES has packed them: then the ring is loaded again, from the pending literal on
+    const bool hold = ds.ctl[3] == ACT_TREES;
+    if (ds.ring_dead && !hold) {
+      pe = (ss ? ss - 1 : 0u) & ~63u;
+      if (pe > p_end) pe = p_end;
+      __syncthreads();
+      if (lane == 0) ds.ring_dead = 0;
+    }
     // ---- the ring runs ahead of the matcher: hash heads, verdicts and bytes of the next positions, PG steps of 64
     //      positions per load (all of it was computed for the whole batch by deflate_front.hip)
     for (;;) {
       uint32_t nb = 0;
-      if (pe < p_end) {
+      if (pe < p_end && !hold) {
         const uint32_t room = (ss + RING - 1 - pe) / kWave;  // slot of position ss - 1 stays intact
         const uint32_t left = (p_end - pe + kWave - 1) / kWave;
         nb = room < left ? room : left;
@@ -1365,7 +1504,7 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
       for (int g = 0; g < PG; g++) {
         if ((uint32_t)g < nb) {
           const uint32_t pos = pe + g * kWave + lane, r = pos & (RING - 1);
-          ds.hh[r] = lk[g] ? pos - lk[g] : 0u;
+          ds.hl[r] = (uint16_t)lk[g];
           ds.flg[r] = (uint8_t)fv[g];
           ds.byt[r] = (uint8_t)bv[g];
         }
@@ -1393,7 +1532,7 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
       if (s0 >= pe) maxk = 0;
       else if (maxk > pe - s0) maxk = pe - s0;
       const uint32_t p = s0 + lane, r = p & (RING - 1);
-      const uint32_t hhv = ds.hh[r];
+      const uint32_t hlv = ds.hl[r], hhv = hlv ? p - hlv : 0u;
       bool triv = lane < maxk;
       if (triv && hhv > base && p - hhv <= (uint32_t)MAX_DIST) triv = ds.flg[r] == FL_ENDED;
       const uint64_t nt = __ballot(!triv);
@@ -1436,7 +1575,7 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
         const uint32_t q = s0 + j, r = q & (RING - 1);
         uint32_t k = 0, lf = 2, df = 0, lq = 2, dq = 0;
         if (q < E) {
-          const uint32_t f = ds.flg[r], c1v = ds.hh[r];
+          const uint32_t f = ds.flg[r], l1v = ds.hl[r], c1v = l1v ? q - l1v : 0u;
           if (f == FL_ENDED || f == FL_MATCH) k = 1;
           if (c1v > base && q - c1v <= (uint32_t)MAX_DIST) k |= 2;
           if (f == FL_MATCH) {
@@ -1527,7 +1666,7 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
           atomicAdd(&ds.lits[byte], 1);
         } else if (lane == nl) {  // emit_match, lib/de.ml:4236-4245
           ws.queue[(qw + cmds + nl) & ((uint32_t)qcap - 1)] = (int)(((L - 3) << 16) | (d - 1) | Q_COPY);
-          atomicAdd(&ds.lits[257 + ds.length_code[L]], 1);
+          atomicAdd(&ds.lits[257 + length_code_of((int)L)], 1);
           atomicAdd(&ds.dsts[distance_code(&ds, (int)(d - 1))], 1);
         }
         cmds += nl + 1;
@@ -1576,7 +1715,8 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
       // after a bulk run that made progress the wave gets another go before the matcher steps
       run.z.steps = (ds.zs.trivial && ds.zs.bulked > 0) ? 1 : 0;
       const uint64_t q0 = prof ? wall_clock64() : 0;
-      int act = stream_step(&ds, &ws, &run, driver, dynamic);
+      int act = driver == DRV_SCRIPT ? script_step(&ds, &run, hist ? hist + (size_t)sid * (L_CODES + D_CODES) : nullptr, L_CODES + D_CODES)
+                                     : stream_step(&ds, &ws, &run, driver, dynamic);
       const uint64_t q1 = prof ? wall_clock64() : 0;
       if (prof) {
         pq[0] += q0 - t_prev;
@@ -1632,8 +1772,9 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
       __syncthreads();
       PROF_MARK(4)
     } else if (ds.ctl[3] == ACT_TREES) {
-      if (prof) trees_wave<true>(&ds, (int)ds.ctl[4], lane);
-      else trees_wave<false>(&ds, (int)ds.ctl[4], lane);
+      trees_wave<PROF>(&ds, (int)ds.ctl[4], lane);
+      if (lane == 0) ds.ring_dead = 1;
+      __syncthreads();
       PROF_MARK(5)
     }
   }
@@ -1669,6 +1810,10 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
     uint32_t body = room ? run.e.o_pos : 0;
     int st = !room || run.e.overflow ? MD_UNEXPECTED_END_OF_OUTPUT : MD_OK;
     if (room && run.qfull) st = MD_QUEUE_FULL;
+    if (driver == DRV_SCRIPT) {
+      if (room && run.sc_bad) st = MD_E_INVALID_ARGUMENT;
+      if (hist) hist[(size_t)sid * (L_CODES + D_CODES)] = room ? run.sc_nrc : 0u;
+    }
     uint32_t total = hdr + body;
     if (format == MD_FORMAT_ZLIB && st == MD_OK) {
       if (cap - total < 4) st = MD_UNEXPECTED_END_OF_OUTPUT;
@@ -1714,9 +1859,14 @@ extern "C" int md_launch_deflate(int format, int level, int qcap, int driver, in
                                  void *queue_ws, uint64_t *dbg, const uint8_t *gz_hdr, uint32_t gz_hdr_len,
                                  const uint32_t *gz_crc, int matcher, uint32_t *hist, hipStream_t stream) {
   if (n == 0) return 0;
-  hipLaunchKernelGGL(md::defl::deflate_kernel, dim3(n), dim3(md::defl::kWave), 0, stream, format, level,
-                     qcap, driver, dynamic, n, in, in_off, in_len, out, out_off, out_cap, out_len, status,
-                     checksum, *fr, (int *)queue_ws, dbg, gz_hdr, gz_hdr_len, gz_crc, matcher, hist);
+  if (dbg)
+    hipLaunchKernelGGL(md::defl::deflate_kernel<true>, dim3(n), dim3(md::defl::kWave), 0, stream, format, level,
+                       qcap, driver, dynamic, n, in, in_off, in_len, out, out_off, out_cap, out_len, status,
+                       checksum, *fr, (int *)queue_ws, dbg, gz_hdr, gz_hdr_len, gz_crc, matcher, hist);
+  else
+    hipLaunchKernelGGL(md::defl::deflate_kernel<false>, dim3(n), dim3(md::defl::kWave), 0, stream, format, level,
+                       qcap, driver, dynamic, n, in, in_off, in_len, out, out_off, out_cap, out_len, status,
+                       checksum, *fr, (int *)queue_ws, dbg, gz_hdr, gz_hdr_len, gz_crc, matcher, hist);
   return (int)hipGetLastError();
 }
 

@@ -254,6 +254,25 @@ int md_de_lz77_compress(md_ctx *ctx, int level, int queue_len, int matcher, cons
 int md_de_def_encode(md_ctx *ctx, int kind, const uint32_t *cmds, size_t ncmds, uint8_t *dst, size_t dst_cap,
                      size_t *written);
 
+/* De.Def.encode (lib/de.ml:2965-3038) driven step by step, the way the reference's own tests drive it
+ * (test/test_ns.ml:388-615, test/test.ml:533-767): one encoder over a queue of queue_len cells and an unbounded
+ * `Buffer destination, fed a list of operations (32-bit words):
+ *   MD_OP_FILL n c1..cn        Queue.push_exn of n commands (De.Queue's encoding, see md_de_lz77_compress);
+ *                              MD_QUEUE_FULL when the queue has no room (exception Queue.Full)
+ *   MD_OP_BLOCK kind last      Def.encode e (`Block {kind; last}); kind MD_BLOCK_*; a Dynamic block is
+ *                              Def.dynamic_of_frequencies ~literals ~distances of the frequencies counted so far
+ *                              (and mutates them the way T.make does)
+ *   MD_OP_FLUSH                Def.encode e `Flush
+ *   MD_OP_SUCC_LITERAL chr / MD_OP_SUCC_LENGTH len / MD_OP_SUCC_DISTANCE dist   De.succ_* (lib/de.ml:2339-2351)
+ *   MD_OP_NEW_FREQS            make_literals () / make_distances ()
+ *   MD_OP_QUEUE_RESET          Queue.reset
+ * results[k] = what the k-th encode answered: 0 `Ok, 1 `Block (`Partial cannot happen with a `Buffer); *nresults =
+ * their number.  dst receives the bytes written.  A malformed list is MD_E_INVALID_ARGUMENT. */
+enum { MD_OP_FILL = 1, MD_OP_BLOCK = 2, MD_OP_FLUSH = 3, MD_OP_SUCC_LITERAL = 4, MD_OP_SUCC_LENGTH = 5,
+       MD_OP_SUCC_DISTANCE = 6, MD_OP_NEW_FREQS = 7, MD_OP_QUEUE_RESET = 8 };
+int md_de_def_run(md_ctx *ctx, int queue_len, const uint32_t *ops, size_t nops, uint8_t *dst, size_t dst_cap,
+                  size_t *written, uint8_t *results, size_t results_cap, size_t *nresults);
+
 /* ---- the resumable state machines (host side; one launch at the end of input) ----
  * De.Inf.decoder / decode / src / flush / dst_rem / src_rem / checksum (lib/de.mli:82-144) and the encoder loop of
  * Zl.Def / Gz.Def / De.Higher with `Manual source and destination (lib/zl.ml:509-555): the caller supplies input

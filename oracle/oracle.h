@@ -116,6 +116,8 @@ int orc_tree_make(int length, int max_length, int *freqs, int nfreqs, int *lengt
 uint8_t *orc_encode_cmds(const int *cmds, int ncmds, int kind, size_t *out_len);
 /* De.Lz77.compress on an input that fits one queue fill (test/test.ml:798-813) */
 int orc_lz77_cmds(const uint8_t *src, size_t n, int level, int queue_len, int *out, int max);
+/* De.Def.encode driven by a list of operations (test/test_ns.ml:388-615); see de_deflate.c */
+uint8_t *orc_def_script(const int *ops, int nops, int queue_len, int *rcs, int max_rcs, int *nrcs, size_t *out_len);
 
 #ifdef __cplusplus
 }

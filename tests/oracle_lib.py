@@ -211,6 +211,18 @@ class Oracle:
         p = self.lib.orc_encode_cmds(arr, len(cmds), {"flat": 0, "fixed": 1, "dynamic": 2}[kind], ctypes.byref(n))
         return self._take(p, n.value)
 
+    def def_script(self, ops, queue=4096):
+        """De.Def.encode driven by a list of operations -> (bytes, [0 `Ok | 1 `Block, ...]) or None (Queue.Full / bad list)"""
+        arr = (ctypes.c_int * max(1, len(ops)))(*[o if o < 2**31 else o - 2**32 for o in ops])
+        rcs, nrc, n = (ctypes.c_int * 64)(), ctypes.c_int(), ctypes.c_size_t()
+        self.lib.orc_def_script.restype = ctypes.c_void_p
+        self.lib.orc_def_script.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
+                                            ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_size_t)]
+        p = self.lib.orc_def_script(arr, len(ops), queue, rcs, 64, ctypes.byref(nrc), ctypes.byref(n))
+        if not p:
+            return None
+        return self._take(p, n.value), list(rcs[:nrc.value])
+
     def lz77_all(self, data, level=4, queue=4096, matcher=0):
         """every queue fill of De.Lz77.compress (or Lz.compress) in order + literals[286] + distances[30]"""
         cap = len(data) + len(data) // max(1, queue - 1) + 8
