@@ -63,6 +63,8 @@ SYMBOLS = [
     ("md_inf_status", ctypes.c_int, [c_vp]),
     ("md_inf_checksum", ctypes.c_uint32, [c_vp]),
     ("md_inf_free", None, [c_vp]),
+    ("md_inf_reset", None, [c_vp]),
+    ("md_inf_message", ctypes.c_char_p, [c_vp]),
     ("md_def_encoder", c_vp, [c_vp, ctypes.c_int, c_pp, c_vp, c_sz]),
     ("md_def_src", ctypes.c_int, [c_vp, c_vp, c_sz, c_sz]),
     ("md_def_encode", ctypes.c_int, [c_vp]),

@@ -85,6 +85,16 @@ __global__ __launch_bounds__(kPlanThreads) void deflate_plan_kernel(uint32_t n, 
   }
 }
 
+// the 4 bytes at pos (little-endian) for pos < p_end (something for the others), without a branch: Lz's last string (pos = len - 3) has
+// only 3 bytes — it is taken from the word one byte earlier; len >= 4 whenever p_end > 1
+__device__ __forceinline__ uint32_t load_w4(const uint8_t *__restrict__ src, uint32_t slen, uint32_t p_end, uint32_t pos) {
+  uint32_t a = pos + 4 <= slen ? pos : slen - 4;
+  a = pos < p_end ? a : 0u;
+  uint32_t v;
+  __builtin_memcpy(&v, src + a, 4);
+  return v >> ((8 * (pos - a)) & 31);  // (whatever for pos >= p_end: nobody looks at it)
+}
+
 // ---- hash chains ----------------------------------------------------------------------------------
 // head[h] <- max(pos), one LDS atomic per position, the steps of a group issued back to back (a wavefront's LDS
 // operations execute in order).  The values a set of equal hashes gets back are >= the head before the set and one of
@@ -112,18 +122,17 @@ __global__ __launch_bounds__(kWave) void deflate_link_kernel(uint32_t n, const u
     for (uint32_t i = lane; i < (uint32_t)HASH_SIZE / 4; i += kWave) h4[i] = make_uint4(0, 0, 0, 0);
   }
   __syncthreads();
+  if (slen < 4) {  // at most one string (Lz, 3 bytes): nothing before it
+    if (lane < p_end) lk[lane] = 0;
+    if (lane < 2) tail[2 * sid + lane] = 0;
+    return;
+  }
   // the input of group k + 2 is requested before group k is worked on: one wavefront per CU has nothing else to hide
   // the HBM latency of its loads behind
+  // (branch-free: a branch around a load makes the compiler wait for every load in flight)
   auto load_group = [&](uint32_t pe, uint32_t (&w)[PGL]) {
 #pragma unroll
-    for (int g = 0; g < PGL; g++) {
-      const uint32_t pos = pe + g * kWave + lane;
-      w[g] = 0;
-      if (pos < p_end) {
-        if (pos + 4 <= slen) __builtin_memcpy(&w[g], src + pos, 4);
-        else w[g] = (uint32_t)src[pos] | ((uint32_t)src[pos + 1] << 8) | ((uint32_t)src[pos + 2] << 16);  // Lz's last string
-      }
-    }
+    for (int g = 0; g < PGL; g++) w[g] = load_w4(src, slen, p_end, pe + g * kWave + lane);
   };
   uint32_t wa[PGL], wb[PGL];
   load_group(0, wa);
@@ -237,11 +246,10 @@ __global__ __launch_bounds__(kWave) void deflate_match_kernel(uint32_t n, uint32
 #pragma unroll
   for (int g = 0; g < PGM; g++) {
     const uint32_t pos = pe + g * kWave + lane;
-    w4[g] = 0;
+    w4[g] = slen >= 4 ? load_w4(src, slen, p_end, pos) : 0u;
     cw[g] = 0;
     if (pos < p_end) {
-      if (pos + 4 <= slen) __builtin_memcpy(&w4[g], src + pos, 4);
-      else w4[g] = (uint32_t)src[pos] | ((uint32_t)src[pos + 1] << 8) | ((uint32_t)src[pos + 2] << 16);
+      if (slen < 4) w4[g] = (uint32_t)src[pos] | ((uint32_t)src[pos + 1] << 8) | ((uint32_t)src[pos + 2] << 16);
       const uint32_t l = lk[pos];
       cw[g] = l ? pos - l : 0u;
     }

@@ -13,8 +13,10 @@
 // streaming rule of lib/de.ml:941-944 (a final end-of-block code shorter than the longest code is accepted at the
 // end of the input) gives the same result on every stream a compressor emits.
 #include <stdint.h>
+#include <stdio.h>
 #include <string.h>
 
+#include <string>
 #include <vector>
 
 #include "mdeflate.h"
@@ -31,6 +33,7 @@ struct md_inf_stream {
   int status;                 // MD_* status of the launch
   size_t consumed;
   uint32_t checksum;
+  std::string message;        // the reference's `Malformed string, with its numbers
 };
 
 extern "C" {
@@ -54,6 +57,18 @@ md_inf_stream *md_inf_decoder(md_ctx *ctx, int format, uint8_t *o, size_t o_len)
 
 void md_inf_free(md_inf_stream *s) { delete s; }
 
+// De.Inf.reset (lib/de.ml:1512-1532; Zl.Inf.reset, Gz.Inf.reset): the same decoder, output buffer and format, a new stream
+void md_inf_reset(md_inf_stream *s) {
+  if (!s) return;
+  s->in.clear();
+  s->out.clear();
+  s->message.clear();
+  s->o_pos = s->served = s->consumed = 0;
+  s->eoi = s->ran = false;
+  s->status = MD_OK;
+  s->checksum = 0;
+}
+
 int md_inf_src(md_inf_stream *s, const uint8_t *buf, size_t off, size_t len) {
   if (!s || (!buf && len) || s->eoi) return MD_E_INVALID_ARGUMENT;
   if (len == 0) s->eoi = true;  // De.Inf.src d buf 0 0: the end of the input
@@ -67,11 +82,84 @@ void md_inf_flush(md_inf_stream *s) {
 size_t md_inf_dst_rem(const md_inf_stream *s) { return s ? s->o_len - s->o_pos : 0; }
 size_t md_inf_src_rem(const md_inf_stream *s) { return s && s->ran ? s->in.size() - s->consumed : 0; }
 int md_inf_status(const md_inf_stream *s) { return s ? s->status : MD_E_INVALID_ARGUMENT; }
+const char *md_inf_message(const md_inf_stream *s) {
+  if (!s) return "Invalid argument";
+  return s->message.empty() ? md_status_string(s->status) : s->message.c_str();
+}
 uint32_t md_inf_checksum(const md_inf_stream *s) { return s ? s->checksum : 0; }
 
+// where the DEFLATE body of a GZip member begins (Gz.Inf's header walk, lib/gz.ml:465-531: FEXTRA's length is read
+// big-endian there); 0 when the header is cut short
+static size_t gz_body_offset(const std::vector<uint8_t> &in) {
+  if (in.size() < 10) return 0;
+  const uint32_t flg = in[3];
+  size_t p = 10;
+  if (flg & 4) {
+    if (in.size() - p < 2) return 0;
+    const size_t xl = ((size_t)in[p] << 8) | in[p + 1];
+    p += 2;
+    if (in.size() - p < xl) return 0;
+    p += xl;
+  }
+  for (int which = 0; which < 2; which++) {
+    if (!(flg & (which == 0 ? 8u : 16u))) continue;
+    for (;;) {
+      if (p >= in.size()) return 0;
+      if (in[p++] == 0) break;
+    }
+  }
+  if (flg & 2) {
+    if (in.size() - p < 2) return 0;
+    p += 2;
+  }
+  return p;
+}
+
+// The reference's `Malformed string for a frame whose trailer disagrees: "Invalid checksum (expect:%04lx, has:%04lx)"
+// (lib/zl.ml:179-181, lib/gz.ml:287-289: expect = the trailer's value, has = the checksum of what was inflated) and
+// "Invalid input size (expect:%ld, inflated:%ld)" (lib/gz.ml:291-293, both as signed 32-bit).  The kernels report the
+// status only, so the trailer is looked up here: one more launch of the raw body finds where it ends.
+static void inf_detail(md_inf_stream *s) {
+  s->message = md_status_string(s->status);
+  if (s->status != MD_INVALID_CHECKSUM && s->status != MD_INVALID_SIZE) return;
+  const size_t body = s->format == MD_FORMAT_ZLIB ? 2 : gz_body_offset(s->in);
+  if (body == 0 || body > s->in.size()) return;
+  uint64_t in_off = body, in_len = s->in.size() - body, out_off = 0, out_cap = s->out.size(), out_len = 0, used = 0;
+  int32_t st = 0;
+  std::vector<uint8_t> scratch(s->out.size() + 16);
+  if (md_inflate_batch_host(s->ctx, MD_FORMAT_DEFLATE, 1, s->in.data(), s->in.size(), &in_off, &in_len, scratch.data(),
+                            scratch.size(), &out_off, &out_cap, &out_len, &used, &st, nullptr) != MD_OK || st != MD_OK)
+    return;
+  const size_t t = body + (size_t)used;
+  char buf[96];
+  if (s->format == MD_FORMAT_ZLIB) {
+    if (s->in.size() - t < 4) return;
+    const uint32_t expect = ((uint32_t)s->in[t] << 24) | ((uint32_t)s->in[t + 1] << 16) | ((uint32_t)s->in[t + 2] << 8) | s->in[t + 3];
+    snprintf(buf, sizeof buf, "Invalid checksum (expect:%04lx, has:%04lx)", (unsigned long)expect, (unsigned long)s->checksum);
+  } else {
+    if (s->in.size() - t < 8) return;
+    const uint32_t crc = (uint32_t)s->in[t] | ((uint32_t)s->in[t + 1] << 8) | ((uint32_t)s->in[t + 2] << 16) | ((uint32_t)s->in[t + 3] << 24);
+    const uint32_t isize = (uint32_t)s->in[t + 4] | ((uint32_t)s->in[t + 5] << 8) | ((uint32_t)s->in[t + 6] << 16) | ((uint32_t)s->in[t + 7] << 24);
+    if (s->status == MD_INVALID_CHECKSUM)
+      snprintf(buf, sizeof buf, "Invalid checksum (expect:%04lx, has:%04lx)", (unsigned long)crc, (unsigned long)s->checksum);
+    else
+      snprintf(buf, sizeof buf, "Invalid input size (expect:%ld, inflated:%ld)", (long)(int32_t)isize, (long)(int32_t)(uint32_t)out_len);
+  }
+  s->message = buf;
+}
+
 static void inf_run(md_inf_stream *s) {
-  // the output size is not known: start from 4x the input and double while the codec runs out of room
-  uint64_t cap = s->in.size() * 4 + 65536;
+  // The output size is not known.  A DEFLATE stream expands at most 1032 times: a small input gets room for that at
+  // once (one launch whatever its ratio); a GZip member says its size (mod 2^32) in its last four bytes; otherwise
+  // start from 4x the input and grow fourfold while the codec runs out of room (5 launches at the worst ratio).
+  const uint64_t n_in = s->in.size();
+  uint64_t cap = n_in * 4 + 65536;
+  if (n_in * 1032 <= (64u << 20)) cap = n_in * 1032 + 65536;
+  else if (s->format == MD_FORMAT_GZIP && n_in >= 18) {
+    const uint8_t *t = s->in.data() + n_in - 4;
+    const uint64_t isize = (uint64_t)t[0] | ((uint64_t)t[1] << 8) | ((uint64_t)t[2] << 16) | ((uint64_t)t[3] << 24);
+    if (isize >= cap && isize <= n_in * 1032) cap = isize + 65536;
+  }
   for (;;) {
     if (cap > MD_MAX_STREAM) cap = MD_MAX_STREAM;
     s->out.resize((size_t)cap);
@@ -87,13 +175,14 @@ static void inf_run(md_inf_stream *s) {
       return;
     }
     if (st == MD_UNEXPECTED_END_OF_OUTPUT && cap < MD_MAX_STREAM) {
-      cap *= 2;
+      cap *= 4;
       continue;
     }
     s->status = st;
     s->consumed = (size_t)used;
     s->checksum = sum;
     s->out.resize((size_t)out_len);
+    if (st != MD_OK) inf_detail(s);
     return;
   }
 }

@@ -52,7 +52,30 @@ class Def:
         return dst.raw[:n.value]
 
 
+    # operations of Def.run (MD_OP_* of include/mdeflate.h)
+    OP_FILL, OP_BLOCK, OP_FLUSH, OP_SUCC_LITERAL, OP_SUCC_LENGTH, OP_SUCC_DISTANCE, OP_NEW_FREQS, OP_QUEUE_RESET = range(1, 9)
+
+    @staticmethod
+    def run(ops, queue=4096, device=0):
+        """`Def.encode` driven step by step (md_de_def_run): ops is the list of operations the reference's tests
+        perform on an encoder with a `Buffer destination — fill the queue, count frequencies, `Block {kind; last},
+        `Flush (test/test_ns.ml:388-615).  -> (bytes written, [0 for `Ok | 1 for `Block, ...])"""
+        eng = _engine.default_engine(device)
+        arr = (ctypes.c_uint32 * max(1, len(ops)))(*ops)
+        cap = 8 * len(ops) + 1024
+        dst, n = ctypes.create_string_buffer(cap), ctypes.c_size_t()
+        res, nres = (ctypes.c_uint8 * 315)(), ctypes.c_size_t()
+        st = eng.lib.md_de_def_run(eng.ctx, queue, arr, len(ops), dst, cap, ctypes.byref(n), res, 315, ctypes.byref(nres))
+        if st < 0:
+            eng._check(st)
+        if st != 0:
+            raise _engine.Error(_engine.STATUS_NAMES[st])
+        return dst.raw[:n.value], list(res[:nres.value])
+
+
 class Inf:
+    last_message = ""
+
     @staticmethod
     def decode_chunks(chunks, o_len=65536, fmt=_engine.FORMAT_DEFLATE, device=0):
         """the streaming protocol of lib/de.mli:82-144 — decoder / src / decode / flush / dst_rem — driven the way
@@ -75,6 +98,7 @@ class Inf:
                 else:
                     out += o.raw[:o_len - lib.md_inf_dst_rem(d)]
                     st = lib.md_inf_status(d)
+                    Inf.last_message = lib.md_inf_message(d).decode()  # the reference's `Malformed string, numbers included
                     if st < 0:
                         eng._check(st)
                     return ("Ok" if sig == END else _engine.STATUS_NAMES[st]), bytes(out), sigs

@@ -279,9 +279,17 @@ int md_de_def_run(md_ctx *ctx, int queue_len, const uint32_t *ops, size_t nops, 
  * with src (length 0 = end of input, as in the reference), calls decode / encode, and consumes its output buffer
  * whenever it gets MD_FLUSH (then md_inf_flush / md_def_dst), until MD_END or MD_MALFORMED (md_*_status gives
  * the MD_* status whose string is the reference's `Malformed message).  See csrc/stream_shim.cpp. */
+/* Memory: the shims buffer the whole input until its end is signalled and hold the whole result until it has been
+ * handed out — O(stream) host memory where the reference's decoder needs its 32 KiB window and one output buffer.
+ * md_inf_message: the reference's `Malformed string with its numbers, e.g. "Invalid checksum (expect:%04lx,
+ * has:%04lx)" (lib/zl.ml:179-181, lib/gz.ml:287-289), "Invalid input size (expect:%ld, inflated:%ld)"
+ * (lib/gz.ml:291-293); md_status_string(md_inf_status) is its fixed part.  md_inf_reset = De.Inf.reset
+ * (lib/de.ml:1512-1532): the same decoder for another stream. */
 enum { MD_AWAIT = 0, MD_FLUSH = 1, MD_END = 2, MD_MALFORMED = 3 };
 typedef struct md_inf_stream md_inf_stream;
 md_inf_stream *md_inf_decoder(md_ctx *ctx, int format, uint8_t *o, size_t o_len);
+void md_inf_reset(md_inf_stream *s);
+const char *md_inf_message(const md_inf_stream *s);
 int md_inf_src(md_inf_stream *s, const uint8_t *buf, size_t off, size_t len);
 int md_inf_decode(md_inf_stream *s);
 void md_inf_flush(md_inf_stream *s);

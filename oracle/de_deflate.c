@@ -1010,6 +1010,77 @@ uint8_t *orc_encode_cmds(const int *cmds, int ncmds, int kind, size_t *out_len) 
   return o.p;
 }
 
+/* De.Def.encode (lib/de.ml:2965-3038) driven step by step, the way test/test_ns.ml:388-615 and test/test.ml:533-767
+ * drive it: one encoder over a queue of queue_len cells and a `Buffer.  ops (32-bit words):
+ *   1 n c1..cn   Queue.push_exn of n commands      2 kind last  encode (`Block {kind; last}); kind 2 = Dynamic
+ *   3            encode `Flush                                    (dynamic_of_frequencies of the live histograms)
+ *   4 chr / 5 len / 6 dist   succ_literal / succ_length / succ_distance (lib/de.ml:2339-2351)
+ *   7            make_literals () / make_distances ()             8  Queue.reset
+ * rcs[k] = 0 `Ok / 1 `Block of the k-th encode.  NULL = Queue.Full or a malformed list. */
+uint8_t *orc_def_script(const int *ops, int nops, int queue_len, int *rcs, int max_rcs, int *nrcs, size_t *out_len) {
+  init_tables();
+  queue_t q = {(int *)calloc((size_t)queue_len, sizeof(int)), 0, 0, (unsigned)queue_len};
+  int lits[LIT_FREQS], dsts[DST_FREQS];
+  memset(lits, 0, sizeof lits);
+  memset(dsts, 0, sizeof dsts);
+  lits[256] = 1;
+  out_t o = {NULL, 0, 0};
+  enc_t e;
+  memset(&e, 0, sizeof e);
+  e.blk.kind = KIND_FIXED;
+  e.q = &q;
+  e.o = &o;
+  e.k = K_FIRST_ENTRY;
+  block_t *b = (block_t *)calloc(1, sizeof *b);
+  int n = 0, bad = 0;
+  for (int i = 0; i < nops && !bad;) {
+    int op = ops[i++], rc = -1;
+    switch (op) {
+    case 1: {
+      if (i >= nops || ops[i] < 0 || ops[i] > nops - i - 1) { bad = 1; break; }
+      int k = ops[i++];
+      for (; k > 0 && !bad; k--) {
+        if (q_available(&q) == 0) bad = 1; /* Queue.Full */
+        else q_push(&q, ops[i++]);
+      }
+      break;
+    }
+    case 2:
+      if (i + 1 >= nops || ops[i] < 0 || ops[i] > 2) { bad = 1; break; }
+      b->kind = ops[i++];
+      b->last = ops[i++] ? 1 : 0;
+      if (b->kind == KIND_DYNAMIC) dynamic_of_frequencies(lits, dsts, &b->dyn);
+      rc = enc_encode(&e, V_BLOCK, b);
+      break;
+    case 3: rc = enc_encode(&e, V_FLUSH, NULL); break;
+    case 4: if (i >= nops) bad = 1; else lits[ops[i++] & 0xff]++; break;
+    case 5: if (i >= nops || ops[i] < 3 || ops[i] > 258) bad = 1; else lits[257 + length_code[ops[i++]]]++; break;
+    case 6: if (i >= nops || ops[i] < 1 || ops[i] > 32768) bad = 1; else dsts[distance_code(ops[i++] - 1)]++; break;
+    case 7:
+      memset(lits, 0, sizeof lits);
+      memset(dsts, 0, sizeof dsts);
+      lits[256] = 1;
+      break;
+    case 8: q.w = q.r = 0; break;
+    default: bad = 1;
+    }
+    if (rc >= 0) {
+      if (n < max_rcs) rcs[n] = rc == R_BLOCK ? 1 : 0;
+      n++;
+    }
+  }
+  free(q.buf);
+  free(b);
+  *nrcs = n;
+  *out_len = o.n;
+  if (bad) {
+    free(o.p);
+    return NULL;
+  }
+  if (!o.p) o.p = (uint8_t *)malloc(1);
+  return o.p;
+}
+
 /* De.Lz77 alone (test/test.ml:798-813): the commands of every queue fill in order — what a caller of
  * De.Lz77.compress takes out of the queue at each `Flush and at `End (lib/de.mli:453-524) — and the cumulative
  * literals / distances histograms.  Returns the number of commands (they are stored while they fit in `max`). */

@@ -534,7 +534,157 @@ def gen_lzo():
     print("lzo.json", len(cases), "cases")
 
 
+# ---------------------------------------------------------------- encoder-built cases
+def all_cmd_lists(body):
+    """Every [`Literal ..; `Copy ..; `End] list of a test body, in source order, as queue commands."""
+    out = []
+    for m in re.finditer(r"\[\s*`(?:Literal|Copy|End)[^\]]*\]", body):
+        cmds = []
+        for t in re.finditer(r"`Literal '((?:\\x[0-9a-fA-F]{2})|(?:\\[0-9]{3})|.)'|`Literal \(Char\.chr (\d+)\)|`Copy \((\d+), (\d+)\)|`End",
+                             m.group(0)):
+            if t.group(0) == "`End":
+                cmds.append(256)
+            elif t.group(1) is not None:
+                c = t.group(1)
+                cmds.append(int(c[2:], 16) if c.startswith("\\x") else int(c[1:]) if c.startswith("\\") else ord(c))
+            elif t.group(2) is not None:
+                cmds.append(int(t.group(2)))
+            else:
+                off, ln = int(t.group(3)), int(t.group(4))
+                cmds.append(((ln - 3) << 16) | (off - 1) | 0x2000000)
+        out.append(cmds)
+    return out
+
+
+def lz77_plain(cmd_lists):
+    out = bytearray()
+    for cmds in cmd_lists:
+        for c in cmds:
+            if c == 256:
+                continue
+            if c & 0x2000000:
+                off, ln = (c & 0xffff) + 1, ((c >> 16) & 0x1ff) + 3
+                for _ in range(ln):
+                    out.append(out[-off])
+            else:
+                out.append(c)
+    return bytes(out)
+
+
+FILL, BLOCK, FLUSH, SUCC_LIT, SUCC_LEN, SUCC_DIST, NEW_FREQS, QRESET = 1, 2, 3, 4, 5, 6, 7, 8
+FLAT, FIXED, DYNAMIC = 0, 1, 2
+
+
+def succ_ops(cmds):
+    """test/test*.ml `encode_dynamic`: the frequencies of a command list"""
+    ops = []
+    for c in cmds:
+        if c == 256:
+            continue
+        if c & 0x2000000:
+            ops += [SUCC_LEN, ((c >> 16) & 0x1ff) + 3, SUCC_DIST, (c & 0xffff) + 1]
+        else:
+            ops += [SUCC_LIT, c]
+    return ops
+
+
+def fill(cmds):
+    return [FILL, len(cmds)] + cmds
+
+
+def qlen(n):
+    q = 4
+    while q < n:
+        q <<= 1
+    return q
+
+
+def gen_encode_cases():
+    """The reference's cases whose input is BUILT by De.Def.encode (test/test_ns.ml:221-252, :353-615, :837-915,
+    :1016-1057 and their streaming twins test/test.ml:507-611, :704-767, :910-1108).  The command lists and expected
+    strings are read from the sources; the order of the Def.encode calls of each test (what it passes and what it
+    demands back: `Ok or `Block) is transcribed by hand below, as a list of operations for md_de_def_run /
+    orc_def_script.  Each case: ops, the answers the test demands (rcs), and what inflating the result must give."""
+    out = []
+    for fname, decoder in (("test_ns.ml", "ns"), ("test.ml", "stream")):
+        text = open(os.path.join(REF, fname), encoding="latin-1").read()
+        cases = {n: (t, b, text.count("\n", 0, text.index("let %s () =" % n)) + 1) for n, t, b in split_cases(text)}
+
+        def add(name, ops, rcs, lists, q=4096, dst_cap=65536, status=0, out_hex=None):
+            t, b, line = cases[name]
+            plain = lz77_plain(lists)
+            m = re.search(r"let expected =", b)
+            if m:  # the string the test itself compares with
+                try:
+                    parts, _ = eval_str(b, m.end(), {})
+                    want = b"".join(x if isinstance(x, bytes) else bytes([x.byte]) * x.count for x in parts)
+                    assert want == plain, (name, want[:20], plain[:20])
+                except (ValueError, IndexError):
+                    pass
+            c = {"name": "%s (%s)" % (t, fname), "ref": "test/%s:%d" % (fname, line), "decoder": decoder, "queue_len": q,
+                 "ops": ops, "rcs": rcs, "dst_cap": dst_cap, "status": status,
+                 "plain": plain.hex() if status == 0 else ""}
+            if out_hex:
+                c["out"] = out_hex
+            out.append(c)
+
+        if decoder == "ns":
+            _, b, _ = cases["invalid_literal_not_enough_output"]
+            l = all_cmd_lists(b)
+            add("invalid_literal_not_enough_output", fill(l[0]) + [BLOCK, FIXED, 1], [0], l, q=qlen(len(l[0])), dst_cap=0, status=2)
+            _, b, _ = cases["invalid_copy_not_enough_output"]
+            l = all_cmd_lists(b)
+            add("invalid_copy_not_enough_output", fill(l[0]) + [BLOCK, FIXED, 1], [0], l, q=qlen(len(l[0])), dst_cap=1, status=2)
+        # huffman length extra: explicit frequencies, one last Dynamic block, then `Flush (`encode`)
+        _, b, _ = cases["huffman_length_extra"]
+        l = all_cmd_lists(b)
+        exp, _ = parse_string_expr(b, re.search(r'"encoding" res', b).end())
+        add("huffman_length_extra", [SUCC_LIT, 0, SUCC_LIT, 0, SUCC_LEN, 258, SUCC_LEN, 256, SUCC_DIST, 1, SUCC_DIST, 1] + fill(l[0]) +
+            [BLOCK, DYNAMIC, 1, FLUSH], [0, 0], l, q=qlen(len(l[0])), out_hex=exp.hex())
+        for name in ("fuzz10", "fuzz11", "fuzz12", "fuzz16", "fuzz17"):  # encode_dynamic lst
+            _, b, _ = cases[name]
+            l = all_cmd_lists(b)[:1]
+            add(name, succ_ops(l[0]) + fill(l[0]) + [BLOCK, DYNAMIC, 1, FLUSH], [0, 0], l, q=qlen(len(l[0])))
+        # dynamic+fixed: go [`Block dyn_a; `Flush; `Fill ..; `Block Fixed last; `Flush], every answer `Ok
+        _, b, _ = cases["dynamic_and_fixed"]
+        l = all_cmd_lists(b)
+        assert len(l) == 2
+        add("dynamic_and_fixed", [QRESET] + fill(l[0]) + [SUCC_LIT, ord("a"), SUCC_LEN, 3, SUCC_DIST, 1, BLOCK, DYNAMIC, 0, FLUSH] +
+            fill(l[1]) + [BLOCK, FIXED, 1, FLUSH], [0, 0, 0, 0], l)
+        # fixed+dynamic: go [`Flush; `Block dyn_b last; `Fill ..; `Flush]
+        _, b, _ = cases["fixed_and_dynamic"]
+        l = all_cmd_lists(b)
+        assert len(l) == 2
+        add("fixed_and_dynamic", [QRESET] + fill(l[0]) + [SUCC_LIT, ord("b"), SUCC_LEN, 3, SUCC_DIST, 1, FLUSH, BLOCK, DYNAMIC, 1] +
+            fill(l[1]) + [FLUSH], [0, 0, 0], l)
+        # dynamic+dynamic: `Block dyn_a must answer `Block (b has no code), `Block dyn_b last `Ok, `Flush `Ok
+        _, b, _ = cases["dynamic_and_dynamic"]
+        l = all_cmd_lists(b)
+        assert len(l) == 1
+        add("dynamic_and_dynamic", [QRESET] + fill(l[0]) + [SUCC_LIT, ord("a"), SUCC_LEN, 3, SUCC_DIST, 1, BLOCK, DYNAMIC, 0,
+                                                              SUCC_LIT, ord("b"), SUCC_LEN, 3, SUCC_DIST, 1, BLOCK, DYNAMIC, 1, FLUSH],
+            [1, 0, 0], l)
+        # fixed+flat: `Flush answers `Block (the queue holds an End), then `Block Flat last
+        _, b, _ = cases["fixed_and_flat"]
+        l = all_cmd_lists(b)
+        add("fixed_and_flat", fill(l[0]) + [FLUSH, BLOCK, FLAT, 1], [1, 0], l, q=qlen(len(l[0])))
+        # flat+fixed
+        _, b, _ = cases["flat_and_fixed"]
+        l = all_cmd_lists(b)
+        tailc = [((3 - 3) << 16) | (1 - 1) | 0x2000000, 256]  # Queue.push_exn q (cmd (`Copy (1, 3))); push_exn q eob
+        if decoder == "ns":  # test_ns.ml:587-615: `Block Flat -> `Ok, push, `Flush -> `Block, `Block Fixed last -> `Ok
+            ops, rcs, lists = fill(l[0]) + [BLOCK, FLAT, 0] + fill(tailc) + [FLUSH, BLOCK, FIXED, 1], [0, 1, 0], [l[0], tailc]
+        else:  # test/test.ml:1080-1108: the `Ok of the last block pushes the two commands once more and flushes again
+            ops = fill(l[0]) + [BLOCK, FLAT, 0] + fill(tailc) + [FLUSH, BLOCK, FIXED, 1] + fill(tailc) + [FLUSH]
+            rcs, lists = [0, 1, 0, 0], [l[0], tailc]  # what follows the last block is not part of the stream
+        add("flat_and_fixed", ops, rcs, lists, q=qlen(len(l[0])))
+    with open(os.path.join(OUT, "encode_cases.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("encode_cases.json", len(out), "cases")
+
+
 def main():
+    gen_encode_cases()
     gen_gzip()
     gen_lzo()
     if not os.path.isdir(REF):

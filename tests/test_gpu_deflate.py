@@ -161,6 +161,44 @@ def test_kats_through_gpu(eng):
     assert st == 0 and zlib.decompress(out, -15) == b"abcde"
 
 
+ENC = load_golden("encode_cases.json")
+
+
+@pytest.mark.parametrize("case", ENC, ids=[c["name"] for c in ENC])
+def test_encode_cases_through_gpu(eng, oracle, case):
+    """the reference's encoder-built cases (test/test_ns.ml:221-252, :353-615, :837-915, :1016-1057; test/test.ml:507-611,
+    :704-767, :910-1108): Def.encode driven on the GPU exactly as the test drives it (md_de_def_run) answers what the test
+    demands, writes the bytes the reference pins (and the oracle's everywhere), and the GPU inflates them to the
+    expected result"""
+    from decompress_amd import de
+    z, rcs = de.Def.run(case["ops"], case["queue_len"])
+    assert rcs == case["rcs"], case["ref"]
+    if "out" in case:
+        assert z == bytes.fromhex(case["out"])
+    assert z == oracle.def_script(case["ops"], case["queue_len"])[0]
+    st, used, out, _ = eng.inflate_many([z], [case["dst_cap"]])[0]
+    assert st == case["status"], case["ref"]
+    if st == 0:
+        assert out == bytes.fromhex(case["plain"])
+        if case["decoder"] == "ns":
+            assert used == len(z)  # Ok (De.bigstring_length src, String.length expected)
+        else:  # test/test.ml: the streaming decoder over the same bytes
+            assert de.Inf.decode_chunks([z, b""])[:2] == ("Ok", out)
+
+
+def test_def_run_misuse(eng):
+    """Queue.Full and malformed operation lists are statuses, not crashes"""
+    from decompress_amd import de
+    import decompress_amd
+    with pytest.raises(decompress_amd.Error, match="Queue.Full"):
+        de.Def.run([de.Def.OP_FILL, 5, 1, 2, 3, 4, 5], queue=4)
+    for bad in ([99], [de.Def.OP_FILL, 3, 1], [de.Def.OP_BLOCK, 7, 1], [de.Def.OP_FILL, 1, 0x2000000 | (300 << 16)],
+                [de.Def.OP_SUCC_LENGTH, 2]):
+        with pytest.raises(decompress_amd.Error):
+            de.Def.run(bad)
+    assert de.Def.run([]) == (b"", [])
+
+
 @pytest.mark.parametrize("name", ["tree_0", "tree_rfc5322_corpus"])
 def test_tree_kats_through_gpu(oracle, name):
     """test/test.ml:1169-1237: the Huffman trees of a given histogram.  A command list with exactly that histogram
@@ -254,6 +292,28 @@ def test_streaming_encoder_shim(eng, oracle):
     lib.md_def_free(s)
     assert bytes(out) == oracle.zl_deflate(data, 6)
     assert sigs.count(0) == 8 and sigs.count(1) >= 10
+
+
+def test_encoder_params_checked_at_construction(eng):
+    """md_def_encoder refuses bad parameters when the encoder is made (a zero queue_len used to divide by zero at the end of
+    the input); md_de_lz77_compress reports the room it needs when cmds_cap is too small"""
+    import decompress_amd
+    from decompress_amd import _lib, de
+    lib = eng.lib
+    o = ctypes.create_string_buffer(64)
+    for bad in (_lib.DeflateParams(), _lib.DeflateParams(6, 4095, 0, 1, 0, None, 0, 0), _lib.DeflateParams(10, 4096, 0, 1, 0, None, 0, 0),
+                _lib.DeflateParams(6, 4096, 7, 1, 0, None, 0, 0), _lib.DeflateParams(6, 4096, 0, 1, 3, None, 0, 0),
+                _lib.DeflateParams(6, 4096, 0, 1, 0, None, 12, 0)):
+        assert not lib.md_def_encoder(eng.ctx, 1, ctypes.byref(bad), o, len(o))
+    assert not lib.md_def_encoder(eng.ctx, 9, ctypes.byref(eng._params(6, 4096, 0, True)), o, len(o))
+    s = lib.md_def_encoder(eng.ctx, 1, ctypes.byref(_lib.DeflateParams(6, 4096, 0, 1, 0, None, 15, 0)), o, len(o))
+    assert s
+    lib.md_def_free(s)
+    src = b"abcdefgh" * 64
+    full, _, _ = de.Lz77.compress(src, level=6)
+    cmds, n = (ctypes.c_uint32 * 4)(), ctypes.c_size_t()
+    st = lib.md_de_lz77_compress(eng.ctx, 6, 4096, 0, src, len(src), cmds, 4, ctypes.byref(n), None, None)
+    assert st == 2 and n.value == len(full)  # Unexpected_end_of_output, *ncmds = the number needed
 
 
 def test_c_abi_single(eng):

@@ -258,6 +258,55 @@ def test_streaming_decoder_shim(eng, oracle):
     assert de.Inf.decode_chunks([b"\x03\x00"], o_len=16)[:2] == ("Ok", b"")
 
 
+def test_malformed_strings_and_reset(eng):
+    """the `Malformed strings of Zl.Inf / Gz.Inf with their numbers (lib/zl.ml:179-181, lib/gz.ml:287-293), byte for
+    byte what the reference's format strings give; De.Inf.reset (lib/de.ml:1512-1532) re-arms the same decoder"""
+    import ctypes
+    import gzip
+    import decompress_amd
+    from decompress_amd import de
+    data = b"a string that goes through the frame " * 40
+    z = bytearray(zlib.compress(data, 6))
+    want = int.from_bytes(z[-4:], "big")
+    z[-1] ^= 0x5a
+    bad = int.from_bytes(z[-4:], "big")
+    verdict, out, _ = de.Inf.decode_chunks([bytes(z)], fmt=decompress_amd.FORMAT_ZLIB)
+    assert verdict == "Invalid_checksum" and out == data
+    assert de.Inf.last_message == "Invalid checksum (expect:%04x, has:%04x)" % (bad, want)
+    g = bytearray(gzip.compress(data, mtime=0))
+    crc = int.from_bytes(g[-8:-4], "little")
+    g[-8] ^= 1
+    verdict, out, _ = de.Inf.decode_chunks([bytes(g)], fmt=decompress_amd.FORMAT_GZIP)
+    assert verdict == "Invalid_checksum"
+    assert de.Inf.last_message == "Invalid checksum (expect:%04x, has:%04x)" % (crc ^ 1, crc)
+    g = bytearray(gzip.compress(data, mtime=0))
+    g[-1] = 0x80  # ISIZE with the sign bit: %ld prints it as a negative 32-bit number
+    verdict, out, _ = de.Inf.decode_chunks([bytes(g)], fmt=decompress_amd.FORMAT_GZIP)
+    isize = int.from_bytes(g[-4:], "little") - (1 << 32)
+    assert de.Inf.last_message == "Invalid input size (expect:%d, inflated:%d)" % (isize, len(data))
+    assert de.Inf.decode_chunks([b"\x00"], fmt=decompress_amd.FORMAT_ZLIB)[0] == "Unexpected_end_of_input"
+    assert de.Inf.last_message == "Unexpected end of input"
+    # one decoder, two streams
+    lib = eng.lib
+    o = ctypes.create_string_buffer(1 << 16)
+    d = lib.md_inf_decoder(eng.ctx, decompress_amd.FORMAT_ZLIB, o, len(o))
+    for payload in (b"first " * 100, b"second stream " * 300):
+        zz = zlib.compress(payload)
+        assert lib.md_inf_decode(d) == de.AWAIT
+        lib.md_inf_src(d, zz, 0, len(zz))
+        lib.md_inf_src(d, b"", 0, 0)
+        assert lib.md_inf_decode(d) == de.END
+        assert o.raw[:len(o) - lib.md_inf_dst_rem(d)] == payload and lib.md_inf_checksum(d) == zlib.adler32(payload)
+        lib.md_inf_reset(d)
+    lib.md_inf_free(d)
+    # a stream at DEFLATE's highest ratio: one launch sized from the 1032x bound, not eight doublings
+    big = bytes(4 << 20)
+    zz = zlib.compress(big, 9)
+    assert len(zz) * 1032 >= len(big)
+    verdict, out, sigs = de.Inf.decode_chunks([zz], fmt=decompress_amd.FORMAT_ZLIB, o_len=1 << 20)
+    assert verdict == "Ok" and out == big
+
+
 def test_full_batch_c2(eng):
     """BASELINE config 2 as one batch: 4096 x 256 KiB zlib streams (512 distinct), every status, consumed count,
     length and Adler-32 checked, 64 streams compared byte for byte"""

@@ -125,3 +125,26 @@ def test_cli_driver_queue_full(oracle):
     assert oracle.deflate_raw(b"geg", 6, 4, 2)[0] is None
     assert oracle.deflate_raw(b"geg", 6, 8, 2)[0] is not None
     assert oracle.deflate_raw(b"geg", 6, 4, 0)[0] is not None
+
+
+# ---- the reference's encoder-built cases (tests/golden/encode_cases.json <- test/test_ns.ml, test/test.ml) ----
+ENC = load_golden("encode_cases.json")
+
+
+@pytest.mark.parametrize("case", ENC, ids=[c["name"] for c in ENC])
+def test_encode_cases(oracle, case):
+    """Def.encode driven exactly as the reference's test drives it: the answers (`Ok / `Block) it demands, the bytes
+    where it pins them, and what inflating the result must give."""
+    res = oracle.def_script(case["ops"], case["queue_len"])
+    assert res is not None, case["ref"]
+    z, rcs = res
+    assert rcs == case["rcs"], case["ref"]
+    if "out" in case:
+        assert z == bytes.fromhex(case["out"])
+    rc, consumed, out = oracle.de_inflate(z, case["dst_cap"])
+    assert rc == case["status"], case["ref"]
+    if rc == 0:
+        assert out == bytes.fromhex(case["plain"])
+        if case["decoder"] == "ns":  # Ok (De.bigstring_length src, String.length expected)
+            assert consumed == len(z)
+        assert zlib.decompressobj(-15).decompress(z) == out
