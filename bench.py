@@ -79,6 +79,7 @@ def parse(argv=None):
     ap.add_argument("--deflate-streams", type=int, default=4096)
     ap.add_argument("--deflate-kib", type=int, default=1024)
     ap.add_argument("--deflate-steps", type=int, default=3)
+    ap.add_argument("--gzip-members", type=int, default=32768, help="config 4: members of the ONE batch all ranks share")
     ap.add_argument("--profile", action="store_true", help="print the in-kernel phase profile of stream 0 (stderr)")
     return ap.parse_args(argv)
 
@@ -206,13 +207,14 @@ def deflate_leg(args, eng, dev, rank, world, dist, fence):
     d_off, d_len = off * nb, torch.full((n,), nb, dtype=torch.int64, device=dev)
     d_ooff, d_cap = off * cap, torch.full((n,), cap, dtype=torch.int64, device=dev)
     d_out = torch.empty(n * cap, dtype=torch.uint8, device=dev)
-    res = eng.deflate_batch(decompress_amd.FORMAT_ZLIB, d_in, d_off, d_len, d_out, d_ooff, d_cap, level=6, queue=4096)
+    res = eng.deflate_batch(decompress_amd.FORMAT_ZLIB, d_in, d_off, d_len, d_out, d_ooff, d_cap, level=6, queue=4096,
+                            total_in=n * nb)
     fence()
     eng.timing_begin()
     t0 = time.perf_counter()
     for _ in range(args.deflate_steps):
         res = eng.deflate_batch(decompress_amd.FORMAT_ZLIB, d_in, d_off, d_len, d_out, d_ooff, d_cap, level=6, queue=4096,
-                                results=res)
+                                results=res, total_in=n * nb)
     kernel_ms = eng.timing_end() / max(1, args.deflate_steps)
     fence()
     elapsed = time.perf_counter() - t0
@@ -227,11 +229,14 @@ def deflate_leg(args, eng, dev, rank, world, dist, fence):
     if not args.no_verify:
         from tests import oracle_lib
         orc = oracle_lib.load()
-        for k in range(0, n, max(1, n // 8)):  # bytes equal the oracle's, and they decode (8 buffers)
+        # bytes equal the oracle's, and they decode (8 buffers); the CPU leg gets one buffer per host thread
+        nsample = min(n, max(8, min(64, host_cores()[0]))) if (world == 1 and not args.no_cpu_baseline) else min(n, 8)
+        for j, k in enumerate(range(0, n, max(1, n // nsample))):
             plain = d_in[k * nb:(k + 1) * nb].cpu().numpy().tobytes()
-            got = d_out[k * cap:k * cap + int(out_len[k].item())].cpu().numpy().tobytes()
-            ok = ok and got == orc.zl_deflate(plain, 6) and zlib.decompress(got) == plain
-            ok = ok and (int(adler[k].item()) & 0xffffffff) == zlib.adler32(plain)
+            if j % max(1, nsample // 8) == 0:
+                got = d_out[k * cap:k * cap + int(out_len[k].item())].cpu().numpy().tobytes()
+                ok = ok and got == orc.zl_deflate(plain, 6) and zlib.decompress(got) == plain
+                ok = ok and (int(adler[k].item()) & 0xffffffff) == zlib.adler32(plain)
             sample.append(plain)
     if world > 1:
         t = torch.tensor([int(ok), comp_bytes], dtype=torch.int64, device=dev)
@@ -261,56 +266,103 @@ def deflate_leg(args, eng, dev, rank, world, dist, fence):
     return leg
 
 
-def gzip_leg(args, eng, dev):
-    """BASELINE config 4's per-GPU share: 4096 gzip members = the 15 files of the reference's test/corpus cycled,
-    Gz.Def level 4 (mtime 0, OS Unix, no name) then Gz.Inf; bytes checked against the oracle on one cycle."""
+def gzip_leg(args, eng, dev, rank, world, dist):
+    """BASELINE config 4, strong scaling: ONE batch of args.gzip_members gzip members (32768 = the 15 files of the
+    reference's test/corpus cycled, 6.64 GiB) sharded over the ranks in contiguous ranges balanced by bytes
+    (shard_by_bytes); every rank runs Gz.Def level 4 (mtime 0, OS Unix, no name) then Gz.Inf on its shard; the
+    compressed members of every rank are then gathered to rank 0 — the path's final gather: sizes by all_gather, bytes by
+    exact-size send/recv (RCCL over xGMI).  Times are max over ranks; bytes checked against the oracle on one cycle."""
     import numpy as np
     import torch
     import decompress_amd
-    from decompress_amd import workloads
-    n = 4096
+    from decompress_amd import shard, workloads
+    n_total = args.gzip_members
     uniq = list(workloads.corpus().values())
-    bufs = [uniq[i % len(uniq)] for i in range(n)]
-    blob, off, ln = workloads.pack(bufs)
+    lengths = [len(uniq[i % len(uniq)]) for i in range(n_total)]
+    spans = shard.shard_by_bytes(lengths, world)
+    lo, hi = spans[rank]
+    n = hi - lo
+    ln = np.array(lengths[lo:hi], dtype=np.int64)
+    off = np.zeros(n, dtype=np.int64)
+    np.cumsum(((ln + 15) // 16 * 16)[:-1], out=off[1:])
+    total = int(ln.sum())
+    # the shard's input, built on the device from one copy of the 15 files
+    d_files = [torch.from_numpy(np.frombuffer(u, dtype=np.uint8).copy()).to(dev) for u in uniq]
+    d_in = torch.zeros(int(off[-1] + ln[-1]) + 64 if n else 64, dtype=torch.uint8, device=dev)
+    for i in range(n):
+        d_in[int(off[i]):int(off[i]) + int(ln[i])] = d_files[(lo + i) % len(uniq)]
     cap = (ln + 8192).astype(np.int64)
     ooff = np.zeros(n, dtype=np.int64)
     np.cumsum(((cap + 255) // 256 * 256)[:-1], out=ooff[1:])
     t = lambda a: torch.from_numpy(a).to(dev)
-    d_in, d_off, d_len = t(blob), t(off), t(ln)
-    d_z = torch.empty(int(ooff[-1] + cap[-1]), dtype=torch.uint8, device=dev)
+    d_off, d_len = t(off), t(ln)
+    d_z = torch.empty(int(ooff[-1] + cap[-1]) if n else 1, dtype=torch.uint8, device=dev)
     d_zoff, d_zcap = t(ooff), t(cap)
     hdr = dict(mtime=0, os=3, hcrc=0, ascii=0, filename=None, comment=None)
-    res = eng.deflate_batch(decompress_amd.FORMAT_GZIP, d_in, d_off, d_len, d_z, d_zoff, d_zcap, level=4, header=hdr)
+
+    def tmax(ms):
+        if world == 1:
+            return ms
+        tt = torch.tensor([ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    kw = dict(level=4, header=hdr, total_in=max(1, total))
+    res = eng.deflate_batch(decompress_amd.FORMAT_GZIP, d_in, d_off, d_len, d_z, d_zoff, d_zcap, **kw)
     torch.cuda.synchronize(dev)
     eng.timing_begin()
-    res = eng.deflate_batch(decompress_amd.FORMAT_GZIP, d_in, d_off, d_len, d_z, d_zoff, d_zcap, level=4, header=hdr, results=res)
-    ms_def = eng.timing_end()
+    res = eng.deflate_batch(decompress_amd.FORMAT_GZIP, d_in, d_off, d_len, d_z, d_zoff, d_zcap, results=res, **kw)
+    ms_def = tmax(eng.timing_end())
     z_len, z_status, _ = res
     ok = bool((z_status == 0).all().item())
-    d_back = torch.zeros(int(blob.size) + 64, dtype=torch.uint8, device=dev)
+    d_back = torch.zeros(d_in.numel(), dtype=torch.uint8, device=dev)
     r = eng.inflate_batch(decompress_amd.FORMAT_GZIP, d_z, d_zoff, z_len.to(torch.int64), d_back, d_off, d_len)
     torch.cuda.synchronize(dev)
     eng.timing_begin()
-    for _ in range(3):
+    for _ in range(2):
         r = eng.inflate_batch(decompress_amd.FORMAT_GZIP, d_z, d_zoff, z_len.to(torch.int64), d_back, d_off, d_len, results=r)
-    ms_inf = eng.timing_end() / 3
+    ms_inf = tmax(eng.timing_end() / 2)
     out_len, consumed, status, crc = r
     ok = ok and bool((status == 0).all().item()) and bool((out_len == d_len).all().item())
-    ok = ok and bool(torch.equal(d_back[:blob.size], d_in[:blob.size]))
-    if not args.no_verify:
+    ok = ok and bool(torch.equal(d_back, d_in))
+    del d_back
+    # ---- the final gather: compressed members packed back to back, sizes, then the bytes to rank 0
+    zl = z_len.to(torch.int64)
+    zstart = torch.cumsum(zl, 0) - zl
+    idx = torch.repeat_interleave(d_zoff - zstart, zl) + torch.arange(int(zl.sum().item()), device=dev)
+    payload = d_z[idx]
+    del idx
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    all_zl = torch.cat(shard.gather_varlen(dist, zl, world))
+    parts, sizes = shard.gather_payload(dist, payload, world, rank, dst=0)
+    torch.cuda.synchronize(dev)
+    gather_ms = tmax((time.perf_counter() - t0) * 1e3)
+    if rank == 0 and not args.no_verify:
+        import gzip as _gz
         from tests import oracle_lib
         orc = oracle_lib.load()
-        zl = z_len.cpu().numpy()
-        for k in range(0, len(uniq), 4):  # 4 of the 15 files: the member's bytes equal the oracle's
-            got = d_z[int(ooff[k]):int(ooff[k]) + int(zl[k])].cpu().numpy().tobytes()
-            ok = ok and got == orc.gz_deflate(bufs[k], level=4)
-    total, comp = float(ln.sum()), float(z_len.sum().item())
-    return {"workload": "C4: 4096 gzip members = the reference's 15 corpus files cycled (%d B), Gz.Def level 4 / Gz.Inf" % int(total),
-            "deflate": {"value": round(total / 2**20 / (ms_def * 1e-3), 1), "unit": "MiB/s", "ms": round(ms_def, 2),
-                        "frac": round((total + comp) / (ms_def * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
-            "inflate": {"value": round(total / 2**20 / (ms_inf * 1e-3), 1), "unit": "MiB/s", "ms": round(ms_inf, 3),
-                        "frac": round((total + comp) / (ms_inf * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
-            "compressed_ratio": round(comp / total, 4), "parity_ok": ok}
+        got_all = torch.cat(parts) if world > 1 else payload
+        starts = (torch.cumsum(all_zl, 0) - all_zl).cpu().numpy()
+        lens_all = all_zl.cpu().numpy()
+        ok = ok and int(all_zl.numel()) == n_total and int(got_all.numel()) == int(lens_all.sum())
+        for k in list(range(0, len(uniq), 4)) + [n_total - 1, n_total // 2]:  # members from every part of the gathered blob
+            m = got_all[int(starts[k]):int(starts[k]) + int(lens_all[k])].cpu().numpy().tobytes()
+            ok = ok and m == orc.gz_deflate(uniq[k % len(uniq)], level=4) and _gz.decompress(m) == uniq[k % len(uniq)]
+    flags = shard.gather_results(dist, torch.tensor([int(ok), total, int(zl.sum().item())], dtype=torch.int64, device=dev), world)
+    if rank != 0:
+        return None
+    ok = all(int(f[0].item()) for f in flags)
+    tot_all, comp_all = float(sum(int(f[1].item()) for f in flags)), float(sum(int(f[2].item()) for f in flags))
+    return {"workload": "C4: %d gzip members = the reference's 15 corpus files cycled (%d B), Gz.Def level 4 / Gz.Inf, one "
+                        "batch sharded over %d GPU(s) by bytes" % (n_total, int(tot_all), world),
+            "scaling": "strong", "members_total": n_total, "members_per_rank": [b - a for a, b in spans],
+            "results_gathered": int(all_zl.numel()), "gathered_bytes": int(sum(sizes)), "gather_ms": round(gather_ms, 2),
+            "deflate": {"value": round(tot_all / 2**20 / (ms_def * 1e-3), 1), "unit": "MiB/s", "ms": round(ms_def, 2),
+                        "frac": round((tot_all + comp_all) / (ms_def * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), 5)},
+            "inflate": {"value": round(tot_all / 2**20 / (ms_inf * 1e-3), 1), "unit": "MiB/s", "ms": round(ms_inf, 3),
+                        "frac": round((tot_all + comp_all) / (ms_inf * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), 5)},
+            "compressed_ratio": round(comp_all / tot_all, 4), "parity_ok": ok}
 
 
 def lzo_leg(args, eng, dev):
@@ -531,11 +583,15 @@ def main():
         leg = deflate_leg(args, eng, dev, rank, world, dist, fence)
         if rank == 0:
             line["deflate"] = leg
-    if world == 1 and not args.no_secondary:  # configs 4 and 5, one GPU's share each (not part of `value`)
+    if not args.no_secondary:  # configs 4 (one batch sharded over the ranks, outputs gathered) and 5 (not part of `value`)
         torch.cuda.empty_cache()
-        line["gzip"] = gzip_leg(args, eng, dev)
+        leg = gzip_leg(args, eng, dev, rank, world, dist)
         torch.cuda.empty_cache()
-        line["lzo"] = lzo_leg(args, eng, dev)
+        lz = lzo_leg(args, eng, dev) if world == 1 else None
+        if rank == 0:
+            line["gzip"] = leg
+            if lz:
+                line["lzo"] = lz
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -6,9 +6,9 @@
 //   prev[c]       = hash_head(c) for every candidate c still in reach        (the chain links)
 // are pure functions of the input.  Two kernels compute them for the whole batch before the sequential kernel runs:
 //
-//   deflate_link_kernel   one workgroup per stream, the 32 K-entry head table in LDS (128 KiB): 8 x 64 positions per
-//                         group, one LDS atomic-max per position returning the old head, equal hashes inside a step
-//                         matched by ballots.  Output link[p] = p - hash_head(p) as 16 bits (0 = none in reach):
+//   deflate_link_kernel   one workgroup (4 wavefronts) per stream, the 32 K-entry head table in LDS (128 KiB): 8 x 64
+//                         positions per group, one LDS atomic-max per position returning the old head (the groups
+//                         take their turn in stream order), equal hashes inside a step matched by ballots.  Output link[p] = p - hash_head(p) as 16 bits (0 = none in reach):
 //                         the only HBM traffic is the input read once and 2 bytes per position written once.
 //   deflate_match_kernel  longest_match (lib/de.ml:4110-4174) run for every position as if reached with
 //                         prev_length = 2 (full and quartered chain), positions independent of each other: the grid
@@ -96,61 +96,76 @@ __device__ __forceinline__ uint32_t load_w4(const uint8_t *__restrict__ src, uin
 }
 
 // ---- hash chains ----------------------------------------------------------------------------------
-// head[h] <- max(pos), one LDS atomic per position, the steps of a group issued back to back (a wavefront's LDS
-// operations execute in order).  The values a set of equal hashes gets back are >= the head before the set and one of
-// them is exactly that value: a lane that shares its hash with another lane of its step is recognised by a returned
-// position inside the step, and such steps sort themselves out by ballots (the predecessor of a lane is the nearest
-// lower lane with its hash, else the smallest value the set got back).
-__global__ __launch_bounds__(kWave) void deflate_link_kernel(uint32_t n, const uint8_t *__restrict__ in,
-                                                             const uint64_t *__restrict__ in_off,
-                                                             const uint64_t *__restrict__ in_len,
-                                                             const uint32_t *__restrict__ p_end_a,
-                                                             const uint64_t *__restrict__ slot, uint16_t *__restrict__ link,
-                                                             uint32_t *__restrict__ tail, const uint32_t *__restrict__ flags,
-                                                             int matcher) {
+// head[h] <- max(pos), one LDS atomic per position.  The head table of a stream is 128 KiB of LDS, so a CU holds one
+// stream — and one wavefront alone runs at the latency of its own instruction stream (9 cycles per instruction
+// measured).  Four wavefronts therefore share the stream: wavefront w takes the groups k = w, w + 4, ... of 8 x 64
+// positions, loads and hashes them ahead, and only the atomics themselves are taken in stream order — a turn counter
+// in LDS lets group k issue its eight atomics once group k - 1 has got its results back (a wavefront's own LDS
+// operations execute in order).  Everything after the atomics (sorting out equal hashes, the stores) overlaps with
+// the other wavefronts' groups.
+// The values a set of equal hashes gets back are >= the head before the set and one of them is exactly that value: a
+// lane that shares its hash with another lane of its step is recognised by a returned position inside the step, and
+// such steps sort themselves out by ballots (the predecessor of a lane is the nearest lower lane with its hash, else
+// the smallest value the set got back).
+constexpr int LW = 4;  // wavefronts per stream
+__global__ __launch_bounds__(LW *kWave) void deflate_link_kernel(uint32_t n, const uint8_t *__restrict__ in,
+                                                                 const uint64_t *__restrict__ in_off,
+                                                                 const uint64_t *__restrict__ in_len,
+                                                                 const uint32_t *__restrict__ p_end_a,
+                                                                 const uint64_t *__restrict__ slot, uint16_t *__restrict__ link,
+                                                                 uint32_t *__restrict__ tail, const uint32_t *__restrict__ flags,
+                                                                 int matcher) {
   __shared__ uint32_t head[HASH_SIZE];  // absolute position, 0 = NIL (position 0 can never match, like the reference)
-  __shared__ uint32_t gmin[kWave];
-  const uint32_t lane = threadIdx.x, sid = blockIdx.x;
+  __shared__ uint32_t gmin_all[LW][kWave];
+  __shared__ uint32_t turn;  // the group whose atomics may be issued
+  const uint32_t lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave, sid = blockIdx.x;
   if (sid >= n || flags[0]) return;
   const uint32_t p_end = p_end_a[sid];
   const uint64_t l64 = in_len[sid];
   const uint32_t slen = l64 > MD_MAX_STREAM ? 0u : (uint32_t)l64;
   const uint8_t *src = in + in_off[sid];
   uint16_t *lk = link + slot[sid];
+  uint32_t *gmin = gmin_all[wv];
   {
     uint4 *h4 = reinterpret_cast<uint4 *>(head);
-    for (uint32_t i = lane; i < (uint32_t)HASH_SIZE / 4; i += kWave) h4[i] = make_uint4(0, 0, 0, 0);
+    for (uint32_t i = threadIdx.x; i < (uint32_t)HASH_SIZE / 4; i += LW * kWave) h4[i] = make_uint4(0, 0, 0, 0);
+    if (threadIdx.x == 0) turn = 0;
   }
   __syncthreads();
   if (slen < 4) {  // at most one string (Lz, 3 bytes): nothing before it
-    if (lane < p_end) lk[lane] = 0;
-    if (lane < 2) tail[2 * sid + lane] = 0;
+    if (threadIdx.x < p_end) lk[threadIdx.x] = 0;
+    if (threadIdx.x < 2) tail[2 * sid + threadIdx.x] = 0;
     return;
   }
-  // the input of group k + 2 is requested before group k is worked on: one wavefront per CU has nothing else to hide
-  // the HBM latency of its loads behind
+  // the input of a wavefront's next two groups is requested before the current one is worked on
   // (branch-free: a branch around a load makes the compiler wait for every load in flight)
   auto load_group = [&](uint32_t pe, uint32_t (&w)[PGL]) {
 #pragma unroll
     for (int g = 0; g < PGL; g++) w[g] = load_w4(src, slen, p_end, pe + g * kWave + lane);
   };
+  constexpr uint32_t kGroup = PGL * kWave;
+  const uint32_t ngroups = (p_end + kGroup - 1) / kGroup;
   uint32_t wa[PGL], wb[PGL];
-  load_group(0, wa);
-  load_group(PGL * kWave, wb);
-  for (uint32_t pe = 0; pe < p_end; pe += PGL * kWave) {
+  load_group(wv * kGroup, wa);
+  load_group((wv + LW) * kGroup, wb);
+  for (uint32_t k = wv; k < ngroups; k += LW) {
+    const uint32_t pe = k * kGroup;
     uint32_t w4[PGL], hv[PGL], ret[PGL];
 #pragma unroll
     for (int g = 0; g < PGL; g++) {
       w4[g] = wa[g];
       wa[g] = wb[g];
+      hv[g] = hash_of(matcher, w4[g]);
     }
-    load_group(pe + 2 * PGL * kWave, wb);
+    load_group(pe + 2 * LW * kGroup, wb);
+    while (__hip_atomic_load(&turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != k) __builtin_amdgcn_s_sleep(1);
 #pragma unroll
     for (int g = 0; g < PGL; g++) {
       const uint32_t pos = pe + g * kWave + lane;
-      hv[g] = hash_of(matcher, w4[g]);
       ret[g] = pos < p_end ? atomicMax(&head[hv[g]], pos) : 0xffffffffu;
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the group's atomics have been performed: the next group may go
+    if (lane == 0) __hip_atomic_store(&turn, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
     for (int g = 0; g < PGL; g++) {
       const uint32_t s0 = pe + g * kWave;
@@ -172,11 +187,11 @@ __global__ __launch_bounds__(kWave) void deflate_link_kernel(uint32_t n, const u
         const uint64_t below = same & lanes_below(lane);
         const uint32_t first = valid ? (uint32_t)__builtin_ctzll(same) : lane;
         gmin[lane] = 0xffffffffu;
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
         if (valid) atomicMin(&gmin[first], ret[g]);
-        __syncthreads();
-        c1 = !valid ? 0u : below ? s0 + 63u - (uint32_t)__builtin_clzll(below) : gmin[lane];
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
+        c1 = !valid ? 0u : below ? s0 + 63u - (uint32_t)__builtin_clzll(below) : __hip_atomic_load(&gmin[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __builtin_amdgcn_wave_barrier();
       }
       if (valid) {
         const uint32_t d = pos - c1;
@@ -188,15 +203,15 @@ __global__ __launch_bounds__(kWave) void deflate_link_kernel(uint32_t n, const u
   // De's position len - 3 (lookahead 3): hash4 reads a 4th byte beyond the data (H7) — zero before the first slide of
   // the reference's 64 KiB buffer, the byte 32 KiB earlier after it.  Which one depends on the matcher's trajectory:
   // both heads are handed over.
-  if (lane < 2) {
+  if (threadIdx.x < 2) {
     uint32_t res = 0;
     if (matcher == MD_MATCHER_DE && slen >= 3) {
       const uint32_t p = slen - 3;
-      const uint32_t b3 = (lane == 1 && slen >= (uint32_t)WSIZE) ? src[slen - WSIZE] : 0u;
+      const uint32_t b3 = (threadIdx.x == 1 && slen >= (uint32_t)WSIZE) ? src[slen - WSIZE] : 0u;
       const uint32_t w = (uint32_t)src[p] | ((uint32_t)src[p + 1] << 8) | ((uint32_t)src[p + 2] << 16) | (b3 << 24);
       res = head[hash_of(matcher, w)];
     }
-    tail[2 * sid + lane] = res;
+    tail[2 * sid + threadIdx.x] = res;
   }
 }
 
@@ -260,6 +275,10 @@ __global__ __launch_bounds__(kWave) void deflate_match_kernel(uint32_t n, uint32
     bestq[g] = MIN_MATCH - 1;
     bdistq[g] = 0;
   }
+  // One link of every chain per iteration.  The usual candidate fails the 3-byte test: that path is straight-line
+  // (loads from a harmless address for lanes that have nothing to do, selects instead of branches — a branch per
+  // lane group costs more scalar instructions than the work it skips); only a candidate that passes goes through
+  // the comparison code.
   for (uint32_t lv = 0; lv < kspec; lv++) {
     bool act[PGM];
     bool any = false;
@@ -274,19 +293,17 @@ __global__ __launch_bounds__(kWave) void deflate_match_kernel(uint32_t n, uint32
     uint32_t v[PGM], nx[PGM];
 #pragma unroll
     for (int g = 0; g < PGM; g++) {
-      v[g] = 0;
-      nx[g] = 0;
-      if (act[g]) {
-        __builtin_memcpy(&v[g], src + cw[g], 4);  // candidate < pos <= len - 3
-        const uint32_t l = lk[cw[g]];
-        nx[g] = l ? cw[g] - l : 0u;
-      }
+      const uint32_t a = act[g] ? cw[g] : 0u;  // candidate < pos <= len - 3; position 0 for idle lanes (len >= 4 here)
+      __builtin_memcpy(&v[g], src + a, 4);
+      const uint32_t l = lk[a];
+      nx[g] = l ? a - l : 0u;
     }
 #pragma unroll
     for (int g = 0; g < PGM; g++) {
-      if (act[g]) {
-        const uint32_t pos = pe + g * kWave + lane;
-        if (((v[g] ^ w4[g]) & 0xffffffu) == 0) {
+      const bool hit = act[g] && ((v[g] ^ w4[g]) & 0xffffffu) == 0;
+      if (__ballot(hit)) {
+        if (hit) {
+          const uint32_t pos = pe + g * kWave + lane;
           if (pos + MIN_LOOKAHEAD > slen) fl[g] = 8;  // too close to the end to compare ahead: the matcher's job
           else {
             // scan_end pre-filter (lib/de.ml:4133-4134): a candidate that differs at the end of the best match so
@@ -307,13 +324,12 @@ __global__ __launch_bounds__(kWave) void deflate_match_kernel(uint32_t n, uint32
             }
           }
         }
-        cnt[g]++;
-        if (cnt[g] == qlimit) {
-          bestq[g] = best[g];
-          bdistq[g] = bdist[g];
-        }
-        cw[g] = nx[g];
       }
+      cnt[g] += act[g] ? 1u : 0u;
+      const bool atq = act[g] && cnt[g] == qlimit;
+      bestq[g] = atq ? best[g] : bestq[g];
+      bdistq[g] = atq ? bdist[g] : bdistq[g];
+      cw[g] = act[g] ? nx[g] : cw[g];
     }
   }
 #pragma unroll
@@ -390,7 +406,7 @@ extern "C" int md_launch_deflate_front(uint32_t n, uint32_t nchunks_max, const u
                                        const md::defl::Front *f, hipStream_t stream) {
   using namespace md::defl;
   if (n == 0 || nchunks_max == 0) return 0;
-  hipLaunchKernelGGL(deflate_link_kernel, dim3(n), dim3(kWave), 0, stream, n, in, in_off, in_len, f->p_end, f->slot, f->link,
+  hipLaunchKernelGGL(deflate_link_kernel, dim3(n), dim3(LW * kWave), 0, stream, n, in, in_off, in_len, f->p_end, f->slot, f->link,
                      (uint32_t *)f->tail, f->flags, matcher);
   const uint32_t per = (nchunks_max + 7) / 8;
   hipLaunchKernelGGL(deflate_match_kernel, dim3(per * 8), dim3(kWave), 0, stream, n, nchunks_max, in, in_off, in_len, f->p_end,

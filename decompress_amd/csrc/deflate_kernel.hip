@@ -211,99 +211,7 @@ __device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
     if (lane == 0) s->tp[i] += (uint32_t)(t_now - t_prev);  \
     t_prev = t_now;                                         \
   }
-// The heap of T.make's merge loop in registers: heap index j lives in lane j % 64 of register pair j / 64.  Every
-// index the loop touches is wave-uniform, so a heap access is a v_readlane / v_writelane with a scalar lane number and
-// the comparisons run on the scalar unit: a level of pqdownheap (lib/de.ml:1879-1899) costs no LDS round trip (it
-// was two dependent ones, by one lane, the other 63 idle).  NS = register pairs (5 hold the 286 literal/length codes).
-template <int NS>
-struct RegHeap {
-  // Named registers, and every access written for a level of the heap known at compile time (levels 0-5 are pair 0,
-  // level 6 pair 1, level 7 pairs 2 and 3, level 8 pair 4): a register chosen by a run-time index is turned into a
-  // scratch-memory table by the compiler.
-  uint32_t l0, l1, l2, l3, l4, h0, h1, h2, h3, h4;
-  static constexpr int MAXL = NS == 1 ? 5 : 8;  // deepest level (63 / 319 entries)
-  static __device__ __forceinline__ uint64_t mk(uint32_t a, uint32_t b) { return ((uint64_t)b << 32) | a; }
-  template <int LV>
-  __device__ __forceinline__ uint64_t get_at(uint32_t j) const {  // j on level LV
-    const uint32_t l = j & 63;
-    if constexpr (LV <= 5) return mk(__builtin_amdgcn_readlane(l0, l), __builtin_amdgcn_readlane(h0, l));
-    else if constexpr (LV == 6) return mk(__builtin_amdgcn_readlane(l1, l), __builtin_amdgcn_readlane(h1, l));
-    else if constexpr (LV == 7) {
-      const uint64_t x = mk(__builtin_amdgcn_readlane(l2, l), __builtin_amdgcn_readlane(h2, l));
-      const uint64_t y = mk(__builtin_amdgcn_readlane(l3, l), __builtin_amdgcn_readlane(h3, l));
-      return (j & 64) ? y : x;
-    } else return mk(__builtin_amdgcn_readlane(l4, l), __builtin_amdgcn_readlane(h4, l));
-  }
-  template <int LV>
-  __device__ __forceinline__ void set_at(uint32_t j, uint64_t v, uint32_t lane) {
-    const bool me = lane == (j & 63);
-    const uint32_t vl = (uint32_t)v, vh = (uint32_t)(v >> 32);
-    if constexpr (LV <= 5) { l0 = me ? vl : l0; h0 = me ? vh : h0; }
-    else if constexpr (LV == 6) { l1 = me ? vl : l1; h1 = me ? vh : h1; }
-    else if constexpr (LV == 7) {
-      const bool up = (j & 64) != 0;
-      l2 = (me && !up) ? vl : l2; h2 = (me && !up) ? vh : h2;
-      l3 = (me && up) ? vl : l3; h3 = (me && up) ? vh : h3;
-    } else { l4 = me ? vl : l4; h4 = me ? vh : h4; }
-  }
-  // any index (once per merge): all pairs are read, the scalar unit picks
-  __device__ __forceinline__ uint64_t get_any(uint32_t j) const {
-    const uint32_t l = j & 63, set = j >> 6;
-    uint64_t r = mk(__builtin_amdgcn_readlane(l0, l), __builtin_amdgcn_readlane(h0, l));
-    if constexpr (NS > 1) {
-      const uint64_t r1 = mk(__builtin_amdgcn_readlane(l1, l), __builtin_amdgcn_readlane(h1, l));
-      const uint64_t r2 = mk(__builtin_amdgcn_readlane(l2, l), __builtin_amdgcn_readlane(h2, l));
-      const uint64_t r3 = mk(__builtin_amdgcn_readlane(l3, l), __builtin_amdgcn_readlane(h3, l));
-      const uint64_t r4 = mk(__builtin_amdgcn_readlane(l4, l), __builtin_amdgcn_readlane(h4, l));
-      r = set == 1 ? r1 : r;
-      r = set == 2 ? r2 : r;
-      r = set == 3 ? r3 : r;
-      r = set == 4 ? r4 : r;
-    }
-    return r;
-  }
-  __device__ __forceinline__ void load(const uint64_t *hk, uint32_t lane) {
-    auto at = [&](uint32_t idx) { return idx < (uint32_t)(L_CODES + 2) ? hk[idx] : (uint64_t)0; };
-    uint64_t v = at(lane);
-    l0 = (uint32_t)v; h0 = (uint32_t)(v >> 32);
-    l1 = l2 = l3 = l4 = h1 = h2 = h3 = h4 = 0;
-    if constexpr (NS > 1) {
-      v = at(64 + lane); l1 = (uint32_t)v; h1 = (uint32_t)(v >> 32);
-      v = at(128 + lane); l2 = (uint32_t)v; h2 = (uint32_t)(v >> 32);
-      v = at(192 + lane); l3 = (uint32_t)v; h3 = (uint32_t)(v >> 32);
-      v = at(256 + lane); l4 = (uint32_t)v; h4 = (uint32_t)(v >> 32);
-    }
-  }
-  // pqdownheap (lib/de.ml:1879-1899) of value v from index k on level L (ties count as smaller: hsmaller)
-  template <int L>
-  __device__ __forceinline__ void sift_from(uint32_t k, uint32_t hlen, uint64_t v, uint32_t lane) {
-    if constexpr (L >= MAXL) set_at<L>(k, v, lane);
-    else {
-      uint32_t j = k << 1;
-      if (j > hlen) {
-        set_at<L>(k, v, lane);
-        return;
-      }
-      uint64_t a = get_at<L + 1>(j);
-      if (j < hlen) {
-        const uint64_t b = get_at<L + 1>(j + 1);
-        if (hsmaller(b, a)) {
-          j++;
-          a = b;
-        }
-      }
-      if (hsmaller(v, a)) {
-        set_at<L>(k, v, lane);
-        return;
-      }
-      set_at<L>(k, a, lane);
-      sift_from<L + 1>(j, hlen, v, lane);
-    }
-  }
-  __device__ __forceinline__ void sift_root(uint32_t hlen, uint64_t v, uint32_t lane) { sift_from<0>(1, hlen, v, lane); }
-};
-
-template <bool TPROF, int NS>
+template <bool TPROF>
 __device__ void tree_make_wave(DS *s, int length, int max_length, int *f, TreeRef t, uint32_t lane) {
   uint64_t t_prev = TPROF ? wall_clock64() : 0;
   for (int n = (int)lane; n < HEAP_SIZE; n += kWave) {
@@ -336,34 +244,28 @@ __device__ void tree_make_wave(DS *s, int length, int max_length, int *f, TreeRe
   }
   const int hmax = HEAP_SIZE - (2 * hlen0 - 1);
   TP_MARK(0)
-  {
-    // the merge loop, lib/de.ml:2027-2049: two smallest out, their parent in — the reference's own sequence of heap
-    // operations (ties are broken by heap position), on wave-uniform values
-    RegHeap<NS> rh;
-    rh.load(s->hk, lane);
-    uint32_t hl = __builtin_amdgcn_readfirstlane((uint32_t)hlen);
-    uint32_t hm = HEAP_SIZE, node = (uint32_t)length;
+  // the merge loop, lib/de.ml:2027-2049: two smallest out, their parent in — the reference's own sequence of heap
+  // operations (ties are broken by heap position), by lane 0 on the LDS heap.  (A heap held in registers with
+  // scalar-unit sifts was measured: no LDS round trips, but ~30 scalar instructions per level on the one scalar unit
+  // the CU's 16 streams share — not faster.)
+  if (lane == 0) {
+    int hm = HEAP_SIZE, node = length;
     do {
-      const uint64_t n = rh.template get_at<0>(1);
-      const uint64_t lastv = rh.get_any(hl);
-      hl--;
-      rh.sift_root(hl, lastv, lane);
-      const uint64_t m = rh.template get_at<0>(1);
+      const uint64_t n = s->hk[1];
+      s->hk[1] = s->hk[hlen--];
+      heap_down(s, hlen, 1);
+      const uint64_t m = s->hk[1];
       const uint32_t ni = (uint32_t)n & 0xffff, mi = (uint32_t)m & 0xffff;
-      hm -= 2;
-      if (lane == 0) {
-        s->heap[hm + 1] = (uint16_t)ni;
-        s->heap[hm] = (uint16_t)mi;
-        s->dads[ni] = s->dads[mi] = (uint16_t)node;
-      }
+      s->heap[--hm] = (uint16_t)ni;
+      s->heap[--hm] = (uint16_t)mi;
       const uint32_t fs = (uint32_t)(n >> 32) + (uint32_t)(m >> 32);
       const uint32_t dn = ((uint32_t)n >> 16), dm = ((uint32_t)m >> 16);
-      rh.sift_root(hl, hkey(fs, (dn >= dm ? dn : dm) + 1, node), lane);
+      s->dads[ni] = s->dads[mi] = (uint16_t)node;
+      s->hk[1] = hkey(fs, (dn >= dm ? dn : dm) + 1, (uint32_t)node);
       node++;
-    } while (hl >= 2);
-    hm--;
-    if (lane == 0) s->heap[hm] = (uint16_t)((uint32_t)rh.template get_at<0>(1) & 0xffff);
-    hlen = (int)hl;
+      heap_down(s, hlen, 1);
+    } while (hlen >= 2);
+    s->heap[--hm] = (uint16_t)((uint32_t)s->hk[1] & 0xffff);
   }
   __syncthreads();
   TP_MARK(1)
@@ -552,15 +454,15 @@ enum { TM_NONE = 0, TM_DYNAMIC = 1, TM_CHOOSE = 2 };
 // (`distances[i] + len`).  Leaves the block kind in s->kind_result.
 template <bool TPROF>
 __device__ void trees_wave(DS *s, int mode, uint32_t lane) {
-  tree_make_wave<TPROF, 5>(s, L_CODES, MAX_BITS, s->lits, tref(&s->lt), lane);
-  tree_make_wave<TPROF, 1>(s, D_CODES, MAX_BITS, s->dsts, tref(&s->dt), lane);
+  tree_make_wave<TPROF>(s, L_CODES, MAX_BITS, s->lits, tref(&s->lt), lane);
+  tree_make_wave<TPROF>(s, D_CODES, MAX_BITS, s->dsts, tref(&s->dt), lane);
   uint64_t t_prev = TPROF ? wall_clock64() : 0;
   if (lane < BL_CODES) s->blf[lane] = 0;
   __syncthreads();
   tree_rle_wave(s, tref(&s->lt), 0, false, lane);
   tree_rle_wave(s, tref(&s->dt), 0, false, lane);
   TP_MARK(4)
-  tree_make_wave<TPROF, 1>(s, BL_CODES, 7, s->blf, tref(&s->bt), lane);
+  tree_make_wave<TPROF>(s, BL_CODES, 7, s->blf, tref(&s->bt), lane);
   if (TPROF) t_prev = wall_clock64();
   const uint64_t used = __ballot(lane < (uint32_t)BL_CODES && s->bt.clen[c_zigzag[lane < 19 ? lane : 0]] != 0);
   int max_blindex = used ? 63 - __builtin_clzll(used) : 0;
@@ -1593,25 +1495,24 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
         if (nb < (uint32_t)PG && nb != left && pe >= ss + 324) nb = 0;
       }
       if (nb == 0) break;
-      uint32_t lk[PG], fv[PG], bv[PG];
-#pragma unroll
-      for (int g = 0; g < PG; g++) {
-        // (no branch around the loads: the compiler would wait for each of them in turn; lanes past p_end read
-        // position p_end - 1 again — nobody looks at their ring cells)
-        uint32_t pos = pe + g * kWave + lane;
-        pos = pos < p_end ? pos : p_end - 1;
-        lk[g] = __builtin_nontemporal_load(ws.link + pos);
-        fv[g] = __builtin_nontemporal_load(ws.flg + pos);
-        bv[g] = src[pos];
-      }
-#pragma unroll
-      for (int g = 0; g < PG; g++) {
-        if ((uint32_t)g < nb) {
-          const uint32_t pos = pe + g * kWave + lane, r = pos & (RING - 1);
-          ds.hl[r] = (uint16_t)lk[g];
-          ds.flg[r] = (uint8_t)fv[g];
-          ds.byt[r] = (uint8_t)bv[g];
-        }
+      // a lane takes 8 consecutive positions: one 16-byte load of links, one 8-byte load of verdicts, one of input
+      // bytes, and three LDS stores — for the whole group (pe is a multiple of 64 here, so a lane's 8 ring cells are
+      // contiguous and aligned; what a partial last step reads past p_end is inside the slot, nobody looks at it)
+      if (lane * 8 < nb * kWave) {
+        const uint32_t q0 = pe + lane * 8, r0 = q0 & (RING - 1);
+        typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+        typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+        const v4u l8v = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(ws.link + q0));
+        const v2u f8v = __builtin_nontemporal_load(reinterpret_cast<const v2u *>(ws.flg + q0));
+        const uint4 l8 = make_uint4(l8v.x, l8v.y, l8v.z, l8v.w);
+        const uint2 f8 = make_uint2(f8v.x, f8v.y);
+        uint2 b8 = make_uint2(0, 0);
+        if (q0 + 8 <= slen) __builtin_memcpy(&b8, src + q0, 8);
+        else
+          for (uint32_t k = 0; k < 8 && q0 + k < slen; k++) (k < 4 ? b8.x : b8.y) |= (uint32_t)src[q0 + k] << (8 * (k & 3));
+        *reinterpret_cast<uint4 *>(&ds.hl[r0]) = l8;
+        *reinterpret_cast<uint2 *>(&ds.flg[r0]) = f8;
+        *reinterpret_cast<uint2 *>(&ds.byt[r0]) = b8;
       }
       pe = pe + nb * kWave < p_end ? pe + nb * kWave : p_end;
       pc[0] += nb;

@@ -8,7 +8,8 @@ for args in "--streams 2048 --stream-kib 1024 --level 6" "--streams 4096 --strea
   timeout 600 python tools/bench_deflate.py $args 2>&1 | tail -1 | tee -a $OUT/bench.jsonl
 done
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace -o trace -- python $REPO/tools/bench_deflate.py --streams 2048 --stream-kib 1024 --level 6 > $OUT/trace_run.txt 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace -o trace -- python $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-text-leg --no-secondary > $OUT/bench_c2c3.json 2> $OUT/trace_run.txt
+tail -1 $OUT/bench_c2c3.json | cut -c1-1500
 find $OUT/trace -name '*kernel_stats*.csv' -exec cp {} $OUT/kernel_stats.csv \;
 python - <<'PY'
 import csv
