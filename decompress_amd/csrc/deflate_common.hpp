@@ -1,7 +1,7 @@
 // deflate_common.hpp — what the three kernels of the deflate path share (gfx950).
 //
 //   deflate_plan_kernel   per-stream slots of the position-indexed workspace (a scan over the batch)
-//   deflate_link_kernel   hash chains: link[p] = distance to the latest earlier position with the hash of p
+//   deflate_link_kernel   hash chains: link[p] = distance to the latest earlier position with the hash of p (+ fp16)
 //                         (insert_string, lib/de.ml:4220-4226; head table in LDS, one workgroup per stream)
 //   deflate_match_kernel  longest_match (lib/de.ml:4110-4174) for EVERY position, every position independent
 //   deflate_kernel        the sequential part: lazy evaluation, De.Queue, De.T, De.Def, the drivers
@@ -39,7 +39,8 @@ struct Front {
   const uint32_t *chunk0;  // [n + 1] first kChunk-position chunk of stream i in the match kernel's grid
   const uint32_t *tail;    // [2 n]   hash head of position len - 3 (De matcher): 4th byte 0 / the byte 32 KiB earlier (H7)
   const uint32_t *flags;   // [1]     bit 0: the batch needs more workspace than the caller's size hint allowed
-  uint16_t *link;          // distance to the previous position with the same hash, 0 = none within 32767
+  uint32_t *link;          // low 16 bits: distance to the previous position with the same hash, 0 = none within
+                           // 32767; high 16 bits: a fingerprint of the 3 bytes at the position (fp16)
   uint8_t *flg;            // FL_*
   uint32_t *m, *mq;        // longest_match ahead over the full / quartered chain, valid where flg == FL_MATCH
 };
@@ -68,6 +69,10 @@ __device__ __forceinline__ uint32_t effective_level(int driver, int matcher, int
 }
 
 __device__ __forceinline__ uint64_t lanes_below(uint32_t lane) { return (1ull << lane) - 1; }
+// 16-bit fingerprint of the 3 bytes a candidate must share with the position (lib/de.ml:4133-4137): a candidate whose
+// fingerprint differs cannot pass the test, so the walk reads one word per candidate and touches the text only for
+// the few that may
+__device__ __forceinline__ uint32_t fp16(uint32_t w4) { return ((w4 & 0xffffffu) * 0x9E3779B1u) >> 16; }
 
 // length of the common prefix of a and b, at most MAX_MATCH: what longest_match's compare loop
 // arrives at (lib/de.ml:4139-4155; its 4-byte steps land exactly on str_end).  Reads a[0..259].

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(LW *kWave) void deflate_link_kernel(uint32_t n, con
                                                                  const uint64_t *__restrict__ in_off,
                                                                  const uint64_t *__restrict__ in_len,
                                                                  const uint32_t *__restrict__ p_end_a,
-                                                                 const uint64_t *__restrict__ slot, uint16_t *__restrict__ link,
+                                                                 const uint64_t *__restrict__ slot, uint32_t *__restrict__ link,
                                                                  uint32_t *__restrict__ tail, const uint32_t *__restrict__ flags,
                                                                  int matcher) {
   __shared__ uint32_t head[HASH_SIZE];  // absolute position, 0 = NIL (position 0 can never match, like the reference)
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(LW *kWave) void deflate_link_kernel(uint32_t n, con
   const uint64_t l64 = in_len[sid];
   const uint32_t slen = l64 > MD_MAX_STREAM ? 0u : (uint32_t)l64;
   const uint8_t *src = in + in_off[sid];
-  uint16_t *lk = link + slot[sid];
+  uint32_t *lk = link + slot[sid];
   uint32_t *gmin = gmin_all[wv];
   {
     uint4 *h4 = reinterpret_cast<uint4 *>(head);
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(LW *kWave) void deflate_link_kernel(uint32_t n, con
   }
   __syncthreads();
   if (slen < 4) {  // at most one string (Lz, 3 bytes): nothing before it
-    if (threadIdx.x < p_end) lk[threadIdx.x] = 0;
+    if (threadIdx.x < p_end) lk[threadIdx.x] = 0;  // (nobody compares its fingerprint)
     if (threadIdx.x < 2) tail[2 * sid + threadIdx.x] = 0;
     return;
   }
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(LW *kWave) void deflate_link_kernel(uint32_t n, con
       }
       if (valid) {
         const uint32_t d = pos - c1;
-        lk[pos] = (uint16_t)((c1 != 0 && d <= 32767u) ? d : 0u);
+        lk[pos] = ((c1 != 0 && d <= 32767u) ? d : 0u) | (fp16(w4[g]) << 16);
       }
     }
   }
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(kWave) void deflate_match_kernel(uint32_t n, uint32
                                                               const uint32_t *__restrict__ p_end_a,
                                                               const uint64_t *__restrict__ slot,
                                                               const uint32_t *__restrict__ chunk0,
-                                                              const uint16_t *__restrict__ link, uint8_t *__restrict__ flg,
+                                                              const uint32_t *__restrict__ link, uint8_t *__restrict__ flg,
                                                               uint32_t *__restrict__ m, uint32_t *__restrict__ mq,
                                                               const uint32_t *__restrict__ flags, uint32_t max_chain,
                                                               uint32_t nice) {
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(kWave) void deflate_match_kernel(uint32_t n, uint32
   const uint32_t slen = (uint32_t)in_len[sid];
   const uint8_t *src = in + in_off[sid];
   const uint64_t so = slot[sid];
-  const uint16_t *lk = link + so;
+  const uint32_t *lk = link + so;
   const uint32_t qlimit = max_chain >> 2, kspec = max_chain < (uint32_t)KSPEC ? max_chain : (uint32_t)KSPEC;
 
   uint32_t w4[PGM], cw[PGM], fl[PGM], cnt[PGM], best[PGM], bdist[PGM], bestq[PGM], bdistq[PGM];
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(kWave) void deflate_match_kernel(uint32_t n, uint32
     cw[g] = 0;
     if (pos < p_end) {
       if (slen < 4) w4[g] = (uint32_t)src[pos] | ((uint32_t)src[pos + 1] << 8) | ((uint32_t)src[pos + 2] << 16);
-      const uint32_t l = lk[pos];
+      const uint32_t l = lk[pos] & 0xffffu;
       cw[g] = l ? pos - l : 0u;
     }
     fl[g] = 0;
@@ -290,18 +290,23 @@ __global__ __launch_bounds__(kWave) void deflate_match_kernel(uint32_t n, uint32
       any = any || act[g];
     }
     if (__ballot(any) == 0) break;
-    uint32_t v[PGM], nx[PGM];
+    uint32_t rec[PGM], nx[PGM];
 #pragma unroll
     for (int g = 0; g < PGM; g++) {
-      const uint32_t a = act[g] ? cw[g] : 0u;  // candidate < pos <= len - 3; position 0 for idle lanes (len >= 4 here)
-      __builtin_memcpy(&v[g], src + a, 4);
-      const uint32_t l = lk[a];
+      const uint32_t a = act[g] ? cw[g] : 0u;  // candidate < pos <= len - 3; position 0 for idle lanes
+      rec[g] = lk[a];
+      const uint32_t l = rec[g] & 0xffffu;
       nx[g] = l ? a - l : 0u;
     }
 #pragma unroll
     for (int g = 0; g < PGM; g++) {
-      const bool hit = act[g] && ((v[g] ^ w4[g]) & 0xffffffu) == 0;
+      bool hit = act[g] && (rec[g] >> 16) == fp16(w4[g]);  // the candidate's 3 bytes may be ours: look at them
       if (__ballot(hit)) {
+        if (hit) {
+          uint32_t v;
+          __builtin_memcpy(&v, src + cw[g], 4);
+          hit = ((v ^ w4[g]) & 0xffffffu) == 0;
+        }
         if (hit) {
           const uint32_t pos = pe + g * kWave + lane;
           if (pos + MIN_LOOKAHEAD > slen) fl[g] = 8;  // too close to the end to compare ahead: the matcher's job
@@ -369,7 +374,7 @@ extern "C" size_t md_front_small_bytes(uint32_t n) {
 }
 extern "C" size_t md_front_big_bytes(uint64_t positions) {
   const size_t np = (size_t)positions;
-  return up256(np * 2) + up256(np) + 2 * up256(np * 4);
+  return up256(np * 4) + up256(np) + 2 * up256(np * 4);
 }
 static inline uint8_t *bump(uint8_t *&p, size_t bytes) {
   uint8_t *r = p;
@@ -385,7 +390,7 @@ extern "C" void md_front_carve(void *small_ws, void *big_ws, uint32_t n, uint64_
   f->tail = (const uint32_t *)bump(p, k * 8);
   f->flags = (const uint32_t *)bump(p, 4);
   p = (uint8_t *)big_ws;
-  f->link = (uint16_t *)bump(p, np * 2);
+  f->link = (uint32_t *)bump(p, np * 4);
   f->flg = (uint8_t *)bump(p, np);
   f->m = (uint32_t *)bump(p, np * 4);
   f->mq = (uint32_t *)bump(p, np * 4);

@@ -506,7 +506,7 @@ __device__ void trees_wave(DS *s, int mode, uint32_t lane) {
 // ---------------------------------------------------------------------------
 // workspace in HBM, per stream
 struct Ws {
-  const uint16_t *link;   // [slot] link[p] = p - hash_head(p), 0 = NIL / out of reach (deflate_link_kernel)
+  const uint32_t *link;   // [slot] low half of link[p] = p - hash_head(p), 0 = NIL / out of reach (deflate_link_kernel)
   const uint8_t *flg;     // [slot] look-ahead verdict FL_* of p (deflate_match_kernel)
   const uint32_t *m, *mq; // [slot] longest_match run ahead: (length << 16) | distance, full / quartered chain
   int *queue;             // [qcap]
@@ -515,7 +515,7 @@ struct Ws {
 __device__ __forceinline__ uint32_t g_ld(const uint32_t *p) { return __builtin_nontemporal_load(p); }
 // hash_head(p) = the position p's chain link points at (absolute; 0 = NIL, like the reference's position 0)
 __device__ __forceinline__ uint32_t link_at(const Ws *ws, uint32_t p) {
-  const uint32_t l = __builtin_nontemporal_load(ws->link + p);
+  const uint32_t l = __builtin_nontemporal_load(ws->link + p) & 0xffffu;
   return l ? p - l : 0u;
 }
 __device__ __forceinline__ int g_ldi(const int *p) { return __builtin_nontemporal_load(p); }
@@ -1336,8 +1336,34 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
   return v;
 }
 
+// the next group of the ring, on its way from the front workspace: 8 positions per lane
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+struct RingPf {
+  v4u la, lb;   // link words of positions q0 .. q0 + 7
+  v2u f;        // their verdicts
+  uint2 b;      // their bytes
+  uint32_t pe;  // the group these belong to (0xffffffff: none)
+  __device__ __forceinline__ void fetch(const Ws &ws, const uint8_t *__restrict__ src, uint32_t slen, uint32_t slot_len,
+                                        uint32_t at, uint32_t lane) {
+    pe = at;
+    const uint32_t q0 = at + lane * 8;
+    la = lb = v4u{0, 0, 0, 0};
+    f = v2u{0, 0};
+    b = make_uint2(0, 0);
+    if (q0 + 8 <= slot_len) {  // (every position a fill uses is inside the slot: it ends 64 past the input at least)
+      la = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(ws.link + q0));
+      lb = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(ws.link + q0 + 4));
+      f = __builtin_nontemporal_load(reinterpret_cast<const v2u *>(ws.flg + q0));
+    }
+    if (q0 + 8 <= slen) __builtin_memcpy(&b, src + q0, 8);
+    else
+      for (uint32_t k = 0; k < 8 && q0 + k < slen; k++) (k < 4 ? b.x : b.y) |= (uint32_t)src[q0 + k] << (8 * (k & 3));
+  }
+};
+
 template <bool PROF>
-__global__ __launch_bounds__(kWave) void deflate_kernel(
+__global__ __launch_bounds__(kWave, 4) void deflate_kernel(
     int format, int level, int qcap, int driver, int dynamic, uint32_t n, const uint8_t *__restrict__ in,
     const uint64_t *__restrict__ in_off, const uint64_t *__restrict__ in_len, uint8_t *__restrict__ out,
     const uint64_t *__restrict__ out_off, const uint64_t *__restrict__ out_cap,
@@ -1373,6 +1399,7 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
   uint64_t cap64 = out_cap[sid];
   uint32_t cap = cap64 > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)cap64;  // more room than 32-bit cursors can use
   const uint64_t so = fr.slot[sid];
+  const uint32_t slot_len = (uint32_t)(fr.slot[sid + 1] - so);
   Ws ws{fr.link + so, fr.flg + so, fr.m + so, fr.mq + so, ws_queue + (size_t)sid * qcap, fr.tail[2 * sid], fr.tail[2 * sid + 1]};
 
   // ---- cooperative setup: histograms, code tables, Adler-32 of the input
@@ -1469,6 +1496,11 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
                                                     : (eff_level != 0 && slen >= 4) ? slen - 3 : 0;
   __syncthreads();
   PROF_MARK(0)
+  RingPf rp;
+  rp.pe = 0xffffffffu;
+  rp.la = rp.lb = v4u{0, 0, 0, 0};
+  rp.f = v2u{0, 0};
+  rp.b = make_uint2(0, 0);
   for (;;) {
     if (ds.ctl[1]) break;
     const uint32_t ss = ds.ctl[0];
@@ -1495,24 +1527,25 @@ __global__ __launch_bounds__(kWave) void deflate_kernel(
         if (nb < (uint32_t)PG && nb != left && pe >= ss + 324) nb = 0;
       }
       if (nb == 0) break;
-      // a lane takes 8 consecutive positions: one 16-byte load of links, one 8-byte load of verdicts, one of input
-      // bytes, and three LDS stores — for the whole group (pe is a multiple of 64 here, so a lane's 8 ring cells are
-      // contiguous and aligned; what a partial last step reads past p_end is inside the slot, nobody looks at it)
+      // a lane takes 8 consecutive positions: two 16-byte loads of link words, one 8-byte load of verdicts, one of
+      // input bytes, and three LDS stores — for the whole group (pe is a multiple of 64 here, so a lane's 8 ring cells
+      // are contiguous and aligned).  The loads were started when the previous group was stored: the fill does not
+      // wait for HBM unless the ring was restarted somewhere else.
+      if (rp.pe != pe) rp.fetch(ws, src, slen, slot_len, pe, lane);
       if (lane * 8 < nb * kWave) {
-        const uint32_t q0 = pe + lane * 8, r0 = q0 & (RING - 1);
-        typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-        typedef uint32_t v2u __attribute__((ext_vector_type(2)));
-        const v4u l8v = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(ws.link + q0));
-        const v2u f8v = __builtin_nontemporal_load(reinterpret_cast<const v2u *>(ws.flg + q0));
-        const uint4 l8 = make_uint4(l8v.x, l8v.y, l8v.z, l8v.w);
-        const uint2 f8 = make_uint2(f8v.x, f8v.y);
-        uint2 b8 = make_uint2(0, 0);
-        if (q0 + 8 <= slen) __builtin_memcpy(&b8, src + q0, 8);
-        else
-          for (uint32_t k = 0; k < 8 && q0 + k < slen; k++) (k < 4 ? b8.x : b8.y) |= (uint32_t)src[q0 + k] << (8 * (k & 3));
+        const uint32_t r0 = (pe + lane * 8) & (RING - 1);
+        // the low halves of the 8 link words (the high halves are the match kernel's fingerprints)
+        const uint4 l8 = make_uint4((rp.la.x & 0xffffu) | (rp.la.y << 16),
+                                    (rp.la.z & 0xffffu) | (rp.la.w << 16), (rp.lb.x & 0xffffu) | (rp.lb.y << 16),
+                                    (rp.lb.z & 0xffffu) | (rp.lb.w << 16));
         *reinterpret_cast<uint4 *>(&ds.hl[r0]) = l8;
-        *reinterpret_cast<uint2 *>(&ds.flg[r0]) = f8;
-        *reinterpret_cast<uint2 *>(&ds.byt[r0]) = b8;
+        *reinterpret_cast<uint2 *>(&ds.flg[r0]) = make_uint2(rp.f.x, rp.f.y);
+        *reinterpret_cast<uint2 *>(&ds.byt[r0]) = rp.b;
+      }
+      {
+        const uint32_t pn = pe + nb * kWave;
+        rp.pe = 0xffffffffu;
+        if (pn < p_end) rp.fetch(ws, src, slen, slot_len, pn, lane);
       }
       pe = pe + nb * kWave < p_end ? pe + nb * kWave : p_end;
       pc[0] += nb;

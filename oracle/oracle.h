@@ -104,6 +104,11 @@ uint8_t *orc_zl_deflate(const uint8_t *src, size_t n, int level, int queue_len, 
 uint8_t *orc_gz_deflate(const uint8_t *src, size_t n, int level, int queue_len, uint32_t mtime, int os,
                         int hcrc, int ascii, const char *name, const char *comment, size_t *out_len);
 void orc_free(void *p);
+/* De.Def.Ns.deflate / compress_bound (lib/de.ml:3040-4010) and Zl.Def.Ns.deflate (lib/zl.ml:596-629), oracle/de_def_ns.c:
+ * ORC_OK with *out_len = the `Ok n` (0 for the stub levels 5..12), ORC_UNEXPECTED_END_OF_OUTPUT, -1 = `Invalid_compression_level */
+int orc_de_def_ns_deflate(const uint8_t *src, size_t n, uint8_t *dst, size_t dst_cap, int level, size_t *out_len);
+size_t orc_de_def_ns_compress_bound(size_t len);
+int orc_zl_def_ns_deflate(const uint8_t *src, size_t n, uint8_t *dst, size_t dst_cap, int level, size_t *out_len);
 
 /* ---- LZO1X (oracle/lzo.c) ---- */
 /* Lzo.uncompress input output (lib/lzo.ml:395-403); a failing stream leaves *written = 0 */

@@ -211,6 +211,21 @@ class Oracle:
         p = self.lib.orc_encode_cmds(arr, len(cmds), {"flat": 0, "fixed": 1, "dynamic": 2}[kind], ctypes.byref(n))
         return self._take(p, n.value)
 
+    def def_ns(self, data, level=4, cap=None, zl=False):
+        """De.Def.Ns.deflate (Zl.Def.Ns.deflate with zl=True) -> (status, bytes); status -1 = Invalid_compression_level"""
+        data = bytes(data)
+        bound = self.lib.orc_de_def_ns_compress_bound
+        bound.restype = ctypes.c_size_t
+        bound.argtypes = [ctypes.c_size_t]
+        if cap is None:
+            cap = bound(len(data)) + (6 if zl else 0)
+        dst, n = ctypes.create_string_buffer(max(1, cap)), ctypes.c_size_t()
+        fn = self.lib.orc_zl_def_ns_deflate if zl else self.lib.orc_de_def_ns_deflate
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t)]
+        st = fn(data, len(data), dst, cap, level, ctypes.byref(n))
+        return st, dst.raw[:n.value]
+
     def def_script(self, ops, queue=4096):
         """De.Def.encode driven by a list of operations -> (bytes, [0 `Ok | 1 `Block, ...]) or None (Queue.Full / bad list)"""
         arr = (ctypes.c_int * max(1, len(ops)))(*[o if o < 2**31 else o - 2**32 for o in ops])
