@@ -54,6 +54,11 @@ SYMBOLS = [
      [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp, c_sz, c_vp, c_sz, c_szp, c_vp, c_vp]),
     ("md_de_def_encode", ctypes.c_int, [c_vp, ctypes.c_int, c_vp, c_sz, c_vp, c_sz, c_szp]),
     ("md_de_def_run", ctypes.c_int, [c_vp, ctypes.c_int, c_vp, c_sz, c_vp, c_sz, c_szp, c_vp, c_sz, c_szp]),
+    ("md_de_def_ns_deflate", ctypes.c_int, [c_vp, ctypes.c_int, c_vp, c_sz, c_vp, c_sz, c_szp]),
+    ("md_zl_def_ns_deflate", ctypes.c_int, [c_vp, ctypes.c_int, c_vp, c_sz, c_vp, c_sz, c_szp]),
+    ("md_de_def_ns_compress_bound", c_sz, [c_sz]),
+    ("md_zl_def_ns_compress_bound", c_sz, [c_sz]),
+    ("md_def_ns_batch_device", ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, c_sz, c_sz] + [c_vp] * 9),
     ("md_inf_decoder", c_vp, [c_vp, ctypes.c_int, c_vp, c_sz]),
     ("md_inf_src", ctypes.c_int, [c_vp, c_vp, c_sz, c_sz]),
     ("md_inf_decode", ctypes.c_int, [c_vp]),

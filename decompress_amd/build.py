@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libmdeflate.so")
-SOURCES = ["inflate_wave.hip", "deflate_front.hip", "deflate_kernel.hip", "gz_kernels.hip", "lzo_kernels.hip", "capi.cpp", "stream_shim.cpp"]
+SOURCES = ["inflate_wave.hip", "deflate_front.hip", "deflate_kernel.hip", "deflate_ns.hip", "gz_kernels.hip", "lzo_kernels.hip", "capi.cpp", "stream_shim.cpp"]
 
 
 def _hipcc():

@@ -32,6 +32,9 @@ extern "C" int md_launch_deflate_front(uint32_t n, uint32_t nchunks_max, const u
                                        const uint64_t *in_len, int matcher, uint32_t max_chain, uint32_t nice,
                                        const md_front *f, hipStream_t stream);
 extern "C" void md_deflate_level_params(int driver, int matcher, int level, uint32_t *max_chain, uint32_t *nice);
+extern "C" int md_launch_def_ns(int format, int level, uint32_t n, uint32_t nchunks_max, const uint8_t *in, const uint64_t *in_off,
+                                const uint64_t *in_len, uint8_t *out, const uint64_t *out_off, const uint64_t *out_cap,
+                                uint64_t *out_len, int32_t *status, uint32_t *checksum, const md_front *f, hipStream_t stream);
 extern "C" int md_launch_deflate(int format, int level, int qcap, int driver, int dynamic, uint32_t n,
                                  const uint8_t *in, const uint64_t *in_off, const uint64_t *in_len,
                                  uint8_t *out, const uint64_t *out_off, const uint64_t *out_cap,
@@ -538,6 +541,101 @@ static int deflate_launch(md_ctx *ctx, int format, int level, int queue_len, int
   if (rc != 0) return fail(ctx, MD_E_HIP, "deflate kernel launch", (hipError_t)rc);
   return MD_OK;
 }
+
+// De.Def.Ns / Zl.Def.Ns: the front workspace as for deflate_launch (no command queues), then the three kernels of
+// deflate_ns.hip.  total_in as in deflate_launch.
+static int def_ns_launch(md_ctx *ctx, int format, int level, size_t n, const uint8_t *d_in, const uint64_t *d_in_off,
+                         const uint64_t *d_in_len, uint8_t *d_out, const uint64_t *d_out_off, const uint64_t *d_out_cap,
+                         uint64_t *d_out_len, int32_t *d_status, uint32_t *d_checksum, size_t total_in) {
+  int grc_ = grow(ctx, &ctx->fsmall, &ctx->fsmall_bytes, md_front_small_bytes((uint32_t)n), "hipMalloc(deflate plan)");
+  if (grc_ != MD_OK) return grc_;
+  md_front fr;
+  uint64_t positions = 0;
+  uint32_t chunks = 0;
+  const bool matcher_runs = level >= 1 && level <= 4;
+  if (matcher_runs && total_in != 0) {
+    positions = (uint64_t)total_in + 319ull * n;
+    const uint64_t c64 = (uint64_t)total_in / 256 + n;
+    if (c64 > 0x7fffffffull) return fail(ctx, MD_E_INVALID_ARGUMENT, "batch too large for one launch");
+    chunks = (uint32_t)c64;
+    grc_ = grow(ctx, &ctx->fbig, &ctx->fbig_bytes, md_front_big_bytes(positions), "hipMalloc(deflate front workspace)");
+    if (grc_ != MD_OK) return grc_;
+  }
+  md_front_carve(ctx->fsmall, ctx->fbig, (uint32_t)n, positions, &fr);
+  int prc = md_launch_deflate_plan((uint32_t)n, d_in_len, 6, MD_MATCHER_DE, level, positions, chunks, &fr, ctx->stream);
+  if (prc != 0) return fail(ctx, MD_E_HIP, "deflate plan kernel launch", (hipError_t)prc);
+  if (matcher_runs && total_in == 0) {
+    uint64_t tot_pos = 0;
+    uint32_t tot_chunks = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&tot_pos, (const uint64_t *)fr.slot + n, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(&tot_chunks, (const uint32_t *)fr.chunk0 + n, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    positions = tot_pos;
+    chunks = tot_chunks;
+    grc_ = grow(ctx, &ctx->fbig, &ctx->fbig_bytes, md_front_big_bytes(positions), "hipMalloc(deflate front workspace)");
+    if (grc_ != MD_OK) return grc_;
+    md_front_carve(ctx->fsmall, ctx->fbig, (uint32_t)n, positions, &fr);
+  }
+  int rc = md_launch_def_ns(format, level, (uint32_t)n, chunks, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap, d_out_len,
+                            d_status, d_checksum, &fr, ctx->stream);
+  if (rc != 0) return fail(ctx, MD_E_HIP, "Def.Ns kernel launch", (hipError_t)rc);
+  return MD_OK;
+}
+
+int md_def_ns_batch_device(md_ctx *ctx, int format, int level, size_t total_in_bytes, size_t n, const uint8_t *d_in,
+                           const uint64_t *d_in_off, const uint64_t *d_in_len, uint8_t *d_out, const uint64_t *d_out_off,
+                           const uint64_t *d_out_cap, uint64_t *d_out_len, int32_t *d_status, uint32_t *d_checksum) {
+  if (!ctx) return MD_E_INVALID_ARGUMENT;
+  if (format != MD_FORMAT_DEFLATE && format != MD_FORMAT_ZLIB) return fail(ctx, MD_E_INVALID_ARGUMENT, "unknown format");
+  if (level < 0 || level > 12) return fail(ctx, MD_E_INVALID_ARGUMENT, "Invalid compression level");  // lib/de.ml:3930
+  if (n == 0) return MD_OK;
+  if (n > 0x7fffffffull) return fail(ctx, MD_E_INVALID_ARGUMENT, "too many streams in one batch");
+  if (!d_in_off || !d_in_len || !d_out_off || !d_out_cap || !d_out_len || !d_status)
+    return fail(ctx, MD_E_INVALID_ARGUMENT, "null descriptor array");
+  MD_ON_DEVICE(ctx);
+  return def_ns_launch(ctx, format, level, n, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap, d_out_len, d_status,
+                       d_checksum, total_in_bytes);
+}
+
+static int def_ns_one(md_ctx *ctx, int format, int level, const uint8_t *src, size_t src_len, uint8_t *dst, size_t dst_cap,
+                      size_t *written) {
+  if (!ctx || !written || (!src && src_len) || (!dst && dst_cap)) return MD_E_INVALID_ARGUMENT;
+  if (level < 0 || level > 12) return fail(ctx, MD_E_INVALID_ARGUMENT, "Invalid compression level");
+  if (src_len > MD_MAX_STREAM) return fail(ctx, MD_E_INVALID_ARGUMENT, "stream longer than MD_MAX_STREAM");
+  MD_ON_DEVICE(ctx);
+  DevBuf din, dout, ddesc;
+  if (din.alloc(src_len + 16) != hipSuccess || dout.alloc(dst_cap + 16) != hipSuccess || ddesc.alloc(6 * 8 + 16) != hipSuccess)
+    return fail(ctx, MD_E_OUT_OF_MEMORY, "hipMalloc");
+  uint64_t desc[5] = {0, src_len, 0, dst_cap, 0};
+  uint64_t *d64 = (uint64_t *)ddesc.p;
+  int32_t *dstatus = (int32_t *)(d64 + 5);
+  hipStream_t st = ctx->stream;
+  if (src_len) HIP_TRY(ctx, hipMemcpyAsync(din.p, src, src_len, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(d64, desc, sizeof desc, hipMemcpyHostToDevice, st));
+  int rc = def_ns_launch(ctx, format, level, 1, (const uint8_t *)din.p, d64, d64 + 1, (uint8_t *)dout.p, d64 + 2, d64 + 3, d64 + 4,
+                         dstatus, nullptr, src_len ? src_len : 1);
+  if (rc != MD_OK) return rc;
+  uint64_t out_len = 0;
+  int32_t status = 0;
+  HIP_TRY(ctx, hipMemcpyAsync(&out_len, d64 + 4, 8, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipMemcpyAsync(&status, dstatus, 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  if (status == MD_OK && out_len) HIP_TRY(ctx, hipMemcpy(dst, dout.p, (size_t)out_len, hipMemcpyDeviceToHost));
+  *written = (size_t)out_len;
+  return status;
+}
+int md_de_def_ns_deflate(md_ctx *ctx, int level, const uint8_t *src, size_t src_len, uint8_t *dst, size_t dst_cap, size_t *written) {
+  return def_ns_one(ctx, MD_FORMAT_DEFLATE, level, src, src_len, dst, dst_cap, written);
+}
+int md_zl_def_ns_deflate(md_ctx *ctx, int level, const uint8_t *src, size_t src_len, uint8_t *dst, size_t dst_cap, size_t *written) {
+  return def_ns_one(ctx, MD_FORMAT_ZLIB, level, src, src_len, dst, dst_cap, written);
+}
+size_t md_de_def_ns_compress_bound(size_t len) {  // lib/de.ml:3994-3997
+  size_t max_blocks = (len + 10000 - 1) / 10000;
+  if (max_blocks < 1) max_blocks = 1;
+  return 5 * max_blocks + len + 1 + 8;
+}
+size_t md_zl_def_ns_compress_bound(size_t len) { return md_de_def_ns_compress_bound(len) + 6; }  // lib/zl.ml:600
 
 static int check_params(md_ctx *ctx, int format, const md_deflate_params *p, md_deflate_params *q) {
   if (!p) return fail(ctx, MD_E_INVALID_ARGUMENT, "null md_deflate_params");

@@ -41,13 +41,14 @@ __global__ __launch_bounds__(kPlanThreads) void deflate_plan_kernel(uint32_t n, 
   const uint32_t per = (n + kPlanThreads - 1) / kPlanThreads;
   const uint32_t lo = t * per < n ? t * per : n, hi = lo + per < n ? lo + per : n;
   const uint32_t eff = effective_level(driver, matcher, level);
-  const bool no_text = driver >= 4;  // DRV_ENCODE / DRV_SCRIPT: the input is a list of commands / operations
+  const bool no_text = driver == 4 || driver == 5;  // DRV_ENCODE / DRV_SCRIPT: the input is a list of commands / operations
   uint64_t pos = 0;
   uint32_t chk = 0;
   for (uint32_t i = lo; i < hi; i++) {
     const uint64_t l64 = in_len[i];
     const uint32_t len = l64 > MD_MAX_STREAM ? 0u : (uint32_t)l64;
-    const uint32_t pe = no_text ? 0u : stream_p_end(matcher, eff, len);
+    // De.Def.Ns (driver 6): every position with 5 bytes left is inserted (lib/de.ml:3829-3833, :3853-3856)
+    const uint32_t pe = driver == 6 ? ((level >= 1 && level <= 4 && len >= 5) ? len - 4 : 0u) : no_text ? 0u : stream_p_end(matcher, eff, len);
     p_end[i] = pe;
     pos += slot_positions(pe, len);
     chk += (pe + kChunk - 1) / kChunk;
@@ -107,7 +108,11 @@ __device__ __forceinline__ uint32_t load_w4(const uint8_t *__restrict__ src, uin
 // lane that shares its hash with another lane of its step is recognised by a returned position inside the step, and
 // such steps sort themselves out by ballots (the predecessor of a lane is the nearest lower lane with its hash, else
 // the smallest value the set got back).
+// NS = De.Def.Ns's hc_matchfinder (lib/de.ml:3765-3856): the hash is 16 bits of 4 bytes times 0x1E35A7BD — twice the
+// table LDS has room for, so the stream is gone through twice, once per half of the hash range (a chain never leaves
+// its half) —, position 0 goes into bucket 0 whatever its bytes (next_hash4 starts at 0), and there is no tail.
 constexpr int LW = 4;  // wavefronts per stream
+template <bool NS>
 __global__ __launch_bounds__(LW *kWave) void deflate_link_kernel(uint32_t n, const uint8_t *__restrict__ in,
                                                                  const uint64_t *__restrict__ in_off,
                                                                  const uint64_t *__restrict__ in_len,
@@ -118,6 +123,9 @@ __global__ __launch_bounds__(LW *kWave) void deflate_link_kernel(uint32_t n, con
   __shared__ uint32_t head[HASH_SIZE];  // absolute position, 0 = NIL (position 0 can never match, like the reference)
   __shared__ uint32_t gmin_all[LW][kWave];
   __shared__ uint32_t turn;  // the group whose atomics may be issued
+  // De.Lz77: position 0 is NIL (it can never be a match source there); Def.Ns: position 0 is an ordinary candidate, so
+  // the table holds position + 1
+  constexpr uint32_t bias = NS ? 1u : 0u;
   const uint32_t lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave, sid = blockIdx.x;
   if (sid >= n || flags[0]) return;
   const uint32_t p_end = p_end_a[sid];
@@ -126,17 +134,19 @@ __global__ __launch_bounds__(LW *kWave) void deflate_link_kernel(uint32_t n, con
   const uint8_t *src = in + in_off[sid];
   uint32_t *lk = link + slot[sid];
   uint32_t *gmin = gmin_all[wv];
+  if (slen < 4) {  // at most one string (Lz, 3 bytes): nothing before it
+    if (threadIdx.x < p_end) lk[threadIdx.x] = 0;  // (nobody compares its fingerprint)
+    if (threadIdx.x < 2 && !NS) tail[2 * sid + threadIdx.x] = 0;
+    return;
+  }
+  for (uint32_t pass = 0; pass < (NS ? 2u : 1u); pass++) {
+  __syncthreads();
   {
     uint4 *h4 = reinterpret_cast<uint4 *>(head);
     for (uint32_t i = threadIdx.x; i < (uint32_t)HASH_SIZE / 4; i += LW * kWave) h4[i] = make_uint4(0, 0, 0, 0);
     if (threadIdx.x == 0) turn = 0;
   }
   __syncthreads();
-  if (slen < 4) {  // at most one string (Lz, 3 bytes): nothing before it
-    if (threadIdx.x < p_end) lk[threadIdx.x] = 0;  // (nobody compares its fingerprint)
-    if (threadIdx.x < 2) tail[2 * sid + threadIdx.x] = 0;
-    return;
-  }
   // the input of a wavefront's next two groups is requested before the current one is worked on
   // (branch-free: a branch around a load makes the compiler wait for every load in flight)
   auto load_group = [&](uint32_t pe, uint32_t (&w)[PGL]) {
@@ -151,18 +161,26 @@ __global__ __launch_bounds__(LW *kWave) void deflate_link_kernel(uint32_t n, con
   for (uint32_t k = wv; k < ngroups; k += LW) {
     const uint32_t pe = k * kGroup;
     uint32_t w4[PGL], hv[PGL], ret[PGL];
+    bool mine[PGL];  // the position's hash is in this pass's half of the range
 #pragma unroll
     for (int g = 0; g < PGL; g++) {
       w4[g] = wa[g];
       wa[g] = wb[g];
-      hv[g] = hash_of(matcher, w4[g]);
+      if (NS) {
+        const uint32_t h = (pe + g * kWave + lane) == 0 ? 0u : (uint32_t)(w4[g] * 0x1E35A7BDu) >> 16;
+        hv[g] = h & (HASH_SIZE - 1);
+        mine[g] = (h >> HASH_BITS) == pass;
+      } else {
+        hv[g] = hash_of(matcher, w4[g]);
+        mine[g] = true;
+      }
     }
     load_group(pe + 2 * LW * kGroup, wb);
     while (__hip_atomic_load(&turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != k) __builtin_amdgcn_s_sleep(1);
 #pragma unroll
     for (int g = 0; g < PGL; g++) {
       const uint32_t pos = pe + g * kWave + lane;
-      ret[g] = pos < p_end ? atomicMax(&head[hv[g]], pos) : 0xffffffffu;
+      ret[g] = (pos < p_end && mine[g]) ? atomicMax(&head[hv[g]], pos + bias) : 0xffffffffu;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the group's atomics have been performed: the next group may go
     if (lane == 0) __hip_atomic_store(&turn, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -171,9 +189,9 @@ __global__ __launch_bounds__(LW *kWave) void deflate_link_kernel(uint32_t n, con
       const uint32_t s0 = pe + g * kWave;
       if (s0 >= p_end) break;  // uniform
       const uint32_t pos = s0 + lane;
-      const bool valid = pos < p_end;
+      const bool valid = pos < p_end && mine[g];
       uint32_t c1;
-      if (__ballot(valid && ret[g] >= s0) == 0) {
+      if (__ballot(valid && ret[g] >= s0 + bias) == 0) {
         c1 = valid ? ret[g] : 0;  // no two lanes share a hash: every returned value is the head before the step
       } else {
         const uint32_t h = hv[g];
@@ -190,16 +208,18 @@ __global__ __launch_bounds__(LW *kWave) void deflate_link_kernel(uint32_t n, con
         __builtin_amdgcn_wave_barrier();
         if (valid) atomicMin(&gmin[first], ret[g]);
         __builtin_amdgcn_wave_barrier();
-        c1 = !valid ? 0u : below ? s0 + 63u - (uint32_t)__builtin_clzll(below) : __hip_atomic_load(&gmin[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        c1 = !valid ? 0u : below ? s0 + bias + 63u - (uint32_t)__builtin_clzll(below) : __hip_atomic_load(&gmin[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __builtin_amdgcn_wave_barrier();
       }
       if (valid) {
-        const uint32_t d = pos - c1;
+        const uint32_t d = pos + bias - c1;
         lk[pos] = ((c1 != 0 && d <= 32767u) ? d : 0u) | (fp16(w4[g]) << 16);
       }
     }
   }
+  }  // pass
   __syncthreads();
+  if (NS) return;
   // De's position len - 3 (lookahead 3): hash4 reads a 4th byte beyond the data (H7) — zero before the first slide of
   // the reference's 64 KiB buffer, the byte 32 KiB earlier after it.  Which one depends on the matcher's trajectory:
   // both heads are handed over.
@@ -411,10 +431,19 @@ extern "C" int md_launch_deflate_front(uint32_t n, uint32_t nchunks_max, const u
                                        const md::defl::Front *f, hipStream_t stream) {
   using namespace md::defl;
   if (n == 0 || nchunks_max == 0) return 0;
-  hipLaunchKernelGGL(deflate_link_kernel, dim3(n), dim3(LW * kWave), 0, stream, n, in, in_off, in_len, f->p_end, f->slot, f->link,
-                     (uint32_t *)f->tail, f->flags, matcher);
+  hipLaunchKernelGGL(deflate_link_kernel<false>, dim3(n), dim3(LW * kWave), 0, stream, n, in, in_off, in_len, f->p_end, f->slot,
+                     f->link, (uint32_t *)f->tail, f->flags, matcher);
   const uint32_t per = (nchunks_max + 7) / 8;
   hipLaunchKernelGGL(deflate_match_kernel, dim3(per * 8), dim3(kWave), 0, stream, n, nchunks_max, in, in_off, in_len, f->p_end,
                      f->slot, f->chunk0, f->link, f->flg, f->m, f->mq, f->flags, max_chain, nice);
+  return (int)hipGetLastError();
+}
+
+// the chains of De.Def.Ns's hc_matchfinder (deflate_ns.hip)
+extern "C" int md_launch_link_ns(uint32_t n, const uint8_t *in, const uint64_t *in_off, const uint64_t *in_len, const md::defl::Front *f,
+                                 hipStream_t stream) {
+  using namespace md::defl;
+  hipLaunchKernelGGL(deflate_link_kernel<true>, dim3(n), dim3(LW * kWave), 0, stream, n, in, in_off, in_len, f->p_end, f->slot,
+                     f->link, (uint32_t *)f->tail, f->flags, 0);
   return (int)hipGetLastError();
 }

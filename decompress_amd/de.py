@@ -73,6 +73,32 @@ class Def:
         return dst.raw[:n.value], list(res[:nres.value])
 
 
+    class Ns:
+        """De.Def.Ns (lib/de.ml:3040-4010): the whole-buffer compressor"""
+
+        @staticmethod
+        def compress_bound(n, device=0):
+            return _engine.default_engine(device).lib.md_de_def_ns_compress_bound(n)
+
+        @staticmethod
+        def deflate(src, level=4, dst_len=None, device=0, _zl=False):
+            """`De.Def.Ns.deflate ?level src dst` -> ("Ok", bytes written) | ("Error", variant); dst_len = the capacity of
+            dst (default compress_bound).  Levels 5..12 are stubs upstream: ("Ok", b"")."""
+            eng = _engine.default_engine(device)
+            src = bytes(src)
+            lib = eng.lib
+            if dst_len is None:
+                dst_len = (lib.md_zl_def_ns_compress_bound if _zl else lib.md_de_def_ns_compress_bound)(len(src))
+            dst, n = ctypes.create_string_buffer(max(1, dst_len)), ctypes.c_size_t()
+            fn = lib.md_zl_def_ns_deflate if _zl else lib.md_de_def_ns_deflate
+            st = fn(eng.ctx, level, src, len(src), dst, dst_len, ctypes.byref(n))
+            if st == -1 and not 0 <= level <= 12:
+                return "Error", "Invalid_compression_level"
+            if st < 0:
+                eng._check(st)
+            return ("Ok", dst.raw[:n.value]) if st == 0 else ("Error", _engine.STATUS_NAMES[st])
+
+
 class Inf:
     last_message = ""
 

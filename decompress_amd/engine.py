@@ -265,6 +265,44 @@ class Engine:
                 for i in range(n)]
 
 
+    # ------------------------------------------------------------------ De.Def.Ns
+    def def_ns_many(self, bufs, level=4, fmt=FORMAT_DEFLATE, caps=None):
+        """list of bytes -> list of (status, compressed bytes, adler32 of input) through md_def_ns_batch_device"""
+        import numpy as np
+
+        torch = self.torch
+        n = len(bufs)
+        if n == 0:
+            return []
+        in_len = np.array([len(s) for s in bufs], dtype=np.int64)
+        in_off = np.zeros(n, dtype=np.int64)
+        np.cumsum(((in_len + 15) // 16 * 16)[:-1], out=in_off[1:])
+        if caps is None:
+            caps = [int(self.lib.md_zl_def_ns_compress_bound(len(s))) for s in bufs]
+        cap = np.array(caps, dtype=np.int64)
+        out_off = np.zeros(n, dtype=np.int64)
+        np.cumsum(((cap + 255) // 256 * 256)[:-1], out=out_off[1:])
+        blob = np.zeros(int(in_off[-1] + in_len[-1]) + 16, dtype=np.uint8)
+        for s, o in zip(bufs, in_off):
+            blob[o:o + len(s)] = np.frombuffer(bytes(s), dtype=np.uint8)
+        dev = self.device
+        d_in = torch.from_numpy(blob).to(dev)
+        d_out = torch.zeros(int(out_off[-1] + cap[-1]) + 16, dtype=torch.uint8, device=dev)
+        t = lambda a: torch.from_numpy(a).to(dev)
+        out_len = torch.empty(n, dtype=torch.int64, device=dev)
+        status = torch.empty(n, dtype=torch.int32, device=dev)
+        checksum = torch.empty(n, dtype=torch.int32, device=dev)
+        d_ioff, d_ilen, d_ooff, d_cap = t(in_off), t(in_len), t(out_off), t(cap)
+        self._check(self.lib.md_def_ns_batch_device(self.ctx, fmt, int(level), max(1, int(in_len.sum())), n, _ptr(d_in), _ptr(d_ioff),
+                                                    _ptr(d_ilen), _ptr(d_out), _ptr(d_ooff), _ptr(d_cap), _ptr(out_len),
+                                                    _ptr(status), _ptr(checksum)))
+        torch.cuda.synchronize(dev)
+        out = d_out.cpu().numpy()
+        out_len, status = out_len.cpu().numpy(), status.cpu().numpy()
+        checksum = checksum.cpu().numpy().view(np.uint32)
+        return [(int(status[i]), out[out_off[i]:out_off[i] + out_len[i]].tobytes(), int(checksum[i])) for i in range(n)]
+
+
 _default = {}
 
 

@@ -20,6 +20,20 @@ class Inf:
             return _engine.default_engine(device).inflate_many(srcs, dst_lens, _engine.FORMAT_ZLIB)
 
 
+class Def:
+    class Ns:
+        """Zl.Def.Ns (lib/zl.ml:596-629): De.Def.Ns inside a zlib frame"""
+
+        @staticmethod
+        def compress_bound(n, device=0):
+            return _engine.default_engine(device).lib.md_zl_def_ns_compress_bound(n)
+
+        @staticmethod
+        def deflate(src, level=4, dst_len=None, device=0):
+            from . import de
+            return de.Def.Ns.deflate(src, level, dst_len, device, _zl=True)
+
+
 class Higher:
     """Zl.Higher (lib/zl.ml:633-667)."""
 

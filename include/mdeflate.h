@@ -273,6 +273,29 @@ enum { MD_OP_FILL = 1, MD_OP_BLOCK = 2, MD_OP_FLUSH = 3, MD_OP_SUCC_LITERAL = 4,
 int md_de_def_run(md_ctx *ctx, int queue_len, const uint32_t *ops, size_t nops, uint8_t *dst, size_t dst_cap,
                   size_t *written, uint8_t *results, size_t results_cap, size_t *nresults);
 
+/* ---- De.Def.Ns / Zl.Def.Ns (lib/de.ml:3040-4010, lib/zl.ml:596-629): the reference's whole-buffer compressor ----
+ * `De.Def.Ns.deflate ?level src dst : (int, [> error ]) result`, an OCaml port of libdeflate's greedy path with its own
+ * block splitting and Huffman construction; output byte-identical to it:
+ *   level 1..4        compress_greedy (search depth 2 / 6 / 12 / 24, nice length 8 / 10 / 14 / 24);
+ *   level 5..12       upstream's compress_lazy is a stub: MD_OK with *written = 0 (lib/de.ml:3927);
+ *   level 0           MD_UNEXPECTED_END_OF_OUTPUT for inputs of 56 bytes or more — upstream's write_uncompressed_blocks
+ *                     never advances its input and can only leave through that error (lib/de.ml:3411-3420); the same
+ *                     when a block of levels 1..4 would be cheapest uncompressed;
+ *   inputs shorter than 56 - 4 * level bytes are one stored block; dst needs 8 bytes of slack (compress_bound has them);
+ *   other levels      MD_E_INVALID_ARGUMENT (`Invalid_compression_level).
+ * md_zl_def_ns_deflate adds Zl.Def.Ns's header (FLEVEL from its own level map, H9) and the Adler-32.
+ * Batch form: as md_deflate_batch_device, format MD_FORMAT_DEFLATE or MD_FORMAT_ZLIB, total_in_bytes as in
+ * md_deflate_params; checksum[i] = Adler-32 of the input (may be NULL). */
+int md_de_def_ns_deflate(md_ctx *ctx, int level, const uint8_t *src, size_t src_len, uint8_t *dst, size_t dst_cap,
+                         size_t *written);
+int md_zl_def_ns_deflate(md_ctx *ctx, int level, const uint8_t *src, size_t src_len, uint8_t *dst, size_t dst_cap,
+                         size_t *written);
+size_t md_de_def_ns_compress_bound(size_t len); /* De.Def.Ns.compress_bound, lib/de.ml:3994-3997 */
+size_t md_zl_def_ns_compress_bound(size_t len); /* lib/zl.ml:600 */
+int md_def_ns_batch_device(md_ctx *ctx, int format, int level, size_t total_in_bytes, size_t n, const uint8_t *d_in,
+                           const uint64_t *d_in_off, const uint64_t *d_in_len, uint8_t *d_out, const uint64_t *d_out_off,
+                           const uint64_t *d_out_cap, uint64_t *d_out_len, int32_t *d_status, uint32_t *d_checksum);
+
 /* ---- the resumable state machines (host side; one launch at the end of input) ----
  * De.Inf.decoder / decode / src / flush / dst_rem / src_rem / checksum (lib/de.mli:82-144) and the encoder loop of
  * Zl.Def / Gz.Def / De.Higher with `Manual source and destination (lib/zl.ml:509-555): the caller supplies input

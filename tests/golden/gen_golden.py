@@ -683,7 +683,25 @@ def gen_encode_cases():
     print("encode_cases.json", len(out), "cases")
 
 
+def gen_def_ns():
+    """test/test_ns.ml:1189-1222 — the two compressed-byte vectors the reference holds for De.Def.Ns"""
+    text = open(os.path.join(REF, "test_ns.ml"), encoding="latin-1").read()
+    cases = {n: (t, b, text.count("\n", 0, text.index("let %s () =" % n)) + 1) for n, t, b in split_cases(text)}
+    out = []
+    for name in ("encoder_0", "encoder_1"):
+        t, b, line = cases[name]
+        src, _ = eval_str(b, re.search(r"let src =", b).end(), {}) if name == "encoder_1" else eval_str(b, re.search(r"bigstring_of_string", b).end(), {})
+        exp, _ = eval_str(b, re.search(r"let expected =", b).end(), {})
+        level = int(re.search(r"~level:(\d+)", b).group(1))
+        out.append({"name": t, "ref": "test/test_ns.ml:%d" % line, "level": level,
+                    "src": b"".join(x for x in src).hex(), "out": b"".join(x for x in exp).hex()})
+    with open(os.path.join(OUT, "def_ns.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("def_ns.json", len(out), "cases")
+
+
 def main():
+    gen_def_ns()
     gen_encode_cases()
     gen_gzip()
     gen_lzo()
