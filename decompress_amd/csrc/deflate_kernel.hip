@@ -178,7 +178,7 @@ __device__ __forceinline__ uint64_t hkey(uint32_t f, uint32_t depth, uint32_t n)
   return ((uint64_t)f << 32) | (uint64_t)((depth << 16) | n);
 }
 // smaller, lib/de.ml:1876-1877: freq, then depth, ties count as smaller
-__device__ __forceinline__ bool hsmaller(uint64_t a, uint64_t b) { return (a >> 16) <= (b >> 16); }
+__device__ __forceinline__ bool hsmaller(uint64_t a, uint64_t b) { return a <= (b | 0xffffull); }  // (a >> 16) <= (b >> 16)
 __device__ void heap_down(DS *s, int hlen, int k) {  // pqdownheap, lib/de.ml:1879-1899
   const uint64_t v = s->hk[k];
   int j = k << 1;
@@ -669,13 +669,19 @@ struct Pack {
 // gives each item its bit offset, the items are OR-ed into an LDS bit buffer behind the bits
 // still held, and the finished bytes go out 4 per lane.  pad = pending_bits of the last block
 // (lib/de.ml:2635-2653): the final partial byte goes out too.
+// inclusive prefix sum over the wavefront in six data-parallel-primitive steps (row shifts inside the rows of 16 lanes,
+// then the two row broadcasts): no LDS round trip — a shuffle-based scan is six dependent ones
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+  return v;
+}
 __device__ void pack_step(DS *s, uint32_t lane, uint64_t v, uint32_t nb, bool pad, Pack &p) {
-  uint32_t incl = nb;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    uint32_t t = __shfl_up(incl, d);
-    if (lane >= (uint32_t)d) incl += t;
-  }
+  const uint32_t incl = wave_incl_scan(nb);
   const uint32_t total = p.bits + (uint32_t)__shfl((int)incl, 63);
   const uint32_t boff = p.bits + incl - nb;
   const uint32_t nwords = (total + 31) / 32 + 1;
@@ -1560,36 +1566,48 @@ __global__ __launch_bounds__(kWave, 4) void deflate_kernel(
       if (lane == 0) ds.zs.bulked = 0;
       __syncthreads();
     }
+    bool short_step = true;  // the literal run ended inside a step (or did not run): the parse step may go on from there
     if (ds.zs.trivial == 1) {
-      const uint32_t s0 = ds.zs.strstart, la = ds.zs.lookahead, base = ds.zs.base;
-      const uint32_t qw = ds.zs.qw, avail = (uint32_t)qcap - (qw - ds.zs.qr);
-      uint32_t maxk = la > (uint32_t)MIN_LOOKAHEAD ? la - MIN_LOOKAHEAD + 1 : 0;
-      if (maxk > (uint32_t)kWave) maxk = kWave;
-      if (avail < 3) maxk = 0;
-      else if (maxk > avail - 2) maxk = avail - 2;
-      if (s0 >= pe) maxk = 0;
-      else if (maxk > pe - s0) maxk = pe - s0;
-      const uint32_t p = s0 + lane, r = p & (RING - 1);
-      const uint32_t hlv = ds.hl[r], hhv = hlv ? p - hlv : 0u;
-      bool triv = lane < maxk;
-      if (triv && hhv > base && p - hhv <= (uint32_t)MAX_DIST) triv = ds.flg[r] == FL_ENDED;
-      const uint64_t nt = __ballot(!triv);
-      const uint32_t K = nt ? (uint32_t)__builtin_ctzll(nt) : (uint32_t)kWave;
-      if (lane < K) {
-        const uint32_t byte = ds.byt[(p - 1) & (RING - 1)];  // the pending literal of the previous position
-        ws.queue[(qw + lane) & ((uint32_t)qcap - 1)] = (int)byte;
-        atomicAdd(&ds.lits[byte], 1);
+      // up to 8 steps of 64 positions per turn of the main loop (its fixed cost per turn was a third of a literal-only
+      // stream's time): the state stays in registers between the steps
+      uint32_t s0 = ds.zs.strstart, la = ds.zs.lookahead, qw = ds.zs.qw, total = 0;
+      const uint32_t base = ds.zs.base, qr = ds.zs.qr;
+      for (int rep = 0; rep < 8; rep++) {
+        const uint32_t avail = (uint32_t)qcap - (qw - qr);
+        uint32_t maxk = la > (uint32_t)MIN_LOOKAHEAD ? la - MIN_LOOKAHEAD + 1 : 0;
+        if (maxk > (uint32_t)kWave) maxk = kWave;
+        if (avail < 3) maxk = 0;
+        else if (maxk > avail - 2) maxk = avail - 2;
+        if (s0 >= pe) maxk = 0;
+        else if (maxk > pe - s0) maxk = pe - s0;
+        const uint32_t p = s0 + lane, r = p & (RING - 1);
+        const uint32_t hlv = ds.hl[r], hhv = hlv ? p - hlv : 0u;
+        bool triv = lane < maxk;
+        if (triv && hhv > base && p - hhv <= (uint32_t)MAX_DIST) triv = ds.flg[r] == FL_ENDED;
+        const uint64_t nt = __ballot(!triv);
+        const uint32_t K = nt ? (uint32_t)__builtin_ctzll(nt) : (uint32_t)kWave;
+        if (lane < K) {
+          const uint32_t byte = ds.byt[(p - 1) & (RING - 1)];  // the pending literal of the previous position
+          ws.queue[(qw + lane) & ((uint32_t)qcap - 1)] = (int)byte;
+          atomicAdd(&ds.lits[byte], 1);
+        }
+        s0 += K;
+        la -= K;
+        qw += K;
+        total += K;
+        pc[1]++;
+        short_step = K < (uint32_t)kWave;
+        if (short_step) break;
       }
       if (lane == 0) {
-        ds.zs.strstart = s0 + K;
-        ds.zs.lookahead = la - K;
-        ds.zs.qw = qw + K;
-        ds.zs.bulked = K;
+        ds.zs.strstart = s0;
+        ds.zs.lookahead = la;
+        ds.zs.qw = qw;
+        ds.zs.bulked = total;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __syncthreads();
-      pc[1]++;
-      pc[2] += K;
+      pc[2] += total;
     }
     // ---- parse step: lazy evaluation (lib/de.ml:4351-4410) of up to 64 positions from the
     //      look-ahead's verdicts, when the literal run above stopped at a match.  Every position
@@ -1597,7 +1615,7 @@ __global__ __launch_bounds__(kWave, 4) void deflate_kernel(
     //      deferred while the next position's match is strictly longer (full chain below
     //      good_length, quartered from there on, no search from max_lazy on), and is emitted when
     //      it is not.  The path from s0 through these chains is then walked and emitted.
-    if (ds.zs.trivial && (ds.zs.trivial == 2 || ds.zs.bulked < (uint32_t)kWave)) {
+    if (ds.zs.trivial && (ds.zs.trivial == 2 || short_step)) {
       const uint32_t s0 = ds.zs.strstart, la = ds.zs.lookahead, base = ds.zs.base;
       uint32_t qw = ds.zs.qw;
       const uint32_t qavail = (uint32_t)qcap - (qw - ds.zs.qr);

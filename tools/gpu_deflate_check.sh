@@ -2,7 +2,7 @@
 # Run ON THE GPU BOX (via gpurun): deflate parity tests, then timings + a kernel trace of the three deflate kernels.
 cd "$(dirname "$0")/.." && REPO=$PWD
 OUT=$REPO/gpurun_out/deflate_check; mkdir -p $OUT
-timeout 1500 python -m pytest tests/test_gpu_deflate.py tests/test_gpu_gzip.py tests/test_cli.py tests/test_c_consumer.py tests/test_gpu_fuzz.py -x -q -m gpu 2>&1 | tail -15 > $OUT/pytest.txt
+timeout 1500 python -m pytest tests/test_gpu_def_ns.py tests/test_gpu_deflate.py tests/test_gpu_gzip.py tests/test_cli.py tests/test_c_consumer.py tests/test_gpu_fuzz.py -x -q -m gpu 2>&1 | tail -15 > $OUT/pytest.txt
 cat $OUT/pytest.txt
 for args in "--streams 2048 --stream-kib 1024 --level 6" "--streams 4096 --stream-kib 256 --level 6" "--streams 1024 --stream-kib 256 --level 6 --kind text" "--streams 1024 --stream-kib 256 --level 4 --kind text"; do
   timeout 600 python tools/bench_deflate.py $args 2>&1 | tail -1 | tee -a $OUT/bench.jsonl
