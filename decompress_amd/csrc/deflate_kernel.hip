@@ -179,18 +179,40 @@ __device__ __forceinline__ uint64_t hkey(uint32_t f, uint32_t depth, uint32_t n)
 }
 // smaller, lib/de.ml:1876-1877: freq, then depth, ties count as smaller
 __device__ __forceinline__ bool hsmaller(uint64_t a, uint64_t b) { return a <= (b | 0xffffull); }  // (a >> 16) <= (b >> 16)
-__device__ void heap_down(DS *s, int hlen, int k) {  // pqdownheap, lib/de.ml:1879-1899
+// pqdownheap, lib/de.ml:1879-1899.  Two levels per LDS round trip: the four grandchildren of the current node sit
+// in 32 contiguous bytes and are fetched together with the two children, so the child that is taken already has its
+// own children in registers (the loop is a chain of dependent LDS reads on one lane: their number sets its pace).
+__device__ void heap_down(DS *s, int hlen, int k) {
   const uint64_t v = s->hk[k];
   int j = k << 1;
   while (j <= hlen) {
     const u64x2 ab = *(const u64x2 *)&s->hk[j];  // children j, j+1 (j even: 16-byte aligned)
+    u64x2 g0 = ab, g1 = ab;
+    const int jj = j << 1;                       // grandchildren jj .. jj+3
+    const bool deep = jj <= hlen && jj + 3 <= L_CODES + 1;
+    if (deep) {
+      g0 = *(const u64x2 *)&s->hk[jj];
+      g1 = *(const u64x2 *)&s->hk[jj + 2];
+    }
     uint64_t a = ab.x;
+    bool right = false;
     if (j < hlen && hsmaller(ab.y, a)) {
-      j++;
+      right = true;
       a = ab.y;
     }
     if (hsmaller(v, a)) break;
     s->hk[k] = a;
+    k = j + (right ? 1 : 0);
+    j = k << 1;
+    if (!deep || j > hlen) continue;  // (the loop test ends it, or the pair is read the plain way)
+    const u64x2 cd = right ? g1 : g0;   // children j, j+1 of the node just taken
+    uint64_t c = cd.x;
+    if (j < hlen && hsmaller(cd.y, c)) {
+      j++;
+      c = cd.y;
+    }
+    if (hsmaller(v, c)) break;
+    s->hk[k] = c;
     k = j;
     j <<= 1;
   }
@@ -680,13 +702,16 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
   v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
   return v;
 }
+// (One wavefront owns the bit buffer, and a wavefront's LDS operations execute in program order: the phases need no
+// barrier.  A workgroup barrier here also waits for the step's global stores to complete — a microsecond per step.)
+__device__ __forceinline__ void lds_order() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 __device__ void pack_step(DS *s, uint32_t lane, uint64_t v, uint32_t nb, bool pad, Pack &p) {
   const uint32_t incl = wave_incl_scan(nb);
-  const uint32_t total = p.bits + (uint32_t)__shfl((int)incl, 63);
+  const uint32_t total = p.bits + (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
   const uint32_t boff = p.bits + incl - nb;
   const uint32_t nwords = (total + 31) / 32 + 1;
   for (uint32_t i = lane; i < nwords; i += kWave) s->bb[i] = i == 0 ? (uint32_t)p.hold : 0u;
-  __syncthreads();
+  lds_order();
   if (nb) {
     const uint32_t w = boff >> 5, sh = boff & 31;
     const uint64_t lo = v << sh;
@@ -694,14 +719,14 @@ __device__ void pack_step(DS *s, uint32_t lane, uint64_t v, uint32_t nb, bool pa
     if ((lo >> 32) != 0) atomicOr(&s->bb[w + 1], (uint32_t)(lo >> 32));
     if (sh + nb > 64) atomicOr(&s->bb[w + 2], (uint32_t)(v >> (64 - sh)));
   }
-  __syncthreads();
+  lds_order();
   uint32_t nbytes = total >> 3, rem = total & 7;
   if (pad) {
     nbytes = (total + 7) >> 3;
     rem = 0;
   }
   for (uint32_t i = lane * 4; i < nbytes; i += kWave * 4) {
-    const uint32_t wv = s->bb[i >> 2];
+    const uint32_t wv = __hip_atomic_load(&s->bb[i >> 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (i + 4 <= nbytes && p.o_pos + i + 4 <= p.o_cap) {
       __builtin_memcpy(p.o + p.o_pos + i, &wv, 4);
     } else {
@@ -711,10 +736,10 @@ __device__ void pack_step(DS *s, uint32_t lane, uint64_t v, uint32_t nb, bool pa
     }
   }
   if (p.o_pos + nbytes > p.o_cap) p.overflow = 1;
-  p.hold = rem ? ((s->bb[nbytes >> 2] >> (8 * (nbytes & 3))) & ((1u << rem) - 1)) : 0;
+  p.hold = rem ? ((__hip_atomic_load(&s->bb[nbytes >> 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> (8 * (nbytes & 3))) & ((1u << rem) - 1)) : 0;
   p.bits = rem;
   p.o_pos += nbytes;
-  __syncthreads();
+  lds_order();
 }
 
 // write, lib/de.ml:2708-2897, by the whole wave: 64 queue commands per step.  Every lane
