@@ -17,18 +17,22 @@ Prints ONE JSON line (rank 0).
                 read + uncompressed bytes written per launch, over the launch duration
                 measured with HIP events on the stream the kernel runs on; peak = 8 TB/s HBM3E
                 (MI355X_MICROARCH.md).  `traffic` = FETCH_SIZE + WRITE_SIZE of that kernel per launch from the
-                committed rocprofv3 --pmc passes of this same command (profiles/r02_final/pmc_summary.json,
-                gfx950 correction of the guide applied), null when the configuration differs.
+                committed rocprofv3 --pmc passes of this same command (profiles/r03_final/pmc_summary.json,
+                gfx950 correction of the guide applied; `traffic_source` names the file and the commit it was
+                collected at), null when the configuration differs.
   cpu_baseline  the repo's C restatement of lib/de.ml (oracle/, kind "port") on the host cores of this box,
                 bounded sample of the same streams.
   deflate       BASELINE.json config[2] on the same GPU(s), outside the inflate timed region: 4096 x 1 MiB
                 printable-ASCII buffers, De.Lz77 + De.Def level 6, queue 4096, Zl driver — its own value,
-                ms_per_step, roofline and cpu_baseline (BASELINE's metric is "inflate+deflate").
+                ms_per_step, roofline and cpu_baseline (BASELINE's metric is "inflate+deflate").  One step = the
+                three kernels of the path (hash chains, longest_match ahead, parse + encode).
   r01_workload  the same kernel on round 1's input (every stream seeded word text), N = 1 only.
-  gzip, lzo     BASELINE.json config[3] / config[4], one GPU's share each (N = 1 only, outside `value`): 4096 gzip
-                members = the reference's corpus files cycled, Gz.Def level 4 then Gz.Inf; 8192 x 128 KiB buffers
-                through Lzo.compress then Lzo.uncompress — MiB/s, ms and HBM fraction per direction, round trip
-                and oracle bytes checked.
+  gzip          BASELINE.json config[3], STRONG scaling (outside `value`): one batch of 32768 gzip members = the
+                reference's corpus files cycled, sharded over the N ranks by bytes; Gz.Def level 4 then Gz.Inf on
+                every shard; the compressed members are then gathered to rank 0 (sizes by all_gather, bytes by
+                exact-size send/recv) — `results_gathered`, `gather_ms`.
+  lzo           BASELINE.json config[4] (N = 1 only): 8192 x 128 KiB buffers through Lzo.compress then
+                Lzo.uncompress — MiB/s, ms and HBM fraction per direction, round trip and oracle bytes checked.
   ranks_seen    an all_reduce over the process group: how many ranks really took part.
 For N > 1 the per-stream results of every rank (sizes and Adler-32 from the kernel) are gathered with
 decompress_amd.shard.gather_varlen — the path's only exchange (RCCL over xGMI).
@@ -47,17 +51,28 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
-PMC_DIR = os.path.join(ROOT, "profiles", "r02_final")
+PMC_DIR = os.path.join(ROOT, "profiles", "r03_final")
 
 
-def pmc_traffic(name, is_default):
-    """HBM bytes per launch from the committed PMC passes (tools/profile_gpu.sh on the default workload)."""
+def pmc_traffic(names, is_default):
+    """HBM bytes per launch from the COMMITTED rocprofv3 --pmc passes of this same command (tools/profile_gpu.sh on the
+    default workload, profiles/r03_final/pmc_summary.json) — not measured by this run: counters and timing cannot be
+    collected in one process.  `names`: the kernels whose traffic adds up (the deflate path is three kernels)."""
     if not is_default:
         return None
     try:
         with open(os.path.join(PMC_DIR, "pmc_summary.json")) as f:
-            return int(json.load(f)[name]["traffic_bytes_per_launch"])
+            d = json.load(f)
+        return int(sum(d[k]["traffic_bytes_per_launch"] for k in names))
     except (OSError, KeyError, ValueError, TypeError):
+        return None
+
+
+def pmc_source():
+    try:
+        with open(os.path.join(PMC_DIR, "pmc_summary.json")) as f:
+            return "profiles/r03_final/pmc_summary.json (committed; collected at %s)" % json.load(f).get("commit", "?")
+    except (OSError, ValueError):
         return None
 
 
@@ -257,8 +272,11 @@ def deflate_leg(args, eng, dev, rank, world, dist, fence):
                                "Zl driver, dynamic blocks" % (n, args.deflate_kib),
                    "compressed_ratio": round(comp_all / (world * n * nb), 4)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic("deflate_kernel", is_default),
-                     "kernel": "md::deflate_kernel", "kernel_ms": round(kernel_ms, 3),
+                     "frac": round(achieved / HBM_PEAK_GBS, 5),
+                     "traffic": pmc_traffic(("deflate_link_kernel", "deflate_match_kernel", "deflate_kernel"), is_default),
+                     "traffic_source": pmc_source(),
+                     "kernel": "md::defl::deflate_link_kernel + deflate_match_kernel + deflate_kernel (one launch of each per step)",
+                     "kernel_ms": round(kernel_ms, 3),
                      "algorithmic_bytes_per_launch": algo},
     }
     if world == 1 and not args.no_cpu_baseline and sample:
@@ -553,7 +571,8 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": pmc_traffic("inflate_wave_kernel", (n, nbytes) == (4096, 262144)),
+                "traffic": pmc_traffic(("inflate_wave_kernel",), (n, nbytes) == (4096, 262144)),
+                "traffic_source": pmc_source(),
                 "kernel": "md::wv::inflate_wave_kernel", "kernel_ms": round(kernel_ms, 4),
                 "algorithmic_bytes_per_launch": algo_bytes,
             },

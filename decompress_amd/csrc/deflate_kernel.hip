@@ -179,40 +179,21 @@ __device__ __forceinline__ uint64_t hkey(uint32_t f, uint32_t depth, uint32_t n)
 }
 // smaller, lib/de.ml:1876-1877: freq, then depth, ties count as smaller
 __device__ __forceinline__ bool hsmaller(uint64_t a, uint64_t b) { return a <= (b | 0xffffull); }  // (a >> 16) <= (b >> 16)
-// pqdownheap, lib/de.ml:1879-1899.  Two levels per LDS round trip: the four grandchildren of the current node sit
-// in 32 contiguous bytes and are fetched together with the two children, so the child that is taken already has its
-// own children in registers (the loop is a chain of dependent LDS reads on one lane: their number sets its pace).
+// pqdownheap, lib/de.ml:1879-1899.  (Fetching the four grandchildren with the two children resolves two levels per
+// LDS round trip and is faster for a stream alone, but costs a third more instructions per level: at 16 streams per
+// CU, where the instruction issue is what the streams share, the batch got slower — measured, not kept.)
 __device__ void heap_down(DS *s, int hlen, int k) {
   const uint64_t v = s->hk[k];
   int j = k << 1;
   while (j <= hlen) {
     const u64x2 ab = *(const u64x2 *)&s->hk[j];  // children j, j+1 (j even: 16-byte aligned)
-    u64x2 g0 = ab, g1 = ab;
-    const int jj = j << 1;                       // grandchildren jj .. jj+3
-    const bool deep = jj <= hlen && jj + 3 <= L_CODES + 1;
-    if (deep) {
-      g0 = *(const u64x2 *)&s->hk[jj];
-      g1 = *(const u64x2 *)&s->hk[jj + 2];
-    }
     uint64_t a = ab.x;
-    bool right = false;
     if (j < hlen && hsmaller(ab.y, a)) {
-      right = true;
+      j++;
       a = ab.y;
     }
     if (hsmaller(v, a)) break;
     s->hk[k] = a;
-    k = j + (right ? 1 : 0);
-    j = k << 1;
-    if (!deep || j > hlen) continue;  // (the loop test ends it, or the pair is read the plain way)
-    const u64x2 cd = right ? g1 : g0;   // children j, j+1 of the node just taken
-    uint64_t c = cd.x;
-    if (j < hlen && hsmaller(cd.y, c)) {
-      j++;
-      c = cd.y;
-    }
-    if (hsmaller(v, c)) break;
-    s->hk[k] = c;
     k = j;
     j <<= 1;
   }

@@ -3,7 +3,7 @@
 # usage: tools/profile_gpu.sh <tag> [bench args...]
 # Summaries land in gpurun_out/prof_<tag>/ ; copy what you want judged to profiles/.
 set -u
-TAG=${1:-r02}; shift || true
+TAG=${1:-r03}; shift || true
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
@@ -29,19 +29,27 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         print(c, "missing"); continue
     for r in csv.DictReader(open(p)):
         if r.get("Counter_Name") == c and "md::" in r["Kernel_Name"]:
-            k = r["Kernel_Name"].split("(")[0].split("<")[0].split("::")[-1]
+            k = r["Kernel_Name"].split("(")[0].split("<")[0].split("::")[-1].split(" ")[-1]
             agg[k][c].append(float(r["Counter_Value"]))
 line = json.loads(open(os.path.join(out, "bench_under_rocprof.json")).read().strip().splitlines()[-1])
 cfg = line["config"]
 wide = {"inflate_wave_kernel": line["roofline"]["algorithmic_bytes_per_launch"] - cfg["streams_per_gpu"] * cfg["stream_bytes"]}
-summ = {"command": cmd.replace(os.path.dirname(out.rstrip("/")).rsplit("/gpurun_out", 1)[0] + "/", ""),
+import subprocess
+try:
+    commit = subprocess.check_output(["git", "-C", os.path.dirname(out.rstrip("/")).rsplit("/gpurun_out", 1)[0], "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+except Exception:  # the GPU box gets a snapshot without .git: the commit is left in a file before the call
+    try:
+        commit = open(os.path.join(os.path.dirname(out.rstrip("/")).rsplit("/gpurun_out", 1)[0], "tools", ".profile_commit")).read().strip()
+    except OSError:
+        commit = "?"
+summ = {"commit": commit, "command": cmd.replace(os.path.dirname(out.rstrip("/")).rsplit("/gpurun_out", 1)[0] + "/", ""),
         "note": "FETCH_SIZE / WRITE_SIZE are KiB per dispatch (rocprofv3, separate --pmc passes); means over the "
                 "dispatches of the run.  traffic_bytes_per_launch_raw = (FETCH + WRITE) x 1024.  On gfx950 FETCH_SIZE "
                 "counts a wide coalesced read (16 bytes per lane) at half its bytes (MI355X_MICROARCH.md, HBM); the "
                 "only such stream here is the inflate kernel's read of the compressed input (wide_read_bytes per "
                 "launch, loaded with global_load_dwordx4), so traffic_bytes_per_launch = raw + wide_read_bytes / 2.  "
-                "The other reads (8-byte loads of match sources, the deflate kernel's 4-byte loads) are not wide "
-                "streams and are taken as counted."}
+                "The other reads (8-byte loads of match sources, the deflate kernels' 4- to 16-byte loads) are "
+                "taken as counted."}
 for k, d in agg.items():
     f = sum(d["FETCH_SIZE"]) / max(1, len(d["FETCH_SIZE"]))
     w = sum(d["WRITE_SIZE"]) / max(1, len(d["WRITE_SIZE"]))
