@@ -17,9 +17,11 @@ __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_re
 typedef MD_LDS uint32_t lds_u32;
 typedef MD_LDS uint16_t lds_u16;
 typedef MD_LDS uint8_t lds_u8;
-typedef uint64_t u64_u __attribute__((aligned(1)));
-typedef uint32_t u32_u __attribute__((aligned(1)));
-typedef uint16_t u16_u __attribute__((aligned(1)));
+// unaligned AND aliasing: the staging buffer is written as bytes / halfwords / words and read back as 8-byte words;
+// without may_alias the compiler may reorder such a load before the stores it depends on (TBAA)
+typedef uint64_t u64_u __attribute__((aligned(1), may_alias));
+typedef uint32_t u32_u __attribute__((aligned(1), may_alias));
+typedef uint16_t u16_u __attribute__((aligned(1), may_alias));
 
 enum { P_ENSURE = 0, P_DECODE1, P_DECODE2, P_EMIT_A, P_FAR, P_NEAR, P_ADLER, P_HEADER, P_NEAR_FAST, P_NEAR_SLOW, P_NEAR_UPD, P_NEAR_LOAD, P_HDR_LENS, P_HDR_LIT, P_FAR_REC, P_FAR_LOAD, P_COUNT };
 enum { C_ROUNDS = 0, C_PASSES, C_LANES, C_TOKENS, C_SLOTS, C_NEAR_IT,
