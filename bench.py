@@ -33,6 +33,8 @@ Prints ONE JSON line (rank 0).
                 exact-size send/recv) — `results_gathered`, `gather_ms`.
   lzo           BASELINE.json config[4] (N = 1 only): 8192 x 128 KiB buffers through Lzo.compress then
                 Lzo.uncompress — MiB/s, ms and HBM fraction per direction, round trip and oracle bytes checked.
+  def_ns        SURVEY 8(f) row 4 (N = 1 only): De.Def.Ns.deflate level 4 over 1024 x 256 KiB buffers, inflated back,
+                oracle bytes checked on a sample.
   ranks_seen    an all_reduce over the process group: how many ranks really took part.
 For N > 1 the per-stream results of every rank (sizes and Adler-32 from the kernel) are gathered with
 decompress_amd.shard.gather_varlen — the path's only exchange (RCCL over xGMI).
@@ -383,6 +385,56 @@ def gzip_leg(args, eng, dev, rank, world, dist):
             "compressed_ratio": round(comp_all / tot_all, 4), "parity_ok": ok}
 
 
+def def_ns_leg(args, eng, dev):
+    """De.Def.Ns.deflate (the reference's default level 4) over 1024 x 256 KiB buffers (half word text,
+    half slices of the reference's corpus), bytes checked against the oracle on a sample, every stream inflated back."""
+    import ctypes
+    import numpy as np
+    import torch
+    import decompress_amd
+    from decompress_amd import workloads
+    n, nb = 1024, 256 * 1024
+    corpus = b"".join(workloads.corpus().values())
+    uniq = [workloads.text(0xD5 + i, nb) if i % 2 == 0 else (corpus * 2)[(i * 40961) % len(corpus):][:nb] for i in range(64)]
+    bufs = [uniq[i % len(uniq)] for i in range(n)]
+    blob, off, ln = workloads.pack(bufs)
+    cap = np.full(n, int(eng.lib.md_de_def_ns_compress_bound(nb)), dtype=np.int64)
+    zoff = np.arange(n, dtype=np.int64) * ((int(cap[0]) + 255) // 256 * 256)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    d_in, d_off, d_len = t(blob), t(off), t(ln)
+    d_z = torch.empty(int(zoff[-1] + cap[-1]) + 64, dtype=torch.uint8, device=dev)
+    d_zoff, d_zcap = t(zoff), t(cap)
+    out_len = torch.empty(n, dtype=torch.int64, device=dev)
+    status = torch.empty(n, dtype=torch.int32, device=dev)
+    p = lambda x: ctypes.c_void_p(x.data_ptr())
+
+    def run():
+        eng._check(eng.lib.md_def_ns_batch_device(eng.ctx, decompress_amd.FORMAT_DEFLATE, 4, n * nb, n, p(d_in), p(d_off), p(d_len),
+                                                  p(d_z), p(d_zoff), p(d_zcap), p(out_len), p(status), None))
+    run()
+    torch.cuda.synchronize(dev)
+    eng.timing_begin()
+    run()
+    ms = eng.timing_end()
+    ok = bool((status == 0).all().item())
+    d_back = torch.zeros(int(blob.size) + 64, dtype=torch.uint8, device=dev)
+    r = eng.inflate_batch(decompress_amd.FORMAT_DEFLATE, d_z, d_zoff, out_len, d_back, d_off, d_len)
+    torch.cuda.synchronize(dev)
+    ok = ok and bool((r[2] == 0).all().item()) and bool(torch.equal(d_back[:blob.size], d_in[:blob.size]))
+    if not args.no_verify:
+        from tests import oracle_lib
+        orc = oracle_lib.load()
+        zl = out_len.cpu().numpy()
+        for k in range(0, len(uniq), 8):
+            got = d_z[int(zoff[k]):int(zoff[k]) + int(zl[k])].cpu().numpy().tobytes()
+            ok = ok and (0, got) == orc.def_ns(bufs[k], 4)
+    total, comp = float(n * nb), float(out_len.sum().item())
+    return {"workload": "De.Def.Ns.deflate level 4, 1024 x 256 KiB buffers (word text / corpus slices)",
+            "value": round(total / 2**20 / (ms * 1e-3), 1), "unit": "MiB/s", "ms": round(ms, 2),
+            "frac": round((total + comp) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "compressed_ratio": round(comp / total, 4),
+            "parity_ok": ok}
+
+
 def lzo_leg(args, eng, dev):
     """BASELINE config 5: 8192 x 128 KiB buffers (half word text, half printable-ASCII noise; 128 distinct),
     Lzo.compress then Lzo.uncompress; bytes checked against the oracle on a sample."""
@@ -607,10 +659,14 @@ def main():
         leg = gzip_leg(args, eng, dev, rank, world, dist)
         torch.cuda.empty_cache()
         lz = lzo_leg(args, eng, dev) if world == 1 else None
+        torch.cuda.empty_cache()
+        dn = def_ns_leg(args, eng, dev) if world == 1 else None
         if rank == 0:
             line["gzip"] = leg
             if lz:
                 line["lzo"] = lz
+            if dn:
+                line["def_ns"] = dn
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:

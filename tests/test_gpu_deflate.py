@@ -89,16 +89,58 @@ def test_round_trip_on_gpu(eng):
         assert st == 0 and out == b and adler == zlib.adler32(b)
 
 
-def test_order_free_head_reconstruction(oracle):
-    """The look-ahead normally trusts same-address atomics of one wave to land in program order and
-    checks it; force the fallback that rebuilds the hash heads without that assumption."""
-    import decompress_amd
+def test_equal_hashes_inside_a_step(eng, oracle):
+    """the link kernel sorts out positions that share a hash inside one 64-position step (and across the steps of a
+    group, and across the four wavefronts' groups) by ballots: inputs made of short periods and runs put dozens of equal
+    hashes into every step"""
     from decompress_amd import workloads
-    e = decompress_amd.Engine(0)
-    e.set_option("deflate_test_flags", 1)
-    bufs = [workloads.text(60, 90000), workloads.ascii_uniform(61, 150000), b"abc" * 30000, b"q" * 5]
-    for b, (st, out, _) in zip(bufs, e.deflate_many(bufs, level=6)):
-        assert st == 0 and out == oracle.deflate_raw(b, 6)[0]
+    bufs = [workloads.text(60, 90000), workloads.ascii_uniform(61, 150000), b"abc" * 30000, b"q" * 5, b"q" * 100000,
+            b"ab" * 50000, bytes(range(256)) * 400, (b"x" * 63 + b"y") * 2000, b"abcdefgh" * 20000]
+    for level in (4, 6, 9):
+        for b, (st, out, _) in zip(bufs, eng.deflate_many(bufs, level=level)):
+            assert st == 0 and out == oracle.deflate_raw(b, level)[0]
+    for b, (st, out, _) in zip(bufs, eng.deflate_many(bufs, level=6, matcher=1)):
+        assert st == 0 and out == oracle.deflate_raw(b, 6, matcher=1)[0]
+
+
+def test_front_workspace_shapes(eng, oracle):
+    """the position-indexed workspace of the link / match kernels over awkward batches: empty and tiny streams between
+    large ones (slots of zero positions), many small streams (more streams than chunks), one stream of many chunks,
+    lengths around the 64 / 256 / 512-position granules; with and without the size hint; a hint that is too small
+    refuses the batch on the device instead of writing past the workspace"""
+    import decompress_amd
+    import numpy as np
+    import torch
+    from decompress_amd import workloads
+    rng = np.random.default_rng(5)
+    big = workloads.text(400, 3 << 20)
+    shapes = [b"", big[:1], big[:3], big[:4], big[:5], big[:63], big[:64], big[:65], big[:255], big[:256], big[:257], big[:511],
+              big[:512], big[:513], b"", big[:70000], big, workloads.ascii_uniform(9, 200000), big[:4], b"", big[:1000]]
+    for level in (1, 6):
+        for (st, z, adler), data in zip(eng.deflate_many(shapes, level=level), shapes):
+            assert st == 0 and z == oracle.deflate_raw(data, level)[0] and adler == zlib.adler32(data)
+    small = [bytes(rng.integers(97, 101, size=int(n), dtype=np.uint8)) for n in rng.integers(0, 300, size=5000)]
+    res = eng.deflate_many(small, level=4)
+    for k in range(0, len(small), 97):
+        assert res[k][0] == 0 and res[k][1] == oracle.deflate_raw(small[k], 4)[0]
+    assert all(st == 0 for st, _, _ in res)
+    # no hint (the totals are read back) and a hint that is too small
+    bufs = [big[:50000], big[:70000]]
+    blob, off, ln = workloads.pack(bufs)
+    dev = eng.device
+    t = lambda a: torch.from_numpy(a).to(dev)
+    cap = np.array([200000, 200000], dtype=np.int64)
+    d_out = torch.zeros(400000, dtype=torch.uint8, device=dev)
+    for hint, ok in ((0, True), (int(ln.sum()), True), (1000, False)):
+        out_len, status, _ = eng.deflate_batch(decompress_amd.FORMAT_DEFLATE, t(blob), t(off), t(ln), d_out, t(np.array([0, 200000])),
+                                               t(cap), level=6, total_in=hint)
+        torch.cuda.synchronize(dev)
+        if ok:
+            assert status.tolist() == [0, 0]
+            got = d_out[:int(out_len[0])].cpu().numpy().tobytes()
+            assert got == oracle.deflate_raw(bufs[0], 6)[0]
+        else:
+            assert status.tolist() == [-1, -1] and out_len.tolist() == [0, 0]
 
 
 def test_lz_matcher_equals_oracle(oracle):
