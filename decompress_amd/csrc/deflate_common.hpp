@@ -88,5 +88,25 @@ __device__ __forceinline__ uint32_t lcp258(const uint8_t *a, const uint8_t *b) {
   return a[257] != b[257] ? 257 : 258;
 }
 
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+// common prefix of two 16-byte strings held in registers (0..16)
+__device__ __forceinline__ uint32_t prefix16(v4u a, v4u b) {
+  const uint64_t lo = (uint64_t)(a.x ^ b.x) | ((uint64_t)(a.y ^ b.y) << 32);
+  const uint64_t hi = (uint64_t)(a.z ^ b.z) | ((uint64_t)(a.w ^ b.w) << 32);
+  return lo ? (uint32_t)__builtin_ctzll(lo) >> 3 : hi ? 8u + ((uint32_t)__builtin_ctzll(hi) >> 3) : 16u;
+}
+// lcp258 for strings known to agree in their first 16 bytes
+__device__ __forceinline__ uint32_t lcp258_from16(const uint8_t *a, const uint8_t *b) {
+#pragma clang loop unroll(disable)
+  for (uint32_t k = 16; k < 256; k += 8) {
+    uint64_t x, y;
+    __builtin_memcpy(&x, a + k, 8);
+    __builtin_memcpy(&y, b + k, 8);
+    if (x != y) return k + ((uint32_t)__builtin_ctzll(x ^ y) >> 3);
+  }
+  if (a[256] != b[256]) return 256;
+  return a[257] != b[257] ? 257 : 258;
+}
+
 }  // namespace defl
 }  // namespace md

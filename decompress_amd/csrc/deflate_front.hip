@@ -261,7 +261,19 @@ __global__ __launch_bounds__(kWave) void deflate_match_kernel(uint32_t n, uint32
   const uint32_t per = (nchunks_max + 7) / 8;
   const uint32_t c = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
   if ((blockIdx.x >> 3) >= per || c >= chunk0[n]) return;
-  uint32_t lo = 0, hi = n;  // the stream of chunk c: the last i with chunk0[i] <= c
+  // the stream of chunk c: the last i with chunk0[i] <= c.  Streams of a batch are usually about the same size:
+  // the proportional guess is right or off by one, and the bisection (a dozen dependent loads, as long as the rest
+  // of a short chain walk) only has the remaining interval to go through
+  uint32_t lo = 0, hi = n;
+  {
+    const uint32_t total = chunk0[n];
+    uint32_t gs = (uint32_t)(((uint64_t)c * n) / total);  // c < total
+    gs = gs < n ? gs : n - 1;
+    const uint32_t a0 = chunk0[gs], a1 = chunk0[gs + 1];
+    if (a0 <= c && c < a1) lo = gs, hi = gs + 1;
+    else if (c < a0) hi = gs;
+    else lo = gs + 1;
+  }
   while (hi - lo > 1) {
     const uint32_t mid = (lo + hi) >> 1;
     if (chunk0[mid] <= c) lo = mid;
@@ -278,10 +290,16 @@ __global__ __launch_bounds__(kWave) void deflate_match_kernel(uint32_t n, uint32
   const uint32_t qlimit = max_chain >> 2, kspec = max_chain < (uint32_t)KSPEC ? max_chain : (uint32_t)KSPEC;
 
   uint32_t w4[PGM], cw[PGM], fl[PGM], cnt[PGM], best[PGM], bdist[PGM], bestq[PGM], bdistq[PGM];
+  v4u own[PGM];  // the 16 bytes at the position: most comparisons end inside them
 #pragma unroll
   for (int g = 0; g < PGM; g++) {
     const uint32_t pos = pe + g * kWave + lane;
     w4[g] = slen >= 4 ? load_w4(src, slen, p_end, pos) : 0u;
+    own[g] = (v4u){0u, 0u, 0u, 0u};
+    if (slen >= (uint32_t)MIN_LOOKAHEAD) {  // (shorter streams never compare: every hit is left to the matcher)
+      const uint32_t a = pos + 16 <= slen ? pos : slen - 16;  // a clamped address only for positions that never compare
+      __builtin_memcpy(&own[g], src + a, 16);
+    }
     cw[g] = 0;
     if (pos < p_end) {
       if (slen < 4) w4[g] = (uint32_t)src[pos] | ((uint32_t)src[pos + 1] << 8) | ((uint32_t)src[pos + 2] << 16);
@@ -322,31 +340,32 @@ __global__ __launch_bounds__(kWave) void deflate_match_kernel(uint32_t n, uint32
     for (int g = 0; g < PGM; g++) {
       bool hit = act[g] && (rec[g] >> 16) == fp16(w4[g]);  // the candidate's 3 bytes may be ours: look at them
       if (__ballot(hit)) {
-        if (hit) {
+        const uint32_t pos = pe + g * kWave + lane;
+        if (hit && pos + MIN_LOOKAHEAD > slen) {  // too close to the end to compare ahead: the matcher's job, if the 3 bytes are there
           uint32_t v;
           __builtin_memcpy(&v, src + cw[g], 4);
-          hit = ((v ^ w4[g]) & 0xffffffu) == 0;
-        }
-        if (hit) {
-          const uint32_t pos = pe + g * kWave + lane;
-          if (pos + MIN_LOOKAHEAD > slen) fl[g] = 8;  // too close to the end to compare ahead: the matcher's job
-          else {
+          if (((v ^ w4[g]) & 0xffffffu) == 0) fl[g] = 8;
+        } else if (hit) {
+          // one 16-byte load of the candidate settles the 3-byte test and every match shorter than 16
+          v4u cand;
+          __builtin_memcpy(&cand, src + cw[g], 16);
+          uint32_t len = prefix16(own[g], cand);
+          if (len == 16) {
             // scan_end pre-filter (lib/de.ml:4133-4134): a candidate that differs at the end of the best match so
             // far cannot be longer
-            uint32_t len = 0;
             bool look = true;
-            if (best[g] >= (uint32_t)MIN_MATCH) {
+            if (best[g] >= 16u) {
               uint16_t x, y;
               __builtin_memcpy(&x, src + pos + best[g] - 1, 2);
               __builtin_memcpy(&y, src + cw[g] + best[g] - 1, 2);
               look = x == y;
             }
-            if (look) len = lcp258(src + pos, src + cw[g]);
-            if (len > best[g]) {
-              best[g] = len;
-              bdist[g] = pos - cw[g];
-              if (len >= nice) fl[g] = FL_MATCH;
-            }
+            len = look ? lcp258_from16(src + pos, src + cw[g]) : 0u;
+          }
+          if (len > best[g]) {  // (len < 3: the fingerprint lied; best >= 2)
+            best[g] = len;
+            bdist[g] = pos - cw[g];
+            if (len >= nice) fl[g] = FL_MATCH;
           }
         }
       }

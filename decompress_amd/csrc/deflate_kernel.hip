@@ -1349,7 +1349,6 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 }
 
 // the next group of the ring, on its way from the front workspace: 8 positions per lane
-typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 typedef uint32_t v2u __attribute__((ext_vector_type(2)));
 struct RingPf {
   v4u la, lb;   // link words of positions q0 .. q0 + 7
