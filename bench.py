@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark: batched zlib inflate (and the deflate leg) on MI355X.
 
-A "step" is one pass of the hot path (Zl.Inf.Ns semantics, one stream per wavefront) over one
+A "step" is one pass of the hot path (Zl.Inf.Ns semantics, one stream per workgroup of two wavefronts) over one
 batch of BASELINE.json config[1]:
     4096 x 256 KiB zlib streams, dynamic Huffman (libz level 6), per GPU.
 Inputs are resident in HBM before the timed region.  Weak scaling: every rank inflates its own
@@ -97,6 +97,7 @@ def parse(argv=None):
     ap.add_argument("--deflate-kib", type=int, default=1024)
     ap.add_argument("--deflate-steps", type=int, default=3)
     ap.add_argument("--gzip-members", type=int, default=32768, help="config 4: members of the ONE batch all ranks share")
+    ap.add_argument("--inflate-waves", type=int, default=2, choices=[1, 2], help="wavefronts per stream of the inflate kernel (2 = decoder + copier, the default form)")
     ap.add_argument("--profile", action="store_true", help="print the in-kernel phase profile of stream 0 (stderr)")
     return ap.parse_args(argv)
 
@@ -510,6 +511,8 @@ def main():
     from decompress_amd import shard, workloads
 
     eng = decompress_amd.Engine(local_rank)
+    if args.inflate_waves != 2:
+        eng.set_option("inflate_waves", args.inflate_waves)
     ranks_seen = 1
     if world > 1:
         t = torch.ones(1, dtype=torch.int64, device=dev)
@@ -615,7 +618,7 @@ def main():
             "config": {
                 "workload": "C2: %d x %d KiB zlib streams per GPU, dynamic Huffman (libz level %d; even streams = "
                             "slices of the reference's test/corpus, odd = seeded word text, SURVEY 8(d)), "
-                            "Zl.Inf.Ns semantics, one stream per wavefront" % (n, args.stream_kib, args.level),
+                            "Zl.Inf.Ns semantics, one stream per pair of wavefronts (decoder + copier)" % (n, args.stream_kib, args.level),
                 "streams_per_gpu": n, "stream_bytes": nbytes, "unique_streams": unique,
                 "compressed_ratio": round(comp_bytes / (n * nbytes), 4), "gen_seconds": round(t_gen, 1),
                 "results_gathered": int(all_len.numel()), "result_digest": digest,

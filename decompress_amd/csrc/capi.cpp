@@ -15,7 +15,7 @@ extern "C" int md_launch_inflate_wave(int format, uint32_t n, const uint8_t *in,
                                       const uint64_t *in_len, uint8_t *out, const uint64_t *out_off,
                                       const uint64_t *out_cap, uint64_t *out_len, uint64_t *consumed,
                                       int32_t *status, uint32_t *checksum, uint64_t *dbg, uint32_t *order,
-                                      hipStream_t stream);
+                                      int waves, hipStream_t stream);
 
 // deflate: the front workspace (deflate_common.hpp) is opaque here
 struct md_front {
@@ -71,6 +71,7 @@ struct md_ctx {
   bool gz_hdr_valid = false;
   void *lzo_ws = nullptr;  // Lzo.compress dictionaries
   size_t lzo_ws_bytes = 0;
+  int inflate_waves = 2;    // wavefronts per stream of the inflate kernel (md_set_option "inflate_waves": 1 = the one-wavefront form)
   int test_flags = 0;       // (kept for callers of md_set_option "deflate_test_flags": no effect since 0.3)
   uint64_t *dbg = nullptr;  // device buffer of the optional in-kernel profile (32 x u64)
   // deflate workspaces, grow-only: command queues (n x queue_len), the per-stream part of the front workspace
@@ -261,6 +262,11 @@ int md_set_option(md_ctx *ctx, const char *key, int value) {
     }
     return MD_OK;
   }
+  if (!strcmp(key, "inflate_waves")) {
+    if (value != 1 && value != 2) return fail(ctx, MD_E_INVALID_ARGUMENT, "inflate_waves is 1 or 2");
+    ctx->inflate_waves = value;
+    return MD_OK;
+  }
   if (!strcmp(key, "deflate_test_flags")) {
     ctx->test_flags = value;
     return MD_OK;
@@ -338,7 +344,7 @@ int md_inflate_batch_device(md_ctx *ctx, int format, size_t n, const uint8_t *d_
     order = ctx->order;
   }
   int rc = md_launch_inflate_wave(format, (uint32_t)n, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap, d_out_len,
-                                  d_consumed, d_status, d_checksum, ctx->dbg, order, ctx->stream);
+                                  d_consumed, d_status, d_checksum, ctx->dbg, order, ctx->inflate_waves, ctx->stream);
   if (rc != 0) return fail(ctx, MD_E_HIP, "inflate kernel launch", (hipError_t)rc);
   return MD_OK;
 }

@@ -23,7 +23,7 @@ typedef uint64_t u64_u __attribute__((aligned(1), may_alias));
 typedef uint32_t u32_u __attribute__((aligned(1), may_alias));
 typedef uint16_t u16_u __attribute__((aligned(1), may_alias));
 
-enum { P_ENSURE = 0, P_DECODE1, P_DECODE2, P_EMIT_A, P_FAR, P_NEAR, P_ADLER, P_HEADER, P_NEAR_FAST, P_NEAR_SLOW, P_NEAR_UPD, P_NEAR_LOAD, P_HDR_LENS, P_HDR_LIT, P_FAR_REC, P_FAR_LOAD, P_COUNT };
+enum { P_ENSURE = 0, P_DECODE1, P_DECODE2, P_EMIT_A, P_FAR, P_NEAR, P_ADLER, P_HEADER, P_NEAR_FAST, P_NEAR_SLOW, P_NEAR_UPD, P_NEAR_LOAD, P_HDR_LENS, P_HDR_LIT, P_FAR_REC, P_FAR_LOAD, P_WAIT_DEC, P_WAIT_COPY, P_COUNT };
 enum { C_ROUNDS = 0, C_PASSES, C_LANES, C_TOKENS, C_SLOTS, C_NEAR_IT,
        C_END_CHAIN, C_END_FIT, C_END_RECORDS, C_END_STAGE, C_END_EOB, C_LONG_NEAR, C_COUNT };  // why rounds ended short
 template <bool ON>

@@ -1,6 +1,14 @@
-// inflate_wave.hip — batched RFC1951 inflate for gfx950 (MI355X): one stream per wavefront, one kernel.
+// inflate_wave.hip — batched RFC1951 inflate for gfx950 (MI355X): one kernel, one workgroup of two wavefronts per stream.
 //
-// The 64 lanes decode 64 consecutive zones (48 .. S bits, re-sized every round from what the last one produced) of
+// The DECODER wavefront finds and decodes tokens (sync, emit below); the COPIER wavefront resolves the matches and
+// writes the round out (copy, flush).  They share the stream's LDS (staging buffer, match records) and hand rounds
+// over through a mailbox in LDS (struct Mail): while the copier works on round r the decoder is already walking the
+// zones of round r + 1, and it waits for the copier only before it writes round r + 1 into the staging buffer.  One
+// stream's rounds are serial, its two halves are not: a stream finishes 1.4x sooner than with one wavefront doing both
+// in turn (that form is still here: md_set_option "inflate_waves" = 1, same results), and with 8 streams = 16
+// wavefronts per CU the kernel is 1.13x faster on C2.
+//
+// The decoder's 64 lanes decode 64 consecutive zones (48 .. S bits, re-sized every round from what the last one produced) of
 // the compressed block per round:
 //
 //   sync   Light passes that only FIND TOKEN BOUNDARIES.  Pass 0: lane i walks the tokens from bit
@@ -48,9 +56,9 @@ constexpr uint32_t SMIN = 48;      // ... and at least: where the data expands s
 constexpr uint32_t KMAX = 64;      // walk steps per lane per pass
 constexpr uint32_t PASSES = 5;     // walks after the first one: at least this many are allowed, more when the zones are small
 constexpr uint32_t PASS_BITS = 1600, PASSES_MAX = 16;  // (a walk costs in proportion to the zone size)
-constexpr uint32_t RMAX = 896;     // match records per round, all lanes together (in stream order)
-constexpr uint32_t FG = 12;        // far-match groups of 64 records whose loads are in flight together
-constexpr uint32_t STAGE = 6144;   // staging bytes (one round of output)
+constexpr uint32_t RMAX = 768;     // match records per round, all lanes together (in stream order)
+constexpr uint32_t FG = 6;         // far-match groups of 64 records whose loads are in flight together
+constexpr uint32_t STAGE = 5568;   // staging bytes (one round of output)
 constexpr uint32_t WIN_WORDS = 544;  // input window: 31 + 64*S + 47 bits and the two words a peek touches
 
 // LUT entry: codelen[3:0] | xb[7:4] | val9[16:8] | next.nbits[20:17] | next.tb[31:21]
@@ -70,6 +78,19 @@ constexpr uint32_t kStEob = 100, kStTrunc = 101;  // lane stop reasons; < 100 = 
 constexpr uint32_t kCountMatch = 1u << 20;         // a walk counts bytes | matches << 20 (64 lanes: < 2^20 bytes, < 2^12 matches)
 constexpr uint32_t kNearBit = 0x8000u;            // match record: len-3[23:16] | near[15] | dist-1[14:0]
 
+// The two wavefronts of a stream talk through this: the decoder posts jobs, the copier reports them done.  A wavefront's
+// LDS operations execute in order, so a job's records and literals are in LDS before `emitted` says so, and the
+// copier's last read of them is over before `copied` does.
+struct Mail {
+  uint32_t emitted;  // jobs posted by the decoder
+  uint32_t copied;   // jobs finished by the copier: staging buffer and records are free again
+  uint32_t kind;     // kJobRound | kJobStored | kJobQuit
+  uint32_t total;    // bytes the job produces
+  uint32_t x;        // match records of the round | body offset of the stored bytes
+  uint32_t stuck;    // the copier's defensive verdict
+  uint32_t a, b;     // Adler-32 state after job `copied`
+};
+constexpr uint32_t kJobRound = 0, kJobStored = 1, kJobQuit = 2;
 struct Smem {  // the kernel's only LDS object: it sits at LDS address 0
   uint32_t win[WIN_WORDS];
   uint32_t lut[kLutWords];
@@ -77,17 +98,24 @@ struct Smem {  // the kernel's only LDS object: it sits at LDS address 0
   uint16_t mpos[RMAX];                     // their staging positions
   alignas(16) uint8_t stage[STAGE + 16];   // one round of output; header scratch while a header is parsed
   uint32_t pend[STAGE / 32 + 2];           // bit per staging byte: still to be produced by a near match
+  uint16_t list[RMAX];                     // the round's near matches (indices into mrec), in stream order
+  Mail mail;
 };
-struct HScratch {       // aliases Smem::stage
+struct HScratch {       // aliases the tail of Smem::win (hscratch_of)
   uint8_t lens[384];    // code lengths: lit/len symbols, then the distance symbols
   uint16_t work[320];   // symbols sorted by (code length, symbol)
   uint32_t ctr;         // sub-table allocation counter
 };
-static_assert(sizeof(Smem) <= 20480, "8 wavefronts per CU");
-static_assert(RMAX * 2 <= WIN_WORDS * 4, "the list of near records fits the window");
-static_assert(sizeof(HScratch) <= STAGE, "header scratch lives in the staging buffer");
+static_assert(sizeof(Smem) <= 20480, "8 streams (16 wavefronts) per CU");
+// A dynamic header is at most 17 + 19 x 3 + 320 x 14 bits = 570 bytes and starts in the window's first word: the window's
+// tail is free while a header is parsed (the staging buffer is not: the copier wavefront may still be writing a round out)
+constexpr uint32_t kHScratchAt = 1136;
+static_assert(kHScratchAt >= 4 + 572 + 8 && kHScratchAt % 16 == 0 && kHScratchAt + sizeof(HScratch) <= WIN_WORDS * 4, "header scratch lives behind the header's bits");
 typedef MD_LDS Smem lds_smem;
 typedef MD_LDS HScratch lds_hscratch;
+__device__ __forceinline__ lds_hscratch *hscratch_of(lds_smem *sm) {
+  return reinterpret_cast<lds_hscratch *>(reinterpret_cast<lds_u8 *>(sm->win) + kHScratchAt);
+}
 
 __device__ __forceinline__ uint32_t mk_entry(uint32_t codelen, uint32_t xb, uint32_t val9, uint32_t nbits, uint32_t tb) {
   return codelen | (xb << 4) | (val9 << 8) | (nbits << 17) | (tb << 21);
@@ -116,8 +144,8 @@ __device__ __forceinline__ uint32_t dist_value(uint32_t m, uint32_t xb, uint32_t
 // ---- input window -----------------------------------------------------------------------------
 // The window holds body bytes [base, base + 4*WIN_WORDS), base a multiple of 4; zero beyond the body.  A lane loads
 // 32 bytes of it (and the first lanes one more word): fetch() starts the loads into registers, put() stores them to
-// LDS.  A round fetches the window of the next one as soon as it knows where that begins, so the copy phases hide
-// the latency (the window's LDS space is in use by then: copy_near_all's list).
+// LDS.  A round fetches the window of the next one as soon as it knows where that begins: the loads are in flight
+// while the round is handed over (or copied).
 struct Window {
   uint32_t w[8], wx;
   uint32_t base;  // of the fetched words; 0xffffffff = nothing fetched
@@ -334,7 +362,7 @@ __device__ __noinline__ int dynamic_tables(lds_smem *sm, uint32_t bp_arg, uint32
   // parse below is compiled as divergent vector code instead of scalar code
   const uint32_t bp = uni(bp_arg), tot = uni(tot_arg);
   const lds_u32 *win = (const lds_u32 *)sm->win;
-  lds_hscratch *hs = reinterpret_cast<lds_hscratch *>(sm->stage);
+  lds_hscratch *hs = hscratch_of(sm);
   UBits ub;
   ub.init(win, bp);
   if ((int32_t)(tot - ub.pos()) < 14) return MD_UNEXPECTED_END_OF_INPUT;
@@ -475,7 +503,7 @@ __device__ __noinline__ int dynamic_tables(lds_smem *sm, uint32_t bp_arg, uint32
 
 // fixed_lit / fixed_dist (lib/de.ml:821-833): 288 lit/len codes of 8/9/7/8 bits, 32 distance codes of 5 bits
 __device__ __noinline__ void fixed_tables(lds_smem *sm, uint32_t lane, uint32_t *lroot_out) {
-  lds_hscratch *hs = reinterpret_cast<lds_hscratch *>(sm->stage);
+  lds_hscratch *hs = hscratch_of(sm);
   uint32_t ll[5], dl[1];
 #pragma unroll
   for (int k = 0; k < 5; k++) {
@@ -995,18 +1023,66 @@ __device__ __forceinline__ void copy_near_all(const lds_u32 *mrec, const lds_u16
   pf.tick(P_NEAR);
 }
 
+// The second half of a round: far matches from HBM, near matches inside the staging buffer, then the round goes out.
+template <class PF>
+__device__ __forceinline__ void copy_round(lds_smem *sm, Sink &sk, uint32_t lane, uint32_t total, uint32_t nrec, bool *stuck, PF &pf) {
+  const lds_u32 *mrec = (const lds_u32 *)sm->mrec;
+  const lds_u16 *mpos = (const lds_u16 *)sm->mpos;
+  lds_u32 *pend = (lds_u32 *)sm->pend;
+  lds_u16 *list = (lds_u16 *)sm->list;
+  const uint32_t R0 = sk.pos, rb = sk.sbase();
+  uint32_t nnear = 0;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // earlier rounds' flushes have landed
+  if (R0 + 40 > sk.cap) {
+    copy_far_guarded<PF>(mrec, mpos, pend, list, sk.stage, sk.g, R0, rb, sk.cap, lane, nrec, &nnear);
+    pf.tick(P_FAR);
+  } else {
+    copy_far(mrec, mpos, pend, list, sk, lane, nrec, &nnear, pf);
+  }
+  copy_near_all(mrec, mpos, pend, list, sk, lane, nnear, stuck, pf);
+  sk.flush(total);
+  pf.tick(P_ADLER);
+}
+
+// ---- the decoder / copier hand-over -------------------------------------------------------------
+__device__ __forceinline__ uint32_t mail_ld(const MD_LDS uint32_t *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void mail_st(MD_LDS uint32_t *p, uint32_t v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// decoder: until the copier has finished everything posted so far (false = the copier gave up)
+__device__ __forceinline__ bool mail_wait_idle(lds_smem *sm, uint32_t sent) {
+  while (mail_ld(&sm->mail.copied) != sent) __builtin_amdgcn_s_sleep(1);
+  asm volatile("" ::: "memory");
+  return uni(mail_ld(&sm->mail.stuck)) == 0;
+}
+// decoder: everything the job needs is in LDS; hand it over
+__device__ __forceinline__ void mail_post(lds_smem *sm, uint32_t lane, uint32_t kind, uint32_t total, uint32_t x, uint32_t &sent) {
+  if (lane == 0) {
+    sm->mail.kind = kind;
+    sm->mail.total = total;
+    sm->mail.x = x;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  sent++;
+  if (lane == 0) mail_st(&sm->mail.emitted, sent);
+}
+
 // ---------------------------------------------------------------------------
 // All rounds of one Huffman block.  bp is a bit position of the body; on return *bp_io is the bit after the EOB.
-template <class PF>
+// PAIR: this wavefront only decodes — a round's records and literals go to the copier wavefront (copier_main), which
+// copies the matches, folds the checksum and writes the round out while this one is already walking the next round's
+// zones; sk is then the decoder's own idea of the output position, and `sent` counts the jobs posted.
+template <class PF, bool PAIR>
 __device__ __forceinline__ int inflate_block(lds_smem *sm, const uint8_t *__restrict__ body, uint32_t body_len, Sink &sk,
                                              uint32_t lroot, uint32_t lane, uint32_t *bp_io, uint32_t *zone_io, Window &wnd,
-                                             PF &pf) {
+                                             uint32_t &sent, PF &pf) {
   uint32_t bp = *bp_io;
   lds_u32 *win = (lds_u32 *)sm->win;
   const lds_u32 *lut = (const lds_u32 *)sm->lut;
   lds_u32 *mrec = (lds_u32 *)sm->mrec;
   lds_u16 *mpos = (lds_u16 *)sm->mpos;
-  lds_u32 *pend = (lds_u32 *)sm->pend;
   const uint32_t total_bits = body_len * 8;
   uint32_t zs = *zone_io;  // zone size of this round (wave-uniform), adapted to the expansion of the last one
   for (;;) {
@@ -1061,6 +1137,11 @@ __device__ __forceinline__ int inflate_block(lds_smem *sm, const uint8_t *__rest
     lo.stopc = 0;
     lo.bytes = 0;
     lo.nm = 0;
+    if constexpr (PAIR) {  // the staging buffer and the record arrays are the copier's until it has written the last round out
+      pf.tick(P_DECODE2);
+      if (!mail_wait_idle(sm, sent)) return MD_E_HIP;
+      pf.tick(P_WAIT_DEC);
+    }
     {
       const uint32_t all = rdlane(off + mynb, nvalid - 1) & (kCountMatch - 1);  // bytes the round will produce
       const bool plain = tot >= rbp + kWave * zs + 64 && R0 >= 32768u && all <= sk.cap - R0 && (R0 - rb) + all <= STAGE - 16;
@@ -1089,19 +1170,13 @@ __device__ __forceinline__ int inflate_block(lds_smem *sm, const uint8_t *__rest
     }
     const uint32_t nbp = base * 8 + rdlane(lo.endp, nvalid - 1);
     wnd.fetch(body, body_len, (nbp >> 5) << 2, lane);  // the next round's (or the next block header's) window: on its way
-    uint32_t nnear = 0;
-    lds_u16 *list = (lds_u16 *)sm->win;  // the window is done with until the next round loads it
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // earlier rounds' flushes have landed
-    if (R0 + 40 > sk.cap) {
-      copy_far_guarded<PF>(mrec, mpos, pend, list, sk.stage, sk.g, R0, rb, sk.cap, lane, nrec, &nnear);
-      pf.tick(P_FAR);
-    } else {
-      copy_far(mrec, mpos, pend, list, sk, lane, nrec, &nnear, pf);
-    }
     bool stuck = false;
-    copy_near_all(mrec, mpos, pend, list, sk, lane, nnear, &stuck, pf);
-    sk.flush(total);
-    pf.tick(P_ADLER);
+    if constexpr (PAIR) {
+      mail_post(sm, lane, kJobRound, total, nrec, sent);
+      sk.pos += total;
+    } else {
+      copy_round(sm, sk, lane, total, nrec, &stuck, pf);
+    }
     pf.count(C_LANES, nvalid);
     if (stuck || (nbp == bp && total == 0 && (lstop == 0 || lstop == kStTrunc))) return MD_E_HIP;  // defensive: no progress
     {  // next round: 64 zones that fill about 7/8 of the staging buffer at this round's bytes-per-bit
@@ -1118,8 +1193,47 @@ __device__ __forceinline__ int inflate_block(lds_smem *sm, const uint8_t *__rest
   return MD_OK;
 }
 
-template <bool PROF>
-__global__ __launch_bounds__(kWave) void inflate_wave_kernel(
+// stored bytes body[p, p + len) -> staging buffer -> output (lib/de.ml:1613-1627), a staging buffer at a time
+__device__ __forceinline__ void copy_stored(Sink &sk, const uint8_t *__restrict__ body, uint32_t p, uint32_t len, uint32_t lane) {
+  const uint8_t *q = body + p;
+  uint32_t left = len;
+  while (left) {
+    const uint32_t seg = left < STAGE - 16 ? left : STAGE - 16;
+    const uint32_t s0 = sk.pos - sk.sbase();
+    for (uint32_t j = lane; j < seg; j += kWave) sk.stage[s0 + j] = q[j];
+    sk.flush(seg);
+    q += seg;
+    left -= seg;
+  }
+}
+
+// The copier wavefront of a stream: takes the decoder's jobs one by one until it is told to quit.
+template <class PF>
+__device__ __forceinline__ void copier_main(lds_smem *sm, const uint8_t *__restrict__ body, Sink &sk, uint32_t lane, PF &pf) {
+  uint32_t done = 0;
+  for (;;) {
+    while (mail_ld(&sm->mail.emitted) == done) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+    const uint32_t kind = uni(sm->mail.kind), total = uni(sm->mail.total), x = uni(sm->mail.x);
+    pf.tick(P_WAIT_COPY);
+    if (kind == kJobQuit) break;
+    bool stuck = false;
+    if (kind == kJobRound) copy_round(sm, sk, lane, total, x, &stuck, pf);
+    else copy_stored(sk, body, x, total, lane);
+    if (lane == 0) {
+      sm->mail.a = sk.a;
+      sm->mail.b = sk.b;
+      if (stuck) sm->mail.stuck = 1;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    done++;
+    if (lane == 0) mail_st(&sm->mail.copied, done);
+  }
+}
+
+// PAIR = two wavefronts per stream (decoder + copier, see inflate_block); otherwise one wavefront does both in turn.
+template <bool PROF, bool PAIR>
+__global__ __launch_bounds__(PAIR ? 2 * kWave : kWave, PAIR ? 4 : 2) void inflate_wave_kernel(
     int format, uint32_t n, const uint8_t *__restrict__ in, const uint64_t *__restrict__ in_off,
     const uint64_t *__restrict__ in_len, uint8_t *out, const uint64_t *__restrict__ out_off,
     const uint64_t *__restrict__ out_cap, uint64_t *__restrict__ out_len,
@@ -1129,14 +1243,15 @@ __global__ __launch_bounds__(kWave) void inflate_wave_kernel(
   lds_smem *sm = (lds_smem *)&smem;
   Prof<PROF> pf;
   pf.init();
-  const uint32_t lane = threadIdx.x;
+  const uint32_t lane = threadIdx.x & (kWave - 1);
+  const uint32_t wave = PAIR ? uni(threadIdx.x / kWave) : 0u;  // 0 = decoder, 1 = copier
   if (blockIdx.x >= n) return;
   const uint32_t sid = order ? order[blockIdx.x] : blockIdx.x;  // workgroups start in index order: longest streams first
 
   const uint8_t *src = in + in_off[sid];
   uint64_t slen64 = in_len[sid], cap64 = out_cap[sid];
   if (slen64 > MD_MAX_INFLATE_IN) {  // 32-bit bit positions: the descriptor is out of range (mdeflate.h)
-    if (lane == 0) {
+    if (threadIdx.x == 0) {
       out_len[sid] = 0;
       consumed[sid] = 0;
       status[sid] = MD_E_INVALID_ARGUMENT;
@@ -1164,7 +1279,7 @@ __global__ __launch_bounds__(kWave) void inflate_wave_kernel(
   }
   const uint8_t *body = src + body_off;
 
-  Sink sk;
+  Sink sk;  // PAIR: the copier's is the real one, the decoder's only follows the output position
   sk.stage = (lds_u8 *)sm->stage;
   sk.g = out + out_off[sid];
   sk.cap = cap;
@@ -1174,14 +1289,32 @@ __global__ __launch_bounds__(kWave) void inflate_wave_kernel(
   sk.b = 0;
   sk.want_adler = (checksum != nullptr) || format == MD_FORMAT_ZLIB;
 
+  if (threadIdx.x < 4) sm->lut[kStopEobI + threadIdx.x] = mk_entry(0, 0, 0, 0, kStopEobI + (threadIdx.x & 1));  // the self-looping STOP entries
+  for (uint32_t i = threadIdx.x; i < STAGE / 32 + 2; i += blockDim.x) sm->pend[i] = 0;
+  if constexpr (PAIR) {
+    if (threadIdx.x < sizeof(Mail) / 4) ((lds_u32 *)&sm->mail)[threadIdx.x] = threadIdx.x == 6 ? 1u : 0u;  // a = 1
+    __syncthreads();
+    if (wave == 1) {
+      copier_main(sm, body, sk, lane, pf);
+      if constexpr (PROF) {
+        if (lane == 0 && sid == 0 && dbg) {
+          const int mine[] = {P_FAR, P_NEAR, P_ADLER, P_NEAR_FAST, P_NEAR_SLOW, P_NEAR_UPD, P_NEAR_LOAD, P_FAR_REC, P_FAR_LOAD, P_WAIT_COPY};
+          for (int i : mine) dbg[i] = pf.acc[i];
+          dbg[P_COUNT + C_NEAR_IT] = pf.cnt[C_NEAR_IT];
+          dbg[P_COUNT + C_LONG_NEAR] = pf.cnt[C_LONG_NEAR];
+        }
+      }
+      return;
+    }
+  }
+
   lds_u32 *win = (lds_u32 *)sm->win;
   const uint32_t total_bits = body_len * 8;
   uint32_t bp = 0;
   uint32_t zone = S;
+  uint32_t sent = 0;  // PAIR: jobs posted
   Window wnd;
   wnd.base = 0xffffffffu;
-  if (lane < 4) sm->lut[kStopEobI + lane] = mk_entry(0, 0, 0, 0, kStopEobI + (lane & 1));  // the self-looping STOP entries
-  for (uint32_t i = lane; i < STAGE / 32 + 2; i += kWave) sm->pend[i] = 0;
 
   if (rc == MD_OK) {
     bool last = false;
@@ -1212,15 +1345,12 @@ __global__ __launch_bounds__(kWave) void inflate_wave_kernel(
         else if (len > body_len - p) rc = MD_UNEXPECTED_END_OF_INPUT;
         else if (len > sk.cap - sk.pos) rc = MD_UNEXPECTED_END_OF_OUTPUT;
         else {
-          const uint8_t *q = body + p;
-          uint32_t left = len;
-          while (left) {
-            const uint32_t seg = left < STAGE - 16 ? left : STAGE - 16;
-            const uint32_t s0 = sk.pos - sk.sbase();
-            for (uint32_t j = lane; j < seg; j += kWave) sk.stage[s0 + j] = q[j];
-            sk.flush(seg);
-            q += seg;
-            left -= seg;
+          if constexpr (PAIR) {
+            if (!mail_wait_idle(sm, sent)) rc = MD_E_HIP;
+            mail_post(sm, lane, kJobStored, len, p, sent);
+            sk.pos += len;
+          } else {
+            copy_stored(sk, body, p, len, lane);
           }
           p += len;
           bp = p * 8;
@@ -1237,9 +1367,15 @@ __global__ __launch_bounds__(kWave) void inflate_wave_kernel(
         }
         lroot = uni(lroot);
         pf.tick(P_HEADER);
-        if (rc == MD_OK) rc = inflate_block(sm, body, body_len, sk, lroot, lane, &bp, &zone, wnd, pf);
+        if (rc == MD_OK) rc = inflate_block<Prof<PROF>, PAIR>(sm, body, body_len, sk, lroot, lane, &bp, &zone, wnd, sent, pf);
       }
     }
+  }
+  if constexpr (PAIR) {  // everything posted is written out; the checksum state comes back, the copier goes home
+    if (!mail_wait_idle(sm, sent) && rc == MD_OK) rc = MD_E_HIP;
+    sk.a = uni(sm->mail.a);
+    sk.b = uni(sm->mail.b);
+    mail_post(sm, lane, kJobQuit, 0, 0, sent);
   }
   uint32_t used = (bp + 7) >> 3;  // i_pos - (bits lsr 3), lib/de.ml:1805
   uint32_t adler = (sk.b << 16) | sk.a;
@@ -1258,8 +1394,15 @@ __global__ __launch_bounds__(kWave) void inflate_wave_kernel(
   }
   if constexpr (PROF) {
     if (lane == 0 && sid == 0 && dbg) {
-      for (int i = 0; i < P_COUNT; i++) dbg[i] = pf.acc[i];
-      for (int i = 0; i < C_COUNT; i++) dbg[P_COUNT + i] = pf.cnt[i];
+      if constexpr (PAIR) {
+        const int mine[] = {P_ENSURE, P_DECODE1, P_DECODE2, P_EMIT_A, P_HEADER, P_HDR_LENS, P_HDR_LIT, P_WAIT_DEC};
+        for (int i : mine) dbg[i] = pf.acc[i];
+        for (int i = 0; i < C_COUNT; i++)
+          if (i != C_NEAR_IT && i != C_LONG_NEAR) dbg[P_COUNT + i] = pf.cnt[i];
+      } else {
+        for (int i = 0; i < P_COUNT; i++) dbg[i] = pf.acc[i];
+        for (int i = 0; i < C_COUNT; i++) dbg[P_COUNT + i] = pf.cnt[i];
+      }
     }
   }
 }
@@ -1308,21 +1451,28 @@ __global__ __launch_bounds__(kOrderThreads) void inflate_order_kernel(uint32_t n
 }  // namespace wv
 }  // namespace md
 
-// `order` = n words of device scratch, or null for index order
+// `order` = n words of device scratch, or null for index order; waves = wavefronts per stream (2, or 1)
 extern "C" int md_launch_inflate_wave(int format, uint32_t n, const uint8_t *in, const uint64_t *in_off,
                                       const uint64_t *in_len, uint8_t *out, const uint64_t *out_off,
                                       const uint64_t *out_cap, uint64_t *out_len, uint64_t *consumed,
                                       int32_t *status, uint32_t *checksum, uint64_t *dbg, uint32_t *order,
-                                      hipStream_t stream) {
+                                      int waves, hipStream_t stream) {
   if (n == 0) return 0;
   using namespace md::wv;
-  dim3 grid(n), block(kWave);
+  const bool single = waves == 1;  // the one-wavefront form of the kernel: same results, kept for comparison
+  dim3 grid(n), block(single ? kWave : 2 * kWave);
   if (order) hipLaunchKernelGGL(inflate_order_kernel, dim3(1), dim3(kOrderThreads), 0, stream, n, in_len, order);
-  if (dbg)
-    hipLaunchKernelGGL((inflate_wave_kernel<true>), grid, block, 0, stream, format, n, in, in_off, in_len, out, out_off,
-                       out_cap, out_len, consumed, status, checksum, dbg, (const uint32_t *)nullptr);
-  else
-    hipLaunchKernelGGL((inflate_wave_kernel<false>), grid, block, 0, stream, format, n, in, in_off, in_len, out, out_off,
-                       out_cap, out_len, consumed, status, checksum, dbg, (const uint32_t *)order);
+  const uint32_t *ord = dbg ? nullptr : order;
+#define MD_LAUNCH_INFLATE(P, Q)                                                                                          \
+  hipLaunchKernelGGL((inflate_wave_kernel<P, Q>), grid, block, 0, stream, format, n, in, in_off, in_len, out, out_off, \
+                     out_cap, out_len, consumed, status, checksum, dbg, ord)
+  if (dbg) {
+    if (single) MD_LAUNCH_INFLATE(true, false);
+    else MD_LAUNCH_INFLATE(true, true);
+  } else {
+    if (single) MD_LAUNCH_INFLATE(false, false);
+    else MD_LAUNCH_INFLATE(false, true);
+  }
+#undef MD_LAUNCH_INFLATE
   return (int)hipGetLastError();
 }

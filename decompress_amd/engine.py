@@ -136,7 +136,7 @@ class Engine:
         self._check(self.lib.md_set_option(self.ctx, key.encode(), int(value)))
 
     PROFILE_FIELDS = ["cyc_ensure", "cyc_decode1", "cyc_decode2", "cyc_emit_a", "cyc_far", "cyc_near",
-                      "cyc_adler", "cyc_header", "cyc_near_fast", "cyc_near_slow", "cyc_near_upd", "cyc_near_load", "cyc_hdr_lens", "cyc_hdr_lit", "cyc_far_rec", "cyc_far_load", "rounds", "passes", "lanes", "tokens", "slots",
+                      "cyc_adler", "cyc_header", "cyc_near_fast", "cyc_near_slow", "cyc_near_upd", "cyc_near_load", "cyc_hdr_lens", "cyc_hdr_lit", "cyc_far_rec", "cyc_far_load", "cyc_wait_dec", "cyc_wait_copy", "rounds", "passes", "lanes", "tokens", "slots",
                       "near_iters", "end_chain", "end_fit", "end_records", "end_stage", "end_eob", "long_near"]
 
     def get_profile(self):

@@ -22,9 +22,12 @@ def eng():
     return decompress_amd.Engine(0)
 
 
-@pytest.fixture(scope="module")
-def eng_ring(eng):  # (one inflate kernel: the name is kept for the tests that were parametrised over kernels)
-    return eng
+@pytest.fixture(params=[2, 1], ids=["two-wavefronts", "one-wavefront"])
+def eng_ring(eng, request):
+    """both forms of the inflate kernel (decoder + copier wavefront per stream, the default; one wavefront doing both)"""
+    eng.set_option("inflate_waves", request.param)
+    yield eng
+    eng.set_option("inflate_waves", 2)
 
 
 def test_golden_ns(eng_ring):
