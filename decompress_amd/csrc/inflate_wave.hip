@@ -57,7 +57,6 @@ constexpr uint32_t KMAX = 64;      // walk steps per lane per pass
 constexpr uint32_t PASSES = 5;     // walks after the first one: at least this many are allowed, more when the zones are small
 constexpr uint32_t PASS_BITS = 1600, PASSES_MAX = 16;  // (a walk costs in proportion to the zone size)
 constexpr uint32_t RMAX = 768;     // match records per round, all lanes together (in stream order)
-constexpr uint32_t FG = 6;         // far-match groups of 64 records whose loads are in flight together
 constexpr uint32_t STAGE = 5568;   // staging bytes (one round of output)
 constexpr uint32_t WIN_WORDS = 544;  // input window: 31 + 64*S + 47 bits and the two words a peek touches
 
@@ -810,11 +809,17 @@ __device__ __forceinline__ void lds_put(lds_u8 *p, uint64_t v, uint32_t n) {
 
 // Far matches (the whole source is older than this round: final in HBM/L2 once the flush of earlier rounds has
 // been waited for; d >= ml) and the heads of matches that straddle the round start.  The round's records are taken
-// in stream order, one per lane, FG x 64 at a time: 2 LDS reads per record, then up to 32 bytes per record in flight,
-// then the stores; what a record has beyond 32 bytes is copied by the whole wave, 8 bytes per lane.  Near matches
-// are marked in the pending map on the way and listed, in stream order, for copy_near_all (*nnear_out of them).  The
-// loads read whole 8-byte words, up to 15 bytes past a record's source: the caller makes sure that stays inside
-// the output buffer.
+// in stream order, one per lane, FH x 64 at a time: 2 LDS reads per record, then 16 bytes per record in flight, then
+// the stores; what a record has beyond 16 bytes is copied by the whole wave, 8 bytes per lane.  Two such sets are
+// alternated, so that the loads of one are in flight while the records of the next are read and the previous one is
+// stored (the loads go to L2 or beyond: a microsecond or more each time).  Near matches are marked in the pending
+// map on the way and listed, in stream order, for copy_near_all (*nnear_out of them).  The loads read whole 8-byte
+// words, up to 15 bytes past a record's source: the caller makes sure that stays inside the output buffer.
+constexpr int FH = 4;
+struct FarSet {
+  uint32_t qs[FH], n[FH], src[FH];
+  uint64_t v0[FH], v1[FH];
+};
 template <class PF>
 __device__ __forceinline__ void copy_far(const lds_u32 *mrec, const lds_u16 *mpos, lds_u32 *pend, lds_u16 *list, const Sink &sk,
                                          uint32_t lane, uint32_t nrec, uint32_t *nnear_out, PF &pf) {
@@ -822,82 +827,83 @@ __device__ __forceinline__ void copy_far(const lds_u32 *mrec, const lds_u16 *mpo
   const uint32_t R0 = sk.pos, rb = sk.sbase();
   const uint8_t *g = sk.g;
   uint32_t nnear = 0;
-  for (uint32_t c0 = 0; c0 < nrec; c0 += FG * kWave) {
-    uint32_t qs[FG], n[FG], src[FG];
-    uint64_t long32 = 0, long16 = 0;
+  // records c0 .. c0 + FH * 64 into `f`, their loads started (no branch on the way: a lane without a record reads g[0..15])
+  auto begin = [&](FarSet &f, uint32_t c0) {
 #pragma unroll
-    for (int u = 0; u < (int)FG; u++) {
-      qs[u] = 0;
-      n[u] = 0;
-      src[u] = 0;
-      if (c0 + u * kWave >= nrec) continue;  // (wave-uniform)
+    for (int u = 0; u < FH; u++) {
       const uint32_t r = c0 + u * kWave + lane;
       const bool has = r < nrec;
       const uint32_t tk = mrec[has ? r : 0u];
-      qs[u] = mpos[has ? r : 0u];
+      f.qs[u] = mpos[has ? r : 0u];
       const uint32_t d = (tk & 0x7fff) + 1, ml = ((tk >> 16) & 0xff) + 3;
-      const uint32_t s = rb + qs[u] - d;
+      const uint32_t s = rb + f.qs[u] - d;
       const bool near = has && (tk & kNearBit);
       const uint32_t head = s < R0 ? R0 - s : 0u;  // a near match that begins before the round start: its head is final too
-      n[u] = !has ? 0u : near ? head : ml;
-      src[u] = n[u] ? s : 0u;
+      f.n[u] = !has ? 0u : near ? head : ml;
+      f.src[u] = f.n[u] ? s : 0u;
       const uint64_t nb = __ballot(near);
       if (near) {
         list[nnear + lane_rank(nb)] = (uint16_t)r;
-        pend_update<true>(pend, qs[u], qs[u] + ml);
+        pend_update<true>(pend, f.qs[u], f.qs[u] + ml);
       }
       nnear += (uint32_t)__builtin_popcountll(nb);
-      long16 |= __ballot(n[u] > 16);
-      long32 |= __ballot(n[u] > 32);
     }
-    pf.tick_all(P_FAR_REC);
-    uint64_t v0[FG], v1[FG], v2[FG], v3[FG];
 #pragma unroll
-    for (int u = 0; u < (int)FG; u++) {
-      v0[u] = 0;
-      v1[u] = 0;
-      v2[u] = 0;
-      v3[u] = 0;
-      if (c0 + u * kWave >= nrec) continue;
-      v0[u] = out_ld64(g + src[u]);
-      v1[u] = out_ld64(g + src[u] + 8);
+    for (int u = 0; u < FH; u++) {
+      f.v0[u] = out_ld64(g + f.src[u]);
+      f.v1[u] = out_ld64(g + f.src[u] + 8);
     }
-    if (long16) {
+  };
+  auto finish = [&](FarSet &f) {
+    uint64_t longer = 0;
+    // every load of the set is waited for here, in one place: a group that nobody needs would otherwise leave its load
+    // "in flight" for the compiler, which then waits for the OTHER set's loads wherever the registers are written next
 #pragma unroll
-      for (int u = 0; u < (int)FG; u++) {
-        if (n[u] > 16) {
-          v2[u] = out_ld64(g + src[u] + 16);
-          v3[u] = out_ld64(g + src[u] + 24);
-        }
+    for (int u = 0; u < FH; u++) asm volatile("" ::"v"(f.v0[u]), "v"(f.v1[u]));
+#pragma unroll
+    for (int u = 0; u < FH; u++) {
+      if (f.n[u]) {
+        lds_u8 *dd = stage + f.qs[u];
+        lds_put(dd, f.v0[u], f.n[u] < 8 ? f.n[u] : 8);
+        if (f.n[u] > 8) lds_put(dd + 8, f.v1[u], f.n[u] < 16 ? f.n[u] - 8 : 8);
       }
+      longer |= __ballot(f.n[u] > 16);
     }
-    pf.tick_all(P_FAR_LOAD);
+    if (longer) {  // the rest of the long ones, one record at a time by the whole wave
 #pragma unroll
-    for (int u = 0; u < (int)FG; u++) {
-      if (c0 + u * kWave >= nrec) continue;
-      if (n[u]) {
-        lds_u8 *dd = stage + qs[u];
-        lds_put(dd, v0[u], n[u] < 8 ? n[u] : 8);
-        if (n[u] > 8) lds_put(dd + 8, v1[u], n[u] < 16 ? n[u] - 8 : 8);
-        if (n[u] > 16) {
-          lds_put(dd + 16, v2[u], n[u] < 24 ? n[u] - 16 : 8);
-          if (n[u] > 24) lds_put(dd + 24, v3[u], n[u] < 32 ? n[u] - 24 : 8);
-        }
-      }
-    }
-    if (long32) {  // the rest of the long ones, one record at a time by the whole wave
-#pragma unroll
-      for (int u = 0; u < (int)FG; u++) {
-        for (uint64_t lm = __ballot(n[u] > 32); lm; lm &= lm - 1) {
+      for (int u = 0; u < FH; u++) {
+        for (uint64_t lm = __ballot(f.n[u] > 16); lm; lm &= lm - 1) {
           const uint32_t l = (uint32_t)__builtin_ctzll(lm);
-          const uint32_t ln = rdlane(n[u], l), lsrc = rdlane(src[u], l), lqs = rdlane(qs[u], l);
-          const uint32_t j = 32 + lane * 8;
+          const uint32_t ln = rdlane(f.n[u], l), lsrc = rdlane(f.src[u], l), lqs = rdlane(f.qs[u], l);
+          const uint32_t j = 16 + lane * 8;
           if (j < ln) lds_put(stage + lqs + j, out_ld64(g + lsrc + j), ln - j < 8 ? ln - j : 8);
         }
       }
     }
-    pf.tick_all(P_FAR);
+  };
+  constexpr uint32_t kSet = FH * kWave;
+  if (nrec) {
+    FarSet fa, fb;
+    begin(fa, 0);
+    // (the last set is finished on a path of its own: were it to join the path that has just started the other set's
+    // loads, the wait in front of the stores would have to be for all loads in flight, the other set's included)
+    for (uint32_t c = 0;;) {
+      if (c + kSet >= nrec) {
+        finish(fa);
+        break;
+      }
+      begin(fb, c + kSet);
+      finish(fa);
+      if (c + 2 * kSet >= nrec) {
+        finish(fb);
+        break;
+      }
+      begin(fa, c + 2 * kSet);
+      finish(fb);
+      c += 2 * kSet;
+    }
   }
+  pf.tick_all(P_FAR);
   *nnear_out = nnear;
 }
 // the same for the last rounds of a stream, where an 8-byte load could reach past the output buffer: guarded loads
@@ -1053,7 +1059,7 @@ __device__ __forceinline__ void mail_st(MD_LDS uint32_t *p, uint32_t v) {
 }
 // decoder: until the copier has finished everything posted so far (false = the copier gave up)
 __device__ __forceinline__ bool mail_wait_idle(lds_smem *sm, uint32_t sent) {
-  while (mail_ld(&sm->mail.copied) != sent) __builtin_amdgcn_s_sleep(1);
+  while (uni(mail_ld(&sm->mail.copied)) != sent) __builtin_amdgcn_s_sleep(2);  // (a poll costs issue slots the other wavefronts want)
   asm volatile("" ::: "memory");
   return uni(mail_ld(&sm->mail.stuck)) == 0;
 }
@@ -1212,7 +1218,7 @@ template <class PF>
 __device__ __forceinline__ void copier_main(lds_smem *sm, const uint8_t *__restrict__ body, Sink &sk, uint32_t lane, PF &pf) {
   uint32_t done = 0;
   for (;;) {
-    while (mail_ld(&sm->mail.emitted) == done) __builtin_amdgcn_s_sleep(1);
+    while (uni(mail_ld(&sm->mail.emitted)) == done) __builtin_amdgcn_s_sleep(2);
     asm volatile("" ::: "memory");
     const uint32_t kind = uni(sm->mail.kind), total = uni(sm->mail.total), x = uni(sm->mail.x);
     pf.tick(P_WAIT_COPY);
