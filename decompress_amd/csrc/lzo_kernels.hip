@@ -326,11 +326,21 @@ __device__ uint32_t compress_chunk(Cmp &c, uint16_t *dict, uint32_t in_pos, uint
   for (;;) {
     // ---- the next probe positions of this run (wave-uniform recurrence, lane j keeps p_j)
     uint32_t p = first, mine = 0, nvalid = 0;
-    for (uint32_t j = 0; j < (uint32_t)kWave; j++) {
-      if (p - in_pos >= idx_end) break;
-      if (lane == j) mine = p;
-      nvalid++;
-      p += 1 + ((p - idx1) >> 5);
+    if (first - idx1 < 24u) {
+      // right after a match (the usual case in compressible input, where the first few probes already hit): the
+      // stride is 1 until the run is 32 long, so the probes up to there need no recurrence; the rest of the run,
+      // if it goes on, is the next step's
+      const uint32_t ahead = 32u - (first - idx1), room = first - in_pos < idx_end ? idx_end - (first - in_pos) : 0u;
+      nvalid = ahead < room ? ahead : room;
+      mine = first + lane;
+      p = first + nvalid;
+    } else {
+      for (uint32_t j = 0; j < (uint32_t)kWave; j++) {
+        if (p - in_pos >= idx_end) break;
+        if (lane == j) mine = p;
+        nvalid++;
+        p += 1 + ((p - idx1) >> 5);
+      }
     }
     if (nvalid == 0) {  // the run reaches the end of the chunk
       idx1 -= t;
