@@ -413,7 +413,7 @@ __device__ uint32_t compress_chunk(Cmp &c, uint16_t *dict, uint32_t in_pos, uint
   }
 }
 
-__global__ __launch_bounds__(kWave) void lzo_compress_kernel(
+__global__ __launch_bounds__(kWave, 8) void lzo_compress_kernel(
     uint32_t n, const uint8_t *__restrict__ in, const uint64_t *__restrict__ in_off,
     const uint64_t *__restrict__ in_len, uint8_t *__restrict__ out, const uint64_t *__restrict__ out_off,
     const uint64_t *__restrict__ out_cap, uint64_t *__restrict__ out_len, int32_t *__restrict__ status,
