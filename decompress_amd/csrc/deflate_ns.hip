@@ -13,10 +13,13 @@
 // a match covers; the exception is the last match of the input, after which nothing is searched any more), so
 //   deflate_link_kernel<NS>   builds the chains (two passes over the 16-bit hash range, head table in LDS),
 //   ns_match_kernel           runs hc_matchfinder_longest_match for EVERY position (depth-limited, nice length),
-//   ns_kernel                 takes the greedy decisions, splits blocks, builds the codes and writes the bits:
-//                             one stream per wavefront, the wave stages 512 positions of (match, byte) in LDS at a time
-//                             and lane 0 runs the sequential part — twice per block, once to count and once to write
-//                             (the decisions are a pure function of the match array, so no token list is kept).
+//   ns_kernel                 takes the greedy decisions, splits blocks, builds the codes and writes the bits: one
+//                             stream per wavefront.  Per block, pass 0 goes through the positions 64 at a time: every
+//                             lane holds the jump of its position (match length or 1), the chain of token starts is
+//                             followed on the scalar unit (a v_readlane per token), the lanes that are token starts
+//                             count their symbols (LDS atomics) and flag their word of the match array; lane 0 builds
+//                             the codes and the header; pass 1 reads the flags back and all lanes encode their tokens
+//                             at once (prefix sum of the bit lengths, OR into an LDS bit buffer, coalesced stores).
 #include "deflate_common.hpp"
 
 namespace md {
@@ -108,6 +111,8 @@ __global__ __launch_bounds__(kWave) void ns_match_kernel(uint32_t n, uint32_t nc
     const uint32_t maxl = slen - ps < (uint32_t)MAX_MATCH_LEN ? slen - ps : (uint32_t)MAX_MATCH_LEN;
     const uint32_t nice = nice_level < maxl ? nice_level : maxl;
     const uint32_t d0 = lk[ps] & 0xffffu;
+    md::defl::v4u own = {0u, 0u, 0u, 0u};  // the 16 bytes at the position: most comparisons end inside them
+    if (maxl >= 16u) __builtin_memcpy(&own, src + ps, 16);
     uint32_t cand = ps - d0, best = MIN_MATCH_LEN - 1, off = 0, depth = max_depth;
     bool act = in_range && d0 != 0;
     while (__ballot(act)) {
@@ -115,7 +120,15 @@ __global__ __launch_bounds__(kWave) void ns_match_kernel(uint32_t n, uint32_t nc
       const uint32_t rec = lk[a];
       if (act) {
         if ((rec >> 16) == myfp) {
-          const uint32_t len = lz_extend(src + pos, src + cand, maxl);
+          uint32_t len;
+          if (maxl >= 16u) {  // one 16-byte load of the candidate settles every match shorter than 16
+            md::defl::v4u cv;
+            __builtin_memcpy(&cv, src + cand, 16);
+            len = md::defl::prefix16(own, cv);
+            if (len == 16u) len = 16u + lz_extend(src + pos + 16, src + cand + 16, maxl - 16u);
+          } else {
+            len = lz_extend(src + pos, src + cand, maxl);
+          }
           if (len >= nice) {
             best = len;
             off = pos - cand;
@@ -136,7 +149,6 @@ __global__ __launch_bounds__(kWave) void ns_match_kernel(uint32_t n, uint32_t nc
 }
 
 // ---- the sequential kernel ----------------------------------------------------------------------------
-constexpr uint32_t STG = 512;  // positions staged in LDS at a time
 struct NsS {
   int freq_l[NUM_LITLEN_SYMS], freq_o[NUM_OFFSET_SYMS];
   uint16_t len_l[NUM_LITLEN_SYMS], len_o[NUM_OFFSET_SYMS], cw_l[NUM_LITLEN_SYMS], cw_o[NUM_OFFSET_SYMS];
@@ -149,9 +161,7 @@ struct NsS {
   uint16_t both[NUM_LITLEN_SYMS + NUM_OFFSET_SYMS];  // litlen lens followed by offset lens, as the header run-length codes them
   int new_obs[10], obs[10], num_new_obs, num_obs;
   int num_litlen_syms, num_offset_syms, num_explicit_lens, num_precode_items;
-  uint32_t stg_m[STG];   // staged match words of positions [stg_base, stg_base + STG)
-  uint8_t stg_b[STG];    // and their bytes
-  uint32_t ctl[8];       // [0] phase request for the wave, [1] stage base, [2] done
+  uint32_t bb[104];      // bit buffer of one encode step: 64 tokens of at most 47 bits behind at most 31 held bits
 };
 
 struct Os {  // output_bitstream, lib/de.ml:3100-3109
@@ -390,6 +400,69 @@ __device__ void precompute_huffman_header(NsS *s) {
   s->num_explicit_lens = n;
 }
 
+constexpr uint32_t kNoMatch = (uint32_t)(MIN_MATCH_LEN - 1) << 16;  // a match word that says "literal"
+constexpr uint32_t kTokenFlag = 0x80000000u;                          // set by pass 0 in the words of the positions the parse stops at
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+// lane 0 has moved the output state: every lane takes it over
+__device__ __forceinline__ void os_bcast(Os &os) {
+  os.o_pos = uni(os.o_pos);
+  os.bits = (int)uni((uint32_t)os.bits);
+  os.hold = ((uint64_t)uni((uint32_t)(os.hold >> 32)) << 32) | uni((uint32_t)os.hold);
+  os.failed = uni(os.failed ? 1u : 0u) != 0;
+}
+// (one wavefront owns the LDS state and a wavefront's LDS operations execute in program order: no barrier)
+__device__ __forceinline__ void lds_order() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+  return v;
+}
+// The output side while all lanes write: bits held (< 32) in front of byte o_pos, nothing is stored at or beyond o_cap.
+struct Pack {
+  uint64_t hold;
+  uint32_t bits, o_pos, o_cap;
+  uint8_t *o;
+};
+// Appends one item of nb <= 47 bits per lane, in lane order (the bit stream add_bits builds, lib/de.ml:3360-3369): a
+// prefix sum of the lengths gives each item its bit offset, the items are OR-ed into the LDS bit buffer behind the bits
+// still held, the finished bytes go out 4 per lane.  Returns the number of bits appended.
+__device__ __forceinline__ uint32_t pack_step(NsS *s, uint32_t lane, uint64_t v, uint32_t nb, Pack &p) {
+  const uint32_t incl = wave_incl_scan(nb);
+  const uint32_t added = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+  const uint32_t total = p.bits + added;
+  const uint32_t boff = p.bits + incl - nb;
+  const uint32_t nwords = (total + 31) / 32 + 1;
+  for (uint32_t i = lane; i < nwords; i += kWave) s->bb[i] = i == 0 ? (uint32_t)p.hold : 0u;
+  lds_order();
+  if (nb) {
+    const uint32_t w = boff >> 5, sh = boff & 31;
+    const uint64_t lo = v << sh;
+    atomicOr(&s->bb[w], (uint32_t)lo);
+    if ((lo >> 32) != 0) atomicOr(&s->bb[w + 1], (uint32_t)(lo >> 32));
+    if (sh + nb > 64) atomicOr(&s->bb[w + 2], (uint32_t)(v >> (64 - sh)));
+  }
+  lds_order();
+  const uint32_t nbytes = total >> 3, rem = total & 7;
+  for (uint32_t i = lane * 4; i < nbytes; i += kWave * 4) {
+    const uint32_t wv = __hip_atomic_load(&s->bb[i >> 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (i + 4 <= nbytes && p.o_pos + i + 4 <= p.o_cap) {
+      __builtin_memcpy(p.o + p.o_pos + i, &wv, 4);
+    } else {
+      for (uint32_t k = 0; k < 4 && i + k < nbytes; k++)
+        if (p.o_pos + i + k < p.o_cap) p.o[p.o_pos + i + k] = (uint8_t)(wv >> (8 * k));
+    }
+  }
+  p.hold = rem ? ((__hip_atomic_load(&s->bb[nbytes >> 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> (8 * (nbytes & 3))) & ((1u << rem) - 1)) : 0;
+  p.bits = rem;
+  p.o_pos += nbytes;
+  lds_order();
+  return added;
+}
+
 // do_end_block_check / should_end_block, lib/de.ml:3717-3751
 __device__ __forceinline__ bool should_end_block(NsS *s, uint32_t in_block_begin, uint32_t in_next, uint32_t in_end) {
   if (s->num_new_obs < 512 || in_next - in_block_begin < (uint32_t)MIN_BLOCK_LENGTH || in_end - in_next < (uint32_t)MIN_BLOCK_LENGTH) return false;
@@ -411,7 +484,6 @@ __device__ __forceinline__ bool should_end_block(NsS *s, uint32_t in_block_begin
   return false;
 }
 
-enum { NS_STAGE = 1, NS_DONE = 2 };
 
 // format: MD_FORMAT_DEFLATE (De.Def.Ns.deflate) or MD_FORMAT_ZLIB (Zl.Def.Ns.deflate: 2 header bytes, the body, the
 // Adler-32 of the input big-endian)
@@ -502,185 +574,206 @@ __global__ __launch_bounds__(kWave) void ns_kernel(int format, int level, uint32
     simple_done = true;
   } else if (level > 4) simple_done = true;  // compress_lazy: "TO DO" upstream, Ok 0
   if (!simple_done) {
-    // compress_greedy, lib/de.ml:3875-3925.  Lane 0 walks the positions; the wave stages STG positions at a time.
+    // compress_greedy, lib/de.ml:3875-3925
+    uint32_t *mwr = fr.m + so;
+    for (uint32_t q = p_end + lane; q < slen; q += kWave) mwr[q] = kNoMatch;  // no match where fewer than 5 bytes are left
     uint32_t i_pos = 0;
-    __syncthreads();
-    {
-      // ---- per block: pass 0 counts (parse), pass 1 writes
-      uint32_t blk_begin = 0, blk_end = 0, pass = 0, p = 0, stage_base = 0xffffffffu;
-      bool block_open = false;
-      int block_type = 0;
-      // the loop below is driven by lane 0's requests: ctl[0] = NS_STAGE (stage positions from ctl[1]) or NS_DONE
-      for (;;) {
+    while (!os.failed && i_pos < slen) {
+      // ---- a block: in_block_begin = i_pos
+      const uint32_t blk_begin = i_pos;
+      uint32_t p = i_pos;
+      for (uint32_t k = lane; k < (uint32_t)NUM_LITLEN_SYMS; k += kWave) s->freq_l[k] = 0;
+      if (lane < (uint32_t)NUM_OFFSET_SYMS) s->freq_o[lane] = 0;
+      if (lane < 10) s->new_obs[lane] = s->obs[lane] = 0;
+      if (lane == 0) s->num_new_obs = s->num_obs = 0;
+      lds_order();
+      uint32_t num_new_obs = 0;  // (wave-uniform copy of s->num_new_obs)
+      const uint32_t in_max_block_end = blk_begin + (slen - blk_begin < (uint32_t)SOFT_MAX_BLOCK_LENGTH ? slen - blk_begin : (uint32_t)SOFT_MAX_BLOCK_LENGTH);
+      // ---- pass 0: the greedy parse, 64 positions at a time
+      while (p < in_max_block_end) {
+        if (num_new_obs >= 512u && p - blk_begin >= (uint32_t)MIN_BLOCK_LENGTH && slen - p >= (uint32_t)MIN_BLOCK_LENGTH) {
+          uint32_t end = 0;  // should_end_block has something to decide before the token at p
+          if (lane == 0) {
+            s->num_new_obs = (int)num_new_obs;
+            end = should_end_block(s, blk_begin, p, slen) ? 1u : 0u;
+          }
+          lds_order();
+          end = uni(end);
+          num_new_obs = uni((uint32_t)s->num_new_obs);
+          if (end) break;
+        }
+        const uint32_t q = p + lane;
+        const uint32_t mm = q < p_end ? __builtin_nontemporal_load(mwr + q) : kNoMatch;
+        const uint32_t byte = q < slen ? src[q] : 0u;
+        const uint32_t best = mm >> 16, off = mm & 0xffffu;
+        const bool is_match = best >= (uint32_t)MIN_MATCH_LEN;
+        const uint32_t jump = is_match ? best : 1u;
+        // the token starts among these positions (scalar unit; the test in front of a token is should_end_block's
+        // `num_new_obs < 512 || ...` with the observations of this step counted in)
+        uint32_t t = 0, cnt = 0;
+        uint64_t mask = 0;
+        while (t < (uint32_t)kWave && p + t < in_max_block_end) {
+          if (cnt && num_new_obs + cnt >= 512u && p + t - blk_begin >= (uint32_t)MIN_BLOCK_LENGTH && slen - (p + t) >= (uint32_t)MIN_BLOCK_LENGTH) break;
+          mask |= 1ull << t;
+          cnt++;
+          t += (uint32_t)__builtin_amdgcn_readlane((int)jump, (int)t);
+        }
+        const bool tok = (mask >> lane) & 1;
+        if (tok) {  // choose_match / choose_literal: the symbol counts, and the flag pass 1 finds the token by
+          if (is_match) {
+            atomicAdd(&s->freq_l[257 + length_slot((int)best)], 1);
+            atomicAdd(&s->freq_o[offset_slot((int)off)], 1);
+          } else {
+            atomicAdd(&s->freq_l[byte], 1);
+          }
+          mwr[q] = mm | kTokenFlag;
+        }
+        // observe_match / observe_literal (sic: upstream observes the POSITION, shifted left: its lowest bit)
+        const uint32_t n8 = (uint32_t)__builtin_popcountll(__ballot(tok && is_match && best < 9u));
+        const uint32_t n9 = (uint32_t)__builtin_popcountll(__ballot(tok && is_match && best >= 9u));
+        const uint32_t n0 = (uint32_t)__builtin_popcountll(__ballot(tok && !is_match && (q & 1u) == 0u));
+        const uint32_t n1 = (uint32_t)__builtin_popcountll(__ballot(tok && !is_match && (q & 1u) != 0u));
         if (lane == 0) {
-          uint32_t req = 0;
-          for (;;) {
-            if (!block_open) {
-              if (os.failed || i_pos == slen) {
-                req = NS_DONE;
-                break;
-              }
-              block_open = true;
-              pass = 0;
-              blk_begin = i_pos;
-              p = i_pos;
-              for (int k = 0; k < NUM_LITLEN_SYMS; k++) s->freq_l[k] = 0;
-              for (int k = 0; k < NUM_OFFSET_SYMS; k++) s->freq_o[k] = 0;
-              for (int k = 0; k < 10; k++) s->new_obs[k] = s->obs[k] = 0;
-              s->num_new_obs = s->num_obs = 0;
+          s->new_obs[8] += (int)n8;
+          s->new_obs[9] += (int)n9;
+          s->new_obs[0] += (int)n0;
+          s->new_obs[1] += (int)n1;
+        }
+        num_new_obs += cnt;
+        p += t;
+      }
+      lds_order();
+      // ---- flush_block, lib/de.ml:3622-3703 (lane 0): codes, header, the three costs
+      const uint32_t blk_end = p;
+      uint32_t block_type = 0;
+      if (lane == 0) {
+        const bool is_final = blk_end == slen;
+        const long block_length = (long)(blk_end - blk_begin);
+        s->num_new_obs = (int)num_new_obs;
+        s->freq_l[END_OF_BLOCK]++;
+        make_huffman_code(s, NUM_LITLEN_SYMS, MAX_LITLEN_CODEWORD_LEN, s->freq_l, s->len_l, s->cw_l);
+        make_huffman_code(s, NUM_OFFSET_SYMS, MAX_OFFSET_CODEWORD_LEN, s->freq_o, s->len_o, s->cw_o);
+        precompute_huffman_header(s);
+        long dynamic_cost = 5 + 5 + 4 + 3 * s->num_explicit_lens, static_cost = 0, uncompressed_cost = 0;
+        for (int sym = 0; sym < NUM_PRECODE_SYMS; sym++) {
+          const int extra = sym == 16 ? 2 : sym == 17 ? 3 : sym == 18 ? 7 : 0;
+          dynamic_cost += (long)s->pre_freq[sym] * (extra + s->pre_len[sym]);
+        }
+        for (int sym = 0; sym <= 255; sym++) dynamic_cost += (long)s->freq_l[sym] * s->len_l[sym];
+        for (int sym = 0; sym <= 143; sym++) static_cost += (long)s->freq_l[sym] * 8;
+        for (int sym = 144; sym <= 255; sym++) static_cost += (long)s->freq_l[sym] * 9;
+        dynamic_cost += s->len_l[256];
+        static_cost += 7;
+        for (int sym = 257; sym <= 257 + 32 - 3; sym++) {
+          const int extra = c_extra_lbits[sym - 257];
+          int sl, sc;
+          static_litlen(sym, &sl, &sc);
+          dynamic_cost += (long)s->freq_l[sym] * (extra + s->len_l[sym]);
+          static_cost += (long)s->freq_l[sym] * (extra + sl);
+        }
+        for (int sym = 0; sym <= 32 - 3; sym++) {
+          const int extra = c_extra_dbits[sym];
+          dynamic_cost += (long)s->freq_o[sym] * (extra + s->len_o[sym]);
+          static_cost += (long)s->freq_o[sym] * (extra + 5);
+        }
+        uncompressed_cost += ((-(os.bits + 3)) & 7) + 32 + 40 * (((block_length + 65535 - 1) / 65535) - 1) + 8 * block_length;
+        const long ms = static_cost < uncompressed_cost ? static_cost : uncompressed_cost;
+        block_type = dynamic_cost < ms ? 2 : static_cost < uncompressed_cost ? 1 : 0;
+        if (block_type == 0) {
+          // write_uncompressed_blocks from block_begin with input left: upstream never advances its input
+          // cursor and leaves by `Unexpected_end_of_output (lib/de.ml:3411-3420)
+          os.failed = true;
+        } else {
+          add_bits(os, is_final ? 1 : 0, 1);
+          add_bits(os, block_type, 2);
+          if (block_type == 2) {  // write_huffman_header, lib/de.ml:3538-3556
+            add_bits(os, (uint32_t)(s->num_litlen_syms - 257), 5);
+            add_bits(os, (uint32_t)(s->num_offset_syms - 1), 5);
+            add_bits(os, (uint32_t)(s->num_explicit_lens - 4) & 0xf, 4);
+            for (int i = 0; i < s->num_explicit_lens; i++) add_bits(os, (uint32_t)s->pre_len[c_zigzag[i]], 3);
+            for (int i = 0; i < s->num_precode_items; i++) {
+              const int item = s->pre_items[i], sym = item & 0x1F;
+              add_bits(os, (uint32_t)s->pre_cw[sym], s->pre_len[sym]);
+              if (sym >= 16) add_bits(os, (uint32_t)(item >> 5), sym == 16 ? 2 : sym == 17 ? 3 : 7);
             }
-            const uint32_t in_max_block_end = blk_begin + (slen - blk_begin < (uint32_t)SOFT_MAX_BLOCK_LENGTH ? slen - blk_begin : (uint32_t)SOFT_MAX_BLOCK_LENGTH);
-            bool need_stage = false;
-            if (pass == 0) {
-              while (p < in_max_block_end && !should_end_block(s, blk_begin, p, slen)) {
-                if (p < stage_base || p >= stage_base + STG) {
-                  need_stage = true;
-                  break;
-                }
-                const uint32_t maxl = slen - p < (uint32_t)MAX_MATCH_LEN ? slen - p : (uint32_t)MAX_MATCH_LEN;
-                const uint32_t mm = (maxl >= 5 && p < p_end) ? s->stg_m[p - stage_base] : ((uint32_t)(MIN_MATCH_LEN - 1) << 16);
-                const uint32_t best = mm >> 16;
-                if (best >= (uint32_t)MIN_MATCH_LEN) {  // choose_match + observe_match
-                  s->freq_l[257 + length_slot((int)best)]++;
-                  s->freq_o[offset_slot((int)(mm & 0xffff))]++;
-                  s->new_obs[8 + (best >= 9 ? 1 : 0)]++;
-                  s->num_new_obs++;
-                  p += best;
-                } else {  // choose_literal + observe_literal (sic: upstream observes the POSITION, shifted left: its lowest bit)
-                  s->freq_l[s->stg_b[p - stage_base]]++;
-                  s->new_obs[p & 1]++;
-                  s->num_new_obs++;
-                  p++;
-                }
-              }
-              if (need_stage) {
-                req = NS_STAGE;
-                s->ctl[1] = p;
-                break;
-              }
-              // ---- flush_block, lib/de.ml:3622-3703: codes, header, the three costs
-              blk_end = p;
-              const bool is_final = blk_end == slen;
-              const long block_length = (long)(blk_end - blk_begin);
-              s->freq_l[END_OF_BLOCK]++;
-              make_huffman_code(s, NUM_LITLEN_SYMS, MAX_LITLEN_CODEWORD_LEN, s->freq_l, s->len_l, s->cw_l);
-              make_huffman_code(s, NUM_OFFSET_SYMS, MAX_OFFSET_CODEWORD_LEN, s->freq_o, s->len_o, s->cw_o);
-              precompute_huffman_header(s);
-              long dynamic_cost = 5 + 5 + 4 + 3 * s->num_explicit_lens, static_cost = 0, uncompressed_cost = 0;
-              for (int sym = 0; sym < NUM_PRECODE_SYMS; sym++) {
-                const int extra = sym == 16 ? 2 : sym == 17 ? 3 : sym == 18 ? 7 : 0;
-                dynamic_cost += (long)s->pre_freq[sym] * (extra + s->pre_len[sym]);
-              }
-              for (int sym = 0; sym <= 255; sym++) dynamic_cost += (long)s->freq_l[sym] * s->len_l[sym];
-              for (int sym = 0; sym <= 143; sym++) static_cost += (long)s->freq_l[sym] * 8;
-              for (int sym = 144; sym <= 255; sym++) static_cost += (long)s->freq_l[sym] * 9;
-              dynamic_cost += s->len_l[256];
-              static_cost += 7;
-              for (int sym = 257; sym <= 257 + 32 - 3; sym++) {
-                const int extra = c_extra_lbits[sym - 257];
-                int sl, sc;
-                static_litlen(sym, &sl, &sc);
-                dynamic_cost += (long)s->freq_l[sym] * (extra + s->len_l[sym]);
-                static_cost += (long)s->freq_l[sym] * (extra + sl);
-              }
-              for (int sym = 0; sym <= 32 - 3; sym++) {
-                const int extra = c_extra_dbits[sym];
-                dynamic_cost += (long)s->freq_o[sym] * (extra + s->len_o[sym]);
-                static_cost += (long)s->freq_o[sym] * (extra + 5);
-              }
-              uncompressed_cost += ((-(os.bits + 3)) & 7) + 32 + 40 * (((block_length + 65535 - 1) / 65535) - 1) + 8 * block_length;
-              const long ms = static_cost < uncompressed_cost ? static_cost : uncompressed_cost;
-              block_type = dynamic_cost < ms ? 2 : static_cost < uncompressed_cost ? 1 : 0;
-              if (block_type == 0) {
-                // write_uncompressed_blocks from block_begin with input left: upstream never advances its input
-                // cursor and leaves by `Unexpected_end_of_output (lib/de.ml:3411-3420)
-                os.failed = true;
-                block_open = false;
-                continue;
-              }
-              add_bits(os, is_final ? 1 : 0, 1);
-              add_bits(os, (uint32_t)block_type, 2);
-              if (block_type == 2) {  // write_huffman_header, lib/de.ml:3538-3556
-                add_bits(os, (uint32_t)(s->num_litlen_syms - 257), 5);
-                add_bits(os, (uint32_t)(s->num_offset_syms - 1), 5);
-                add_bits(os, (uint32_t)(s->num_explicit_lens - 4) & 0xf, 4);
-                for (int i = 0; i < s->num_explicit_lens; i++) add_bits(os, (uint32_t)s->pre_len[c_zigzag[i]], 3);
-                for (int i = 0; i < s->num_precode_items; i++) {
-                  const int item = s->pre_items[i], sym = item & 0x1F;
-                  add_bits(os, (uint32_t)s->pre_cw[sym], s->pre_len[sym]);
-                  if (sym >= 16) add_bits(os, (uint32_t)(item >> 5), sym == 16 ? 2 : sym == 17 ? 3 : 7);
-                }
-              }
-              pass = 1;
-              p = blk_begin;
-            }
-            // ---- pass 1: write_sequences (lib/de.ml:3558-3614) — the same greedy walk, now with codes
-            while (p < blk_end && !os.failed) {
-              if (p < stage_base || p >= stage_base + STG) {
-                need_stage = true;
-                break;
-              }
-              const uint32_t maxl = slen - p < (uint32_t)MAX_MATCH_LEN ? slen - p : (uint32_t)MAX_MATCH_LEN;
-              const uint32_t mm = (maxl >= 5 && p < p_end) ? s->stg_m[p - stage_base] : ((uint32_t)(MIN_MATCH_LEN - 1) << 16);
-              const uint32_t best = mm >> 16;
-              if (best >= (uint32_t)MIN_MATCH_LEN) {
-                const int lslot = length_slot((int)best), off = (int)(mm & 0xffff), oslot = offset_slot(off);
-                int l, c;
-                if (block_type == 2) {
-                  l = s->len_l[257 + lslot];
-                  c = s->cw_l[257 + lslot];
-                } else static_litlen(257 + lslot, &l, &c);
-                add_bits(os, (uint32_t)c, l);
-                add_bits(os, (uint32_t)((int)best - c_base_length[lslot] - 3), c_extra_lbits[lslot]);
-                if (block_type == 2) add_bits(os, (uint32_t)s->cw_o[oslot], s->len_o[oslot]);
-                else add_bits(os, __brev((unsigned)oslot) >> 27, 5);
-                add_bits(os, (uint32_t)(off - c_base_dist[oslot] - 1), c_extra_dbits[oslot]);
-                p += best;
+          }
+        }
+      }
+      block_type = uni(block_type);
+      os_bcast(os);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the codes are in LDS, the token flags in the match array
+      if (os.failed) break;
+      // ---- pass 1: write_sequences (lib/de.ml:3558-3614) and write_end_of_block, every lane its token
+      {
+        const uint32_t o1 = os.o_pos, b1 = (uint32_t)os.bits;
+        Pack pk{os.hold, b1, o1, os.o_len, os.o};
+        uint32_t sbits = 0;
+        for (uint32_t base = blk_begin; base < blk_end; base += kWave) {
+          const uint32_t q = base + lane;
+          const uint32_t mm = q < blk_end ? __builtin_nontemporal_load(mwr + q) : 0u;
+          uint64_t v = 0;
+          uint32_t nb = 0;
+          if (mm & kTokenFlag) {
+            const uint32_t best = (mm >> 16) & 0x1ffu, off = mm & 0xffffu;
+            if (best >= (uint32_t)MIN_MATCH_LEN) {
+              const int lslot = length_slot((int)best), oslot = offset_slot((int)off);
+              int l, c, l2, c2;
+              if (block_type == 2) {
+                l = s->len_l[257 + lslot];
+                c = s->cw_l[257 + lslot];
+                l2 = s->len_o[oslot];
+                c2 = s->cw_o[oslot];
               } else {
-                const int lit = s->stg_b[p - stage_base];
-                int l, c;
-                if (block_type == 2) {
-                  l = s->len_l[lit];
-                  c = s->cw_l[lit];
-                } else static_litlen(lit, &l, &c);
-                add_bits(os, (uint32_t)c, l);
-                p++;
+                static_litlen(257 + lslot, &l, &c);
+                l2 = 5;
+                c2 = (int)(__brev((unsigned)oslot) >> 27);
               }
-            }
-            if (need_stage) {
-              req = NS_STAGE;
-              s->ctl[1] = p;
-              break;
-            }
-            {  // write_end_of_block
+              v = (uint64_t)(uint32_t)c;
+              nb = (uint32_t)l;
+              v |= (uint64_t)(best - c_base_length[lslot] - 3u) << nb;
+              nb += c_extra_lbits[lslot];
+              v |= (uint64_t)(uint32_t)c2 << nb;
+              nb += (uint32_t)l2;
+              v |= (uint64_t)(off - (uint32_t)c_base_dist[oslot] - 1u) << nb;
+              nb += c_extra_dbits[oslot];
+            } else {
+              const int lit = src[q];
               int l, c;
               if (block_type == 2) {
-                l = s->len_l[END_OF_BLOCK];
-                c = s->cw_l[END_OF_BLOCK];
-              } else static_litlen(END_OF_BLOCK, &l, &c);
-              add_bits(os, (uint32_t)c, l);
-              flush_bits(os);
+                l = s->len_l[lit];
+                c = s->cw_l[lit];
+              } else static_litlen(lit, &l, &c);
+              v = (uint64_t)(uint32_t)c;
+              nb = (uint32_t)l;
             }
-            i_pos = blk_end;
-            block_open = false;
           }
-          s->ctl[0] = req;
+          sbits += pack_step(s, lane, v, nb, pk);
         }
-        __syncthreads();
-        if (s->ctl[0] == NS_DONE) break;
-        {  // stage STG positions from the 64-aligned base below ctl[1]
-          const uint32_t base = s->ctl[1] & ~63u;
-          for (uint32_t k = lane; k < STG; k += kWave) {
-            const uint32_t q = base + k;
-            s->stg_m[k] = q < p_end ? __builtin_nontemporal_load(mw + q) : ((uint32_t)(MIN_MATCH_LEN - 1) << 16);
-            s->stg_b[k] = q < slen ? src[q] : (uint8_t)0;
+        {  // write_end_of_block
+          uint64_t v = 0;
+          uint32_t nb = 0;
+          if (lane == 0) {
+            int l, c;
+            if (block_type == 2) {
+              l = s->len_l[END_OF_BLOCK];
+              c = s->cw_l[END_OF_BLOCK];
+            } else static_litlen(END_OF_BLOCK, &l, &c);
+            v = (uint64_t)(uint32_t)c;
+            nb = (uint32_t)l;
           }
-          stage_base = base;  // (lane 0's copy is the one that is used)
+          sbits += pack_step(s, lane, v, nb, pk);
         }
-        __syncthreads();
+        // what add_bits and flush_bits would have said on the way: the first group of 16 bits goes out when 16 are
+        // held and needs two bytes of room each time; flush_bits then one more byte for 8 held bits
+        const uint32_t groups = (b1 + sbits) >> 4, held = (b1 + sbits) & 15u;
+        if ((groups >= 1 && o1 + 2 * groups > os.o_len) || (held >= 8 && o1 + 2 * groups >= os.o_len)) os.failed = true;
+        os.o_pos = pk.o_pos;
+        os.bits = (int)pk.bits;
+        os.hold = pk.hold;
       }
-      if (lane == 0) res = flush_output(os);
+      i_pos = blk_end;
     }
+    if (lane == 0) res = flush_output(os);
   }
   if (lane == 0) {
     int st = (!room || os.failed) ? MD_UNEXPECTED_END_OF_OUTPUT : MD_OK;
