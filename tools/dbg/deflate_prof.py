@@ -11,11 +11,11 @@ eng.timing_begin()
 outs = eng.deflate_many(bufs, level=6, fmt=decompress_amd.FORMAT_ZLIB)
 ms = eng.timing_end()
 p = eng.get_profile_raw()
-names = ["setup", "lookahead", "bulk", "lane0", "pack", "trees"]
+names = ["setup", "ring fill", "parse (literal runs + lazy steps)", "lane0", "pack", "trees"]
 tot = sum(p[:6])
 print("kernel ms %.2f  ticks of stream 0: %d (100 MHz -> %.2f ms)" % (ms, tot, tot / 1e5))
 for k, v in zip(names, p[:6]):
-    print("  %-10s %6.1f%%  %.2f ms" % (k, 100.0 * v / max(tot, 1), v / 1e5))
+    print("  %-36s %6.1f%%  %.2f ms" % (k, 100.0 * v / max(tot, 1), v / 1e5))
 print("  prep batches %d  bulk steps %d  bulk literals %d  iterations %d" % tuple(p[8:12]))
 print("  matcher steps %d  longest_match calls %d  chain links %d" % tuple(p[12:15]))
 for i, nm in enumerate(["PREP", "WRITE", "DONE", "TREES"]):
