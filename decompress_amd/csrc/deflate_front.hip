@@ -244,7 +244,7 @@ __global__ __launch_bounds__(LW *kWave) void deflate_link_kernel(uint32_t n, con
 // window limit is pos - MAX_DIST whatever the window base: before the first slide the base is 0, after a slide
 // strstart - base >= MAX_DIST.  The head candidate is admitted at distance == MAX_DIST, links only below it
 // (lib/de.ml:4367-4369 vs :4165).
-__global__ __launch_bounds__(kWave) void deflate_match_kernel(uint32_t n, uint32_t nchunks_max, const uint8_t *__restrict__ in,
+__global__ __launch_bounds__(kWave, 6) void deflate_match_kernel(uint32_t n, uint32_t nchunks_max, const uint8_t *__restrict__ in,
                                                               const uint64_t *__restrict__ in_off,
                                                               const uint64_t *__restrict__ in_len,
                                                               const uint32_t *__restrict__ p_end_a,
@@ -289,29 +289,33 @@ __global__ __launch_bounds__(kWave) void deflate_match_kernel(uint32_t n, uint32
   const uint32_t *lk = link + so;
   const uint32_t qlimit = max_chain >> 2, kspec = max_chain < (uint32_t)KSPEC ? max_chain : (uint32_t)KSPEC;
 
-  uint32_t w4[PGM], cw[PGM], fl[PGM], cnt[PGM], best[PGM], bdist[PGM], bestq[PGM], bdistq[PGM];
-  v4u own[PGM];  // the 16 bytes at the position: most comparisons end inside them
+  // the chunk's own text, 16 bytes beyond its last position, in LDS: a comparison starts with the 16 bytes at the
+  // position against the 16 bytes at the candidate (held in registers they cost a sixth of the wavefronts per CU)
+  __shared__ alignas(16) uint8_t own_text[kChunk + 16];
+  if (lane <= kChunk / 16) {
+    const uint32_t a = pe + lane * 16;
+    v4u v = {0u, 0u, 0u, 0u};
+    if (a + 16 <= slen) __builtin_memcpy(&v, src + a, 16);
+    else
+      for (uint32_t k = 0; a + k < slen; k++) v[k >> 2] |= (uint32_t)src[a + k] << (8 * (k & 3));
+    *reinterpret_cast<v4u *>(own_text + lane * 16) = v;
+  }
+  // per position: its 4 bytes, the candidate, fc = verdict (FL_*, 0 = walking) | links walked << 4, and the best match so
+  // far as it will be stored (length << 16 | distance): of the full chain, and of its first quarter
+  uint32_t w4[PGM], cw[PGM], fc[PGM], mv[PGM], mqv[PGM];
 #pragma unroll
   for (int g = 0; g < PGM; g++) {
     const uint32_t pos = pe + g * kWave + lane;
     w4[g] = slen >= 4 ? load_w4(src, slen, p_end, pos) : 0u;
-    own[g] = (v4u){0u, 0u, 0u, 0u};
-    if (slen >= (uint32_t)MIN_LOOKAHEAD) {  // (shorter streams never compare: every hit is left to the matcher)
-      const uint32_t a = pos + 16 <= slen ? pos : slen - 16;  // a clamped address only for positions that never compare
-      __builtin_memcpy(&own[g], src + a, 16);
-    }
     cw[g] = 0;
     if (pos < p_end) {
       if (slen < 4) w4[g] = (uint32_t)src[pos] | ((uint32_t)src[pos + 1] << 8) | ((uint32_t)src[pos + 2] << 16);
       const uint32_t l = lk[pos] & 0xffffu;
       cw[g] = l ? pos - l : 0u;
     }
-    fl[g] = 0;
-    cnt[g] = 0;
-    best[g] = MIN_MATCH - 1;
-    bdist[g] = 0;
-    bestq[g] = MIN_MATCH - 1;
-    bdistq[g] = 0;
+    fc[g] = 0;
+    mv[g] = (uint32_t)(MIN_MATCH - 1) << 16;
+    mqv[g] = (uint32_t)(MIN_MATCH - 1) << 16;
   }
   // One link of every chain per iteration.  The usual candidate fails the 3-byte test: that path is straight-line
   // (loads from a harmless address for lanes that have nothing to do, selects instead of branches — a branch per
@@ -324,7 +328,7 @@ __global__ __launch_bounds__(kWave) void deflate_match_kernel(uint32_t n, uint32
     for (int g = 0; g < PGM; g++) {
       const uint32_t pos = pe + g * kWave + lane;
       const uint32_t lower = pos > (uint32_t)MAX_DIST ? pos - MAX_DIST : 0;
-      act[g] = pos < p_end && fl[g] == 0 && (lv == 0 ? (cw[g] != 0 && pos - cw[g] <= (uint32_t)MAX_DIST) : cw[g] > lower);
+      act[g] = pos < p_end && (fc[g] & 15u) == 0 && (lv == 0 ? (cw[g] != 0 && pos - cw[g] <= (uint32_t)MAX_DIST) : cw[g] > lower);
       any = any || act[g];
     }
     if (__ballot(any) == 0) break;
@@ -344,35 +348,36 @@ __global__ __launch_bounds__(kWave) void deflate_match_kernel(uint32_t n, uint32
         if (hit && pos + MIN_LOOKAHEAD > slen) {  // too close to the end to compare ahead: the matcher's job, if the 3 bytes are there
           uint32_t v;
           __builtin_memcpy(&v, src + cw[g], 4);
-          if (((v ^ w4[g]) & 0xffffffu) == 0) fl[g] = 8;
+          if (((v ^ w4[g]) & 0xffffffu) == 0) fc[g] |= 8u;
         } else if (hit) {
           // one 16-byte load of the candidate settles the 3-byte test and every match shorter than 16
           v4u cand;
           __builtin_memcpy(&cand, src + cw[g], 16);
-          uint32_t len = prefix16(own[g], cand);
+          v4u own;
+          __builtin_memcpy(&own, own_text + g * kWave + lane, 16);
+          uint32_t len = prefix16(own, cand);
           if (len == 16) {
             // scan_end pre-filter (lib/de.ml:4133-4134): a candidate that differs at the end of the best match so
             // far cannot be longer
             bool look = true;
-            if (best[g] >= 16u) {
+            const uint32_t bl = mv[g] >> 16;
+            if (bl >= 16u) {
               uint16_t x, y;
-              __builtin_memcpy(&x, src + pos + best[g] - 1, 2);
-              __builtin_memcpy(&y, src + cw[g] + best[g] - 1, 2);
+              __builtin_memcpy(&x, src + pos + bl - 1, 2);
+              __builtin_memcpy(&y, src + cw[g] + bl - 1, 2);
               look = x == y;
             }
             len = look ? lcp258_from16(src + pos, src + cw[g]) : 0u;
           }
-          if (len > best[g]) {  // (len < 3: the fingerprint lied; best >= 2)
-            best[g] = len;
-            bdist[g] = pos - cw[g];
-            if (len >= nice) fl[g] = FL_MATCH;
+          if (len > (mv[g] >> 16)) {  // (len < 3: the fingerprint lied; best >= 2)
+            mv[g] = (len << 16) | (pos - cw[g]);
+            if (len >= nice) fc[g] |= (uint32_t)FL_MATCH;
           }
         }
       }
-      cnt[g] += act[g] ? 1u : 0u;
-      const bool atq = act[g] && cnt[g] == qlimit;
-      bestq[g] = atq ? best[g] : bestq[g];
-      bdistq[g] = atq ? bdist[g] : bdistq[g];
+      fc[g] += act[g] ? 16u : 0u;
+      const bool atq = act[g] && (fc[g] >> 4) == qlimit;
+      mqv[g] = atq ? mv[g] : mqv[g];
       cw[g] = act[g] ? nx[g] : cw[g];
     }
   }
@@ -381,20 +386,17 @@ __global__ __launch_bounds__(kWave) void deflate_match_kernel(uint32_t n, uint32
     const uint32_t pos = pe + g * kWave + lane;
     if (pos < p_end) {
       const uint32_t lower = pos > (uint32_t)MAX_DIST ? pos - MAX_DIST : 0;
-      uint32_t f = fl[g];
+      uint32_t f = fc[g] & 15u;
+      const uint32_t cnt = fc[g] >> 4;
       if (f == 0) {
         // chain exhausted (or never entered), or max_chain links walked: the verdict is final
-        const bool entered = cnt[g] != 0;
+        const bool entered = cnt != 0;
         const bool more = entered ? cw[g] > lower : (cw[g] != 0 && pos - cw[g] <= (uint32_t)MAX_DIST);
-        if (!more || cnt[g] >= max_chain) f = best[g] >= (uint32_t)MIN_MATCH ? FL_MATCH : FL_ENDED;
+        if (!more || cnt >= max_chain) f = (mv[g] >> 16) >= (uint32_t)MIN_MATCH ? FL_MATCH : FL_ENDED;
       }
       if (f == FL_MATCH) {
-        if (cnt[g] < qlimit) {
-          bestq[g] = best[g];
-          bdistq[g] = bdist[g];
-        }
-        m[so + pos] = (best[g] << 16) | bdist[g];
-        mq[so + pos] = (bestq[g] << 16) | bdistq[g];
+        m[so + pos] = mv[g];
+        mq[so + pos] = cnt < qlimit ? mv[g] : mqv[g];
       }
       flg[so + pos] = (uint8_t)(f == FL_MATCH || f == FL_ENDED ? f : 0);
     }

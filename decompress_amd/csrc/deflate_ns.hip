@@ -33,6 +33,7 @@ constexpr int NUM_OFFSET_SYMS = 32, MAX_OFFSET_CODEWORD_LEN = 15, NUM_SYMBOL_BIT
 constexpr int MIN_MATCH_LEN = 3, MAX_MATCH_LEN = 258, SOFT_MAX_BLOCK_LENGTH = 300000, NUM_PRECODE_SYMS = 19;
 constexpr int END_OF_BLOCK = 256, MAX_PRE_CODEWORD_LEN = 7, MAX_MAX_CODEWORD_LEN = 15;
 constexpr uint32_t kChunkNs = 4 * kWave;
+constexpr int NG = 4;  // groups of 64 positions per step of the sequential kernel's two passes
 
 __constant__ uint8_t c_zigzag[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 __constant__ uint8_t c_base_length[31] = {0,  1,  2,  3,  4,  5,  6,  7,  8,  10,  12,  14,  16,  20,  24, 28,
@@ -589,7 +590,7 @@ __global__ __launch_bounds__(kWave) void ns_kernel(int format, int level, uint32
       lds_order();
       uint32_t num_new_obs = 0;  // (wave-uniform copy of s->num_new_obs)
       const uint32_t in_max_block_end = blk_begin + (slen - blk_begin < (uint32_t)SOFT_MAX_BLOCK_LENGTH ? slen - blk_begin : (uint32_t)SOFT_MAX_BLOCK_LENGTH);
-      // ---- pass 0: the greedy parse, 64 positions at a time
+      // ---- pass 0: the greedy parse, NG x 64 positions at a time (one round trip to the match array per step)
       while (p < in_max_block_end) {
         if (num_new_obs >= 512u && p - blk_begin >= (uint32_t)MIN_BLOCK_LENGTH && slen - p >= (uint32_t)MIN_BLOCK_LENGTH) {
           uint32_t end = 0;  // should_end_block has something to decide before the token at p
@@ -602,37 +603,56 @@ __global__ __launch_bounds__(kWave) void ns_kernel(int format, int level, uint32
           num_new_obs = uni((uint32_t)s->num_new_obs);
           if (end) break;
         }
-        const uint32_t q = p + lane;
-        const uint32_t mm = q < p_end ? __builtin_nontemporal_load(mwr + q) : kNoMatch;
-        const uint32_t byte = q < slen ? src[q] : 0u;
-        const uint32_t best = mm >> 16, off = mm & 0xffffu;
-        const bool is_match = best >= (uint32_t)MIN_MATCH_LEN;
-        const uint32_t jump = is_match ? best : 1u;
+        uint32_t mm[NG], byte[NG], jump[NG];
+#pragma unroll
+        for (int g = 0; g < NG; g++) {
+          const uint32_t q = p + g * kWave + lane;
+          mm[g] = q < p_end ? __builtin_nontemporal_load(mwr + q) : kNoMatch;
+          byte[g] = q < slen ? src[q] : 0u;
+        }
+#pragma unroll
+        for (int g = 0; g < NG; g++) jump[g] = (mm[g] >> 16) >= (uint32_t)MIN_MATCH_LEN ? mm[g] >> 16 : 1u;
         // the token starts among these positions (scalar unit; the test in front of a token is should_end_block's
         // `num_new_obs < 512 || ...` with the observations of this step counted in)
         uint32_t t = 0, cnt = 0;
-        uint64_t mask = 0;
-        while (t < (uint32_t)kWave && p + t < in_max_block_end) {
-          if (cnt && num_new_obs + cnt >= 512u && p + t - blk_begin >= (uint32_t)MIN_BLOCK_LENGTH && slen - (p + t) >= (uint32_t)MIN_BLOCK_LENGTH) break;
-          mask |= 1ull << t;
-          cnt++;
-          t += (uint32_t)__builtin_amdgcn_readlane((int)jump, (int)t);
-        }
-        const bool tok = (mask >> lane) & 1;
-        if (tok) {  // choose_match / choose_literal: the symbol counts, and the flag pass 1 finds the token by
-          if (is_match) {
-            atomicAdd(&s->freq_l[257 + length_slot((int)best)], 1);
-            atomicAdd(&s->freq_o[offset_slot((int)off)], 1);
-          } else {
-            atomicAdd(&s->freq_l[byte], 1);
+        uint64_t mask[NG];
+        bool due = false;
+#pragma unroll
+        for (int g = 0; g < NG; g++) {
+          mask[g] = 0;
+          while (!due && t < (uint32_t)(g + 1) * kWave && p + t < in_max_block_end) {
+            if (cnt && num_new_obs + cnt >= 512u && p + t - blk_begin >= (uint32_t)MIN_BLOCK_LENGTH && slen - (p + t) >= (uint32_t)MIN_BLOCK_LENGTH) {
+              due = true;
+              break;
+            }
+            mask[g] |= 1ull << (t - g * kWave);
+            cnt++;
+            t += (uint32_t)__builtin_amdgcn_readlane((int)jump[g], (int)(t - g * kWave));
           }
-          mwr[q] = mm | kTokenFlag;
         }
-        // observe_match / observe_literal (sic: upstream observes the POSITION, shifted left: its lowest bit)
-        const uint32_t n8 = (uint32_t)__builtin_popcountll(__ballot(tok && is_match && best < 9u));
-        const uint32_t n9 = (uint32_t)__builtin_popcountll(__ballot(tok && is_match && best >= 9u));
-        const uint32_t n0 = (uint32_t)__builtin_popcountll(__ballot(tok && !is_match && (q & 1u) == 0u));
-        const uint32_t n1 = (uint32_t)__builtin_popcountll(__ballot(tok && !is_match && (q & 1u) != 0u));
+        uint32_t n8 = 0, n9 = 0, n0 = 0, n1 = 0;
+#pragma unroll
+        for (int g = 0; g < NG; g++) {
+          if (mask[g] == 0) continue;  // (wave-uniform)
+          const uint32_t q = p + g * kWave + lane;
+          const uint32_t best = mm[g] >> 16, off = mm[g] & 0xffffu;
+          const bool is_match = best >= (uint32_t)MIN_MATCH_LEN;
+          const bool tok = (mask[g] >> lane) & 1;
+          if (tok) {  // choose_match / choose_literal: the symbol counts, and the flag pass 1 finds the token by
+            if (is_match) {
+              atomicAdd(&s->freq_l[257 + length_slot((int)best)], 1);
+              atomicAdd(&s->freq_o[offset_slot((int)off)], 1);
+            } else {
+              atomicAdd(&s->freq_l[byte[g]], 1);
+            }
+            mwr[q] = mm[g] | kTokenFlag;
+          }
+          // observe_match / observe_literal (sic: upstream observes the POSITION, shifted left: its lowest bit)
+          n8 += (uint32_t)__builtin_popcountll(__ballot(tok && is_match && best < 9u));
+          n9 += (uint32_t)__builtin_popcountll(__ballot(tok && is_match && best >= 9u));
+          n0 += (uint32_t)__builtin_popcountll(__ballot(tok && !is_match && (q & 1u) == 0u));
+          n1 += (uint32_t)__builtin_popcountll(__ballot(tok && !is_match && (q & 1u) != 0u));
+        }
         if (lane == 0) {
           s->new_obs[8] += (int)n8;
           s->new_obs[9] += (int)n9;
@@ -708,46 +728,56 @@ __global__ __launch_bounds__(kWave) void ns_kernel(int format, int level, uint32
         const uint32_t o1 = os.o_pos, b1 = (uint32_t)os.bits;
         Pack pk{os.hold, b1, o1, os.o_len, os.o};
         uint32_t sbits = 0;
-        for (uint32_t base = blk_begin; base < blk_end; base += kWave) {
-          const uint32_t q = base + lane;
-          const uint32_t mm = q < blk_end ? __builtin_nontemporal_load(mwr + q) : 0u;
-          uint64_t v = 0;
-          uint32_t nb = 0;
-          if (mm & kTokenFlag) {
-            const uint32_t best = (mm >> 16) & 0x1ffu, off = mm & 0xffffu;
-            if (best >= (uint32_t)MIN_MATCH_LEN) {
-              const int lslot = length_slot((int)best), oslot = offset_slot((int)off);
-              int l, c, l2, c2;
-              if (block_type == 2) {
-                l = s->len_l[257 + lslot];
-                c = s->cw_l[257 + lslot];
-                l2 = s->len_o[oslot];
-                c2 = s->cw_o[oslot];
-              } else {
-                static_litlen(257 + lslot, &l, &c);
-                l2 = 5;
-                c2 = (int)(__brev((unsigned)oslot) >> 27);
-              }
-              v = (uint64_t)(uint32_t)c;
-              nb = (uint32_t)l;
-              v |= (uint64_t)(best - c_base_length[lslot] - 3u) << nb;
-              nb += c_extra_lbits[lslot];
-              v |= (uint64_t)(uint32_t)c2 << nb;
-              nb += (uint32_t)l2;
-              v |= (uint64_t)(off - (uint32_t)c_base_dist[oslot] - 1u) << nb;
-              nb += c_extra_dbits[oslot];
-            } else {
-              const int lit = src[q];
-              int l, c;
-              if (block_type == 2) {
-                l = s->len_l[lit];
-                c = s->cw_l[lit];
-              } else static_litlen(lit, &l, &c);
-              v = (uint64_t)(uint32_t)c;
-              nb = (uint32_t)l;
-            }
+        for (uint32_t base = blk_begin; base < blk_end; base += NG * kWave) {
+          uint32_t mw4[NG], lit4[NG];
+#pragma unroll
+          for (int g = 0; g < NG; g++) {
+            const uint32_t q = base + g * kWave + lane;
+            mw4[g] = q < blk_end ? __builtin_nontemporal_load(mwr + q) : 0u;
+            lit4[g] = q < blk_end ? src[q] : 0u;  // (blk_end <= slen)
           }
-          sbits += pack_step(s, lane, v, nb, pk);
+#pragma unroll
+          for (int g = 0; g < NG; g++) {
+            if (base + g * kWave >= blk_end) break;  // (wave-uniform)
+            const uint32_t mm = mw4[g];
+            uint64_t v = 0;
+            uint32_t nb = 0;
+            if (mm & kTokenFlag) {
+              const uint32_t best = (mm >> 16) & 0x1ffu, off = mm & 0xffffu;
+              if (best >= (uint32_t)MIN_MATCH_LEN) {
+                const int lslot = length_slot((int)best), oslot = offset_slot((int)off);
+                int l, c, l2, c2;
+                if (block_type == 2) {
+                  l = s->len_l[257 + lslot];
+                  c = s->cw_l[257 + lslot];
+                  l2 = s->len_o[oslot];
+                  c2 = s->cw_o[oslot];
+                } else {
+                  static_litlen(257 + lslot, &l, &c);
+                  l2 = 5;
+                  c2 = (int)(__brev((unsigned)oslot) >> 27);
+                }
+                v = (uint64_t)(uint32_t)c;
+                nb = (uint32_t)l;
+                v |= (uint64_t)(best - c_base_length[lslot] - 3u) << nb;
+                nb += c_extra_lbits[lslot];
+                v |= (uint64_t)(uint32_t)c2 << nb;
+                nb += (uint32_t)l2;
+                v |= (uint64_t)(off - (uint32_t)c_base_dist[oslot] - 1u) << nb;
+                nb += c_extra_dbits[oslot];
+              } else {
+                const int lit = (int)lit4[g];
+                int l, c;
+                if (block_type == 2) {
+                  l = s->len_l[lit];
+                  c = s->cw_l[lit];
+                } else static_litlen(lit, &l, &c);
+                v = (uint64_t)(uint32_t)c;
+                nb = (uint32_t)l;
+              }
+            }
+            sbits += pack_step(s, lane, v, nb, pk);
+          }
         }
         {  // write_end_of_block
           uint64_t v = 0;

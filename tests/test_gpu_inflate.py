@@ -146,6 +146,39 @@ def test_errors_match_oracle(eng_ring, oracle):
         assert (st, used) == (ost, oused)
 
 
+def test_hand_over_between_block_kinds(eng_ring, oracle):
+    """Streams whose blocks change kind all the time — stored, fixed, dynamic, empty (sync-flush) blocks of every size
+    around the staging buffer — with room for all of the output, for a part of it, and cut short: the decoder and the
+    copier wavefront hand over Huffman rounds and stored bytes in every order.  Same status / count / bytes as the oracle."""
+    rng = random.Random(0x2a7e)
+    sizes = [0, 1, 5, 64, 700, 5551, 5552, 5553, 5568, 6200, 11104, 20000, 65535, 65536, 70000]
+    kinds = ["text", "rand", "runs", "far"]
+    srcs, caps, plains = [], [], []
+    for case in range(48):
+        body, plain = bytearray(), bytearray()
+        nseg = rng.randrange(2, 9)
+        for k in range(nseg):
+            data = _mk(rng, rng.choice(sizes), rng.choice(kinds))
+            level, strat = rng.choice(((0, 0), (1, 0), (6, 0), (9, 0), (6, zlib.Z_FIXED), (6, zlib.Z_HUFFMAN_ONLY)))
+            co = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strat)
+            # every segment but the last ends on a byte boundary with non-final blocks; a segment starts without history
+            body += co.compress(data) + (co.flush() if k == nseg - 1 else co.flush(zlib.Z_SYNC_FLUSH))
+            plain += data
+        raw, plain = bytes(body), bytes(plain)
+        assert zlib.decompress(raw, -15) == plain
+        for cap in (len(plain), len(plain) + 7, len(plain) // 2, max(0, len(plain) - 1)):
+            srcs.append(raw); caps.append(cap); plains.append(plain)
+        cut = rng.randrange(1, len(raw))
+        srcs.append(raw[:cut]); caps.append(len(plain)); plains.append(plain)
+    res = eng_ring.inflate_many(srcs, caps)
+    for src, cap, plain, (st, used, out, _) in zip(srcs, caps, plains, res):
+        ost, oused, oout = oracle.de_inflate(src, cap)
+        assert (st, used) == (ost, oused), (len(src), cap, st, ost)
+        assert out == oout
+        if st == 0:
+            assert out == plain
+
+
 def test_stored_config1(eng_ring, oracle):
     eng = eng_ring
     """BASELINE config 1: 64 KiB of stored blocks (65535 + 1)."""
