@@ -616,18 +616,38 @@ __global__ __launch_bounds__(kWave) void ns_kernel(int format, int level, uint32
         // `num_new_obs < 512 || ...` with the observations of this step counted in)
         uint32_t t = 0, cnt = 0;
         uint64_t mask[NG];
-        bool due = false;
+        // can should_end_block become due inside this step?  Not while fewer than 512 observations can have been made
+        // at its end, and not before the block (or after the input's end minus) MIN_BLOCK_LENGTH: the usual step
+        // walks without asking
+        const uint32_t step_end = p + (uint32_t)(NG * kWave) + (uint32_t)MAX_MATCH_LEN;
+        const bool may_be_due = num_new_obs + (uint32_t)(NG * kWave) >= 512u && step_end - blk_begin >= (uint32_t)MIN_BLOCK_LENGTH &&
+                                slen - p >= (uint32_t)MIN_BLOCK_LENGTH;
+        const uint32_t t_end = in_max_block_end - p;  // > 0
+        if (!may_be_due) {
 #pragma unroll
-        for (int g = 0; g < NG; g++) {
-          mask[g] = 0;
-          while (!due && t < (uint32_t)(g + 1) * kWave && p + t < in_max_block_end) {
-            if (cnt && num_new_obs + cnt >= 512u && p + t - blk_begin >= (uint32_t)MIN_BLOCK_LENGTH && slen - (p + t) >= (uint32_t)MIN_BLOCK_LENGTH) {
-              due = true;
-              break;
+          for (int g = 0; g < NG; g++) {
+            mask[g] = 0;
+            const uint32_t lim = t_end < (uint32_t)(g + 1) * kWave ? t_end : (uint32_t)(g + 1) * kWave;
+            while (t < lim) {
+              mask[g] |= 1ull << (t - g * kWave);
+              cnt++;
+              t += (uint32_t)__builtin_amdgcn_readlane((int)jump[g], (int)(t - g * kWave));
             }
-            mask[g] |= 1ull << (t - g * kWave);
-            cnt++;
-            t += (uint32_t)__builtin_amdgcn_readlane((int)jump[g], (int)(t - g * kWave));
+          }
+        } else {
+          bool due = false;
+#pragma unroll
+          for (int g = 0; g < NG; g++) {
+            mask[g] = 0;
+            while (!due && t < (uint32_t)(g + 1) * kWave && t < t_end) {
+              if (cnt && num_new_obs + cnt >= 512u && p + t - blk_begin >= (uint32_t)MIN_BLOCK_LENGTH && slen - (p + t) >= (uint32_t)MIN_BLOCK_LENGTH) {
+                due = true;
+                break;
+              }
+              mask[g] |= 1ull << (t - g * kWave);
+              cnt++;
+              t += (uint32_t)__builtin_amdgcn_readlane((int)jump[g], (int)(t - g * kWave));
+            }
           }
         }
         uint32_t n8 = 0, n9 = 0, n0 = 0, n1 = 0;
@@ -728,14 +748,28 @@ __global__ __launch_bounds__(kWave) void ns_kernel(int format, int level, uint32
         const uint32_t o1 = os.o_pos, b1 = (uint32_t)os.bits;
         Pack pk{os.hold, b1, o1, os.o_len, os.o};
         uint32_t sbits = 0;
+        // the words and bytes of the next step are on their way while this one is packed (branch-free: a lane beyond
+        // the block reads position 0)
+        auto fetch = [&](uint32_t base, uint32_t (&mw)[NG], uint32_t (&lit)[NG]) {
+#pragma unroll
+          for (int g = 0; g < NG; g++) {
+            const uint32_t q = base + g * kWave + lane;
+            const uint32_t a = q < blk_end ? q : 0u;  // (blk_end <= slen)
+            mw[g] = __builtin_nontemporal_load(mwr + a);
+            lit[g] = src[a];
+          }
+        };
+        uint32_t nmw[NG], nlit[NG];
+        fetch(blk_begin, nmw, nlit);
         for (uint32_t base = blk_begin; base < blk_end; base += NG * kWave) {
           uint32_t mw4[NG], lit4[NG];
 #pragma unroll
           for (int g = 0; g < NG; g++) {
             const uint32_t q = base + g * kWave + lane;
-            mw4[g] = q < blk_end ? __builtin_nontemporal_load(mwr + q) : 0u;
-            lit4[g] = q < blk_end ? src[q] : 0u;  // (blk_end <= slen)
+            mw4[g] = q < blk_end ? nmw[g] : 0u;
+            lit4[g] = nlit[g];
           }
+          fetch(base + NG * kWave, nmw, nlit);
 #pragma unroll
           for (int g = 0; g < NG; g++) {
             if (base + g * kWave >= blk_end) break;  // (wave-uniform)
