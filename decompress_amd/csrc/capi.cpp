@@ -30,7 +30,8 @@ extern "C" int md_launch_deflate_plan(uint32_t n, const uint64_t *in_len, int dr
                                       uint64_t cap_positions, uint32_t cap_chunks, const md_front *f, hipStream_t stream);
 extern "C" int md_launch_deflate_front(uint32_t n, uint32_t nchunks_max, const uint8_t *in, const uint64_t *in_off,
                                        const uint64_t *in_len, int matcher, uint32_t max_chain, uint32_t nice,
-                                       const md_front *f, hipStream_t stream);
+                                       const md_front *f, const uint32_t *order, hipStream_t stream);
+extern "C" int md_launch_stream_order(uint32_t n, const uint64_t *in_len, uint32_t *order, hipStream_t stream);
 extern "C" void md_deflate_level_params(int driver, int matcher, int level, uint32_t *max_chain, uint32_t *nice);
 extern "C" int md_launch_def_ns(int format, int level, uint32_t n, uint32_t nchunks_max, const uint8_t *in, const uint64_t *in_off,
                                 const uint64_t *in_len, uint8_t *out, const uint64_t *out_off, const uint64_t *out_cap,
@@ -40,7 +41,7 @@ extern "C" int md_launch_deflate(int format, int level, int qcap, int driver, in
                                  uint8_t *out, const uint64_t *out_off, const uint64_t *out_cap,
                                  uint64_t *out_len, int32_t *status, uint32_t *checksum, const md_front *fr, void *queue_ws,
                                  uint64_t *dbg, const uint8_t *gz_hdr, uint32_t gz_hdr_len,
-                                 const uint32_t *gz_crc, int matcher, uint32_t *hist, hipStream_t stream);
+                                 const uint32_t *gz_crc, int matcher, uint32_t *hist, const uint32_t *order, hipStream_t stream);
 
 extern "C" int md_launch_gz_header(uint32_t n, const uint8_t *in, const uint64_t *in_off, const uint64_t *in_len,
                                    uint64_t *body_off, uint64_t *body_len, int32_t *hstatus, hipStream_t stream);
@@ -120,6 +121,7 @@ struct DeviceGuard {
   if (!guard_.ok) return fail(ctx, MD_E_HIP, "hipSetDevice")
 
 constexpr size_t kOrderFrom = 2049;  // 256 CUs x 8 resident wavefronts: smaller batches start all at once
+constexpr size_t kOrderFromDeflate = 257;  // the link kernel holds one stream per CU
 
 bool is_gfx950(int dev) {
   hipDeviceProp_t p;
@@ -298,6 +300,21 @@ static int gz_scratch(md_ctx *ctx, size_t n) {
   return MD_OK;
 }
 
+// the scratch for the launch order of a large batch (4 bytes per stream): kept by the context, only ever grows — the
+// one allocation a batch call can make, on its first large batch
+static int order_scratch(md_ctx *ctx, size_t n) {
+  if (n <= ctx->order_words) return MD_OK;
+  if (ctx->order) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipFree(ctx->order));
+    ctx->order = nullptr;
+    ctx->order_words = 0;
+  }
+  if (hipMalloc((void **)&ctx->order, n * 4) != hipSuccess) return fail(ctx, MD_E_OUT_OF_MEMORY, "hipMalloc(launch order)");
+  ctx->order_words = n;
+  return MD_OK;
+}
+
 int md_inflate_batch_device(md_ctx *ctx, int format, size_t n, const uint8_t *d_in,
                             const uint64_t *d_in_off, const uint64_t *d_in_len, uint8_t *d_out,
                             const uint64_t *d_out_off, const uint64_t *d_out_cap,
@@ -331,16 +348,8 @@ int md_inflate_batch_device(md_ctx *ctx, int format, size_t n, const uint8_t *d_
   // order is kept and only ever grows (the one allocation a batch call can make, on its first large batch)
   uint32_t *order = nullptr;
   if (n >= kOrderFrom) {
-    if (n > ctx->order_words) {
-      if (ctx->order) {
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        HIP_TRY(ctx, hipFree(ctx->order));
-        ctx->order = nullptr;
-        ctx->order_words = 0;
-      }
-      if (hipMalloc((void **)&ctx->order, n * 4) != hipSuccess) return fail(ctx, MD_E_OUT_OF_MEMORY, "hipMalloc(launch order)");
-      ctx->order_words = n;
-    }
+    const int orc = order_scratch(ctx, n);
+    if (orc != MD_OK) return orc;
     order = ctx->order;
   }
   int rc = md_launch_inflate_wave(format, (uint32_t)n, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap, d_out_len,
@@ -537,13 +546,22 @@ static int deflate_launch(md_ctx *ctx, int format, int level, int queue_len, int
     int e = md_launch_crc32((uint32_t)n, d_in, d_in_off, d_in_len, gz_crc, ctx->stream);
     if (e != 0) return fail(ctx, MD_E_HIP, "crc32 kernel launch", (hipError_t)e);
   }
+  // more streams than the link kernel (one per CU) or the sequential kernel (16 per CU) hold at once: longest first
+  uint32_t *order = nullptr;
+  if (n >= kOrderFromDeflate) {
+    const int orc = order_scratch(ctx, n);
+    if (orc != MD_OK) return orc;
+    order = ctx->order;
+    int oe = md_launch_stream_order((uint32_t)n, d_in_len, order, ctx->stream);
+    if (oe != 0) return fail(ctx, MD_E_HIP, "launch order kernel", (hipError_t)oe);
+  }
   if (matcher_runs && chunks != 0) {
-    int frc = md_launch_deflate_front((uint32_t)n, chunks, d_in, d_in_off, d_in_len, matcher, max_chain, nice, &fr, ctx->stream);
+    int frc = md_launch_deflate_front((uint32_t)n, chunks, d_in, d_in_off, d_in_len, matcher, max_chain, nice, &fr, order, ctx->stream);
     if (frc != 0) return fail(ctx, MD_E_HIP, "deflate front kernel launch", (hipError_t)frc);
   }
   int rc = md_launch_deflate(format, level, queue_len, driver, dynamic, (uint32_t)n, d_in, d_in_off, d_in_len, d_out,
                              d_out_off, d_out_cap, d_out_len, d_status, d_checksum, &fr, ctx->ws, ctx->dbg,
-                             gz_hdr, gz_hdr_len, gz_crc, matcher, d_hist, ctx->stream);
+                             gz_hdr, gz_hdr_len, gz_crc, matcher, d_hist, order, ctx->stream);
   if (rc != 0) return fail(ctx, MD_E_HIP, "deflate kernel launch", (hipError_t)rc);
   return MD_OK;
 }

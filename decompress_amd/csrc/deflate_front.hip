@@ -120,15 +120,16 @@ __global__ __launch_bounds__(LW *kWave) void deflate_link_kernel(uint32_t n, con
                                                                  const uint32_t *__restrict__ p_end_a,
                                                                  const uint64_t *__restrict__ slot, uint32_t *__restrict__ link,
                                                                  uint32_t *__restrict__ tail, const uint32_t *__restrict__ flags,
-                                                                 int matcher) {
+                                                                 int matcher, const uint32_t *__restrict__ order) {
   __shared__ uint32_t head[HASH_SIZE];  // absolute position, 0 = NIL (position 0 can never match, like the reference)
   __shared__ uint32_t gmin_all[LW][kWave];
   __shared__ uint32_t turn;  // the group whose atomics may be issued
   // De.Lz77: position 0 is NIL (it can never be a match source there); Def.Ns: position 0 is an ordinary candidate, so
   // the table holds position + 1
   constexpr uint32_t bias = NS ? 1u : 0u;
-  const uint32_t lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave, sid = blockIdx.x;
-  if (sid >= n || flags[0]) return;
+  const uint32_t lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+  if (blockIdx.x >= n || flags[0]) return;
+  const uint32_t sid = order ? order[blockIdx.x] : blockIdx.x;  // a CU holds one stream: the longest go first
   const uint32_t p_end = p_end_a[sid];
   const uint64_t l64 = in_len[sid];
   const uint32_t slen = l64 > MD_MAX_STREAM ? 0u : (uint32_t)l64;
@@ -450,11 +451,11 @@ extern "C" int md_launch_deflate_plan(uint32_t n, const uint64_t *in_len, int dr
 // link[] / tail[], then flg[] / m[] / mq[]: nchunks_max >= chunk0[n]
 extern "C" int md_launch_deflate_front(uint32_t n, uint32_t nchunks_max, const uint8_t *in, const uint64_t *in_off,
                                        const uint64_t *in_len, int matcher, uint32_t max_chain, uint32_t nice,
-                                       const md::defl::Front *f, hipStream_t stream) {
+                                       const md::defl::Front *f, const uint32_t *order, hipStream_t stream) {
   using namespace md::defl;
   if (n == 0 || nchunks_max == 0) return 0;
   hipLaunchKernelGGL(deflate_link_kernel<false>, dim3(n), dim3(LW * kWave), 0, stream, n, in, in_off, in_len, f->p_end, f->slot,
-                     f->link, (uint32_t *)f->tail, f->flags, matcher);
+                     f->link, (uint32_t *)f->tail, f->flags, matcher, order);
   const uint32_t per = (nchunks_max + 7) / 8;
   hipLaunchKernelGGL(deflate_match_kernel, dim3(per * 8), dim3(kWave), 0, stream, n, nchunks_max, in, in_off, in_len, f->p_end,
                      f->slot, f->chunk0, f->link, f->flg, f->m, f->mq, f->flags, max_chain, nice);
@@ -464,8 +465,9 @@ extern "C" int md_launch_deflate_front(uint32_t n, uint32_t nchunks_max, const u
 // the chains of De.Def.Ns's hc_matchfinder (deflate_ns.hip)
 extern "C" int md_launch_link_ns(uint32_t n, const uint8_t *in, const uint64_t *in_off, const uint64_t *in_len, const md::defl::Front *f,
                                  hipStream_t stream) {
+  const uint32_t *order = nullptr;
   using namespace md::defl;
   hipLaunchKernelGGL(deflate_link_kernel<true>, dim3(n), dim3(LW * kWave), 0, stream, n, in, in_off, in_len, f->p_end, f->slot,
-                     f->link, (uint32_t *)f->tail, f->flags, 0);
+                     f->link, (uint32_t *)f->tail, f->flags, 0, order);
   return (int)hipGetLastError();
 }

@@ -1380,7 +1380,7 @@ __global__ __launch_bounds__(kWave, 4) void deflate_kernel(
     const uint64_t *__restrict__ out_off, const uint64_t *__restrict__ out_cap,
     uint64_t *__restrict__ out_len, int32_t *__restrict__ status, uint32_t *__restrict__ checksum,
     Front fr, int *__restrict__ ws_queue, uint64_t *__restrict__ dbg, const uint8_t *__restrict__ gz_hdr, uint32_t gz_hdr_len,
-    const uint32_t *__restrict__ gz_crc, int matcher, uint32_t *__restrict__ hist) {
+    const uint32_t *__restrict__ gz_crc, int matcher, uint32_t *__restrict__ hist, const uint32_t *__restrict__ order) {
   __shared__ DS ds;
   // optional phase profile of stream 0 (md_set_option "profile"): [0] setup [1] look-ahead [2] bulk
   // literal runs [3] matcher/driver (lane 0) [4] bit packing [5] trees, in clock ticks; [8..] event counts
@@ -1393,8 +1393,9 @@ __global__ __launch_bounds__(kWave, 4) void deflate_kernel(
     pt[i] += t_now - t_prev;              \
     t_prev = t_now;                       \
   }
-  const uint32_t lane = threadIdx.x, sid = blockIdx.x;
-  if (sid >= n) return;
+  const uint32_t lane = threadIdx.x;
+  if (blockIdx.x >= n) return;
+  const uint32_t sid = order ? order[blockIdx.x] : blockIdx.x;  // workgroups start in index order: longest streams first
   const uint8_t *src = in + in_off[sid];
   if (in_len[sid] > MD_MAX_STREAM || fr.flags[0]) {  // 32-bit cursors: the descriptor is out of range (mdeflate.h);
                                                        // or the batch is larger than md_deflate_params.total_in_bytes said
@@ -1918,16 +1919,17 @@ extern "C" int md_launch_deflate(int format, int level, int qcap, int driver, in
                                  uint8_t *out, const uint64_t *out_off, const uint64_t *out_cap,
                                  uint64_t *out_len, int32_t *status, uint32_t *checksum, const md::defl::Front *fr,
                                  void *queue_ws, uint64_t *dbg, const uint8_t *gz_hdr, uint32_t gz_hdr_len,
-                                 const uint32_t *gz_crc, int matcher, uint32_t *hist, hipStream_t stream) {
+                                 const uint32_t *gz_crc, int matcher, uint32_t *hist, const uint32_t *order, hipStream_t stream) {
   if (n == 0) return 0;
+  if (dbg) order = nullptr;  // (the profile is stream 0's)
   if (dbg)
     hipLaunchKernelGGL(md::defl::deflate_kernel<true>, dim3(n), dim3(md::defl::kWave), 0, stream, format, level,
                        qcap, driver, dynamic, n, in, in_off, in_len, out, out_off, out_cap, out_len, status,
-                       checksum, *fr, (int *)queue_ws, dbg, gz_hdr, gz_hdr_len, gz_crc, matcher, hist);
+                       checksum, *fr, (int *)queue_ws, dbg, gz_hdr, gz_hdr_len, gz_crc, matcher, hist, order);
   else
     hipLaunchKernelGGL(md::defl::deflate_kernel<false>, dim3(n), dim3(md::defl::kWave), 0, stream, format, level,
                        qcap, driver, dynamic, n, in, in_off, in_len, out, out_off, out_cap, out_len, status,
-                       checksum, *fr, (int *)queue_ws, dbg, gz_hdr, gz_hdr_len, gz_crc, matcher, hist);
+                       checksum, *fr, (int *)queue_ws, dbg, gz_hdr, gz_hdr_len, gz_crc, matcher, hist, order);
   return (int)hipGetLastError();
 }
 

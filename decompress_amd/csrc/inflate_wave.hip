@@ -1457,6 +1457,13 @@ __global__ __launch_bounds__(kOrderThreads) void inflate_order_kernel(uint32_t n
 }  // namespace wv
 }  // namespace md
 
+// the launch order of a batch (longest first) on its own: the deflate kernels take it too
+extern "C" int md_launch_stream_order(uint32_t n, const uint64_t *in_len, uint32_t *order, hipStream_t stream) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(md::wv::inflate_order_kernel, dim3(1), dim3(md::wv::kOrderThreads), 0, stream, n, in_len, order);
+  return (int)hipGetLastError();
+}
+
 // `order` = n words of device scratch, or null for index order; waves = wavefronts per stream (2, or 1)
 extern "C" int md_launch_inflate_wave(int format, uint32_t n, const uint8_t *in, const uint64_t *in_off,
                                       const uint64_t *in_len, uint8_t *out, const uint64_t *out_off,
