@@ -91,7 +91,7 @@ def test_round_trip_on_gpu(eng):
 
 def test_equal_hashes_inside_a_step(eng, oracle):
     """the link kernel sorts out positions that share a hash inside one 64-position step (and across the steps of a
-    group, and across the four wavefronts' groups) by ballots: inputs made of short periods and runs put dozens of equal
+    group, and across the wavefronts' groups) by ballots: inputs made of short periods and runs put dozens of equal
     hashes into every step"""
     from decompress_amd import workloads
     bufs = [workloads.text(60, 90000), workloads.ascii_uniform(61, 150000), b"abc" * 30000, b"q" * 5, b"q" * 100000,
