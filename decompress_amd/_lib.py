@@ -20,6 +20,12 @@ class GzHeader(ctypes.Structure):
                 ("filename", ctypes.c_char_p), ("comment", ctypes.c_char_p)]
 
 
+class InfResume(ctypes.Structure):
+    """md_inf_resume (mdeflate.h): the last block boundary inside a piece of a stream"""
+    _fields_ = [("bits", ctypes.c_uint64), ("out", ctypes.c_uint64), ("adler", ctypes.c_uint32), ("last", ctypes.c_uint32),
+                ("consumed", ctypes.c_uint64), ("checksum", ctypes.c_uint32)]
+
+
 class DeflateParams(ctypes.Structure):
     """md_deflate_params of include/mdeflate.h"""
     _fields_ = [("level", ctypes.c_int), ("queue_len", ctypes.c_int), ("driver", ctypes.c_int), ("dynamic", ctypes.c_int),
@@ -69,6 +75,8 @@ SYMBOLS = [
     ("md_inf_checksum", ctypes.c_uint32, [c_vp]),
     ("md_inf_free", None, [c_vp]),
     ("md_inf_reset", None, [c_vp]),
+    ("md_inf_chunk_bytes", None, [c_vp, c_sz]),
+    ("md_de_inf_continue_host", ctypes.c_int, [c_vp, c_vp, c_sz, ctypes.c_uint, c_vp, c_sz, c_sz, ctypes.c_uint32, c_vp, c_vp, c_vp]),
     ("md_inf_message", ctypes.c_char_p, [c_vp]),
     ("md_def_encoder", c_vp, [c_vp, ctypes.c_int, c_pp, c_vp, c_sz]),
     ("md_def_src", ctypes.c_int, [c_vp, c_vp, c_sz, c_sz]),

@@ -15,7 +15,7 @@ extern "C" int md_launch_inflate_wave(int format, uint32_t n, const uint8_t *in,
                                       const uint64_t *in_len, uint8_t *out, const uint64_t *out_off,
                                       const uint64_t *out_cap, uint64_t *out_len, uint64_t *consumed,
                                       int32_t *status, uint32_t *checksum, uint64_t *dbg, uint32_t *order,
-                                      int waves, hipStream_t stream);
+                                      int waves, const void *cont_ptrs, hipStream_t stream);
 
 // deflate: the front workspace (deflate_common.hpp) is opaque here
 struct md_front {
@@ -353,7 +353,7 @@ int md_inflate_batch_device(md_ctx *ctx, int format, size_t n, const uint8_t *d_
     order = ctx->order;
   }
   int rc = md_launch_inflate_wave(format, (uint32_t)n, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap, d_out_len,
-                                  d_consumed, d_status, d_checksum, ctx->dbg, order, ctx->inflate_waves, ctx->stream);
+                                  d_consumed, d_status, d_checksum, ctx->dbg, order, ctx->inflate_waves, nullptr, ctx->stream);
   if (rc != 0) return fail(ctx, MD_E_HIP, "inflate kernel launch", (hipError_t)rc);
   return MD_OK;
 }
@@ -409,6 +409,50 @@ int md_inflate_batch_host(md_ctx *ctx, int format, size_t n, const uint8_t *h_in
   HIP_TRY(ctx, hipMemcpyAsync(status, dstatus, n * 4, hipMemcpyDeviceToHost, st));
   if (checksum) HIP_TRY(ctx, hipMemcpyAsync(checksum, dsum, n * 4, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
+  return MD_OK;
+}
+
+// One piece of a raw DEFLATE stream that is decoded as it arrives (mdeflate.h): the inflate kernel on one stream with
+// a starting bit, the window in front of the output buffer and the checksum state handed in, and the last block
+// boundary inside the piece handed back.
+int md_de_inf_continue_host(md_ctx *ctx, const uint8_t *src, size_t src_len, unsigned start_bit, uint8_t *dst, size_t hist_len,
+                            size_t dst_cap, uint32_t adler_in, size_t *dst_len, int *status, md_inf_resume *resume) {
+  if (!ctx || (!src && src_len) || !dst || !dst_len || !status || !resume) return MD_E_INVALID_ARGUMENT;
+  if (start_bit > 7 || hist_len > 32768 || hist_len > dst_cap || dst_cap > MD_MAX_STREAM || src_len > MD_MAX_INFLATE_IN)
+    return fail(ctx, MD_E_INVALID_ARGUMENT, "md_de_inf_continue_host: start_bit <= 7, hist_len <= 32768 and <= dst_cap");
+  MD_ON_DEVICE(ctx);
+  DevBuf din, dout, ddesc;
+  // descriptors: in_off in_len out_off out_cap out_len consumed resume_bits resume_out (u64); status, checksum,
+  // start_bit, hist_len, adler_in, resume_adler, resume_last (u32)
+  if (din.alloc(src_len + 16) != hipSuccess || dout.alloc(dst_cap + 16) != hipSuccess || ddesc.alloc(8 * 8 + 7 * 4) != hipSuccess)
+    return fail(ctx, MD_E_OUT_OF_MEMORY, "hipMalloc");
+  uint64_t h64[8] = {0, (uint64_t)src_len, 0, (uint64_t)dst_cap, 0, 0, 0, 0};
+  uint32_t h32[7] = {0, 0, start_bit, (uint32_t)hist_len, adler_in, 0, 0};
+  uint64_t *d64 = (uint64_t *)ddesc.p;
+  uint32_t *d32 = (uint32_t *)(d64 + 8);
+  hipStream_t st = ctx->stream;
+  if (src_len) HIP_TRY(ctx, hipMemcpyAsync(din.p, src, src_len, hipMemcpyHostToDevice, st));
+  if (hist_len) HIP_TRY(ctx, hipMemcpyAsync(dout.p, dst, hist_len, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(d64, h64, sizeof h64, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(d32, h32, sizeof h32, hipMemcpyHostToDevice, st));
+  const void *cont[7] = {d32 + 2, d32 + 3, d32 + 4, d64 + 6, d64 + 7, d32 + 5, d32 + 6};
+  int rc = md_launch_inflate_wave(MD_FORMAT_DEFLATE, 1, (const uint8_t *)din.p, d64 + 0, d64 + 1, (uint8_t *)dout.p, d64 + 2,
+                                  d64 + 3, d64 + 4, d64 + 5, (int32_t *)d32, d32 + 1, nullptr, nullptr, ctx->inflate_waves,
+                                  cont, st);
+  if (rc != 0) return fail(ctx, MD_E_HIP, "inflate kernel launch", (hipError_t)rc);
+  HIP_TRY(ctx, hipMemcpyAsync(h64, d64, sizeof h64, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipMemcpyAsync(h32, d32, sizeof h32, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  const size_t produced = (size_t)h64[4];
+  if (produced > hist_len) HIP_TRY(ctx, hipMemcpy(dst + hist_len, (const uint8_t *)dout.p + hist_len, produced - hist_len, hipMemcpyDeviceToHost));
+  *dst_len = produced;
+  *status = (int32_t)h32[0];
+  resume->bits = h64[6];
+  resume->out = h64[7];
+  resume->adler = h32[5];
+  resume->last = h32[6];
+  resume->consumed = h64[5];
+  resume->checksum = h32[1];
   return MD_OK;
 }
 

@@ -43,6 +43,7 @@
 // blocks (lib/de.ml:1613-1627) and the zlib frame (lib/zl.ml:400-417) run between rounds.  The first
 // failing token in stream order decides the status and everything before it is written
 // (oracle/de_inflate.c).
+#include <string.h>
 #include "inflate_util.hpp"
 
 namespace md {
@@ -1237,6 +1238,17 @@ __device__ __forceinline__ void copier_main(lds_smem *sm, const uint8_t *__restr
   }
 }
 
+// A stream decoded in pieces (md_de_inf_continue_host: the `Flush steps of De.Inf.decode while input is still arriving,
+// lib/de.ml:1427-1474): the piece starts start_bit bits into its first byte, the output buffer begins with hist_len
+// bytes of what was decoded before (the window), the checksum goes on from adler_in; the kernel says where the last
+// block that was complete in this piece ended (bit position, output position, checksum state there) so that the next
+// piece can start at that block boundary.  All pointers null: a whole stream, nothing to report (the batch path).
+struct Cont {
+  const uint32_t *start_bit, *hist_len, *adler_in;
+  uint64_t *resume_bits, *resume_out;
+  uint32_t *resume_adler, *resume_last;
+};
+
 // PAIR = two wavefronts per stream (decoder + copier, see inflate_block); otherwise one wavefront does both in turn.
 template <bool PROF, bool PAIR>
 __global__ __launch_bounds__(PAIR ? 2 * kWave : kWave, PAIR ? 4 : 2) void inflate_wave_kernel(
@@ -1244,7 +1256,7 @@ __global__ __launch_bounds__(PAIR ? 2 * kWave : kWave, PAIR ? 4 : 2) void inflat
     const uint64_t *__restrict__ in_len, uint8_t *out, const uint64_t *__restrict__ out_off,
     const uint64_t *__restrict__ out_cap, uint64_t *__restrict__ out_len,
     uint64_t *__restrict__ consumed, int32_t *__restrict__ status, uint32_t *__restrict__ checksum,
-    uint64_t *__restrict__ dbg, const uint32_t *__restrict__ order) {
+    uint64_t *__restrict__ dbg, const uint32_t *__restrict__ order, Cont cont) {
   __shared__ Smem smem;  // static: LDS addresses fold into the instructions' offset fields
   lds_smem *sm = (lds_smem *)&smem;
   Prof<PROF> pf;
@@ -1289,16 +1301,17 @@ __global__ __launch_bounds__(PAIR ? 2 * kWave : kWave, PAIR ? 4 : 2) void inflat
   sk.stage = (lds_u8 *)sm->stage;
   sk.g = out + out_off[sid];
   sk.cap = cap;
-  sk.pos = 0;
+  const uint32_t hist = cont.hist_len ? cont.hist_len[sid] : 0u, adler0 = cont.adler_in ? cont.adler_in[sid] : 1u;
+  sk.pos = hist < cap ? hist : cap;  // (the history is the caller's: it fits the buffer)
   sk.lane = lane;
-  sk.a = 1;
-  sk.b = 0;
-  sk.want_adler = (checksum != nullptr) || format == MD_FORMAT_ZLIB;
+  sk.a = adler0 & 0xffffu;
+  sk.b = adler0 >> 16;
+  sk.want_adler = (checksum != nullptr) || format == MD_FORMAT_ZLIB || cont.resume_adler != nullptr;
 
   if (threadIdx.x < 4) sm->lut[kStopEobI + threadIdx.x] = mk_entry(0, 0, 0, 0, kStopEobI + (threadIdx.x & 1));  // the self-looping STOP entries
   for (uint32_t i = threadIdx.x; i < STAGE / 32 + 2; i += blockDim.x) sm->pend[i] = 0;
   if constexpr (PAIR) {
-    if (threadIdx.x < sizeof(Mail) / 4) ((lds_u32 *)&sm->mail)[threadIdx.x] = threadIdx.x == 6 ? 1u : 0u;  // a = 1
+    if (threadIdx.x < sizeof(Mail) / 4) ((lds_u32 *)&sm->mail)[threadIdx.x] = threadIdx.x == 6 ? sk.a : threadIdx.x == 7 ? sk.b : 0u;
     __syncthreads();
     if (wave == 1) {
       copier_main(sm, body, sk, lane, pf);
@@ -1316,11 +1329,17 @@ __global__ __launch_bounds__(PAIR ? 2 * kWave : kWave, PAIR ? 4 : 2) void inflat
 
   lds_u32 *win = (lds_u32 *)sm->win;
   const uint32_t total_bits = body_len * 8;
-  uint32_t bp = 0;
+  uint32_t bp = cont.start_bit ? cont.start_bit[sid] & 7u : 0u;
   uint32_t zone = S;
   uint32_t sent = 0;  // PAIR: jobs posted
   Window wnd;
   wnd.base = 0xffffffffu;
+  if (cont.resume_bits && lane == 0) {  // no block complete yet
+    cont.resume_bits[sid] = bp;
+    cont.resume_out[sid] = sk.pos;
+    cont.resume_adler[sid] = adler0;
+    cont.resume_last[sid] = 0;
+  }
 
   if (rc == MD_OK) {
     bool last = false;
@@ -1374,6 +1393,19 @@ __global__ __launch_bounds__(PAIR ? 2 * kWave : kWave, PAIR ? 4 : 2) void inflat
         lroot = uni(lroot);
         pf.tick(P_HEADER);
         if (rc == MD_OK) rc = inflate_block<Prof<PROF>, PAIR>(sm, body, body_len, sk, lroot, lane, &bp, &zone, wnd, sent, pf);
+      }
+      if (cont.resume_bits && rc == MD_OK) {  // a block is complete: the next piece of the stream could start here
+        if constexpr (PAIR) {                 // (the checksum state is the copier's)
+          if (!mail_wait_idle(sm, sent)) rc = MD_E_HIP;
+          sk.a = uni(sm->mail.a);
+          sk.b = uni(sm->mail.b);
+        }
+        if (lane == 0) {
+          cont.resume_bits[sid] = bp;
+          cont.resume_out[sid] = sk.pos;
+          cont.resume_adler[sid] = (sk.b << 16) | sk.a;
+          cont.resume_last[sid] = last ? 1u : 0u;
+        }
       }
     }
   }
@@ -1469,16 +1501,18 @@ extern "C" int md_launch_inflate_wave(int format, uint32_t n, const uint8_t *in,
                                       const uint64_t *in_len, uint8_t *out, const uint64_t *out_off,
                                       const uint64_t *out_cap, uint64_t *out_len, uint64_t *consumed,
                                       int32_t *status, uint32_t *checksum, uint64_t *dbg, uint32_t *order,
-                                      int waves, hipStream_t stream) {
+                                      int waves, const void *cont_ptrs, hipStream_t stream) {
   if (n == 0) return 0;
   using namespace md::wv;
   const bool single = waves == 1;  // the one-wavefront form of the kernel: same results, kept for comparison
   dim3 grid(n), block(single ? kWave : 2 * kWave);
   if (order) hipLaunchKernelGGL(inflate_order_kernel, dim3(1), dim3(kOrderThreads), 0, stream, n, in_len, order);
   const uint32_t *ord = dbg ? nullptr : order;
+  Cont cont{};  // (seven device pointers in the order of struct Cont, or null)
+  if (cont_ptrs) memcpy(&cont, cont_ptrs, sizeof cont);
 #define MD_LAUNCH_INFLATE(P, Q)                                                                                          \
   hipLaunchKernelGGL((inflate_wave_kernel<P, Q>), grid, block, 0, stream, format, n, in, in_off, in_len, out, out_off, \
-                     out_cap, out_len, consumed, status, checksum, dbg, ord)
+                     out_cap, out_len, consumed, status, checksum, dbg, ord, cont)
   if (dbg) {
     if (single) MD_LAUNCH_INFLATE(true, false);
     else MD_LAUNCH_INFLATE(true, true);

@@ -4,10 +4,13 @@
 // De.Inf.decode (lib/de.ml:1427-1474, signature lib/de.mli:82-144) and Zl.Def.encode / De.Def.encode's drivers
 // (lib/zl.ml:509-555, lib/de.mli:300-412) hand a few KiB to the codec per call; a kernel launch per 64 KiB step
 // cannot pay for itself, so the shim keeps the reference's calling protocol on the HOST — it collects the chunks
-// the caller supplies through src, runs ONE batch-of-one launch of the HIP path when the caller signals the end
-// of input (src with length 0, as in the reference), and then hands the result out through the caller's output
-// buffer in `Flush steps.  There is no CPU codec here: without a gfx950 device the launch fails and the stream
-// reports the call-level error.
+// the caller supplies through src and runs the HIP path on them in large pieces: a stream that ends before a piece
+// (md_inf_chunk_bytes, 1 MiB) is full is ONE batch-of-one launch when the caller signals the end of input (src with
+// length 0, as in the reference); a longer DEFLATE / ZLIB stream is decoded piece by piece up to the last block
+// boundary inside each piece (md_de_inf_continue_host: starting bit, 32 KiB window and checksum state go in, the
+// boundary comes back), so that output is handed out through `Flush steps while input is still arriving and only the
+// undecoded tail and the window are kept.  There is no CPU codec here: without a gfx950 device the launch fails and
+// the stream reports the call-level error.
 //
 // Divergence (documented): the kernels have De.Inf.Ns's whole-buffer end-of-input rule; the
 // streaming rule of lib/de.ml:941-944 (a final end-of-block code shorter than the longest code is accepted at the
@@ -34,7 +37,26 @@ struct md_inf_stream {
   size_t consumed;
   uint32_t checksum;
   std::string message;        // the reference's `Malformed string, with its numbers
+  // decoding in pieces (DEFLATE / ZLIB): `in` is then the undecoded tail, `out` what the last piece produced
+  size_t chunk, need;         // input buffered before a piece is decoded; before the NEXT piece (grows when a piece holds no block end)
+  bool piecewise, hdr_done, body_done, finished;
+  unsigned in_bit;            // the next block starts this many bits into in[0]
+  std::vector<uint8_t> hist;  // the window: the last <= 32 KiB of output
+  uint32_t adler;             // checksum state at the last block boundary
 };
+static void inf_clear(md_inf_stream *s) {
+  s->in.clear();
+  s->out.clear();
+  s->hist.clear();
+  s->message.clear();
+  s->o_pos = s->served = s->consumed = 0;
+  s->eoi = s->ran = s->piecewise = s->hdr_done = s->body_done = s->finished = false;
+  s->status = MD_OK;
+  s->checksum = 0;
+  s->need = s->chunk;
+  s->in_bit = 0;
+  s->adler = 1;
+}
 
 extern "C" {
 
@@ -46,12 +68,8 @@ md_inf_stream *md_inf_decoder(md_ctx *ctx, int format, uint8_t *o, size_t o_len)
   s->format = format;
   s->o = o;
   s->o_len = o_len;
-  s->o_pos = 0;
-  s->served = 0;
-  s->eoi = s->ran = false;
-  s->status = MD_OK;
-  s->consumed = 0;
-  s->checksum = 0;
+  s->chunk = (size_t)1 << 20;
+  inf_clear(s);
   return s;
 }
 
@@ -59,14 +77,11 @@ void md_inf_free(md_inf_stream *s) { delete s; }
 
 // De.Inf.reset (lib/de.ml:1512-1532; Zl.Inf.reset, Gz.Inf.reset): the same decoder, output buffer and format, a new stream
 void md_inf_reset(md_inf_stream *s) {
-  if (!s) return;
-  s->in.clear();
-  s->out.clear();
-  s->message.clear();
-  s->o_pos = s->served = s->consumed = 0;
-  s->eoi = s->ran = false;
-  s->status = MD_OK;
-  s->checksum = 0;
+  if (s) inf_clear(s);
+}
+void md_inf_chunk_bytes(md_inf_stream *s, size_t bytes) {
+  if (!s || s->piecewise) return;
+  s->chunk = s->need = bytes ? bytes : 1;
 }
 
 int md_inf_src(md_inf_stream *s, const uint8_t *buf, size_t off, size_t len) {
@@ -80,7 +95,7 @@ void md_inf_flush(md_inf_stream *s) {
   if (s) s->o_pos = 0;
 }
 size_t md_inf_dst_rem(const md_inf_stream *s) { return s ? s->o_len - s->o_pos : 0; }
-size_t md_inf_src_rem(const md_inf_stream *s) { return s && s->ran ? s->in.size() - s->consumed : 0; }
+size_t md_inf_src_rem(const md_inf_stream *s) { return s && (s->ran || s->finished) ? s->in.size() - s->consumed : 0; }
 int md_inf_status(const md_inf_stream *s) { return s ? s->status : MD_E_INVALID_ARGUMENT; }
 const char *md_inf_message(const md_inf_stream *s) {
   if (!s) return "Invalid argument";
@@ -187,20 +202,113 @@ static void inf_run(md_inf_stream *s) {
   }
 }
 
+// One piece of a stream that is decoded as it arrives: everything up to the last block boundary inside the buffered
+// input goes to `out`, the rest of the input stays; at the end of the input whatever is left is decoded for good.
+static void inf_piece(md_inf_stream *s) {
+  const bool final = s->eoi;
+  s->out.clear();
+  s->served = 0;
+  auto fail_with = [&](int st) {
+    s->status = st;
+    s->message = md_status_string(st);
+    s->finished = true;
+  };
+  if (s->format == MD_FORMAT_ZLIB && !s->hdr_done) {  // Zl.Inf's header, lib/zl.ml:142-165 (as the kernel checks it)
+    if (s->in.size() < 2) {
+      if (final) fail_with(MD_UNEXPECTED_END_OF_INPUT);
+      else s->need = 2;
+      return;
+    }
+    const unsigned cmf = s->in[0], flg = s->in[1];
+    if (((cmf << 8) + flg) % 31 != 0 || (cmf & 0xf) != 8) return fail_with(MD_INVALID_HEADER);
+    s->in.erase(s->in.begin(), s->in.begin() + 2);
+    s->hdr_done = true;
+  }
+  if (!s->body_done) {
+    const size_t hl = s->hist.size();
+    uint64_t cap = (uint64_t)hl + s->in.size() * 4 + 65536;
+    std::vector<uint8_t> buf;
+    size_t dst_len = 0;
+    int st = 0;
+    md_inf_resume rs;
+    static const uint8_t none = 0;
+    for (;;) {
+      if (cap > MD_MAX_STREAM) cap = MD_MAX_STREAM;
+      buf.resize((size_t)cap);
+      if (hl) memcpy(buf.data(), s->hist.data(), hl);
+      const int rc = md_de_inf_continue_host(s->ctx, s->in.empty() ? &none : s->in.data(), s->in.size(), s->in_bit, buf.data(), hl,
+                                             (size_t)cap, s->adler, &dst_len, &st, &rs);
+      if (rc != MD_OK) return fail_with(rc);
+      if (st == MD_UNEXPECTED_END_OF_OUTPUT && cap < MD_MAX_STREAM) {
+        cap *= 4;
+        continue;
+      }
+      break;
+    }
+    if (st == MD_UNEXPECTED_END_OF_INPUT && !final) {
+      // the piece ends inside a block: hand out what lies before that block, keep the rest of the input
+      const size_t upto = (size_t)rs.out;
+      const bool progress = rs.bits > s->in_bit;
+      s->out.assign(buf.begin() + hl, buf.begin() + upto);
+      const size_t keep = upto < 32768 ? upto : 32768;
+      s->hist.assign(buf.begin() + (upto - keep), buf.begin() + upto);
+      s->adler = rs.adler;
+      s->in.erase(s->in.begin(), s->in.begin() + (size_t)(rs.bits >> 3));
+      s->in_bit = (unsigned)(rs.bits & 7);
+      s->need = progress ? s->chunk : (s->in.size() * 2 > s->chunk ? s->in.size() * 2 : s->chunk);
+      return;
+    }
+    s->out.assign(buf.begin() + hl, buf.begin() + dst_len);  // everything decoded, also in front of an error
+    s->checksum = rs.checksum;
+    if (st != MD_OK) return fail_with(st);
+    s->body_done = true;
+    s->in.erase(s->in.begin(), s->in.begin() + (size_t)rs.consumed);
+    s->in_bit = 0;
+    if (s->format == MD_FORMAT_DEFLATE) {
+      s->status = MD_OK;
+      s->finished = true;
+      return;
+    }
+  }
+  // Zl.Inf's trailer: the Adler-32 of the output, big-endian (lib/zl.ml:171-186)
+  if (s->in.size() < 4) {
+    if (final) fail_with(MD_UNEXPECTED_END_OF_INPUT);
+    else s->need = 4;
+    return;
+  }
+  const uint32_t expect = ((uint32_t)s->in[0] << 24) | ((uint32_t)s->in[1] << 16) | ((uint32_t)s->in[2] << 8) | s->in[3];
+  s->in.erase(s->in.begin(), s->in.begin() + 4);
+  if (expect != s->checksum) {
+    char msg[96];
+    snprintf(msg, sizeof msg, "Invalid checksum (expect:%04lx, has:%04lx)", (unsigned long)expect, (unsigned long)s->checksum);
+    s->status = MD_INVALID_CHECKSUM;
+    s->message = msg;
+  } else {
+    s->status = MD_OK;
+  }
+  s->finished = true;
+}
+
 int md_inf_decode(md_inf_stream *s) {
   if (!s) return MD_MALFORMED;
-  if (!s->eoi) return MD_AWAIT;
-  if (!s->ran) {
-    inf_run(s);
-    s->ran = true;
+  for (;;) {
+    // what has been decoded goes to the caller's buffer first
+    const size_t left = s->out.size() - s->served, room = s->o_len - s->o_pos;
+    const size_t n = left < room ? left : room;
+    if (n) memcpy(s->o + s->o_pos, s->out.data() + s->served, n);
+    s->o_pos += n;
+    s->served += n;
+    if (s->served < s->out.size() || (n && s->o_pos == s->o_len && s->finished && s->status != MD_OK)) return MD_FLUSH;  // the buffer is full
+    if (s->finished) return s->status == MD_OK ? MD_END : MD_MALFORMED;
+    if (!s->piecewise && s->eoi) {  // the whole stream in one launch
+      inf_run(s);
+      s->ran = s->finished = true;
+      continue;
+    }
+    if (s->format == MD_FORMAT_GZIP || (!s->eoi && s->in.size() < s->need)) return MD_AWAIT;
+    s->piecewise = true;
+    inf_piece(s);
   }
-  const size_t left = s->out.size() - s->served, room = s->o_len - s->o_pos;
-  const size_t n = left < room ? left : room;
-  if (n) memcpy(s->o + s->o_pos, s->out.data() + s->served, n);
-  s->o_pos += n;
-  s->served += n;
-  if (s->served < s->out.size() || (n && s->o_pos == s->o_len && s->status != MD_OK)) return MD_FLUSH;  // the buffer is full
-  return s->status == MD_OK ? MD_END : MD_MALFORMED;
 }
 
 // ---- the encoder side: Zl.Def.encoder / Gz.Def.encoder / De.Higher's loop with `Manual src and dst ----

@@ -296,14 +296,39 @@ int md_def_ns_batch_device(md_ctx *ctx, int format, int level, size_t total_in_b
                            const uint64_t *d_in_off, const uint64_t *d_in_len, uint8_t *d_out, const uint64_t *d_out_off,
                            const uint64_t *d_out_cap, uint64_t *d_out_len, int32_t *d_status, uint32_t *d_checksum);
 
+/* ---- a DEFLATE stream decoded in pieces (De.Inf.decode's `Flush while input is still arriving, lib/de.ml:1427-1474) ----
+ * md_de_inf_continue_host decodes as much of a raw DEFLATE stream as the piece src[0, src_len) holds.  The piece
+ * starts start_bit (0..7) bits into src[0]; dst begins with hist_len (<= 32768) bytes of what was decoded before
+ * it — the window: matches may reach into them —, decoding writes from dst[hist_len] on, and adler_in is the Adler-32
+ * state to go on from (1 for a new stream).  On return *dst_len is the output position reached (history included),
+ * *status the stream status for this piece (MD_OK: the final block ended inside it; MD_UNEXPECTED_END_OF_INPUT: the
+ * piece ended inside a block — decode the next piece from `resume`; anything else as md_inflate_batch_host), and
+ * resume describes the end of the last block that was complete in the piece: bits from src[0] (start_bit included),
+ * output position and checksum state there, whether it was the final block.  What lies between resume->out and
+ * *dst_len belongs to the incomplete block: it is valid output, but the next piece starts at the block boundary and
+ * produces it again.  (md_inf_decode does this by itself for MD_FORMAT_DEFLATE / MD_FORMAT_ZLIB once a stream is
+ * longer than md_inf_chunk_bytes.) */
+typedef struct md_inf_resume {
+  uint64_t bits, out;       /* end of the last complete block: input bits from src[0], output position (history included) */
+  uint32_t adler, last;     /* Adler-32 state there; 1 when that block was the final one */
+  uint64_t consumed;        /* status MD_OK: input bytes of the piece the stream used (as md_inflate_batch_host) */
+  uint32_t checksum;        /* Adler-32 state at *dst_len */
+} md_inf_resume;
+int md_de_inf_continue_host(md_ctx *ctx, const uint8_t *src, size_t src_len, unsigned start_bit, uint8_t *dst, size_t hist_len,
+                            size_t dst_cap, uint32_t adler_in, size_t *dst_len, int *status, md_inf_resume *resume);
+
 /* ---- the resumable state machines (host side; one launch at the end of input) ----
  * De.Inf.decoder / decode / src / flush / dst_rem / src_rem / checksum (lib/de.mli:82-144) and the encoder loop of
  * Zl.Def / Gz.Def / De.Higher with `Manual source and destination (lib/zl.ml:509-555): the caller supplies input
  * with src (length 0 = end of input, as in the reference), calls decode / encode, and consumes its output buffer
  * whenever it gets MD_FLUSH (then md_inf_flush / md_def_dst), until MD_END or MD_MALFORMED (md_*_status gives
  * the MD_* status whose string is the reference's `Malformed message).  See csrc/stream_shim.cpp. */
-/* Memory: the shims buffer the whole input until its end is signalled and hold the whole result until it has been
- * handed out — O(stream) host memory where the reference's decoder needs its 32 KiB window and one output buffer.
+/* Memory: the encoder shim and the GZip decoder buffer the whole input until its end is signalled and hold the whole
+ * result until it has been handed out — O(stream) host memory where the reference needs its window and one output
+ * buffer.  The DEFLATE / ZLIB decoder works in pieces: once md_inf_chunk_bytes (default 1 MiB) of input are buffered
+ * it decodes up to the last block boundary inside them (md_de_inf_continue_host), hands that output out through
+ * `Flush steps while input is still arriving, and keeps only the undecoded tail and the 32 KiB window; a stream that
+ * ends before a piece is full is decoded in one launch as before.
  * md_inf_message: the reference's `Malformed string with its numbers, e.g. "Invalid checksum (expect:%04lx,
  * has:%04lx)" (lib/zl.ml:179-181, lib/gz.ml:287-289), "Invalid input size (expect:%ld, inflated:%ld)"
  * (lib/gz.ml:291-293); md_status_string(md_inf_status) is its fixed part.  md_inf_reset = De.Inf.reset
@@ -312,6 +337,7 @@ enum { MD_AWAIT = 0, MD_FLUSH = 1, MD_END = 2, MD_MALFORMED = 3 };
 typedef struct md_inf_stream md_inf_stream;
 md_inf_stream *md_inf_decoder(md_ctx *ctx, int format, uint8_t *o, size_t o_len);
 void md_inf_reset(md_inf_stream *s);
+void md_inf_chunk_bytes(md_inf_stream *s, size_t bytes); /* input buffered before a piece is decoded (>= 1) */
 const char *md_inf_message(const md_inf_stream *s);
 int md_inf_src(md_inf_stream *s, const uint8_t *buf, size_t off, size_t len);
 int md_inf_decode(md_inf_stream *s);

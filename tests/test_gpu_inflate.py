@@ -294,6 +294,120 @@ def test_streaming_decoder_shim(eng, oracle):
     assert de.Inf.decode_chunks([b"\x03\x00"], o_len=16)[:2] == ("Ok", b"")
 
 
+def _continue(eng, src, start_bit, hist, cap, adler):
+    """md_de_inf_continue_host on one piece -> (status, output position, new bytes, resume)"""
+    from decompress_amd import _lib
+    dst = ctypes.create_string_buffer(bytes(hist), max(1, cap))
+    n, st, rs = ctypes.c_size_t(), ctypes.c_int(), _lib.InfResume()
+    eng._check(eng.lib.md_de_inf_continue_host(eng.ctx, bytes(src), len(src), start_bit, dst, len(hist), cap, adler,
+                                               ctypes.byref(n), ctypes.byref(st), ctypes.byref(rs)))
+    return st.value, n.value, dst.raw[len(hist):n.value], rs
+
+
+def test_stream_decoded_in_pieces_by_hand(eng_ring):
+    """md_de_inf_continue_host: a raw stream cut at arbitrary bytes is decoded piece by piece — every piece starts at the
+    block boundary (a bit position) the last one reported, with the last 32 KiB of output in front of its buffer and the
+    checksum state handed on — and the pieces add up to the stream: bytes, Adler-32, where it ends."""
+    eng = eng_ring
+    rng = random.Random(0x51ce)
+    for kind, level, strat in (("text", 6, 0), ("far", 6, 0), ("runs", 9, 0), ("rand", 0, 0), ("text", 6, zlib.Z_FIXED)):
+        plain = _mk(rng, 600000, kind)
+        co = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strat)
+        raw = co.compress(plain) + co.flush() + b"trailing"
+        got, hist, adler, pos, bit, pieces = bytearray(), b"", 1, 0, 0, 0
+        step = max(200, len(raw) // 7)
+        end = step
+        while True:
+            piece = raw[pos:min(end, len(raw))]
+            st, n, new, rs = _continue(eng, piece, bit, hist, len(hist) + 700000, adler)
+            pieces += 1
+            if st == 0:
+                got += new
+                assert rs.last == 1 and rs.out == n
+                assert zlib.adler32(bytes(got)) == rs.checksum == rs.adler
+                assert pos + rs.consumed == len(raw) - len(b"trailing")
+                break
+            assert st == 1, st  # MD_UNEXPECTED_END_OF_INPUT: the piece ended inside a block
+            assert end < len(raw), "the whole stream was there"
+            upto = rs.out - len(hist)
+            assert new[:upto] == plain[len(got):len(got) + upto]  # (what follows belongs to the incomplete block: valid too)
+            assert new == plain[len(got):len(got) + len(new)]
+            got += new[:upto]
+            assert rs.adler == zlib.adler32(bytes(got))
+            hist = bytes(got[-32768:])
+            adler = rs.adler
+            pos += rs.bits >> 3
+            bit = rs.bits & 7
+            end += step
+        assert bytes(got) == plain and pieces >= 3
+
+
+def test_streaming_decoder_hands_out_before_the_end(eng, oracle):
+    """The De.Inf.decode protocol on streams longer than a piece: output comes out through `Flush while input is still
+    being supplied, the result is the whole-buffer one (bytes, checksum, status, message, unread input) — for raw and
+    ZLIB streams, intact, corrupted in the middle, cut short, with a wrong checksum."""
+    import decompress_amd
+    from decompress_amd import de
+    rng = random.Random(0x57e)
+    plain = _mk(rng, 900000, "text") + _mk(rng, 300000, "far") + _mk(rng, 200000, "runs")
+    z = zlib.compress(plain, 6)
+    raw = z[2:-4]
+    cases = [
+        ("raw", decompress_amd.FORMAT_DEFLATE, raw + b"xyz", 0, 3),
+        ("zlib", decompress_amd.FORMAT_ZLIB, z, 0, 0),
+        ("zlib-checksum", decompress_amd.FORMAT_ZLIB, z[:-1] + bytes([z[-1] ^ 1]), 9, 0),
+        ("zlib-cut", decompress_amd.FORMAT_ZLIB, z[:len(z) // 2], 1, 0),
+        ("raw-flipped", decompress_amd.FORMAT_DEFLATE, raw[:len(raw) // 2] + bytes([raw[len(raw) // 2] ^ 0x10]) + raw[len(raw) // 2 + 1:], None, None),
+    ]
+    for name, fmt, src, want_status, want_rem in cases:
+        for chunk in (4096, 150000):
+            pieces = [src[i:i + 50000] for i in range(0, len(src), 50000)]
+            state = {"fed": 0, "out_before_end": 0}
+
+            def feed():
+                for pc in pieces:
+                    state["fed"] += 1
+                    yield pc
+            eng_ = eng
+            lib = eng_.lib
+            o = ctypes.create_string_buffer(65536)
+            d = lib.md_inf_decoder(eng_.ctx, fmt, o, 65536)
+            lib.md_inf_chunk_bytes(d, chunk)
+            out, it = bytearray(), feed()
+            try:
+                while True:
+                    sig = lib.md_inf_decode(d)
+                    if sig == de.AWAIT:
+                        c = next(it, b"")
+                        lib.md_inf_src(d, bytes(c), 0, len(c))
+                    else:
+                        out += o.raw[:65536 - lib.md_inf_dst_rem(d)]
+                        lib.md_inf_flush(d)
+                        if sig == de.FLUSH and state["fed"] < len(pieces):
+                            state["out_before_end"] += 1
+                        if sig in (de.END, de.MALFORMED):
+                            st, rem, msg = lib.md_inf_status(d), lib.md_inf_src_rem(d), lib.md_inf_message(d).decode()
+                            break
+            finally:
+                lib.md_inf_free(d)
+            # the whole-buffer answer
+            if name == "zlib-cut":  # (the streaming decoder takes everything that is there; Zl.Inf.Ns sets the last 4 bytes aside)
+                ost, oused, oout = oracle.de_inflate(src[2:], len(plain) + 16)
+            elif fmt == decompress_amd.FORMAT_ZLIB:
+                ost, oused, oout = oracle.zl_inflate(src, len(plain) + 16)
+            else:
+                ost, oused, oout = oracle.de_inflate(src, len(plain) + 16)
+            assert st == ost, (name, chunk, st, ost)
+            assert bytes(out) == oout, (name, chunk, len(out), len(oout))
+            if want_status is not None:
+                assert st == want_status
+            if want_rem is not None and st == 0:
+                assert rem == want_rem
+            if name == "zlib-checksum":
+                assert msg.startswith("Invalid checksum (expect:") and "has:" in msg
+            assert state["out_before_end"] > 0, (name, chunk)  # output was handed out while input was still arriving
+
+
 def test_malformed_strings_and_reset(eng):
     """the `Malformed strings of Zl.Inf / Gz.Inf with their numbers (lib/zl.ml:179-181, lib/gz.ml:287-293), byte for
     byte what the reference's format strings give; De.Inf.reset (lib/de.ml:1512-1532) re-arms the same decoder"""
