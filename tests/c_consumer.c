@@ -60,6 +60,31 @@ int main(void) {
     }
   }
   CHECK(got == N && md_inf_status(s) == MD_OK);
+  /* the same decoder on the same stream again (De.Inf.reset), now in pieces: with 2000 bytes buffered it decodes up to
+     the last block boundary, so output arrives while input is still being supplied */
+  md_inf_reset(s);
+  md_inf_chunk_bytes(s, 2000);
+  fed = got = 0;
+  size_t early = 0;
+  for (;;) {
+    int sig = md_inf_decode(s);
+    if (sig == MD_AWAIT) {
+      size_t k = zn - fed < 1000 ? zn - fed : 1000;
+      CHECK(md_inf_src(s, z, fed, k) == MD_OK);
+      fed += k;
+    } else if (sig == MD_FLUSH || sig == MD_END) {
+      size_t k = sizeof obuf - md_inf_dst_rem(s);
+      CHECK(memcmp(obuf, plain + got, k) == 0);
+      got += k;
+      if (fed < zn) early += k;
+      if (sig == MD_END) break;
+      md_inf_flush(s);
+    } else {
+      CHECK(!"malformed");
+    }
+  }
+  CHECK(got == N && md_inf_status(s) == MD_OK && md_inf_src_rem(s) == 0);
+  CHECK(zn < 4000 || early > 0);
   md_inf_free(s);
   /* De.Lz77.compress and De.Def.encode on their own: "abcde" (test/test.ml:798-813) */
   uint32_t cmds[16], lits[286], dsts[30];
