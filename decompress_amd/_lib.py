@@ -23,7 +23,7 @@ class GzHeader(ctypes.Structure):
 class InfResume(ctypes.Structure):
     """md_inf_resume (mdeflate.h): the last block boundary inside a piece of a stream"""
     _fields_ = [("bits", ctypes.c_uint64), ("out", ctypes.c_uint64), ("adler", ctypes.c_uint32), ("last", ctypes.c_uint32),
-                ("consumed", ctypes.c_uint64), ("checksum", ctypes.c_uint32)]
+                ("consumed", ctypes.c_uint64), ("checksum", ctypes.c_uint32), ("crc_out", ctypes.c_uint32), ("crc_end", ctypes.c_uint32)]
 
 
 class DeflateParams(ctypes.Structure):
@@ -76,7 +76,7 @@ SYMBOLS = [
     ("md_inf_free", None, [c_vp]),
     ("md_inf_reset", None, [c_vp]),
     ("md_inf_chunk_bytes", None, [c_vp, c_sz]),
-    ("md_de_inf_continue_host", ctypes.c_int, [c_vp, c_vp, c_sz, ctypes.c_uint, c_vp, c_sz, c_sz, ctypes.c_uint32, c_vp, c_vp, c_vp]),
+    ("md_de_inf_continue_host", ctypes.c_int, [c_vp, c_vp, c_sz, ctypes.c_uint, c_vp, c_sz, c_sz, ctypes.c_uint32, ctypes.c_uint, c_vp, c_vp, c_vp]),
     ("md_inf_message", ctypes.c_char_p, [c_vp]),
     ("md_def_encoder", c_vp, [c_vp, ctypes.c_int, c_pp, c_vp, c_sz]),
     ("md_def_src", ctypes.c_int, [c_vp, c_vp, c_sz, c_sz]),

@@ -416,7 +416,8 @@ int md_inflate_batch_host(md_ctx *ctx, int format, size_t n, const uint8_t *h_in
 // a starting bit, the window in front of the output buffer and the checksum state handed in, and the last block
 // boundary inside the piece handed back.
 int md_de_inf_continue_host(md_ctx *ctx, const uint8_t *src, size_t src_len, unsigned start_bit, uint8_t *dst, size_t hist_len,
-                            size_t dst_cap, uint32_t adler_in, size_t *dst_len, int *status, md_inf_resume *resume) {
+                            size_t dst_cap, uint32_t adler_in, unsigned flags, size_t *dst_len, int *status,
+                            md_inf_resume *resume) {
   if (!ctx || (!src && src_len) || !dst || !dst_len || !status || !resume) return MD_E_INVALID_ARGUMENT;
   if (start_bit > 7 || hist_len > 32768 || hist_len > dst_cap || dst_cap > MD_MAX_STREAM || src_len > MD_MAX_INFLATE_IN)
     return fail(ctx, MD_E_INVALID_ARGUMENT, "md_de_inf_continue_host: start_bit <= 7, hist_len <= 32768 and <= dst_cap");
@@ -424,7 +425,7 @@ int md_de_inf_continue_host(md_ctx *ctx, const uint8_t *src, size_t src_len, uns
   DevBuf din, dout, ddesc;
   // descriptors: in_off in_len out_off out_cap out_len consumed resume_bits resume_out (u64); status, checksum,
   // start_bit, hist_len, adler_in, resume_adler, resume_last (u32)
-  if (din.alloc(src_len + 16) != hipSuccess || dout.alloc(dst_cap + 16) != hipSuccess || ddesc.alloc(8 * 8 + 7 * 4) != hipSuccess)
+  if (din.alloc(src_len + 16) != hipSuccess || dout.alloc(dst_cap + 16) != hipSuccess || ddesc.alloc(8 * 8 + 8 * 4 + 4 * 8 + 2 * 4) != hipSuccess)
     return fail(ctx, MD_E_OUT_OF_MEMORY, "hipMalloc");
   uint64_t h64[8] = {0, (uint64_t)src_len, 0, (uint64_t)dst_cap, 0, 0, 0, 0};
   uint32_t h32[7] = {0, 0, start_bit, (uint32_t)hist_len, adler_in, 0, 0};
@@ -453,6 +454,21 @@ int md_de_inf_continue_host(md_ctx *ctx, const uint8_t *src, size_t src_len, uns
   resume->last = h32[6];
   resume->consumed = h64[5];
   resume->checksum = h32[1];
+  resume->crc_out = resume->crc_end = 0;
+  if (flags & MD_CONT_CRC32) {  // CRC-32 of the new output up to the block boundary, and up to where decoding got
+    uint64_t *c64 = (uint64_t *)(d32 + 8);
+    uint32_t *c32 = (uint32_t *)(c64 + 4);
+    const uint64_t to_out = resume->out > hist_len ? resume->out - hist_len : 0, to_end = produced > hist_len ? produced - hist_len : 0;
+    const uint64_t hc[4] = {(uint64_t)hist_len, (uint64_t)hist_len, to_out, to_end};
+    uint32_t crc[2] = {0, 0};
+    HIP_TRY(ctx, hipMemcpyAsync(c64, hc, sizeof hc, hipMemcpyHostToDevice, st));
+    int e = md_launch_crc32(2, (const uint8_t *)dout.p, c64, c64 + 2, c32, st);
+    if (e != 0) return fail(ctx, MD_E_HIP, "crc32 kernel launch", (hipError_t)e);
+    HIP_TRY(ctx, hipMemcpyAsync(crc, c32, sizeof crc, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    resume->crc_out = crc[0];
+    resume->crc_end = crc[1];
+  }
   return MD_OK;
 }
 

@@ -6,7 +6,7 @@
 // cannot pay for itself, so the shim keeps the reference's calling protocol on the HOST — it collects the chunks
 // the caller supplies through src and runs the HIP path on them in large pieces: a stream that ends before a piece
 // (md_inf_chunk_bytes, 1 MiB) is full is ONE batch-of-one launch when the caller signals the end of input (src with
-// length 0, as in the reference); a longer DEFLATE / ZLIB stream is decoded piece by piece up to the last block
+// length 0, as in the reference); a longer stream is decoded piece by piece up to the last block
 // boundary inside each piece (md_de_inf_continue_host: starting bit, 32 KiB window and checksum state go in, the
 // boundary comes back), so that output is handed out through `Flush steps while input is still arriving and only the
 // undecoded tail and the window are kept.  There is no CPU codec here: without a gfx950 device the launch fails and
@@ -43,6 +43,8 @@ struct md_inf_stream {
   unsigned in_bit;            // the next block starts this many bits into in[0]
   std::vector<uint8_t> hist;  // the window: the last <= 32 KiB of output
   uint32_t adler;             // checksum state at the last block boundary
+  uint32_t crc;               // GZip: CRC-32 of the output handed out so far
+  uint64_t total_out;         // ... and its length
 };
 static void inf_clear(md_inf_stream *s) {
   s->in.clear();
@@ -56,6 +58,8 @@ static void inf_clear(md_inf_stream *s) {
   s->need = s->chunk;
   s->in_bit = 0;
   s->adler = 1;
+  s->crc = 0;
+  s->total_out = 0;
 }
 
 extern "C" {
@@ -202,6 +206,57 @@ static void inf_run(md_inf_stream *s) {
   }
 }
 
+// ---- CRC-32 over pieces: crc(A || B) = crc(A) * x^(8|B|) mod P xor crc(B) in GF(2)[x] / P, reflected (bit 31 = x^0);
+// the pieces' CRCs come from the device (crc32_kernel), the few header bytes are done here
+static uint32_t crc_bytes(uint32_t c, const uint8_t *p, size_t n) {  // (running value, not complemented)
+  for (size_t i = 0; i < n; i++) {
+    c ^= p[i];
+    for (int k = 0; k < 8; k++) c = (c >> 1) ^ (0xedb88320u & (0u - (c & 1)));
+  }
+  return c;
+}
+static uint32_t gf_mul(uint32_t a, uint32_t b) {
+  uint32_t p = 0;
+  for (int k = 0; k < 32; k++) {
+    p ^= b & (0u - ((a >> 31) & 1));
+    a <<= 1;
+    b = (b >> 1) ^ (0xedb88320u & (0u - (b & 1)));
+  }
+  return p;
+}
+static uint32_t crc_concat(uint32_t crc_a, uint32_t crc_b, uint64_t len_b) {
+  uint32_t sq = 0x00800000u, r = 0x80000000u;  // x^8, x^0
+  for (uint64_t n = len_b; n; n >>= 1) {
+    if (n & 1) r = gf_mul(r, sq);
+    sq = gf_mul(sq, sq);
+  }
+  return gf_mul(crc_a, r) ^ crc_b;
+}
+// Gz.Inf's header walk with its checks (lib/gz.ml:463-491, as gz_header_kernel does it for the batch path): the offset
+// of the body, or 0 with *st = MD_OK when the header is not all there yet, or 0 with the status of a bad header
+static size_t gz_header_check(const std::vector<uint8_t> &in, int *st) {
+  *st = MD_OK;
+  if (in.size() >= 2 && (in[0] != 0x1f || in[1] != 0x8b)) {
+    *st = MD_INVALID_GZIP_HEADER;
+    return 0;
+  }
+  const size_t body = gz_body_offset(in);
+  if (body == 0) return 0;
+  const uint32_t flg = in[3];
+  if (flg & 2) {  // FHCRC: the upper half of the CRC-32 of the fixed bytes + name + comment (FEXTRA excluded), big-endian
+    uint32_t c = crc_bytes(0xffffffffu, in.data(), 10);
+    size_t p = 10;
+    if (flg & 4) p += 2 + (((size_t)in[10] << 8) | in[11]);
+    c = crc_bytes(c, in.data() + p, body - 2 - p);
+    const uint32_t want = ((c ^ 0xffffffffu) & 0xffff0000u) >> 16, have = ((uint32_t)in[body - 2] << 8) | in[body - 1];
+    if (want != have) {
+      *st = MD_INVALID_GZIP_HEADER_CHECKSUM;
+      return 0;
+    }
+  }
+  return body;
+}
+
 // One piece of a stream that is decoded as it arrives: everything up to the last block boundary inside the buffered
 // input goes to `out`, the rest of the input stays; at the end of the input whatever is left is decoded for good.
 static void inf_piece(md_inf_stream *s) {
@@ -213,6 +268,18 @@ static void inf_piece(md_inf_stream *s) {
     s->message = md_status_string(st);
     s->finished = true;
   };
+  if (s->format == MD_FORMAT_GZIP && !s->hdr_done) {
+    int hst = MD_OK;
+    const size_t body = gz_header_check(s->in, &hst);
+    if (hst != MD_OK) return fail_with(hst);
+    if (body == 0) {
+      if (final) fail_with(MD_UNEXPECTED_END_OF_INPUT);
+      else s->need = s->in.size() + 1;
+      return;
+    }
+    s->in.erase(s->in.begin(), s->in.begin() + body);
+    s->hdr_done = true;
+  }
   if (s->format == MD_FORMAT_ZLIB && !s->hdr_done) {  // Zl.Inf's header, lib/zl.ml:142-165 (as the kernel checks it)
     if (s->in.size() < 2) {
       if (final) fail_with(MD_UNEXPECTED_END_OF_INPUT);
@@ -237,7 +304,7 @@ static void inf_piece(md_inf_stream *s) {
       buf.resize((size_t)cap);
       if (hl) memcpy(buf.data(), s->hist.data(), hl);
       const int rc = md_de_inf_continue_host(s->ctx, s->in.empty() ? &none : s->in.data(), s->in.size(), s->in_bit, buf.data(), hl,
-                                             (size_t)cap, s->adler, &dst_len, &st, &rs);
+                                             (size_t)cap, s->adler, s->format == MD_FORMAT_GZIP ? MD_CONT_CRC32 : 0u, &dst_len, &st, &rs);
       if (rc != MD_OK) return fail_with(rc);
       if (st == MD_UNEXPECTED_END_OF_OUTPUT && cap < MD_MAX_STREAM) {
         cap *= 4;
@@ -250,6 +317,8 @@ static void inf_piece(md_inf_stream *s) {
       const size_t upto = (size_t)rs.out;
       const bool progress = rs.bits > s->in_bit;
       s->out.assign(buf.begin() + hl, buf.begin() + upto);
+      s->crc = s->total_out ? crc_concat(s->crc, rs.crc_out, upto - hl) : rs.crc_out;
+      s->total_out += upto - hl;
       const size_t keep = upto < 32768 ? upto : 32768;
       s->hist.assign(buf.begin() + (upto - keep), buf.begin() + upto);
       s->adler = rs.adler;
@@ -259,7 +328,9 @@ static void inf_piece(md_inf_stream *s) {
       return;
     }
     s->out.assign(buf.begin() + hl, buf.begin() + dst_len);  // everything decoded, also in front of an error
-    s->checksum = rs.checksum;
+    s->crc = s->total_out ? crc_concat(s->crc, rs.crc_end, dst_len - hl) : rs.crc_end;
+    s->total_out += dst_len - hl;
+    s->checksum = s->format == MD_FORMAT_GZIP ? s->crc : rs.checksum;
     if (st != MD_OK) return fail_with(st);
     s->body_done = true;
     s->in.erase(s->in.begin(), s->in.begin() + (size_t)rs.consumed);
@@ -269,6 +340,30 @@ static void inf_piece(md_inf_stream *s) {
       s->finished = true;
       return;
     }
+  }
+  if (s->format == MD_FORMAT_GZIP) {  // Gz.Inf's trailer (lib/gz.ml:344-356): CRC-32 first, then ISIZE, little-endian
+    if (s->in.size() < 8) {
+      if (final) fail_with(MD_UNEXPECTED_END_OF_INPUT);
+      else s->need = 8;
+      return;
+    }
+    const uint8_t *t = s->in.data();
+    const uint32_t crc = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+    const uint32_t isize = (uint32_t)t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
+    char msg[96];
+    s->status = MD_OK;
+    if (crc != s->crc) {
+      snprintf(msg, sizeof msg, "Invalid checksum (expect:%04lx, has:%04lx)", (unsigned long)crc, (unsigned long)s->crc);
+      s->status = MD_INVALID_CHECKSUM;
+      s->message = msg;
+    } else if (isize != (uint32_t)s->total_out) {
+      snprintf(msg, sizeof msg, "Invalid input size (expect:%ld, inflated:%ld)", (long)(int32_t)isize, (long)(int32_t)(uint32_t)s->total_out);
+      s->status = MD_INVALID_SIZE;
+      s->message = msg;
+    }
+    s->in.erase(s->in.begin(), s->in.begin() + 8);
+    s->finished = true;
+    return;
   }
   // Zl.Inf's trailer: the Adler-32 of the output, big-endian (lib/zl.ml:171-186)
   if (s->in.size() < 4) {
@@ -305,7 +400,7 @@ int md_inf_decode(md_inf_stream *s) {
       s->ran = s->finished = true;
       continue;
     }
-    if (s->format == MD_FORMAT_GZIP || (!s->eoi && s->in.size() < s->need)) return MD_AWAIT;
+    if (!s->eoi && s->in.size() < s->need) return MD_AWAIT;
     s->piecewise = true;
     inf_piece(s);
   }

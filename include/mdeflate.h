@@ -306,16 +306,18 @@ int md_def_ns_batch_device(md_ctx *ctx, int format, int level, size_t total_in_b
  * resume describes the end of the last block that was complete in the piece: bits from src[0] (start_bit included),
  * output position and checksum state there, whether it was the final block.  What lies between resume->out and
  * *dst_len belongs to the incomplete block: it is valid output, but the next piece starts at the block boundary and
- * produces it again.  (md_inf_decode does this by itself for MD_FORMAT_DEFLATE / MD_FORMAT_ZLIB once a stream is
- * longer than md_inf_chunk_bytes.) */
+ * produces it again.  (md_inf_decode does this by itself once a stream is longer than md_inf_chunk_bytes.) */
 typedef struct md_inf_resume {
   uint64_t bits, out;       /* end of the last complete block: input bits from src[0], output position (history included) */
   uint32_t adler, last;     /* Adler-32 state there; 1 when that block was the final one */
   uint64_t consumed;        /* status MD_OK: input bytes of the piece the stream used (as md_inflate_batch_host) */
   uint32_t checksum;        /* Adler-32 state at *dst_len */
+  uint32_t crc_out, crc_end; /* flags & MD_CONT_CRC32: CRC-32 of dst[hist_len, out) and of dst[hist_len, *dst_len) */
 } md_inf_resume;
+enum { MD_CONT_CRC32 = 1 }; /* also compute the CRC-32 of the piece's new output (Gz.Inf's checksum, lib/gz.ml:503) */
 int md_de_inf_continue_host(md_ctx *ctx, const uint8_t *src, size_t src_len, unsigned start_bit, uint8_t *dst, size_t hist_len,
-                            size_t dst_cap, uint32_t adler_in, size_t *dst_len, int *status, md_inf_resume *resume);
+                            size_t dst_cap, uint32_t adler_in, unsigned flags, size_t *dst_len, int *status,
+                            md_inf_resume *resume);
 
 /* ---- the resumable state machines (host side; one launch at the end of input) ----
  * De.Inf.decoder / decode / src / flush / dst_rem / src_rem / checksum (lib/de.mli:82-144) and the encoder loop of
@@ -323,9 +325,9 @@ int md_de_inf_continue_host(md_ctx *ctx, const uint8_t *src, size_t src_len, uns
  * with src (length 0 = end of input, as in the reference), calls decode / encode, and consumes its output buffer
  * whenever it gets MD_FLUSH (then md_inf_flush / md_def_dst), until MD_END or MD_MALFORMED (md_*_status gives
  * the MD_* status whose string is the reference's `Malformed message).  See csrc/stream_shim.cpp. */
-/* Memory: the encoder shim and the GZip decoder buffer the whole input until its end is signalled and hold the whole
- * result until it has been handed out — O(stream) host memory where the reference needs its window and one output
- * buffer.  The DEFLATE / ZLIB decoder works in pieces: once md_inf_chunk_bytes (default 1 MiB) of input are buffered
+/* Memory: the encoder shim buffers the whole input until its end is signalled and holds the whole result until it has
+ * been handed out — O(stream) host memory where the reference needs its window and one output buffer.  The decoder
+ * (DEFLATE, ZLIB, GZip) works in pieces: once md_inf_chunk_bytes (default 1 MiB) of input are buffered
  * it decodes up to the last block boundary inside them (md_de_inf_continue_host), hands that output out through
  * `Flush steps while input is still arriving, and keeps only the undecoded tail and the 32 KiB window; a stream that
  * ends before a piece is full is decoded in one launch as before.

@@ -294,12 +294,12 @@ def test_streaming_decoder_shim(eng, oracle):
     assert de.Inf.decode_chunks([b"\x03\x00"], o_len=16)[:2] == ("Ok", b"")
 
 
-def _continue(eng, src, start_bit, hist, cap, adler):
-    """md_de_inf_continue_host on one piece -> (status, output position, new bytes, resume)"""
+def _continue(eng, src, start_bit, hist, cap, adler, flags=1):
+    """md_de_inf_continue_host on one piece (with the CRC-32 of its new output) -> (status, output position, new bytes, resume)"""
     from decompress_amd import _lib
     dst = ctypes.create_string_buffer(bytes(hist), max(1, cap))
     n, st, rs = ctypes.c_size_t(), ctypes.c_int(), _lib.InfResume()
-    eng._check(eng.lib.md_de_inf_continue_host(eng.ctx, bytes(src), len(src), start_bit, dst, len(hist), cap, adler,
+    eng._check(eng.lib.md_de_inf_continue_host(eng.ctx, bytes(src), len(src), start_bit, dst, len(hist), cap, adler, flags,
                                                ctypes.byref(n), ctypes.byref(st), ctypes.byref(rs)))
     return st.value, n.value, dst.raw[len(hist):n.value], rs
 
@@ -324,6 +324,7 @@ def test_stream_decoded_in_pieces_by_hand(eng_ring):
             if st == 0:
                 got += new
                 assert rs.last == 1 and rs.out == n
+                assert rs.crc_end == rs.crc_out == zlib.crc32(new)
                 assert zlib.adler32(bytes(got)) == rs.checksum == rs.adler
                 assert pos + rs.consumed == len(raw) - len(b"trailing")
                 break
@@ -332,6 +333,7 @@ def test_stream_decoded_in_pieces_by_hand(eng_ring):
             upto = rs.out - len(hist)
             assert new[:upto] == plain[len(got):len(got) + upto]  # (what follows belongs to the incomplete block: valid too)
             assert new == plain[len(got):len(got) + len(new)]
+            assert rs.crc_out == zlib.crc32(new[:upto]) and rs.crc_end == zlib.crc32(new)
             got += new[:upto]
             assert rs.adler == zlib.adler32(bytes(got))
             hist = bytes(got[-32768:])
@@ -358,6 +360,21 @@ def test_streaming_decoder_hands_out_before_the_end(eng, oracle):
         ("zlib-checksum", decompress_amd.FORMAT_ZLIB, z[:-1] + bytes([z[-1] ^ 1]), 9, 0),
         ("zlib-cut", decompress_amd.FORMAT_ZLIB, z[:len(z) // 2], 1, 0),
         ("raw-flipped", decompress_amd.FORMAT_DEFLATE, raw[:len(raw) // 2] + bytes([raw[len(raw) // 2] ^ 0x10]) + raw[len(raw) // 2 + 1:], None, None),
+    ]
+    # GZip members: header with FEXTRA (big-endian length, as the reference reads it), FNAME, FCOMMENT and FHCRC
+    def gz_member(body, data, crc_xor=0, size_add=0, hcrc_xor=0):
+        fixed = bytes([0x1f, 0x8b, 8, 2 | 4 | 8 | 16]) + b"\0\0\0\0" + bytes([0, 3])
+        extra, name, comment = b"\x00\x05hello", b"a name\0", b"a comment\0"
+        hcrc = ((zlib.crc32(fixed + name + comment) >> 16) & 0xffff) ^ hcrc_xor
+        head = fixed + extra + name + comment + bytes([hcrc >> 8, hcrc & 0xff])
+        tail = ((zlib.crc32(data) ^ crc_xor) & 0xffffffff).to_bytes(4, "little") + ((len(data) + size_add) & 0xffffffff).to_bytes(4, "little")
+        return head + body + tail
+    cases += [
+        ("gzip", decompress_amd.FORMAT_GZIP, gz_member(raw, plain) + b"rest", 0, 4),
+        ("gzip-crc", decompress_amd.FORMAT_GZIP, gz_member(raw, plain, crc_xor=1), 9, 0),
+        ("gzip-size", decompress_amd.FORMAT_GZIP, gz_member(raw, plain, size_add=1), 12, 0),
+        ("gzip-hcrc", decompress_amd.FORMAT_GZIP, gz_member(raw, plain, hcrc_xor=1), 11, 0),
+        ("gzip-cut", decompress_amd.FORMAT_GZIP, gz_member(raw, plain)[:len(raw) // 2], 1, 0),
     ]
     for name, fmt, src, want_status, want_rem in cases:
         for chunk in (4096, 150000):
@@ -393,6 +410,12 @@ def test_streaming_decoder_hands_out_before_the_end(eng, oracle):
             # the whole-buffer answer
             if name == "zlib-cut":  # (the streaming decoder takes everything that is there; Zl.Inf.Ns sets the last 4 bytes aside)
                 ost, oused, oout = oracle.de_inflate(src[2:], len(plain) + 16)
+            elif name == "gzip-cut":
+                ost, oused, oout = oracle.de_inflate(src[len(gz_member(b"", b"")) - 8:], len(plain) + 16)
+            elif fmt == decompress_amd.FORMAT_GZIP:
+                ost, oused, oout, _ = oracle.gz_inflate(src, len(plain) + 16)
+                if ost in (9, 12):  # a wrong trailer: everything was inflated and handed out before it was read
+                    oout = plain
             elif fmt == decompress_amd.FORMAT_ZLIB:
                 ost, oused, oout = oracle.zl_inflate(src, len(plain) + 16)
             else:
@@ -403,8 +426,13 @@ def test_streaming_decoder_hands_out_before_the_end(eng, oracle):
                 assert st == want_status
             if want_rem is not None and st == 0:
                 assert rem == want_rem
-            if name == "zlib-checksum":
+            if name in ("zlib-checksum", "gzip-crc"):
                 assert msg.startswith("Invalid checksum (expect:") and "has:" in msg
+            if name == "gzip-size":
+                assert msg == "Invalid input size (expect:%d, inflated:%d)" % (len(plain) + 1, len(plain))
+            if name == "gzip-hcrc":
+                assert len(out) == 0 and state["out_before_end"] == 0
+                continue
             assert state["out_before_end"] > 0, (name, chunk)  # output was handed out while input was still arriving
 
 
