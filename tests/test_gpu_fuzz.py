@@ -138,3 +138,61 @@ def test_random_buffers_deflate_every_byte():
     capacities: every compressed byte and status equals the oracle's (Queue.Full included)"""
     from tests import stress_deflate
     assert stress_deflate.run(12, 20260928, verbose=False) == 0
+
+
+def test_streaming_decoder_random_pieces(eng):
+    """The decoder protocol fed in random pieces with random piece sizes (md_inf_chunk_bytes): streams of mixed block
+    kinds (stored / fixed / dynamic / empty blocks, so block ends fall on every bit offset and stored blocks cross the
+    pieces), raw, ZLIB and GZip framed, some cut short.  What comes out is what zlib inflates, signal by signal."""
+    import ctypes
+    import gzip
+    from decompress_amd import de
+    import decompress_amd
+    rng = random.Random(0xfeed)
+    lib = eng.lib
+    for case in range(200):
+        body, plain = bytearray(), bytearray()
+        nseg = rng.randrange(1, 7)
+        for k in range(nseg):
+            data = _plain(rng, rng.choice((0, 1, 7, 300, 5000, 40000, 70000, 150000)))
+            level, strat = rng.choice(((0, 0), (1, 0), (6, 0), (9, 0), (6, zlib.Z_FIXED), (6, zlib.Z_HUFFMAN_ONLY)))
+            co = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strat)
+            body += co.compress(data) + (co.flush() if k == nseg - 1 else co.flush(rng.choice((zlib.Z_SYNC_FLUSH, zlib.Z_FULL_FLUSH))))
+            plain += data
+        raw, plain = bytes(body), bytes(plain)
+        fmt = rng.choice((decompress_amd.FORMAT_DEFLATE, decompress_amd.FORMAT_ZLIB, decompress_amd.FORMAT_GZIP))
+        if fmt == decompress_amd.FORMAT_ZLIB:
+            src = b"\x78\x9c" + raw + zlib.adler32(plain).to_bytes(4, "big")
+        elif fmt == decompress_amd.FORMAT_GZIP:
+            src = b"\x1f\x8b\x08\x00\0\0\0\0\x00\x03" + raw + zlib.crc32(plain).to_bytes(4, "little") + (len(plain) & 0xffffffff).to_bytes(4, "little")
+        else:
+            src = raw
+        cut = rng.random() < 0.2 and len(src) > 20
+        if cut:
+            src = src[:rng.randrange(10, len(src) - 1)]
+        o_len = rng.choice((1, 100, 4096, 65536))
+        o = ctypes.create_string_buffer(o_len)
+        d = lib.md_inf_decoder(eng.ctx, fmt, o, o_len)
+        lib.md_inf_chunk_bytes(d, rng.choice((1, 50, 700, 9000, 100000)))
+        out, pos = bytearray(), 0
+        try:
+            for _ in range(10_000_000):
+                sig = lib.md_inf_decode(d)
+                if sig == de.AWAIT:
+                    k = min(len(src) - pos, rng.choice((1, 13, 1000, 30000, 1 << 20)))
+                    lib.md_inf_src(d, src, pos, k)  # k == 0: the end of the input
+                    pos += k
+                else:
+                    out += o.raw[:o_len - lib.md_inf_dst_rem(d)]
+                    lib.md_inf_flush(d)
+                    if sig in (de.END, de.MALFORMED):
+                        break
+            st = lib.md_inf_status(d)
+        finally:
+            lib.md_inf_free(d)
+        if cut:
+            assert sig == de.MALFORMED and st != 0, (case, fmt, st)
+            assert plain.startswith(bytes(out)), (case, fmt, len(out))
+        else:
+            assert sig == de.END and st == 0, (case, fmt, st)
+            assert bytes(out) == plain, (case, fmt, len(out), len(plain))
