@@ -76,6 +76,7 @@ SYMBOLS = [
     ("md_inf_free", None, [c_vp]),
     ("md_inf_reset", None, [c_vp]),
     ("md_inf_chunk_bytes", None, [c_vp, c_sz]),
+    ("md_inflate_continue_batch_device", ctypes.c_int, [c_vp, c_sz] + [c_vp] * 17),
     ("md_de_inf_continue_host", ctypes.c_int, [c_vp, c_vp, c_sz, ctypes.c_uint, c_vp, c_sz, c_sz, ctypes.c_uint32, ctypes.c_uint, c_vp, c_vp, c_vp]),
     ("md_inf_message", ctypes.c_char_p, [c_vp]),
     ("md_def_encoder", c_vp, [c_vp, ctypes.c_int, c_pp, c_vp, c_sz]),

@@ -412,6 +412,33 @@ int md_inflate_batch_host(md_ctx *ctx, int format, size_t n, const uint8_t *h_in
   return MD_OK;
 }
 
+// Pieces of n streams at once (mdeflate.h): the inflate kernel with its continuation arguments, descriptors in HBM.
+int md_inflate_continue_batch_device(md_ctx *ctx, size_t n, const uint8_t *d_in, const uint64_t *d_in_off,
+                                     const uint64_t *d_in_len, uint8_t *d_out, const uint64_t *d_out_off,
+                                     const uint64_t *d_out_cap, const uint32_t *d_start_bit, const uint32_t *d_hist_len,
+                                     const uint32_t *d_adler_in, uint64_t *d_out_len, uint64_t *d_consumed,
+                                     int32_t *d_status, uint32_t *d_checksum, uint64_t *d_resume_bits,
+                                     uint64_t *d_resume_out, uint32_t *d_resume_adler, uint32_t *d_resume_last) {
+  if (!ctx) return MD_E_INVALID_ARGUMENT;
+  if (n == 0) return MD_OK;
+  if (n > 0xffffffffull) return fail(ctx, MD_E_INVALID_ARGUMENT, "too many streams");
+  if (!d_in || !d_in_off || !d_in_len || !d_out || !d_out_off || !d_out_cap || !d_start_bit || !d_hist_len || !d_adler_in ||
+      !d_out_len || !d_consumed || !d_status || !d_resume_bits || !d_resume_out || !d_resume_adler || !d_resume_last)
+    return fail(ctx, MD_E_INVALID_ARGUMENT, "null device pointer");
+  MD_ON_DEVICE(ctx);
+  uint32_t *order = nullptr;
+  if (n >= kOrderFrom) {
+    const int orc = order_scratch(ctx, n);
+    if (orc != MD_OK) return orc;
+    order = ctx->order;
+  }
+  const void *cont[7] = {d_start_bit, d_hist_len, d_adler_in, d_resume_bits, d_resume_out, d_resume_adler, d_resume_last};
+  int rc = md_launch_inflate_wave(MD_FORMAT_DEFLATE, (uint32_t)n, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap, d_out_len,
+                                  d_consumed, d_status, d_checksum, ctx->dbg, order, ctx->inflate_waves, cont, ctx->stream);
+  if (rc != 0) return fail(ctx, MD_E_HIP, "inflate kernel launch", (hipError_t)rc);
+  return MD_OK;
+}
+
 // One piece of a raw DEFLATE stream that is decoded as it arrives (mdeflate.h): the inflate kernel on one stream with
 // a starting bit, the window in front of the output buffer and the checksum state handed in, and the last block
 // boundary inside the piece handed back.

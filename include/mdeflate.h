@@ -315,6 +315,16 @@ typedef struct md_inf_resume {
   uint32_t crc_out, crc_end; /* flags & MD_CONT_CRC32: CRC-32 of dst[hist_len, out) and of dst[hist_len, *dst_len) */
 } md_inf_resume;
 enum { MD_CONT_CRC32 = 1 }; /* also compute the CRC-32 of the piece's new output (Gz.Inf's checksum, lib/gz.ml:503) */
+/* The same for n streams at once, everything resident in HBM (raw DEFLATE; descriptors as md_inflate_batch_device):
+ * piece i starts d_start_bit[i] bits into its first byte, its output buffer begins with d_hist_len[i] bytes of window,
+ * its checksum goes on from d_adler_in[i]; results as md_inflate_batch_device (d_out_len includes the window) plus the
+ * last block boundary inside each piece: d_resume_bits / d_resume_out (u64), d_resume_adler, d_resume_last (u32). */
+int md_inflate_continue_batch_device(md_ctx *ctx, size_t n, const uint8_t *d_in, const uint64_t *d_in_off,
+                                     const uint64_t *d_in_len, uint8_t *d_out, const uint64_t *d_out_off,
+                                     const uint64_t *d_out_cap, const uint32_t *d_start_bit, const uint32_t *d_hist_len,
+                                     const uint32_t *d_adler_in, uint64_t *d_out_len, uint64_t *d_consumed,
+                                     int32_t *d_status, uint32_t *d_checksum, uint64_t *d_resume_bits,
+                                     uint64_t *d_resume_out, uint32_t *d_resume_adler, uint32_t *d_resume_last);
 int md_de_inf_continue_host(md_ctx *ctx, const uint8_t *src, size_t src_len, unsigned start_bit, uint8_t *dst, size_t hist_len,
                             size_t dst_cap, uint32_t adler_in, unsigned flags, size_t *dst_len, int *status,
                             md_inf_resume *resume);

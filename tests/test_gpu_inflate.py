@@ -344,6 +344,68 @@ def test_stream_decoded_in_pieces_by_hand(eng_ring):
         assert bytes(got) == plain and pieces >= 3
 
 
+def test_batch_of_streams_in_two_pieces(eng):
+    """md_inflate_continue_batch_device: 300 streams of different kinds, each cut somewhere in the middle — the first
+    launch decodes every first half up to its last block boundary, the second goes on from there with the window in
+    front of its output; together they are the streams (bytes and Adler-32), all 300 in two launches."""
+    import torch
+    rng = random.Random(0xba7c)
+    n = 300
+    plains, raws = [], []
+    for i in range(n):
+        data = _mk(rng, rng.choice((3000, 70000, 200000)), rng.choice(("text", "far", "runs", "rand")))
+        co = zlib.compressobj(rng.choice((0, 1, 6, 9)), zlib.DEFLATED, -15, 8, rng.choice((0, 0, zlib.Z_FIXED)))
+        plains.append(data)
+        raws.append(co.compress(data) + co.flush())
+    dev = eng.device
+    t = lambda a, dt: torch.tensor(a, dtype=dt, device=dev)
+    p = lambda x: ctypes.c_void_p(x.data_ptr())
+
+    def launch(pieces, start_bits, hists, adlers, cap):
+        blob = b"".join(x + b"\0" * (-len(x) % 16) for x in pieces)
+        offs = np.cumsum([0] + [len(x) + (-len(x) % 16) for x in pieces[:-1]]).astype(np.int64)
+        d_in = torch.from_numpy(np.frombuffer(blob + b"\0" * 16, dtype=np.uint8).copy()).to(dev)
+        d_out = torch.zeros(n * cap, dtype=torch.uint8, device=dev)
+        for i, h in enumerate(hists):
+            if h:
+                d_out[i * cap:i * cap + len(h)] = torch.from_numpy(np.frombuffer(h, dtype=np.uint8).copy()).to(dev)
+        d_in_off, d_in_len = t(offs, torch.int64), t([len(x) for x in pieces], torch.int64)
+        d_out_off, d_out_cap = t([i * cap for i in range(n)], torch.int64), t([cap] * n, torch.int64)
+        d_bit, d_hist, d_adl = t(start_bits, torch.int32), t([len(h) for h in hists], torch.int32), t([a - (1 << 32) if a >= 1 << 31 else a for a in adlers], torch.int32)
+        out_len, consumed = torch.zeros(n, dtype=torch.int64, device=dev), torch.zeros(n, dtype=torch.int64, device=dev)
+        status, checksum = torch.zeros(n, dtype=torch.int32, device=dev), torch.zeros(n, dtype=torch.int32, device=dev)
+        r_bits, r_out = torch.zeros(n, dtype=torch.int64, device=dev), torch.zeros(n, dtype=torch.int64, device=dev)
+        r_adl, r_last = torch.zeros(n, dtype=torch.int32, device=dev), torch.zeros(n, dtype=torch.int32, device=dev)
+        eng._check(eng.lib.md_inflate_continue_batch_device(eng.ctx, n, p(d_in), p(d_in_off), p(d_in_len), p(d_out), p(d_out_off), p(d_out_cap),
+                                                            p(d_bit), p(d_hist), p(d_adl), p(out_len), p(consumed), p(status), p(checksum),
+                                                            p(r_bits), p(r_out), p(r_adl), p(r_last)))
+        torch.cuda.synchronize()
+        u32 = lambda x: [v & 0xffffffff for v in x.cpu().tolist()]
+        return (d_out.cpu().numpy(), status.cpu().tolist(), out_len.cpu().tolist(), r_bits.cpu().tolist(), r_out.cpu().tolist(),
+                u32(r_adl), r_last.cpu().tolist(), u32(checksum))
+
+    cap = 32768 + 210000
+    cuts = [rng.randrange(1, len(r)) for r in raws]
+    out1, st1, len1, bits1, ro1, adl1, last1, _ = launch([r[:c] for r, c in zip(raws, cuts)], [0] * n, [b""] * n, [1] * n, cap)
+    firsts, hists, rest, sbits = [], [], [], []
+    for i in range(n):
+        assert st1[i] in (0, 1), (i, st1[i])  # complete already (the cut fell behind the final block's last bit) or cut inside a block
+        upto = len1[i] if st1[i] == 0 else ro1[i]
+        firsts.append(out1[i * cap:i * cap + upto].tobytes())
+        assert plains[i].startswith(firsts[i])
+        assert adl1[i] == zlib.adler32(firsts[i]) or st1[i] == 0
+        hists.append(firsts[i][-32768:])
+        rest.append(raws[i][bits1[i] >> 3:] if st1[i] == 1 else b"\x03\x00")  # (finished streams get an empty final block)
+        sbits.append(bits1[i] & 7 if st1[i] == 1 else 0)
+    adlers = [adl1[i] if st1[i] == 1 else zlib.adler32(firsts[i]) for i in range(n)]
+    out2, st2, len2, _, _, _, last2, sum2 = launch(rest, sbits, hists, adlers, cap)
+    for i in range(n):
+        assert st2[i] == 0 and last2[i] == 1, (i, st2[i])
+        whole = firsts[i] + out2[i * cap + len(hists[i]):i * cap + len2[i]].tobytes()
+        assert whole == plains[i], (i, len(whole), len(plains[i]))
+        assert sum2[i] == zlib.adler32(plains[i])
+
+
 def test_streaming_decoder_hands_out_before_the_end(eng, oracle):
     """The De.Inf.decode protocol on streams longer than a piece: output comes out through `Flush while input is still
     being supplied, the result is the whole-buffer one (bytes, checksum, status, message, unread input) — for raw and
