@@ -1332,6 +1332,7 @@ __global__ __launch_bounds__(PAIR ? 2 * kWave : kWave, PAIR ? 4 : 2) void inflat
   uint32_t bp = cont.start_bit ? cont.start_bit[sid] & 7u : 0u;
   uint32_t zone = S;
   uint32_t sent = 0;  // PAIR: jobs posted
+  uint32_t fixed_lroot = 0;  // != 0: the tables in LDS are the fixed ones (and this is their root width)
   Window wnd;
   wnd.base = 0xffffffffu;
   if (cont.resume_bits && lane == 0) {  // no block complete yet
@@ -1384,9 +1385,15 @@ __global__ __launch_bounds__(PAIR ? 2 * kWave : kWave, PAIR ? 4 : 2) void inflat
         rc = MD_INVALID_KIND_OF_BLOCK;
       } else {
         uint32_t lroot = 0;
-        if (type == 1) fixed_tables(sm, lane, &lroot);
-        else {
+        if (type == 1) {
+          if (fixed_lroot == 0) {  // (a run of fixed blocks builds their tables once)
+            fixed_tables(sm, lane, &lroot);
+            fixed_lroot = uni(lroot);
+          }
+          lroot = fixed_lroot;
+        } else {
           uint32_t hend = 0;
+          fixed_lroot = 0;
           rc = dynamic_tables(sm, rbp + 3, tot, lane, &hend, &lroot, pf);
           bp = base * 8 + hend;
         }
