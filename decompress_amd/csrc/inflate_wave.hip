@@ -61,19 +61,28 @@ constexpr uint32_t RMAX = 768;     // match records per round, all lanes togethe
 constexpr uint32_t STAGE = 5568;   // staging bytes (one round of output)
 constexpr uint32_t WIN_WORDS = 544;  // input window: 31 + 64*S + 47 bits and the two words a peek touches
 
-// LUT entry: codelen[3:0] | xb[7:4] | val9[16:8] | next.nbits[20:17] | next.tb[31:21]
-//   codelen  bits this step consumes for the code (a LINK entry consumes the root bits, the
-//            sub-table entry behind it the rest of the code)
-//   xb       extra bits that follow the code
-//   val9     literal byte | length base (3..258) | distance base m, base = (m << xb) + 1 (500 = invalid symbol) | 511 = LINK
-//   next     the table the following step indexes: lit root (0), distance root, a sub-table, or
-//            one of the two self-looping STOP entries (end of block / empty distance slot)
+// LUT entry: n[4:0] | xb[8:5] | val8[16:9] | next.nbits[20:17] | next.tb[31:21]
+//   n      bits this step consumes: the code (a LINK entry: the root bits, the sub-table entry behind it: the rest of
+//          the code) and the extra bits that follow it
+//   xb     how many of them are extra bits (the last xb of the n)
+//   val8   literal byte | length base - 3 (0..255) | distance base m (0..3), base = (m << xb) + 1
+//   next   the table the following step indexes: the lit/len root, the distance root, a sub-table (this is a LINK
+//          entry then), or one of the two self-looping STOP entries (end of block / no such code)
+// The tables lie in this order: lit/len sub-tables, distance root and sub-tables, lit/len root, the STOP entries -
+// and every table starts on an EVEN entry.  So (1) `e >> 17` has the next index width in its low FIVE bits (what
+// v_bfe_u32 takes as its width operand) and `e >> 21` is the next table: a step needs no masks; (2) "this step ended a
+// token at or beyond `lim`, or ran into a STOP entry" is ONE unsigned compare: (e & kTbMask) | p >= (kLitB << 21) | lim.
 constexpr uint32_t kLitSize = 852, kDistSize = 592;  // zlib ENOUGH (lib/de.ml:579-580)
-constexpr uint32_t kDistB = kLitSize;
-constexpr uint32_t kStopEobI = kLitSize + kDistSize;
-constexpr uint32_t kStopBadI = kStopEobI + 1;
-constexpr uint32_t kLutWords = kStopEobI + 4;
-constexpr uint32_t kLinkVal = 511;
+constexpr uint32_t kLitRootMax = 512;                // the lit/len root is at most 9 bits wide (De.Inf.huffman's root)
+constexpr uint32_t kLitSubB = 0;                     // lit/len sub-tables: they exist only behind a 9-bit root
+constexpr uint32_t kDistB = kLitSize - kLitRootMax;  // 340
+constexpr uint32_t kLitB = kDistB + kDistSize;       // 932
+constexpr uint32_t kStopEobI = kLitB + kLitRootMax;  // 1444
+constexpr uint32_t kStopBadI = kStopEobI + 2;
+constexpr uint32_t kLutWords = kStopBadI + 2;
+constexpr uint32_t kTbMask = 0xffe00000u;
+constexpr uint32_t kLoopy = 0x100u;  // with the root width of a block: an incomplete code, a walk can stand still
+static_assert(kDistB % 2 == 0 && kLitB % 2 == 0 && kStopEobI % 2 == 0 && kLutWords == 1448, "even table bases");
 constexpr uint32_t kStEob = 100, kStTrunc = 101;  // lane stop reasons; < 100 = MD_* status
 constexpr uint32_t kCountMatch = 1u << 20;         // a walk counts bytes | matches << 20 (64 lanes: < 2^20 bytes, < 2^12 matches)
 constexpr uint32_t kNearBit = 0x8000u;            // match record: len-3[23:16] | near[15] | dist-1[14:0]
@@ -117,26 +126,35 @@ __device__ __forceinline__ lds_hscratch *hscratch_of(lds_smem *sm) {
   return reinterpret_cast<lds_hscratch *>(reinterpret_cast<lds_u8 *>(sm->win) + kHScratchAt);
 }
 
-__device__ __forceinline__ uint32_t mk_entry(uint32_t codelen, uint32_t xb, uint32_t val9, uint32_t nbits, uint32_t tb) {
-  return codelen | (xb << 4) | (val9 << 8) | (nbits << 17) | (tb << 21);
+__device__ __forceinline__ uint32_t mk_entry(uint32_t n, uint32_t xb, uint32_t val8, uint32_t nbits, uint32_t tb) {
+  return n | (xb << 5) | (val8 << 9) | (nbits << 17) | (tb << 21);
 }
-// leaf entries; `codelen` = bits the step consumes
+__device__ __forceinline__ uint32_t e_n(uint32_t e) { return e & 31; }
+__device__ __forceinline__ uint32_t e_xb(uint32_t e) { return (e >> 5) & 15; }
+__device__ __forceinline__ uint32_t e_val(uint32_t e) { return (e >> 9) & 255; }
+__device__ __forceinline__ uint32_t e_tb(uint32_t e) { return e >> 21; }
+// a LINK entry leads to a sub-table: neither a root nor a STOP entry
+__device__ __forceinline__ bool e_link(uint32_t e) { return e_tb(e) < kLitB && e_tb(e) != kDistB; }
+// the state a walk starts in: "the next step indexes the lit/len root"
+__device__ __forceinline__ uint32_t e_root(uint32_t lroot) { return mk_entry(0, 0, 0, lroot, kLitB); }
+// leaf entries; `codelen` = bits of the code this step consumes
 __device__ __forceinline__ uint32_t lit_leaf(uint32_t sym, uint32_t codelen, uint32_t lroot, uint32_t droot) {
-  if (sym < 256) return mk_entry(codelen, 0, sym, lroot, 0);
+  if (sym < 256) return mk_entry(codelen, 0, sym, lroot, kLitB);
   if (sym == 256) return mk_entry(codelen, 0, 0, 0, kStopEobI);
-  const uint32_t l = (sym - 257) & 31;  // lib/de.ml:293-311 (+3 folded in; 29,30 -> 3)
+  const uint32_t l = (sym - 257) & 31;  // lib/de.ml:293-311 (29,30 -> length 3)
   const uint32_t xb = (l >= 8 && l < 28) ? (l - 4) >> 2 : 0;
-  const uint32_t base = (l < 8 ? l : l < 28 ? (4 + (l & 3)) << xb : l == 28 ? 255 : 0) + 3;
-  return mk_entry(codelen, xb, base, droot, kDistB);
+  const uint32_t base3 = l < 8 ? l : l < 28 ? (4 + (l & 3)) << xb : l == 28 ? 255 : 0;  // length base - 3
+  return mk_entry(codelen + xb, xb, base3, droot, kDistB);
 }
 // a distance leaf carries the base of its symbol as `m`, base = (m << xb) + 1: m = the symbol itself for 0..3, 2 or 3
-// for 4..29 (lib/de.ml:313-325); the invalid symbols 30 and 31 carry kBadDist (any value >= 30 that is not LINK)
-constexpr uint32_t kBadDist = 500;
+// for 4..29 (lib/de.ml:313-325); the invalid symbols 30 and 31 lead to the STOP entry of "no such code" and, unlike an
+// empty table slot, consume their code (slow_token tells them apart by that)
 __device__ __forceinline__ uint32_t dist_leaf(uint32_t dv, uint32_t codelen, uint32_t lroot) {
   dv &= 31;
-  const uint32_t xb = (dv >= 4 && dv < 30) ? (dv - 2) >> 1 : 0;
-  const uint32_t m = dv < 4 ? dv : dv < 30 ? ((dv & 1) | 2) : kBadDist;
-  return mk_entry(codelen, xb, m, lroot, 0);
+  if (dv >= 30) return mk_entry(codelen, 0, 0, 0, kStopBadI);
+  const uint32_t xb = dv >= 4 ? (dv - 2) >> 1 : 0;
+  const uint32_t m = dv < 4 ? dv : ((dv & 1) | 2);
+  return mk_entry(codelen + xb, xb, m, lroot, kLitB);
 }
 // leaf value + extra bits -> distance (lib/de.ml:321-325, +1 folded in)
 __device__ __forceinline__ uint32_t dist_value(uint32_t m, uint32_t xb, uint32_t x) { return (m << xb) + 1 + x; }
@@ -270,10 +288,11 @@ __device__ __forceinline__ void canon_counts(const uint32_t (&len)[K], uint32_t 
   c.root = root;
 }
 
-// Builds one walk table into lut[tb0 ..).  len[k] = code length of symbol lane + 64k (0 beyond the alphabet).
-// LEAF(sym, codelen) encodes a leaf.  Returns false when the table would need more than `size` entries (D3).
+// Builds one walk table: its root into lut[tb0 ..), its sub-tables into lut[sub0 ..).  len[k] = code length of symbol
+// lane + 64k (0 beyond the alphabet).  LEAF(sym, codelen) encodes a leaf.  Returns false when the table would need
+// more than `size` entries (D3).
 template <int K, class LEAF>
-__device__ __forceinline__ bool build_walk(const uint32_t (&len)[K], const Canon &c, lds_u32 *lut, uint32_t tb0,
+__device__ __forceinline__ bool build_walk(const uint32_t (&len)[K], const Canon &c, lds_u32 *lut, uint32_t tb0, uint32_t sub0,
                                            uint32_t size, lds_hscratch *hs, uint32_t lane, uint32_t zero_entry, LEAF leaf) {
   const uint32_t root = c.root, rmask = (1u << root) - 1;
   // codes by rank inside their length class; symbols sorted by (length, symbol) for the root search
@@ -313,7 +332,7 @@ __device__ __forceinline__ bool build_walk(const uint32_t (&len)[K], const Canon
     if (v) {
       const uint32_t sub = v - root;
       const uint32_t off = __hip_atomic_fetch_add(&hs->ctr, 1u << sub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      e = mk_entry(root, 0, kLinkVal, sub, (tb0 + nroot + off) & 2047);
+      e = mk_entry(root, 0, 0, sub, (sub0 + off) & 2047);  // (sub-table sizes are even, so are their places)
     } else {
       const uint32_t cw = __brev(i) >> (32 - root);  // the root bits as an MSB-first code prefix
       uint32_t fl = 0, ft = 0;
@@ -355,6 +374,7 @@ constexpr uint64_t kZig1 = 12ull | 3ull << 5 | 13ull << 10 | 2ull << 15 | 14ull 
 
 // Dynamic block header (lib/de.ml:1733-1793) at window bit `bp`.  On MD_OK the walk tables are in lut,
 // *lroot_out is the index width of the lit/len root table and *bp_out the bit after the header.
+// *lroot_out also says (bit 8) that one of the two codes is incomplete: a walk over its zero entries needs a step budget.
 template <class PF>
 __device__ __noinline__ int dynamic_tables(lds_smem *sm, uint32_t bp_arg, uint32_t tot_arg, uint32_t lane, uint32_t *bp_out,
                                            uint32_t *lroot_out, PF &pf) {
@@ -485,7 +505,7 @@ __device__ __noinline__ int dynamic_tables(lds_smem *sm, uint32_t bp_arg, uint32
     if (cd_.left == 0xffffffffu || (cd_.left > 0 && cd_.max != 1)) return MD_INVALID_DICTIONARY;
     droot = cd_.root;
   }
-  if (!build_walk<5>(ll, cl_, lut, 0, kLitSize, hs, lane, mk_entry(0, 0, 0, lroot, 0),
+  if (!build_walk<5>(ll, cl_, lut, kLitB, kLitSubB, kLitSize, hs, lane, e_root(lroot),
                      [=](uint32_t sym, uint32_t codelen) { return lit_leaf(sym, codelen, lroot, droot); }))
     return MD_INVALID_DICTIONARY;
   pf.tick_lds(P_HDR_LIT);
@@ -494,10 +514,11 @@ __device__ __noinline__ int dynamic_tables(lds_smem *sm, uint32_t bp_arg, uint32
       lut[kDistB] = dist_leaf(0, 1, lroot);
       lut[kDistB + 1] = mk_entry(0, 0, 0, 0, kStopBadI);
     }
-  } else if (!build_walk<1>(dl, cd_, lut, kDistB, kDistSize, hs, lane, mk_entry(0, 0, 0, lroot, 0),
+  } else if (!build_walk<1>(dl, cd_, lut, kDistB, kDistB + (1u << droot), kDistSize, hs, lane, e_root(lroot),
                             [=](uint32_t sym, uint32_t codelen) { return dist_leaf(sym, codelen, lroot); }))
     return MD_INVALID_DICTIONARY;
-  *lroot_out = lroot;
+  const bool loopy = cl_.left > 0 || (cd_.max != 0 && cd_.left > 0);
+  *lroot_out = lroot | (loopy ? kLoopy : 0u);
   return MD_OK;
 }
 
@@ -516,65 +537,75 @@ __device__ __noinline__ void fixed_tables(lds_smem *sm, uint32_t lane, uint32_t 
   canon_counts<1>(dl, 6, cd_);
   const uint32_t lroot = cl_.root, droot = cd_.root;
   lds_u32 *lut = (lds_u32 *)sm->lut;
-  build_walk<5>(ll, cl_, lut, 0, kLitSize, hs, lane, mk_entry(0, 0, 0, lroot, 0),
+  build_walk<5>(ll, cl_, lut, kLitB, kLitSubB, kLitSize, hs, lane, e_root(lroot),
                 [=](uint32_t sym, uint32_t codelen) { return lit_leaf(sym, codelen, lroot, droot); });
-  build_walk<1>(dl, cd_, lut, kDistB, kDistSize, hs, lane, mk_entry(0, 0, 0, lroot, 0),
+  build_walk<1>(dl, cd_, lut, kDistB, kDistB + (1u << droot), kDistSize, hs, lane, e_root(lroot),
                 [=](uint32_t sym, uint32_t codelen) { return dist_leaf(sym, codelen, lroot); });
   *lroot_out = lroot;
 }
 
 // ---- the walks ----------------------------------------------------------------------------------
-// One token-boundary walk of this lane's zone [start, limit).  COUNT adds the bytes the tokens produce.
-// A divergent per-lane loop: finished lanes leave the exec mask, the wave leaves when it is empty.
-// A lane's bit cursor: three consecutive window words in registers (w2 is fetched a step ahead), so the only
-// LDS access a step waits for is its table entry.
+// A lane's bit cursor: two consecutive window words in registers and the one after them on its way (fetched a step
+// ahead), so the only LDS access a step waits for is its table entry.
 struct Cursor {
-  uint32_t w0, w1, w2, r, wa;  // window words at byte address wa, wa + 4, wa + 8; r = bit offset in w0
+  uint32_t w0, w1, w2, wa;  // window words at byte address wa, wa + 4, wa + 8
   __device__ __forceinline__ void init(const lds_u32 *win, uint32_t p) {
     wa = (p >> 5) << 2;
     const lds_u32 *q = reinterpret_cast<const lds_u32 *>(reinterpret_cast<const lds_u8 *>(win) + wa);
     w0 = q[0];
     w1 = q[1];
     w2 = q[2];
-    r = p & 31;
   }
-  __device__ __forceinline__ uint32_t peek() const { return __builtin_amdgcn_alignbit(w1, w0, r); }
-  __device__ __forceinline__ void skip(const lds_u32 *win, uint32_t n) {  // n < 32
-    const uint32_t r2 = r + n;
-    const bool ge = r2 >= 32;
+  __device__ __forceinline__ uint32_t peek(uint32_t p) const { return __builtin_amdgcn_alignbit(w1, w0, p); }  // (uses p & 31)
+  __device__ __forceinline__ void seek(const lds_u32 *win, uint32_t pn) {  // pn at most one word further on
+    const uint32_t wan = (pn >> 5) << 2;
+    const bool ge = wan != wa;
     w0 = ge ? w1 : w0;
     w1 = ge ? w2 : w1;
-    wa += ge ? 4u : 0u;
-    r = r2 & 31;
+    wa = wan;
     w2 = *reinterpret_cast<const lds_u32 *>(reinterpret_cast<const lds_u8 *>(win) + wa + 8);
   }
 };
+// the table entry the step in state `e` (the entry of the step before) finds at the bits w
+__device__ __forceinline__ uint32_t lut_step(const lds_u32 *lut, uint32_t e, uint32_t w) {
+  return lut_at(lut, e >> 21, __builtin_amdgcn_ubfe(w, 0, e >> 17));  // (v_bfe_u32 takes the low 5 bits of the width: the next index width)
+}
 
-template <bool COUNT>
+// One token-boundary walk of this lane's zone [start, limit).  COUNT adds what the tokens produce: a byte per return
+// to the lit/len root (a literal, or the last byte of a match), length - 1 and a match at every length code.
+// A divergent per-lane loop: finished lanes leave the exec mask, the wave leaves when it is empty.  The walk goes on
+// while `key` < `thr` (see the table layout); every step of a complete code consumes a bit, so it ends.  BUDGET: the
+// block has an incomplete code (allowed when the only code is 1 bit long, lib/de.ml:549-550), whose unused slot
+// consumes nothing (lib/de.ml:521: a zero entry is "0 bits, symbol 0"): the walk is then limited to KMAX steps.
+template <bool COUNT, bool BUDGET>
 __device__ __forceinline__ void sync_pass(const lds_u32 *win, const lds_u32 *lut, uint32_t lroot, bool go, uint32_t start,
                                           uint32_t limit, uint32_t &end, uint32_t &stop, uint32_t &nb) {
   if (go) {
-    uint32_t p = start, tb = 0, nbits = lroot, cnt = 0, slot = 0;
-    Cursor c;
-    c.init(win, start);
-    // a step that starts a token (tb == 0) is taken while the zone and the step budget last
-    while ((tb < kStopEobI) & ((tb != 0) | ((p < limit) & (slot < KMAX)))) {
-      const uint32_t w = c.peek();
-      const uint32_t e = lut_at(lut, tb, __builtin_amdgcn_ubfe(w, 0, nbits));
-      const uint32_t codelen = e & 15, xb = (e >> 4) & 15, ntb = e >> 21;
-      if (COUNT) {  // bytes in the low 20 bits, matches above (kCountMatch)
-        const uint32_t len1 = ((e >> 8) & 511) + __builtin_amdgcn_ubfe(w, codelen, xb) + (kCountMatch - 1);
-        cnt += (tb == 0 ? 1u : 0u) + (ntb == kDistB ? len1 : 0u);
-      }
-      p += codelen + xb;
-      c.skip(win, codelen + xb);
-      nbits = (e >> 17) & 15;
-      tb = ntb;
-      slot++;
+    uint32_t p = start, e = e_root(lroot), cnt = 0;
+    if (p < limit) {
+      const uint32_t thr = (kLitB << 21) | limit;
+      uint32_t slot = 0, key;
+      Cursor c;
+      c.init(win, start);
+      do {
+        const uint32_t w = c.peek(p);
+        const uint32_t en = lut_step(lut, e, w);
+        const uint32_t n = e_n(en);
+        if (COUNT) {  // bytes in the low 20 bits, matches above (kCountMatch)
+          const uint32_t xb = e_xb(en);
+          const uint32_t len1 = e_val(en) + __builtin_amdgcn_ubfe(w, n - xb, xb) + (kCountMatch + 2);  // length - 1, and a match
+          cnt += (e_tb(en) == kLitB ? 1u : 0u) + (e_tb(en) == kDistB ? len1 : 0u);
+        }
+        p += n;
+        c.seek(win, p);
+        e = en;
+        key = (en & kTbMask) | p;
+        if (BUDGET && ++slot >= KMAX && e_tb(en) == kLitB) break;
+      } while (key < thr);
     }
     end = p;
-    stop = tb >= kStopEobI ? tb : 0u;
-    if (COUNT) nb = cnt - (tb == kStopEobI ? 1u : 0u);  // the end-of-block code was counted as a token
+    stop = e_tb(e) >= kStopEobI ? e_tb(e) : 0u;
+    if (COUNT) nb = cnt;
   }
 }
 
@@ -591,14 +622,14 @@ __device__ __noinline__ uint32_t slow_token(const lds_u32 *win, const lds_u32 *l
                                             uint32_t tot, uint32_t cap, uint32_t *pend_out) {
   uint32_t p = ptok;
   uint32_t w = peek(win, p);
-  uint32_t e = lut_at(lut, 0, __builtin_amdgcn_ubfe(w, 0, lroot));
-  if (((e >> 8) & 511) == kLinkVal) {
-    p += e & 15;
+  uint32_t e = lut_step(lut, e_root(lroot), w);
+  if (e_link(e)) {
+    p += e_n(e);
     w = peek(win, p);
-    e = lut_at(lut, e >> 21, __builtin_amdgcn_ubfe(w, 0, (e >> 17) & 15));
+    e = lut_step(lut, e, w);
   }
-  uint32_t codelen = e & 15, xb = (e >> 4) & 15, val9 = (e >> 8) & 511, ntb = e >> 21;
-  uint32_t pn = p + codelen + xb;
+  uint32_t n = e_n(e), xb = e_xb(e), ntb = e_tb(e);
+  uint32_t pn = p + n;
   if (pn > tot) return MD_UNEXPECTED_END_OF_INPUT;  // D1
   if (ntb == kStopEobI) {
     *pend_out = pn;
@@ -608,22 +639,21 @@ __device__ __noinline__ uint32_t slow_token(const lds_u32 *win, const lds_u32 *l
     if (q >= cap) return MD_UNEXPECTED_END_OF_OUTPUT;
     return kStTrunc;
   }
-  const uint32_t mlen = val9 + __builtin_amdgcn_ubfe(w, codelen, xb);
+  const uint32_t mlen = e_val(e) + 3 + __builtin_amdgcn_ubfe(w, n - xb, xb);
   p = pn;
   w = peek(win, p);
-  e = lut_at(lut, kDistB, __builtin_amdgcn_ubfe(w, 0, (e >> 17) & 15));
-  if ((e >> 21) == kStopBadI) return MD_INVALID_DISTANCE_CODE;  // D2
-  if (((e >> 8) & 511) == kLinkVal) {
-    p += e & 15;
+  e = lut_step(lut, e, w);
+  if (e_tb(e) == kStopBadI && e_n(e) == 0) return MD_INVALID_DISTANCE_CODE;  // D2: an empty slot
+  if (e_link(e)) {
+    p += e_n(e);
     w = peek(win, p);
-    e = lut_at(lut, e >> 21, __builtin_amdgcn_ubfe(w, 0, (e >> 17) & 15));
-    if ((e >> 21) == kStopBadI) return MD_INVALID_DISTANCE_CODE;
+    e = lut_step(lut, e, w);
   }
-  codelen = e & 15, xb = (e >> 4) & 15, val9 = (e >> 8) & 511;
-  pn = p + codelen + xb;
+  n = e_n(e), xb = e_xb(e);
+  pn = p + n;
   if (pn > tot) return MD_UNEXPECTED_END_OF_INPUT;
-  if (val9 >= 30) return MD_INVALID_DISTANCE_CODE;
-  const uint32_t d = dist_value(val9, xb, __builtin_amdgcn_ubfe(w, codelen, xb));
+  if (e_tb(e) == kStopBadI) return MD_INVALID_DISTANCE_CODE;  // the symbols 30 and 31
+  const uint32_t d = dist_value(e_val(e), xb, __builtin_amdgcn_ubfe(w, n - xb, xb));
   const uint32_t lim = q < 32768u ? q : 32768u;
   if (d > lim) return MD_INVALID_DISTANCE;
   if (mlen > cap - q) return MD_UNEXPECTED_END_OF_OUTPUT;
@@ -634,53 +664,57 @@ __device__ __noinline__ uint32_t slow_token(const lds_u32 *win, const lds_u32 *l
 // unusual stops the lane in front of the token (ptok) and is classified afterwards by slow_token.  CHECKED = false
 // leaves out the tests the caller has ruled out for the whole round: the end of the input is beyond the window, the
 // output position is past 32 KiB (no distance can reach before the start) and everything counted fits the staging
-// buffer and the output capacity.
-template <bool CHECKED>
+// buffer and the output capacity; the only stops left are the STOP entries, which end the loop like the zone's end
+// does.  A length code leaves the match length in mlen until its distance code returns to the root: a step that
+// returns to the root with mlen == 0 is a literal.
+template <bool CHECKED, bool BUDGET>
 __device__ __forceinline__ void emit_pass(const lds_u32 *win, const lds_u32 *lut, uint32_t lroot, lds_u32 *mrec,
                                           lds_u16 *mpos, lds_u8 *stage, uint32_t rec0, uint32_t tot, bool go, uint32_t start,
                                           uint32_t limit, uint32_t q0, uint32_t rb, uint32_t R0, uint32_t cap, LaneOut &lo) {
   // rec0 = the lane's first record: the walk before counted the matches, the lanes' records follow each other
-  uint32_t p = start, ptok = start, tb = 0, nbits = lroot;
+  uint32_t p = start, ptok = start, e = e_root(lroot);
   uint32_t q = q0, rec = rec0, mlen = 0;
   bool stopped = false;
   const uint32_t qlim = rb + STAGE - 16;  // the staging buffer holds output positions [rb, qlim)
   const uint32_t qmax = cap < qlim ? cap : qlim;
-  if (go) {
-    uint32_t slot = 0;
+  if (go && p < limit) {
+    const uint32_t thr = (kLitB << 21) | limit;
+    uint32_t slot = 0, key;
     Cursor c;
     c.init(win, start);
-    while ((!stopped) & ((tb != 0) | ((p < limit) & (slot < KMAX)))) {
-      ptok = tb == 0 ? p : ptok;
-      const uint32_t w = c.peek();
-      const uint32_t e = lut_at(lut, tb, __builtin_amdgcn_ubfe(w, 0, nbits));
-      const uint32_t codelen = e & 15, xb = (e >> 4) & 15, val9 = (e >> 8) & 511, ntb = e >> 21;
-      const uint32_t x = __builtin_amdgcn_ubfe(w, codelen, xb);
-      const uint32_t pn = p + codelen + xb;
-      const bool in_dist = tb >= kDistB, to_root = ntb == 0;
-      const bool lit = to_root & !in_dist, mat = to_root & in_dist, is_len = ntb == kDistB;
-      const uint32_t d = dist_value(val9, xb, x);
-      const uint32_t lim = q < 32768u ? q : 32768u;
-      const uint32_t need = mat ? mlen : 1u;
-      const bool rare = CHECKED ? (ntb >= kStopEobI) | ((val9 != kLinkVal) & (pn > tot)) |
-                                      (mat & ((val9 >= 30u) | (d > lim))) | ((lit | mat) & (q + need > qmax))
-                                : (ntb >= kStopEobI) | (mat & (val9 >= 30u));
-      stopped = rare;
-      if (!rare) {
-        stage[lit ? q - rb : STAGE + 15] = (uint8_t)val9;  // (a slack byte when the step is not a literal: no branch)
-        if (mat) {
-          mrec[rec] = ((mlen - 3) << 16) | ((q - d + mlen > R0) ? kNearBit : 0u) | (d - 1);
-          mpos[rec] = (uint16_t)(q - rb);
-          rec++;
-        }
-        mlen = is_len ? val9 + x : mlen;
-        q += lit ? 1u : mat ? need : 0u;
-        p = pn;
-        c.skip(win, codelen + xb);
-        nbits = (e >> 17) & 15;
-        tb = ntb;
+    do {
+      const uint32_t w = c.peek(p);
+      const uint32_t en = lut_step(lut, e, w);
+      const uint32_t n = e_n(en), xb = e_xb(en), ntb = e_tb(en);
+      const uint32_t x = __builtin_amdgcn_ubfe(w, n - xb, xb);
+      const uint32_t pn = p + n;
+      const bool to_root = ntb == kLitB, is_len = ntb == kDistB;
+      const bool mat = to_root & (mlen != 0), lit = to_root & (mlen == 0);
+      const uint32_t d1 = (e_val(en) << xb) + x;  // distance - 1 (when this is the distance step)
+      if (CHECKED) {
+        const uint32_t lim = q < 32768u ? q : 32768u;
+        const uint32_t need = mat ? mlen : 1u;
+        stopped = (ntb >= kStopEobI) | (pn > tot) | (mat & (d1 >= lim)) | (to_root & (q + need > qmax));
+        if (stopped) break;
       }
-      slot++;
-    }
+      stage[lit ? q - rb : STAGE + 15] = (uint8_t)(en >> 9);  // (a slack byte when the step is not a literal: no branch)
+      if (mat) {
+        mrec[rec] = ((mlen - 3) << 16) | ((q - d1 + mlen > R0 + 1) ? kNearBit : 0u) | d1;
+        mpos[rec] = (uint16_t)(q - rb);
+        rec++;
+      }
+      q += to_root ? (mlen > 1u ? mlen : 1u) : 0u;
+      mlen = is_len ? e_val(en) + 3 + x : to_root ? 0u : mlen;
+      p = pn;
+      ptok = to_root ? pn : ptok;  // the start of the token the next step belongs to
+      c.seek(win, p);
+      e = en;
+      key = (en & kTbMask) | p;
+      if (BUDGET && ++slot >= KMAX && to_root) break;
+    } while (key < thr);
+    // (unchecked: the walk has gone through the code that leads to a STOP entry - an end-of-block code or an invalid
+    // distance symbol; nothing was written for that token, which began at ptok)
+    if (!CHECKED) stopped = e_tb(e) >= kStopEobI;
   }
   uint32_t stopc = 0, endp = p;
   if (go && stopped) {
@@ -1081,7 +1115,8 @@ __device__ __forceinline__ void mail_post(lds_smem *sm, uint32_t lane, uint32_t 
 // PAIR: this wavefront only decodes — a round's records and literals go to the copier wavefront (copier_main), which
 // copies the matches, folds the checksum and writes the round out while this one is already walking the next round's
 // zones; sk is then the decoder's own idea of the output position, and `sent` counts the jobs posted.
-template <class PF, bool PAIR>
+// BUDGET: the block has an incomplete code (see sync_pass); that form is not made for speed.
+template <class PF, bool PAIR, bool BUDGET>
 __device__ __forceinline__ int inflate_block(lds_smem *sm, const uint8_t *__restrict__ body, uint32_t body_len, Sink &sk,
                                              uint32_t lroot, uint32_t lane, uint32_t *bp_io, uint32_t *zone_io, Window &wnd,
                                              uint32_t &sent, PF &pf) {
@@ -1101,7 +1136,7 @@ __device__ __forceinline__ int inflate_block(lds_smem *sm, const uint8_t *__rest
     pf.count(C_PASSES);
     uint32_t start = rbp + lane * zs, end = 0, stop = 0, nb = 0;
     const uint32_t limit = rbp + (lane + 1) * zs;
-    sync_pass<false>(win, lut, lroot, true, start, limit, end, stop, nb);
+    sync_pass<false, BUDGET>(win, lut, lroot, true, start, limit, end, stop, nb);
     pf.tick(P_DECODE1);
     bool counted = false;
     const uint32_t passes = zs * PASSES >= PASS_BITS ? PASSES : PASS_BITS / zs > PASSES_MAX ? PASSES_MAX : PASS_BITS / zs;
@@ -1111,7 +1146,7 @@ __device__ __forceinline__ int inflate_block(lds_smem *sm, const uint8_t *__rest
       if (__ballot(redo) == 0) break;
       if (redo && lane > 0) start = pe;
       pf.count(C_PASSES);
-      sync_pass<true>(win, lut, lroot, redo, start, limit, end, stop, nb);
+      sync_pass<true, BUDGET>(win, lut, lroot, redo, start, limit, end, stop, nb);
       counted = counted || redo;
     }
     pf.tick(P_DECODE2);
@@ -1152,8 +1187,8 @@ __device__ __forceinline__ int inflate_block(lds_smem *sm, const uint8_t *__rest
     {
       const uint32_t all = rdlane(off + mynb, nvalid - 1) & (kCountMatch - 1);  // bytes the round will produce
       const bool plain = tot >= rbp + kWave * zs + 64 && R0 >= 32768u && all <= sk.cap - R0 && (R0 - rb) + all <= STAGE - 16;
-      if (plain) emit_pass<false>(win, lut, lroot, mrec, mpos, sk.stage, roff, tot, mine, start, limit, q0, rb, R0, sk.cap, lo);
-      else emit_pass<true>(win, lut, lroot, mrec, mpos, sk.stage, roff, tot, mine, start, limit, q0, rb, R0, sk.cap, lo);
+      if (plain && !BUDGET) emit_pass<false, false>(win, lut, lroot, mrec, mpos, sk.stage, roff, tot, mine, start, limit, q0, rb, R0, sk.cap, lo);
+      else emit_pass<true, BUDGET>(win, lut, lroot, mrec, mpos, sk.stage, roff, tot, mine, start, limit, q0, rb, R0, sk.cap, lo);
     }
     pf.tick(P_EMIT_A);
     // the first stopped lane (stream order) ends the round
@@ -1308,7 +1343,7 @@ __global__ __launch_bounds__(PAIR ? 2 * kWave : kWave, PAIR ? 4 : 2) void inflat
   sk.b = adler0 >> 16;
   sk.want_adler = (checksum != nullptr) || format == MD_FORMAT_ZLIB || cont.resume_adler != nullptr;
 
-  if (threadIdx.x < 4) sm->lut[kStopEobI + threadIdx.x] = mk_entry(0, 0, 0, 0, kStopEobI + (threadIdx.x & 1));  // the self-looping STOP entries
+  if (threadIdx.x < 4) sm->lut[kStopEobI + threadIdx.x] = mk_entry(0, 0, 0, 0, kStopEobI + (threadIdx.x & 2));  // the self-looping STOP entries
   for (uint32_t i = threadIdx.x; i < STAGE / 32 + 2; i += blockDim.x) sm->pend[i] = 0;
   if constexpr (PAIR) {
     if (threadIdx.x < sizeof(Mail) / 4) ((lds_u32 *)&sm->mail)[threadIdx.x] = threadIdx.x == 6 ? sk.a : threadIdx.x == 7 ? sk.b : 0u;
@@ -1399,7 +1434,10 @@ __global__ __launch_bounds__(PAIR ? 2 * kWave : kWave, PAIR ? 4 : 2) void inflat
         }
         lroot = uni(lroot);
         pf.tick(P_HEADER);
-        if (rc == MD_OK) rc = inflate_block<Prof<PROF>, PAIR>(sm, body, body_len, sk, lroot, lane, &bp, &zone, wnd, sent, pf);
+        if (rc == MD_OK) {
+          if (lroot & kLoopy) rc = inflate_block<Prof<PROF>, PAIR, true>(sm, body, body_len, sk, lroot & 15, lane, &bp, &zone, wnd, sent, pf);
+          else rc = inflate_block<Prof<PROF>, PAIR, false>(sm, body, body_len, sk, lroot, lane, &bp, &zone, wnd, sent, pf);
+        }
       }
       if (cont.resume_bits && rc == MD_OK) {  // a block is complete: the next piece of the stream could start here
         if constexpr (PAIR) {                 // (the checksum state is the copier's)
