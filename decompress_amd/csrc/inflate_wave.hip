@@ -844,17 +844,35 @@ __device__ __forceinline__ void lds_put(lds_u8 *p, uint64_t v, uint32_t n) {
 
 // Far matches (the whole source is older than this round: final in HBM/L2 once the flush of earlier rounds has
 // been waited for; d >= ml) and the heads of matches that straddle the round start.  The round's records are taken
-// in stream order, one per lane, FH x 64 at a time: 2 LDS reads per record, then 16 bytes per record in flight, then
-// the stores; what a record has beyond 16 bytes is copied by the whole wave, 8 bytes per lane.  Two such sets are
-// alternated, so that the loads of one are in flight while the records of the next are read and the previous one is
-// stored (the loads go to L2 or beyond: a microsecond or more each time).  Near matches are marked in the pending
-// map on the way and listed, in stream order, for copy_near_all (*nnear_out of them).  The loads read whole 8-byte
-// words, up to 15 bytes past a record's source: the caller makes sure that stays inside the output buffer.
-constexpr int FH = 4;
-struct FarSet {
-  uint32_t qs[FH], n[FH], src[FH];
-  uint64_t v0[FH], v1[FH];
+// in stream order, one per lane and row of 64.  FIRST the loads of ALL rows are started - 2 LDS reads per record, one
+// unaligned 16-byte load each: the source lies in L2 or beyond, two microseconds away on a busy chip, and a round
+// should wait for that once, not once per group of rows (three sets of four rows, two of them in flight, spent more
+// time waiting than working) - and while they are in flight the near matches are marked in the pending map and listed,
+// in stream order, for copy_near_all (*nnear_out of them).  THEN the rows are gone through again as their data
+// arrives: the record is read once more (cheaper than keeping three more registers per row) and its bytes are stored
+// with exact-length LDS stores; what a record has beyond 16 bytes is copied by the whole wave, 8 bytes per lane.
+// The loads read whole 8-byte words, up to 15 bytes past a record's source: the caller makes sure that stays inside
+// the output buffer.
+constexpr int FR = RMAX / kWave;  // rows of a full record pool
+struct FarRow {
+  uint32_t qs, n, src;
+  bool near, has;
+  uint32_t ml;
 };
+__device__ __forceinline__ FarRow far_row(const lds_u32 *mrec, const lds_u16 *mpos, uint32_t r, uint32_t nrec, uint32_t rb, uint32_t R0) {
+  FarRow f;
+  f.has = r < nrec;
+  const uint32_t tk = mrec[f.has ? r : 0u];
+  f.qs = mpos[f.has ? r : 0u];
+  const uint32_t d = (tk & 0x7fff) + 1;
+  f.ml = ((tk >> 16) & 0xff) + 3;
+  const uint32_t s = rb + f.qs - d;
+  f.near = f.has && (tk & kNearBit);
+  const uint32_t head = s < R0 ? R0 - s : 0u;  // a near match that begins before the round start: its head is final too
+  f.n = !f.has ? 0u : f.near ? head : f.ml;
+  f.src = f.n ? s : 0u;  // (a lane without a record reads g[0..15]: no branch around the load)
+  return f;
+}
 template <class PF>
 __device__ __forceinline__ void copy_far(const lds_u32 *mrec, const lds_u16 *mpos, lds_u32 *pend, lds_u16 *list, const Sink &sk,
                                          uint32_t lane, uint32_t nrec, uint32_t *nnear_out, PF &pf) {
@@ -862,80 +880,57 @@ __device__ __forceinline__ void copy_far(const lds_u32 *mrec, const lds_u16 *mpo
   const uint32_t R0 = sk.pos, rb = sk.sbase();
   const uint8_t *g = sk.g;
   uint32_t nnear = 0;
-  // records c0 .. c0 + FH * 64 into `f`, their loads started (no branch on the way: a lane without a record reads g[0..15])
-  auto begin = [&](FarSet &f, uint32_t c0) {
+  uint64_t v0[FR], v1[FR];
+  // (straight-line: a load behind a branch makes the compiler wait for it at the join; a row beyond the last record
+  // reads g[0..15] with every lane, one cache line)
 #pragma unroll
-    for (int u = 0; u < FH; u++) {
-      const uint32_t r = c0 + u * kWave + lane;
-      const bool has = r < nrec;
-      const uint32_t tk = mrec[has ? r : 0u];
-      f.qs[u] = mpos[has ? r : 0u];
-      const uint32_t d = (tk & 0x7fff) + 1, ml = ((tk >> 16) & 0xff) + 3;
-      const uint32_t s = rb + f.qs[u] - d;
-      const bool near = has && (tk & kNearBit);
-      const uint32_t head = s < R0 ? R0 - s : 0u;  // a near match that begins before the round start: its head is final too
-      f.n[u] = !has ? 0u : near ? head : ml;
-      f.src[u] = f.n[u] ? s : 0u;
-      const uint64_t nb = __ballot(near);
-      if (near) {
-        list[nnear + lane_rank(nb)] = (uint16_t)r;
-        pend_update<true>(pend, f.qs[u], f.qs[u] + ml);
-      }
-      nnear += (uint32_t)__builtin_popcountll(nb);
+  for (int u = 0; u < FR; u++) {
+    const FarRow f = far_row(mrec, mpos, u * kWave + lane, nrec, rb, R0);
+    v0[u] = out_ld64(g + f.src);
+    v1[u] = out_ld64(g + f.src + 8);
+  }
+  pf.tick_lds(P_FAR_REC);
+  // the near matches, while the loads are on their way
+  for (uint32_t c0 = 0; c0 < nrec; c0 += kWave) {
+    const uint32_t r = c0 + lane;
+    const bool has = r < nrec;
+    const uint32_t tk = mrec[has ? r : 0u];
+    const bool near = has && (tk & kNearBit);
+    const uint64_t nb = __ballot(near);
+    if (near) {
+      const uint32_t qs = mpos[r], ml = ((tk >> 16) & 0xff) + 3;
+      list[nnear + lane_rank(nb)] = (uint16_t)r;
+      pend_update<true>(pend, qs, qs + ml);
     }
+    nnear += (uint32_t)__builtin_popcountll(nb);
+  }
+  pf.tick_lds(P_FAR);
+  uint64_t longer = 0;  // rows with a record of more than 16 bytes
 #pragma unroll
-    for (int u = 0; u < FH; u++) {
-      f.v0[u] = out_ld64(g + f.src[u]);
-      f.v1[u] = out_ld64(g + f.src[u] + 8);
+  for (int u = 0; u < FR; u++) {
+    if ((uint32_t)u * kWave < nrec) {
+      const FarRow f = far_row(mrec, mpos, u * kWave + lane, nrec, rb, R0);
+      if constexpr (PF::on) {
+        asm volatile("" ::"v"(v0[u]), "v"(v1[u]));
+        pf.tick_all(P_FAR_LOAD);
+      }
+      if (f.n) {
+        lds_u8 *dd = stage + f.qs;
+        lds_put(dd, v0[u], f.n < 8 ? f.n : 8);
+        if (f.n > 8) lds_put(dd + 8, v1[u], f.n < 16 ? f.n - 8 : 8);
+      }
+      if (__ballot(f.n > 16)) longer |= 1ull << u;
     }
-  };
-  auto finish = [&](FarSet &f) {
-    uint64_t longer = 0;
-    // every load of the set is waited for here, in one place: a group that nobody needs would otherwise leave its load
-    // "in flight" for the compiler, which then waits for the OTHER set's loads wherever the registers are written next
-#pragma unroll
-    for (int u = 0; u < FH; u++) asm volatile("" ::"v"(f.v0[u]), "v"(f.v1[u]));
-#pragma unroll
-    for (int u = 0; u < FH; u++) {
-      if (f.n[u]) {
-        lds_u8 *dd = stage + f.qs[u];
-        lds_put(dd, f.v0[u], f.n[u] < 8 ? f.n[u] : 8);
-        if (f.n[u] > 8) lds_put(dd + 8, f.v1[u], f.n[u] < 16 ? f.n[u] - 8 : 8);
-      }
-      longer |= __ballot(f.n[u] > 16);
-    }
-    if (longer) {  // the rest of the long ones, one record at a time by the whole wave
-#pragma unroll
-      for (int u = 0; u < FH; u++) {
-        for (uint64_t lm = __ballot(f.n[u] > 16); lm; lm &= lm - 1) {
-          const uint32_t l = (uint32_t)__builtin_ctzll(lm);
-          const uint32_t ln = rdlane(f.n[u], l), lsrc = rdlane(f.src[u], l), lqs = rdlane(f.qs[u], l);
-          const uint32_t j = 16 + lane * 8;
-          if (j < ln) lds_put(stage + lqs + j, out_ld64(g + lsrc + j), ln - j < 8 ? ln - j : 8);
-        }
-      }
-    }
-  };
-  constexpr uint32_t kSet = FH * kWave;
-  if (nrec) {
-    FarSet fa, fb;
-    begin(fa, 0);
-    // (the last set is finished on a path of its own: were it to join the path that has just started the other set's
-    // loads, the wait in front of the stores would have to be for all loads in flight, the other set's included)
-    for (uint32_t c = 0;;) {
-      if (c + kSet >= nrec) {
-        finish(fa);
-        break;
-      }
-      begin(fb, c + kSet);
-      finish(fa);
-      if (c + 2 * kSet >= nrec) {
-        finish(fb);
-        break;
-      }
-      begin(fa, c + 2 * kSet);
-      finish(fb);
-      c += 2 * kSet;
+  }
+  pf.tick_lds(P_FAR);
+  for (; longer; longer &= longer - 1) {  // the rest of the long ones, one record at a time by the whole wave
+    const uint32_t u = (uint32_t)__builtin_ctzll(longer);
+    const FarRow f = far_row(mrec, mpos, u * kWave + lane, nrec, rb, R0);
+    for (uint64_t lm = __ballot(f.n > 16); lm; lm &= lm - 1) {
+      const uint32_t l = (uint32_t)__builtin_ctzll(lm);
+      const uint32_t ln = rdlane(f.n, l), lsrc = rdlane(f.src, l), lqs = rdlane(f.qs, l);
+      const uint32_t j = 16 + lane * 8;
+      if (j < ln) lds_put(stage + lqs + j, out_ld64(g + lsrc + j), ln - j < 8 ? ln - j : 8);
     }
   }
   pf.tick_all(P_FAR);
