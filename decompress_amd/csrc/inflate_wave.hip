@@ -890,47 +890,91 @@ __device__ __forceinline__ void copy_far(const lds_u32 *mrec, const lds_u16 *mpo
     v1[u] = out_ld64(g + f.src + 8);
   }
   pf.tick_lds(P_FAR_REC);
-  // the near matches, while the loads are on their way
+  // while the loads are on their way: the near matches are listed (from the bottom of `list`) and marked, and so are
+  // the records that take more than 16 bytes from the old output (from the top of `list`; should the two lists meet,
+  // the near matches keep their places and the long records are copied by the slow loop at the end)
+  uint32_t nlong = 0;
+  bool spill = false;
   for (uint32_t c0 = 0; c0 < nrec; c0 += kWave) {
-    const uint32_t r = c0 + lane;
-    const bool has = r < nrec;
-    const uint32_t tk = mrec[has ? r : 0u];
-    const bool near = has && (tk & kNearBit);
-    const uint64_t nb = __ballot(near);
-    if (near) {
-      const uint32_t qs = mpos[r], ml = ((tk >> 16) & 0xff) + 3;
-      list[nnear + lane_rank(nb)] = (uint16_t)r;
-      pend_update<true>(pend, qs, qs + ml);
+    const FarRow f = far_row(mrec, mpos, c0 + lane, nrec, rb, R0);
+    const uint64_t nb = __ballot(f.near);
+    if (f.near) {
+      list[nnear + lane_rank(nb)] = (uint16_t)(c0 + lane);
+      pend_update<true>(pend, f.qs, f.qs + f.ml);
     }
     nnear += (uint32_t)__builtin_popcountll(nb);
+    const uint64_t lb = __ballot(f.n > 16);
+    const uint32_t lc = (uint32_t)__builtin_popcountll(lb);
+    if (nnear + nlong + lc > RMAX) {  // the two lists would meet (a record can be in both): the long ones go the slow way
+      spill = true;
+      nlong = 0;
+    }
+    if (lb && !spill) {
+      if (f.n > 16) list[RMAX - 1 - (nlong + lane_rank(lb))] = (uint16_t)(c0 + lane);
+      nlong += lc;
+    }
   }
   pf.tick_lds(P_FAR);
-  uint64_t longer = 0;  // rows with a record of more than 16 bytes
 #pragma unroll
   for (int u = 0; u < FR; u++) {
     if ((uint32_t)u * kWave < nrec) {
       const FarRow f = far_row(mrec, mpos, u * kWave + lane, nrec, rb, R0);
       if constexpr (PF::on) {
-        asm volatile("" ::"v"(v0[u]), "v"(v1[u]));
-        pf.tick_all(P_FAR_LOAD);
+        if (u == 0) {
+          asm volatile("" ::"v"(v0[u]), "v"(v1[u]));
+          pf.tick_all(P_FAR_LOAD);
+        }
       }
       if (f.n) {
         lds_u8 *dd = stage + f.qs;
         lds_put(dd, v0[u], f.n < 8 ? f.n : 8);
         if (f.n > 8) lds_put(dd + 8, v1[u], f.n < 16 ? f.n - 8 : 8);
       }
-      if (__ballot(f.n > 16)) longer |= 1ull << u;
     }
   }
   pf.tick_lds(P_FAR);
-  for (; longer; longer &= longer - 1) {  // the rest of the long ones, one record at a time by the whole wave
-    const uint32_t u = (uint32_t)__builtin_ctzll(longer);
-    const FarRow f = far_row(mrec, mpos, u * kWave + lane, nrec, rb, R0);
-    for (uint64_t lm = __ballot(f.n > 16); lm; lm &= lm - 1) {
-      const uint32_t l = (uint32_t)__builtin_ctzll(lm);
-      const uint32_t ln = rdlane(f.n, l), lsrc = rdlane(f.src, l), lqs = rdlane(f.qs, l);
-      const uint32_t j = 16 + lane * 8;
-      if (j < ln) lds_put(stage + lqs + j, out_ld64(g + lsrc + j), ln - j < 8 ? ln - j : 8);
+  // bytes 16 .. 31 of the long ones: one record per lane again, all loads first
+  for (uint32_t c0 = 0; c0 < nlong; c0 += kWave) {
+    const bool has = c0 + lane < nlong;
+    const uint32_t r = has ? list[RMAX - 1 - (c0 + lane)] : 0u;
+    const FarRow f = far_row(mrec, mpos, r, nrec, rb, R0);
+    const uint32_t n = has ? f.n : 0u;  // > 16 where there is a record
+    const uint64_t w0 = out_ld64(g + (n ? f.src + 16 : 0u)), w1 = out_ld64(g + (n ? f.src + 24 : 0u));
+    if (n) {
+      lds_u8 *dd = stage + f.qs + 16;
+      lds_put(dd, w0, n < 24 ? n - 16 : 8);
+      if (n > 24) lds_put(dd + 8, w1, n < 32 ? n - 24 : 8);
+    }
+    // what is beyond 32 bytes: by the whole wave, 8 bytes per lane, four records' loads in flight at a time
+    for (uint64_t lm = __ballot(n > 32); lm;) {
+      uint32_t ln[4], lsrc[4], lqs[4];
+      uint64_t d[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const bool any = lm != 0;
+        const uint32_t l = any ? (uint32_t)__builtin_ctzll(lm) : 0u;
+        lm &= lm - 1;  // (0 stays 0)
+        ln[k] = any ? rdlane(n, l) : 0u;
+        lsrc[k] = rdlane(f.src, l);
+        lqs[k] = rdlane(f.qs, l);
+      }
+      const uint32_t j = 32 + lane * 8;
+#pragma unroll
+      for (int k = 0; k < 4; k++) d[k] = out_ld64(g + (j < ln[k] ? lsrc[k] + j : 0u));
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if (j < ln[k]) lds_put(stage + lqs[k] + j, d[k], ln[k] - j < 8 ? ln[k] - j : 8);
+    }
+  }
+  if (spill) {  // (never seen: more long records than `list` has room for) one record at a time, all its bytes beyond 16
+    for (uint32_t c0 = 0; c0 < nrec; c0 += kWave) {
+      const FarRow f = far_row(mrec, mpos, c0 + lane, nrec, rb, R0);
+      for (uint64_t lm = __ballot(f.n > 16); lm; lm &= lm - 1) {
+        const uint32_t l = (uint32_t)__builtin_ctzll(lm);
+        const uint32_t ln = rdlane(f.n, l), lsrc = rdlane(f.src, l), lqs = rdlane(f.qs, l);
+        const uint32_t j = 16 + lane * 8;
+        if (j < ln) lds_put(stage + lqs + j, out_ld64(g + lsrc + j), ln - j < 8 ? ln - j : 8);
+      }
     }
   }
   pf.tick_all(P_FAR);
