@@ -740,44 +740,44 @@ struct Sink {
   bool want_adler;
   __device__ __forceinline__ uint32_t sbase() const { return pos & ~15u; }  // staging index of position x is x - sbase()
 
-  // write stage[...] for positions [pos, pos+total) to HBM, fold Adler-32, advance pos
+  // write stage[...] for positions [pos, pos+total) to HBM, fold Adler-32, advance pos: whole 16-byte chunks one per
+  // lane, the bytes of the (at most two) partial chunks at either end one per lane
   __device__ __forceinline__ void flush(uint32_t total) {
     const uint32_t rb = sbase();
     const uint32_t endp = pos + total;
+    const uint32_t full0 = (pos + 15) & ~15u, full1 = endp & ~15u;  // whole chunks: [full0, full1) (if full0 < full1)
     uint32_t s1 = 0, s2 = 0;
-    for (uint32_t ps = rb; ps < endp; ps += 1024) {
+    for (uint32_t ps = full0; ps < full1; ps += 1024) {
       const uint32_t cpos = ps + lane * 16;
-      const uint32_t lo = cpos > pos ? cpos : pos;
-      const uint32_t hi = cpos + 16 < endp ? cpos + 16 : endp;
-      if (lo < hi) {
+      if (cpos < full1) {
         const lds_u32 *sp = reinterpret_cast<const lds_u32 *>(stage + (cpos - rb));  // 16-byte aligned
         const uint32_t w0 = sp[0], w1 = sp[1], w2 = sp[2], w3 = sp[3];
         const uint4 v = make_uint4(w0, w1, w2, w3);
-        if (hi - lo == 16) {
-          __builtin_memcpy(g + cpos, &v, 16);
-          if (want_adler) {
-            // sum d_k and sum k*d_k over the 16 bytes
-            uint32_t t1 = __builtin_amdgcn_udot4(w0, 0x01010101u, 0u, false);
-            t1 = __builtin_amdgcn_udot4(w1, 0x01010101u, t1, false);
-            t1 = __builtin_amdgcn_udot4(w2, 0x01010101u, t1, false);
-            t1 = __builtin_amdgcn_udot4(w3, 0x01010101u, t1, false);
-            uint32_t tk = __builtin_amdgcn_udot4(w0, 0x03020100u, 0u, false);
-            tk = __builtin_amdgcn_udot4(w1, 0x07060504u, tk, false);
-            tk = __builtin_amdgcn_udot4(w2, 0x0b0a0908u, tk, false);
-            tk = __builtin_amdgcn_udot4(w3, 0x0f0e0d0cu, tk, false);
-            s1 += t1;
-            s2 += (endp - cpos) * t1 - tk;
-          }
-        } else {
-          for (uint32_t x = lo; x < hi; x++) {
-            const uint32_t k = x - cpos;
-            const uint32_t wk = k < 4 ? w0 : k < 8 ? w1 : k < 12 ? w2 : w3;
-            const uint32_t d = (wk >> (8 * (k & 3))) & 0xff;
-            g[x] = (uint8_t)d;
-            s1 += d;
-            s2 += (endp - x) * d;
-          }
+        __builtin_memcpy(g + cpos, &v, 16);
+        if (want_adler) {
+          // sum d_k and sum k*d_k over the 16 bytes
+          uint32_t t1 = __builtin_amdgcn_udot4(w0, 0x01010101u, 0u, false);
+          t1 = __builtin_amdgcn_udot4(w1, 0x01010101u, t1, false);
+          t1 = __builtin_amdgcn_udot4(w2, 0x01010101u, t1, false);
+          t1 = __builtin_amdgcn_udot4(w3, 0x01010101u, t1, false);
+          uint32_t tk = __builtin_amdgcn_udot4(w0, 0x03020100u, 0u, false);
+          tk = __builtin_amdgcn_udot4(w1, 0x07060504u, tk, false);
+          tk = __builtin_amdgcn_udot4(w2, 0x0b0a0908u, tk, false);
+          tk = __builtin_amdgcn_udot4(w3, 0x0f0e0d0cu, tk, false);
+          s1 += t1;
+          s2 += (endp - cpos) * t1 - tk;
         }
+      }
+    }
+    {  // lanes 0..15: the bytes in front of the first whole chunk; lanes 16..31: the bytes behind the last one
+      const uint32_t head1 = full0 < endp ? full0 : endp;     // head: [pos, head1)
+      const uint32_t tail0 = full1 > head1 ? full1 : head1;   // tail: [tail0, endp)
+      const uint32_t x = lane < 16 ? pos + lane : tail0 + (lane - 16);
+      if (lane < 16 ? x < head1 : (lane < 32 && x < endp)) {
+        const uint32_t d = stage[x - rb];
+        g[x] = (uint8_t)d;
+        s1 += d;
+        s2 += (endp - x) * d;
       }
     }
     if (want_adler) {  // per lane: <= 96 bytes x 255 x 6160 < 2^32
@@ -850,7 +850,8 @@ __device__ __forceinline__ void lds_put(lds_u8 *p, uint64_t v, uint32_t n) {
 // time waiting than working) - and while they are in flight the near matches are marked in the pending map and listed,
 // in stream order, for copy_near_all (*nnear_out of them).  THEN the rows are gone through again as their data
 // arrives: the record is read once more (cheaper than keeping three more registers per row) and its bytes are stored
-// with exact-length LDS stores; what a record has beyond 16 bytes is copied by the whole wave, 8 bytes per lane.
+// with exact-length LDS stores; bytes 16 .. 31 of the longer records follow in a second batch of the same kind, and
+// what is beyond 32 bytes is copied by the whole wave, 8 bytes per lane, four records at a time.
 // The loads read whole 8-byte words, up to 15 bytes past a record's source: the caller makes sure that stays inside
 // the output buffer.
 constexpr int FR = RMAX / kWave;  // rows of a full record pool
