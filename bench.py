@@ -17,7 +17,7 @@ Prints ONE JSON line (rank 0).
                 read + uncompressed bytes written per launch, over the launch duration
                 measured with HIP events on the stream the kernel runs on; peak = 8 TB/s HBM3E
                 (MI355X_MICROARCH.md).  `traffic` = FETCH_SIZE + WRITE_SIZE of that kernel per launch from the
-                committed rocprofv3 --pmc passes of this same command (profiles/r03_final/pmc_summary.json,
+                committed rocprofv3 --pmc passes of this same command (profiles/r04_final/pmc_summary.json,
                 gfx950 correction of the guide applied; `traffic_source` names the file and the commit it was
                 collected at), null when the configuration differs.
   cpu_baseline  the repo's C restatement of lib/de.ml (oracle/, kind "port") on the host cores of this box,
@@ -53,29 +53,52 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
-PMC_DIR = os.path.join(ROOT, "profiles", "r03_final")
+PMC_DIR = os.path.join(ROOT, "profiles", "r04_final")
+
+
+def _csrc_digest():
+    """Digest of the kernel sources: a committed counter profile describes the kernels only as long as this is unchanged."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "decompress_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".hpp", ".cpp", ".h")):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+def _pmc_summary():
+    """The committed rocprofv3 --pmc summary, or None when it is missing or STALE: collected from other kernel sources
+    than the ones in this tree (tools/profile_gpu.sh stamps it with _csrc_digest())."""
+    try:
+        with open(os.path.join(PMC_DIR, "pmc_summary.json")) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        return None
+    return d if d.get("csrc_digest") == _csrc_digest() else None
 
 
 def pmc_traffic(names, is_default):
     """HBM bytes per launch from the COMMITTED rocprofv3 --pmc passes of this same command (tools/profile_gpu.sh on the
-    default workload, profiles/r03_final/pmc_summary.json) — not measured by this run: counters and timing cannot be
-    collected in one process.  `names`: the kernels whose traffic adds up (the deflate path is three kernels)."""
-    if not is_default:
+    default workload, profiles/<round>/pmc_summary.json) — not measured by this run: counters and timing cannot be
+    collected in one process.  null when the workload differs or when a kernel source has changed since the profile
+    was taken.  `names`: the kernels whose traffic adds up (the deflate path is three kernels)."""
+    d = _pmc_summary() if is_default else None
+    if d is None:
         return None
     try:
-        with open(os.path.join(PMC_DIR, "pmc_summary.json")) as f:
-            d = json.load(f)
         return int(sum(d[k]["traffic_bytes_per_launch"] for k in names))
-    except (OSError, KeyError, ValueError, TypeError):
+    except (KeyError, ValueError, TypeError):
         return None
 
 
 def pmc_source():
-    try:
-        with open(os.path.join(PMC_DIR, "pmc_summary.json")) as f:
-            return "profiles/r03_final/pmc_summary.json (committed; collected at %s)" % json.load(f).get("commit", "?")
-    except (OSError, ValueError):
-        return None
+    d = _pmc_summary()
+    if d is None:
+        return "none (no committed counter profile matches the kernel sources of this tree)"
+    return "%s/pmc_summary.json (committed; collected at %s, kernel sources %s)" % (
+        os.path.relpath(PMC_DIR, ROOT), d.get("commit", "?"), d.get("csrc_digest"))
 
 
 def parse(argv=None):

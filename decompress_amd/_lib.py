@@ -40,6 +40,7 @@ c_szp = ctypes.POINTER(c_sz)
 SYMBOLS = [
     ("md_version", ctypes.c_int, []),
     ("md_status_string", ctypes.c_char_p, [ctypes.c_int]),
+    ("md_shard_plan", ctypes.c_int, [ctypes.c_uint64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     ("md_last_error_string", ctypes.c_char_p, [c_vp]),
     ("md_device_count", ctypes.c_int, []),
     ("md_create", c_vp, [ctypes.c_int, c_vp]),

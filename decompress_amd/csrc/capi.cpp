@@ -76,9 +76,12 @@ struct md_ctx {
   int test_flags = 0;       // (kept for callers of md_set_option "deflate_test_flags": no effect since 0.3)
   uint64_t *dbg = nullptr;  // device buffer of the optional in-kernel profile (32 x u64)
   // deflate workspaces, grow-only: command queues (n x queue_len), the per-stream part of the front workspace
-  // (slots, chunk starts: n-sized) and its per-position part (hash-chain links, look-ahead verdicts: 11 bytes per input byte)
+  // (slots, chunk starts: n-sized) and its per-position part (hash-chain links, look-ahead verdicts: 13 bytes per input byte)
   void *ws = nullptr, *fsmall = nullptr, *fbig = nullptr;
   size_t ws_bytes = 0, fsmall_bytes = 0, fbig_bytes = 0;
+  // the decoder in pieces (md_de_inf_continue_host): input, output and descriptor scratch, grow-only
+  void *cont_in = nullptr, *cont_out = nullptr, *cont_desc = nullptr;
+  size_t cont_in_bytes = 0, cont_out_bytes = 0, cont_desc_bytes = 0;
   uint32_t *order = nullptr;  // inflate: launch order of a large batch (n words)
   size_t order_words = 0;
   std::string err;
@@ -133,6 +136,30 @@ bool is_gfx950(int dev) {
 extern "C" {
 
 int md_version(void) { return MD_VERSION; }
+
+// contiguous ranges of the stream index balanced by bytes (decompress_amd/shard.py shard_by_bytes is
+// the same arithmetic, in doubles): rank r's range ends with the last stream whose middle lies at or before r + 1
+// world-ths of the total.
+int md_shard_plan(uint64_t n, const uint64_t *lengths, int world, uint64_t *lo, uint64_t *hi) {
+  if (world < 1 || !lo || !hi || (n && !lengths)) return MD_E_INVALID_ARGUMENT;
+  double total = 0.0;
+  for (uint64_t i = 0; i < n; i++) total += (double)lengths[i];
+  double acc = 0.0;
+  uint64_t at = 0;
+  for (int r = 0; r < world; r++) {
+    const double target = total * (double)(r + 1) / (double)world;
+    uint64_t end = at;
+    while (end < n && acc + (double)lengths[end] / 2.0 <= target) {
+      acc += (double)lengths[end];
+      end++;
+    }
+    if (r == world - 1) end = n;
+    lo[r] = at;
+    hi[r] = end;
+    at = end;
+  }
+  return MD_OK;
+}
 
 const char *md_status_string(int s) {
   switch (s) {
@@ -221,6 +248,9 @@ void md_destroy(md_ctx *ctx) {
   if (ctx->fsmall) hipFree(ctx->fsmall);
   if (ctx->fbig) hipFree(ctx->fbig);
   if (ctx->order) hipFree(ctx->order);
+  if (ctx->cont_in) hipFree(ctx->cont_in);
+  if (ctx->cont_out) hipFree(ctx->cont_out);
+  if (ctx->cont_desc) hipFree(ctx->cont_desc);
   if (ctx->dbg) hipFree(ctx->dbg);
   if (ctx->gz_tmp) hipFree(ctx->gz_tmp);
   if (ctx->lzo_ws) hipFree(ctx->lzo_ws);
@@ -442,6 +472,8 @@ int md_inflate_continue_batch_device(md_ctx *ctx, size_t n, const uint8_t *d_in,
 // One piece of a raw DEFLATE stream that is decoded as it arrives (mdeflate.h): the inflate kernel on one stream with
 // a starting bit, the window in front of the output buffer and the checksum state handed in, and the last block
 // boundary inside the piece handed back.
+static int grow(md_ctx *ctx, void **buf, size_t *have, size_t need, const char *what);
+
 int md_de_inf_continue_host(md_ctx *ctx, const uint8_t *src, size_t src_len, unsigned start_bit, uint8_t *dst, size_t hist_len,
                             size_t dst_cap, uint32_t adler_in, unsigned flags, size_t *dst_len, int *status,
                             md_inf_resume *resume) {
@@ -449,11 +481,18 @@ int md_de_inf_continue_host(md_ctx *ctx, const uint8_t *src, size_t src_len, uns
   if (start_bit > 7 || hist_len > 32768 || hist_len > dst_cap || dst_cap > MD_MAX_STREAM || src_len > MD_MAX_INFLATE_IN)
     return fail(ctx, MD_E_INVALID_ARGUMENT, "md_de_inf_continue_host: start_bit <= 7, hist_len <= 32768 and <= dst_cap");
   MD_ON_DEVICE(ctx);
-  DevBuf din, dout, ddesc;
+  // the context's scratch, grow-only: a long stream comes in many pieces, and three hipMalloc / hipFree per piece
+  // cost more than a short piece's kernel
   // descriptors: in_off in_len out_off out_cap out_len consumed resume_bits resume_out (u64); status, checksum,
   // start_bit, hist_len, adler_in, resume_adler, resume_last (u32)
-  if (din.alloc(src_len + 16) != hipSuccess || dout.alloc(dst_cap + 16) != hipSuccess || ddesc.alloc(8 * 8 + 8 * 4 + 4 * 8 + 2 * 4) != hipSuccess)
-    return fail(ctx, MD_E_OUT_OF_MEMORY, "hipMalloc");
+  struct { void *p; } din, dout, ddesc;
+  int grc_ = grow(ctx, &ctx->cont_in, &ctx->cont_in_bytes, src_len + 16, "hipMalloc(decoder piece input)");
+  if (grc_ == MD_OK) grc_ = grow(ctx, &ctx->cont_out, &ctx->cont_out_bytes, dst_cap + 16, "hipMalloc(decoder piece output)");
+  if (grc_ == MD_OK) grc_ = grow(ctx, &ctx->cont_desc, &ctx->cont_desc_bytes, 8 * 8 + 8 * 4 + 4 * 8 + 2 * 4, "hipMalloc(decoder piece descriptors)");
+  if (grc_ != MD_OK) return grc_;
+  din.p = ctx->cont_in;
+  dout.p = ctx->cont_out;
+  ddesc.p = ctx->cont_desc;
   uint64_t h64[8] = {0, (uint64_t)src_len, 0, (uint64_t)dst_cap, 0, 0, 0, 0};
   uint32_t h32[7] = {0, 0, start_bit, (uint32_t)hist_len, adler_in, 0, 0};
   uint64_t *d64 = (uint64_t *)ddesc.p;
@@ -934,10 +973,13 @@ int md_de_def_run(md_ctx *ctx, int queue_len, const uint32_t *ops, size_t nops, 
   memset(res, 0, sizeof res);
   int st = deflate_partial(ctx, 4, queue_len, 5, 0, MD_MATCHER_DE, ops, nops * 4, dst, dst_cap, written, res);
   if (st < 0 && st != MD_E_INVALID_ARGUMENT) return st;
-  const size_t n = res[0];
+  // the kernel reports the first 315 answers; *nresults = how many of them results[] received
+  size_t n = res[0] < 315 ? res[0] : 315;
+  if (n > results_cap) n = results_cap;
+  for (size_t i = 0; i < n; i++) results[i] = (uint8_t)res[1 + i];
   if (nresults) *nresults = n;
-  for (size_t i = 0; i < n && i < results_cap && i < 315; i++) results[i] = (uint8_t)res[1 + i];
   if (st == MD_E_INVALID_ARGUMENT) return fail(ctx, st, "not a De.Def operation list");
+  if (st >= 0 && res[0] > n) return fail(ctx, MD_E_INVALID_ARGUMENT, "more encode answers than results[] (or the kernel's 315) can hold");
   return st;
 }
 

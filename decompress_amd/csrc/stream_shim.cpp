@@ -236,7 +236,9 @@ static uint32_t crc_concat(uint32_t crc_a, uint32_t crc_b, uint64_t len_b) {
 // of the body, or 0 with *st = MD_OK when the header is not all there yet, or 0 with the status of a bad header
 static size_t gz_header_check(const std::vector<uint8_t> &in, int *st) {
   *st = MD_OK;
-  if (in.size() >= 2 && (in[0] != 0x1f || in[1] != 0x8b)) {
+  // (the reference looks at the ID bytes only once the ten fixed bytes are there, lib/gz.ml:463-491: a cut header of
+  // fewer bytes is "unexpected end of input" whatever its first bytes are)
+  if (in.size() >= 10 && (in[0] != 0x1f || in[1] != 0x8b)) {
     *st = MD_INVALID_GZIP_HEADER;
     return 0;
   }
@@ -324,7 +326,10 @@ static void inf_piece(md_inf_stream *s) {
       s->adler = rs.adler;
       s->in.erase(s->in.begin(), s->in.begin() + (size_t)(rs.bits >> 3));
       s->in_bit = (unsigned)(rs.bits & 7);
-      s->need = progress ? s->chunk : (s->in.size() * 2 > s->chunk ? s->in.size() * 2 : s->chunk);
+      // (after progress: a new attempt only once input beyond the undecoded tail has arrived - that tail holds no
+      // complete block, decoding it again alone could not find one)
+      s->need = progress ? (s->in.size() + 1 > s->chunk ? s->in.size() + 1 : s->chunk)
+                         : (s->in.size() * 2 > s->chunk ? s->in.size() * 2 : s->chunk);
       return;
     }
     s->out.assign(buf.begin() + hl, buf.begin() + dst_len);  // everything decoded, also in front of an error

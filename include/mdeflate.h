@@ -111,6 +111,14 @@ const char *md_last_error_string(const md_ctx *ctx);
 /* Number of usable gfx950 devices (0 when none / no driver). */
 int md_device_count(void);
 
+/* Multi-GPU: streams are independent, so a batch shards with no data-path exchange - one context
+ * (md_create(device)), one host thread and one HIP stream per device, every device given a contiguous range of the
+ * stream index.  md_shard_plan cuts a batch of n streams into `world` such ranges balanced by the sum of `lengths`
+ * (normally the uncompressed sizes): rank r owns streams [lo[r], hi[r]); the ranges are contiguous, cover 0..n and may
+ * be empty.  Pure host arithmetic (no device is touched), the same cut as decompress_amd.shard.shard_by_bytes.
+ * Returns MD_OK, or MD_E_INVALID_ARGUMENT (world < 1, a null pointer with n or world != 0). */
+int md_shard_plan(uint64_t n, const uint64_t *lengths, int world, uint64_t *lo, uint64_t *hi);
+
 /* One context per GPU.  `hip_stream`:
  *   NULL            the context creates its own non-blocking stream (not ordered with any other stream:
  *                   the caller synchronises, e.g. md_synchronize, before touching the buffers elsewhere);
@@ -192,8 +200,9 @@ typedef struct md_deflate_params {
                   * 0 or 15 = De.make_window ~bits:15, the only size the reference's callers use and the only one
                   * the kernels implement; anything else is MD_E_INVALID_ARGUMENT */
   size_t total_in_bytes; /* batch calls with device descriptors: an upper bound of the sum of in_len[i], or 0 when the
-                  * caller does not know it.  The engine sizes a per-position workspace (11 bytes per input byte:
-                  * hash-chain links and look-ahead verdicts) from it; with 0 it reads the sum back from the device first,
+                  * caller does not know it.  The engine sizes a per-position workspace (13 bytes per input byte
+                  * plus 319 positions of padding per stream: hash-chain links, flags and two look-ahead verdicts;
+                  * grow-only for the life of the context - 52 GiB for 4 GiB of input) from it; with 0 it reads the sum back from the device first,
                   * i.e. the call waits for the work already enqueued on the context's stream.  A batch whose descriptors
                   * add up to more than the hint gets status[i] = MD_E_INVALID_ARGUMENT for every stream. */
 } md_deflate_params;
@@ -267,7 +276,9 @@ int md_de_def_encode(md_ctx *ctx, int kind, const uint32_t *cmds, size_t ncmds, 
  *   MD_OP_NEW_FREQS            make_literals () / make_distances ()
  *   MD_OP_QUEUE_RESET          Queue.reset
  * results[k] = what the k-th encode answered: 0 `Ok, 1 `Block (`Partial cannot happen with a `Buffer); *nresults =
- * their number.  dst receives the bytes written.  A malformed list is MD_E_INVALID_ARGUMENT. */
+ * how many answers results[] received.  At most 315 encodes per call (and results_cap): a list with more is
+ * MD_E_INVALID_ARGUMENT after its bytes have been written.  dst receives the bytes written.  A malformed list is
+ * MD_E_INVALID_ARGUMENT. */
 enum { MD_OP_FILL = 1, MD_OP_BLOCK = 2, MD_OP_FLUSH = 3, MD_OP_SUCC_LITERAL = 4, MD_OP_SUCC_LENGTH = 5,
        MD_OP_SUCC_DISTANCE = 6, MD_OP_NEW_FREQS = 7, MD_OP_QUEUE_RESET = 8 };
 int md_de_def_run(md_ctx *ctx, int queue_len, const uint32_t *ops, size_t nops, uint8_t *dst, size_t dst_cap,

@@ -58,3 +58,22 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".h", ".hpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "liboracle" not in txt and "oracle_lib" not in txt and "orc_" not in txt, f
+
+
+def test_shard_plan_equals_shard_by_bytes():
+    """md_shard_plan (C ABI, for non-Python callers) cuts a batch exactly like shard.shard_by_bytes."""
+    import random
+    from decompress_amd import shard
+    lib = _lib.load()
+    rng = random.Random(7)
+    cases = [[], [5], [1000] * 4096, [21504, 768771, 111261, 377109] * 50]
+    cases += [[rng.randrange(0, 1 << rng.randrange(1, 22)) for _ in range(rng.randrange(1, 300))] for _ in range(40)]
+    for lengths in cases:
+        for world in (1, 2, 3, 8):
+            n = len(lengths)
+            arr = (ctypes.c_uint64 * max(n, 1))(*lengths)
+            lo = (ctypes.c_uint64 * world)()
+            hi = (ctypes.c_uint64 * world)()
+            assert lib.md_shard_plan(n, arr, world, lo, hi) == 0
+            assert [(int(a), int(b)) for a, b in zip(lo, hi)] == shard.shard_by_bytes(lengths, world)
+    assert lib.md_shard_plan(3, None, 2, None, None) < 0 and lib.md_shard_plan(0, None, 0, None, None) < 0

@@ -71,3 +71,59 @@ def test_round_trip_through_gpu_inflate(eng):
     back = eng.inflate_many([z for _, z, _ in res], [len(b) for b in bufs])
     for b, (st, used, out, _), (_, z, _) in zip(bufs, back, res):
         assert (st, used, out) == (0, len(z), b)
+
+
+def _fuzz_buffer(rng):
+    """inputs in the spirit of fuzz/fuzz_ns.ml: bytes of a small alphabet, runs, copies of earlier pieces, noise"""
+    kind = rng.randrange(5)
+    n = rng.choice([0, 1, 5, 55, 56, 57, 300, 4000, 33000, 70000]) + rng.randrange(200)
+    if kind == 0:
+        return bytes(rng.randrange(256) for _ in range(min(n, 6000)))
+    if kind == 1:
+        return bytes(rng.choice(b"abcd") for _ in range(n))
+    if kind == 2:
+        return b"".join(bytes([rng.randrange(256)]) * rng.randrange(1, 400) for _ in range(n // 60 + 1))
+    out = bytearray(rng.randrange(256) for _ in range(rng.randrange(1, 64)))
+    while len(out) < n:  # LZ-like: literals and copies at random distances and lengths
+        if rng.random() < 0.3:
+            out += bytes(rng.randrange(256) for _ in range(rng.randrange(1, 6)))
+        else:
+            d = rng.randrange(1, min(len(out), 40000) + 1)
+            for _ in range(rng.randrange(3, 300)):
+                out.append(out[-d])
+    return bytes(out[:n]) if kind == 3 else bytes(out[:n]) * 2
+
+
+def test_fuzz_vs_oracle(eng, oracle):
+    """differential fuzz of md_de_def_ns_deflate / md_zl_def_ns_deflate (fuzz/fuzz_ns.ml's compress side): status and
+    bytes equal the oracle's for random (input, level, output room); whatever came out also inflates back to the input
+    through the Inf.Ns oracle AND through libz"""
+    import decompress_amd
+    rng = random.Random(20260928)
+    for round_ in range(6):
+        bufs = [_fuzz_buffer(rng) for _ in range(48)]
+        level = rng.choice([1, 2, 3, 4, 4, rng.randrange(0, 13)])
+        zl = round_ % 3 == 2
+        res = eng.def_ns_many(bufs, level=level, fmt=decompress_amd.FORMAT_ZLIB if zl else decompress_amd.FORMAT_DEFLATE)
+        for data, (st, z, _) in zip(bufs, res):
+            ost, oz = oracle.def_ns(data, level, zl=zl)
+            assert st == ost, (level, len(data), zl)
+            if st == 0:
+                assert z == oz, (level, len(data), zl)
+                if level in (1, 2, 3, 4) or len(data) < 56 - 4 * level:  # (a stub level compresses to nothing: Ok 0)
+                    raw = z[2:-4] if zl else z
+                    assert zlib.decompress(raw, -15) == data
+                    assert oracle.de_inflate(raw, len(data)) == (0, len(raw), data)
+
+
+def test_small_output_room(eng, oracle):
+    """the failure cases follow the output room exactly as the oracle's add_bits / flush_bits accounting does"""
+    from decompress_amd import de, workloads
+    data = workloads.text(9, 5000)
+    full = oracle.def_ns(data, 4)[1]
+    for room in sorted({0, 1, 7, 8, 9, 16, 100, len(full) - 9, len(full) - 1, len(full), len(full) + 1, len(full) + 7, len(full) + 8, len(full) + 64}):
+        if room < 0:
+            continue
+        ost, oz = oracle.def_ns(data, 4, cap=room)
+        verdict, z = de.Def.Ns.deflate(data, 4, dst_len=room)
+        assert (verdict == "Ok") == (ost == 0) and (ost != 0 or z == oz), room

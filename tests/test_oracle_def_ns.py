@@ -53,3 +53,42 @@ def test_levels_and_edges(oracle):
     big = bytes(rng.choice(b"ab") for _ in range(700000))  # several blocks (soft maximum 300000)
     st, z = oracle.def_ns(big, 3)
     assert st == 0 and zlib.decompress(z, -15) == big
+
+
+def _oracle_blocks(z):
+    from tests.deflate_tokens import tokens
+    blocks = []
+    for t in tokens(z):
+        if t[0] == 'B':
+            blocks.append((t[2], []))
+        elif t[1] == 'L':
+            blocks[-1][1].append(t[2])
+        else:
+            blocks[-1][1].append((t[2], t[3]))
+    return blocks
+
+
+def test_second_reading_agrees(oracle):
+    """The parse (blocks and tokens) of oracle/de_def_ns.c against tests/def_ns_formula.py, a second restatement written
+    independently from the formulas of lib/de.ml:3704-3925: hash chains, window slides, depth / nice-length cut-offs,
+    greedy choice, the block-split statistics.  (Beyond the reference's two vectors this path stays 'parity unpinned':
+    two readings agreeing is the strongest check this image allows.)"""
+    from decompress_amd import workloads
+    from tests import def_ns_formula
+    corpus = workloads.corpus()
+    cases = [(name, data[:100000], 4) for name, data in sorted(corpus.items())]
+    cases += [(name, data[:60000], 1 + i % 3) for i, (name, data) in enumerate(sorted(corpus.items())) if i % 3 == 0]
+    big = max(corpus.values(), key=len)
+    cases.append(("several blocks", big[:330000], 2))  # the soft maximum (300000) and the split statistics at work
+    rng = random.Random(11)
+    cases.append(("runs", b"".join(bytes([rng.randrange(4)]) * rng.randrange(1, 600) for _ in range(400)), 3))
+    cases.append(("window slides", bytes(rng.choice(b"abcd") for _ in range(70000)), 4))
+    checked = 0
+    for name, data, level in cases:
+        st, z = oracle.def_ns(data, level, cap=len(data) + len(data) // 4 + 1024)
+        if st != 0:  # (a block the encoder wants to store: upstream's write_uncompressed_blocks cannot - nothing to compare)
+            continue
+        assert zlib.decompress(z, -15) == data
+        assert _oracle_blocks(z) == def_ns_formula.parse(data, level), (name, level)
+        checked += 1
+    assert checked >= 15

@@ -3,7 +3,7 @@
 # usage: tools/profile_gpu.sh <tag> [bench args...]
 # Summaries land in gpurun_out/prof_<tag>/ ; copy what you want judged to profiles/.
 set -u
-TAG=${1:-r03}; shift || true
+TAG=${1:-r04}; shift || true
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
@@ -42,7 +42,9 @@ except Exception:  # the GPU box gets a snapshot without .git: the commit is lef
         commit = open(os.path.join(os.path.dirname(out.rstrip("/")).rsplit("/gpurun_out", 1)[0], "tools", ".profile_commit")).read().strip()
     except OSError:
         commit = "?"
-summ = {"commit": commit, "command": cmd.replace(os.path.dirname(out.rstrip("/")).rsplit("/gpurun_out", 1)[0] + "/", ""),
+sys.path.insert(0, os.path.dirname(out.rstrip("/")).rsplit("/gpurun_out", 1)[0])
+import bench as _bench
+summ = {"commit": commit, "csrc_digest": _bench._csrc_digest(), "command": cmd.replace(os.path.dirname(out.rstrip("/")).rsplit("/gpurun_out", 1)[0] + "/", ""),
         "note": "FETCH_SIZE / WRITE_SIZE are KiB per dispatch (rocprofv3, separate --pmc passes); means over the "
                 "dispatches of the run.  traffic_bytes_per_launch_raw = (FETCH + WRITE) x 1024.  On gfx950 FETCH_SIZE "
                 "counts a wide coalesced read (16 bytes per lane) at half its bytes (MI355X_MICROARCH.md, HBM); the "
