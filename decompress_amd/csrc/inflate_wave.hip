@@ -55,6 +55,7 @@ constexpr uint32_t SMIN = 48;      // ... and at least: where the data expands s
                                    // staging buffer, the zones shrink so that all 64 lanes still have work (cost then
                                    // follows the output, not the number of zones thrown away)
 constexpr uint32_t KMAX = 64;      // walk steps per lane per pass
+constexpr uint32_t RUNIN_NUM = 1, RUNIN_DEN = 2;  // run-in of the speculative pass, as a fraction of the zone
 constexpr uint32_t PASSES = 5;     // walks after the first one: at least this many are allowed, more when the zones are small
 constexpr uint32_t PASS_BITS = 1600, PASSES_MAX = 16;  // (a walk costs in proportion to the zone size)
 constexpr uint32_t RMAX = 768;     // match records per round, all lanes together (in stream order)
@@ -1176,7 +1177,12 @@ __device__ __forceinline__ int inflate_block(lds_smem *sm, const uint8_t *__rest
     pf.count(C_PASSES);
     uint32_t start = rbp + lane * zs, end = 0, stop = 0, nb = 0;
     const uint32_t limit = rbp + (lane + 1) * zs;
-    sync_pass<false, BUDGET>(win, lut, lroot, true, start, limit, end, stop, nb);
+    // the speculative pass starts a RUN-IN ahead of the zone (inside the zone before): all it has to deliver is the
+    // boundary at the zone's END, and the longer the walk, the likelier that it has synchronised by then - fewer lanes
+    // walk again in passes 2+, which cost a full pass each for a handful of lanes (the pass without counts is the
+    // cheap one: 24 instructions a step against 34)
+    const uint32_t runin = lane ? (zs * RUNIN_NUM) / RUNIN_DEN : 0u;
+    sync_pass<false, BUDGET>(win, lut, lroot, true, start - runin, limit, end, stop, nb);
     pf.tick(P_DECODE1);
     bool counted = false;
     const uint32_t passes = zs * PASSES >= PASS_BITS ? PASSES : PASS_BITS / zs > PASSES_MAX ? PASSES_MAX : PASS_BITS / zs;
