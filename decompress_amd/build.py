@@ -42,7 +42,7 @@ def build(force=False, verbose=False):
         return SO
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-Wno-unused-value", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
-           "-o", SO] + sources()
+           "-o", SO] + os.environ.get("MD_HIPCC_FLAGS", "").split() + sources()
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

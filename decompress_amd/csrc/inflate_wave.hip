@@ -1425,39 +1425,71 @@ __global__ __launch_bounds__(PAIR ? 2 * kWave : kWave, PAIR ? 4 : 2) void inflat
 
   if (rc == MD_OK) {
     bool last = false;
+    uint32_t lds_base = 0xffffffffu;  // the window in LDS begins at this byte of the body (nothing else has been loaded since)
     while (!last && rc == MD_OK) {
-      const uint32_t base = (bp >> 5) << 2;
-      wnd.ensure(win, body, body_len, base, lane);
-      const uint32_t rbp = bp - base * 8, tot = total_bits - base * 8;
+      // a block header that still lies in the first part of the window in LDS is read from there: runs of tiny blocks
+      // (flush points, empty blocks) would otherwise load 2 KiB from the input for every few bytes of it
+      uint32_t base = (bp >> 5) << 2;
+      if (lds_base != 0xffffffffu && bp >= lds_base * 8 && bp - lds_base * 8 <= 4096) base = lds_base;
+      else {
+        wnd.ensure(win, body, body_len, base, lane);
+        lds_base = base;
+      }
+      uint32_t rbp = bp - base * 8;
+      const uint32_t tot = total_bits - base * 8;
       if ((int32_t)(tot - rbp) < 3) {
         rc = MD_UNEXPECTED_END_OF_INPUT;
         break;
       }
       const uint32_t hdr = uni(peek(win, rbp));
       last = hdr & 1;
-      const uint32_t type = (hdr >> 1) & 3;
+      uint32_t type = (hdr >> 1) & 3;
       bp += 3;
-      if (type == 0) {
+      rbp += 3;
+      bool block_done = false;  // the block was dealt with here (an empty fixed one)
+      if (type == 1) {
+        // a run of EMPTY fixed blocks - header, then the 7-bit end-of-block code 0000000 (lib/de.ml:821-833) - is walked
+        // through right here: ten bits a block instead of a round each
+        for (;;) {
+          if (rbp + 7 > tot || rbp + 64 > WIN_WORDS * 32 - 64 || (uni(peek(win, rbp)) & 0x7fu) != 0) break;  // not one of them
+          rbp += 7;
+          bp += 7;
+          block_done = true;  // the block whose header was consumed last is complete
+          if (last || rbp + 3 > tot) break;
+          const uint32_t h = uni(peek(win, rbp)) & 7u;
+          if (((h >> 1) & 3) != 1) break;  // another kind of block: back to the loop above
+          last = h & 1;
+          rbp += 3;
+          bp += 3;
+          block_done = false;
+        }
+      }
+      if (block_done) {
+        // nothing to decode
+      } else if (type == 0) {
         // flat, lib/de.ml:1613-1627
         uint32_t p = (bp + 7) >> 3;
         if (body_len - p < 4) {
           rc = MD_UNEXPECTED_END_OF_INPUT;
           break;
         }
-        const uint32_t h4 = (uint32_t)body[p] | ((uint32_t)body[p + 1] << 8) | ((uint32_t)body[p + 2] << 16) |
-                            ((uint32_t)body[p + 3] << 24);
+        uint32_t h4;
+        if (p + 4 <= base + (WIN_WORDS - 2) * 4) h4 = uni(peek(win, (p - base) * 8));
+        else h4 = (uint32_t)body[p] | ((uint32_t)body[p + 1] << 8) | ((uint32_t)body[p + 2] << 16) | ((uint32_t)body[p + 3] << 24);
         uint32_t len = h4 & 0xffff, nlen = h4 >> 16;
         p += 4;
         if (nlen != 0xffff - len) rc = MD_INVALID_COMPLEMENT_OF_LENGTH;
         else if (len > body_len - p) rc = MD_UNEXPECTED_END_OF_INPUT;
         else if (len > sk.cap - sk.pos) rc = MD_UNEXPECTED_END_OF_OUTPUT;
         else {
-          if constexpr (PAIR) {
-            if (!mail_wait_idle(sm, sent)) rc = MD_E_HIP;
-            mail_post(sm, lane, kJobStored, len, p, sent);
-            sk.pos += len;
-          } else {
-            copy_stored(sk, body, p, len, lane);
+          if (len) {  // (an empty stored block - a flush point - is its header and nothing else)
+            if constexpr (PAIR) {
+              if (!mail_wait_idle(sm, sent)) rc = MD_E_HIP;
+              mail_post(sm, lane, kJobStored, len, p, sent);
+              sk.pos += len;
+            } else {
+              copy_stored(sk, body, p, len, lane);
+            }
           }
           p += len;
           bp = p * 8;
@@ -1475,7 +1507,7 @@ __global__ __launch_bounds__(PAIR ? 2 * kWave : kWave, PAIR ? 4 : 2) void inflat
         } else {
           uint32_t hend = 0;
           fixed_lroot = 0;
-          rc = dynamic_tables(sm, rbp + 3, tot, lane, &hend, &lroot, pf);
+          rc = dynamic_tables(sm, rbp, tot, lane, &hend, &lroot, pf);
           bp = base * 8 + hend;
         }
         lroot = uni(lroot);
@@ -1483,6 +1515,7 @@ __global__ __launch_bounds__(PAIR ? 2 * kWave : kWave, PAIR ? 4 : 2) void inflat
         if (rc == MD_OK) {
           if (lroot & kLoopy) rc = inflate_block<Prof<PROF>, PAIR, true>(sm, body, body_len, sk, lroot & 15, lane, &bp, &zone, wnd, sent, pf);
           else rc = inflate_block<Prof<PROF>, PAIR, false>(sm, body, body_len, sk, lroot, lane, &bp, &zone, wnd, sent, pf);
+          lds_base = 0xffffffffu;
         }
       }
       if (cont.resume_bits && rc == MD_OK) {  // a block is complete: the next piece of the stream could start here

@@ -179,6 +179,47 @@ def test_hand_over_between_block_kinds(eng_ring, oracle):
             assert out == plain
 
 
+def test_runs_of_tiny_blocks(eng_ring, oracle):
+    """Runs of empty fixed blocks (zlib's Z_PARTIAL_FLUSH: header + end-of-block code, ten bits) and empty stored blocks
+    (Z_SYNC_FLUSH) between small data blocks: the kernel walks such runs through the window it has in LDS instead of
+    spending a round on each - whole, cut at every byte of a run, and with too little output room: status / count / bytes
+    as the oracle's."""
+    rng = random.Random(0xe3b)
+    srcs, caps = [], []
+    for case in range(24):
+        co = zlib.compressobj(6, zlib.DEFLATED, -15, 8, rng.choice((0, zlib.Z_FIXED)))
+        body, plain = bytearray(), bytearray()
+        for k in range(rng.randrange(2, 12)):
+            data = _mk(rng, rng.choice((0, 0, 1, 40, 300, 6000)), rng.choice(("text", "runs")))
+            body += co.compress(data)
+            plain += data
+            for _ in range(rng.choice((1, 1, 3, 40, 700))):
+                body += co.flush(rng.choice((zlib.Z_PARTIAL_FLUSH, zlib.Z_PARTIAL_FLUSH, zlib.Z_SYNC_FLUSH)))
+        body += co.flush()
+        raw, plain = bytes(body), bytes(plain)
+        assert zlib.decompress(raw, -15) == plain
+        srcs += [raw, raw, raw]
+        caps += [len(plain), len(plain) + 3, len(plain) // 2]
+        for cut in sorted({rng.randrange(1, len(raw)) for _ in range(12)} | {len(raw) - 1, len(raw) - 2}):
+            srcs.append(raw[:cut])
+            caps.append(len(plain))
+    # ten-bit blocks by hand: a long run that ends the stream, one that ends without a final block, one followed by noise
+    def bits_to_bytes(bits):
+        b = bytearray((len(bits) + 7) // 8)
+        for i, v in enumerate(bits):
+            b[i >> 3] |= v << (i & 7)
+        return bytes(b)
+    empty, final = [0, 1, 0] + [0] * 7, [1, 1, 0] + [0] * 7
+    for run in (1, 2, 3, 100, 1700, 1800, 5000):
+        srcs += [bits_to_bytes(empty * run + final), bits_to_bytes(empty * run), bits_to_bytes(empty * run + [0, 1, 1]),
+                 bits_to_bytes(empty * run + [0, 0, 0]) + b"\x05\x00\xfa\xffhello" + bits_to_bytes(final)]
+        caps += [16, 16, 16, 16]
+    res = eng_ring.inflate_many(srcs, caps)
+    for src, cap, (st, used, out, _) in zip(srcs, caps, res):
+        ost, oused, oout = oracle.de_inflate(src, cap)
+        assert (st, used, out) == (ost, oused, oout), (len(src), cap, st, ost)
+
+
 def test_stored_config1(eng_ring, oracle):
     eng = eng_ring
     """BASELINE config 1: 64 KiB of stored blocks (65535 + 1)."""
