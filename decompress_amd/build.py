@@ -40,7 +40,8 @@ def stale():
 def build(force=False, verbose=False):
     if not force and not stale():
         return SO
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    # -falign-loops=64: loop heads on instruction-fetch lines (measured: inflate C2 4.67 -> 4.60 ms, deflate C3 142.5 -> 141.3)
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-falign-loops=64", "-fPIC", "-shared",
            "-Wno-unused-value", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
            "-o", SO] + os.environ.get("MD_HIPCC_FLAGS", "").split() + sources()
     if verbose:
