@@ -46,6 +46,7 @@ SYMBOLS = [
     ("md_create", c_vp, [ctypes.c_int, c_vp]),
     ("md_destroy", None, [c_vp]),
     ("md_synchronize", ctypes.c_int, [c_vp]),
+    ("md_set_option", ctypes.c_int, [c_vp, ctypes.c_char_p, ctypes.c_int]),
     ("md_timing_begin", ctypes.c_int, [c_vp]),
     ("md_timing_end", ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_float)]),
     ("md_inflate_batch_device", ctypes.c_int,
@@ -114,8 +115,7 @@ class GzMeta(ctypes.Structure):
                [(k, ctypes.c_int) for k in ("has_extra", "has_name", "has_comment")] + \
                [(k, c_sz) for k in ("extra_off", "extra_len", "name_off", "name_len", "comment_off", "comment_len")]
 # exported but not part of the public header (tuning knobs)
-EXTRA = [("md_set_option", ctypes.c_int, [c_vp, ctypes.c_char_p, ctypes.c_int]),
-         ("md_get_profile", ctypes.c_int, [c_vp, c_vp])]
+EXTRA = [("md_get_profile", ctypes.c_int, [c_vp, c_vp])]
 
 _lib = None
 

@@ -73,6 +73,7 @@ struct md_ctx {
   void *lzo_ws = nullptr;  // Lzo.compress dictionaries
   size_t lzo_ws_bytes = 0;
   int inflate_waves = 2;    // wavefronts per stream of the inflate kernel (md_set_option "inflate_waves": 1 = the one-wavefront form)
+  size_t front_cap_bytes = 0;  // md_set_option "deflate_workspace_cap_mib": batches whose per-position workspace would be larger go in slices
   int test_flags = 0;       // (kept for callers of md_set_option "deflate_test_flags": no effect since 0.3)
   uint64_t *dbg = nullptr;  // device buffer of the optional in-kernel profile (32 x u64)
   // deflate workspaces, grow-only: command queues (n x queue_len), the per-stream part of the front workspace
@@ -297,6 +298,24 @@ int md_set_option(md_ctx *ctx, const char *key, int value) {
   if (!strcmp(key, "inflate_waves")) {
     if (value != 1 && value != 2) return fail(ctx, MD_E_INVALID_ARGUMENT, "inflate_waves is 1 or 2");
     ctx->inflate_waves = value;
+    return MD_OK;
+  }
+  if (!strcmp(key, "deflate_workspace_cap_mib")) {  // 0 = no cap (one launch per batch)
+    if (value < 0) return fail(ctx, MD_E_INVALID_ARGUMENT, "deflate_workspace_cap_mib >= 0");
+    ctx->front_cap_bytes = (size_t)value << 20;
+    return MD_OK;
+  }
+  if (!strcmp(key, "release_workspace")) {  // give the grow-only scratch of this context back (it grows again on demand)
+    MD_ON_DEVICE(ctx);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    void **bufs[] = {&ctx->ws, &ctx->fsmall, &ctx->fbig, (void **)&ctx->order, &ctx->cont_in, &ctx->cont_out, &ctx->cont_desc};
+    size_t *sizes[] = {&ctx->ws_bytes, &ctx->fsmall_bytes, &ctx->fbig_bytes, &ctx->order_words, &ctx->cont_in_bytes,
+                       &ctx->cont_out_bytes, &ctx->cont_desc_bytes};
+    for (size_t i = 0; i < sizeof bufs / sizeof bufs[0]; i++) {
+      if (*bufs[i]) hipFree(*bufs[i]);
+      *bufs[i] = nullptr;
+      *sizes[i] = 0;
+    }
     return MD_OK;
   }
   if (!strcmp(key, "deflate_test_flags")) {
@@ -827,6 +846,23 @@ int md_deflate_batch_device(md_ctx *ctx, int format, const md_deflate_params *pa
   if (!d_in_off || !d_in_len || !d_out_off || !d_out_cap || !d_out_len || !d_status)
     return fail(ctx, MD_E_INVALID_ARGUMENT, "null descriptor array");
   MD_ON_DEVICE(ctx);
+  // The per-position workspace is 13 bytes per input byte (md_front_big_bytes): with a cap set (md_set_option
+  // "deflate_workspace_cap_mib") a batch that would need more is taken in slices of consecutive streams, each sized
+  // from its own lengths (one read-back per slice).  Same bytes out; the sequential kernel then runs with fewer streams
+  // per CU than it is laid out for, so this trades time for memory.
+  if (ctx->front_cap_bytes && q.total_in_bytes && n > 1 && md_front_big_bytes((uint64_t)q.total_in_bytes + 319ull * n) > ctx->front_cap_bytes) {
+    size_t slices = (md_front_big_bytes((uint64_t)q.total_in_bytes + 319ull * n) + ctx->front_cap_bytes - 1) / ctx->front_cap_bytes;
+    if (slices > n) slices = n;
+    const size_t per = (n + slices - 1) / slices;
+    for (size_t i0 = 0; i0 < n; i0 += per) {
+      const size_t k = n - i0 < per ? n - i0 : per;
+      rc = deflate_launch(ctx, format, q.level, q.queue_len, q.driver, q.dynamic, q.matcher, q.gz_header, k, d_in, d_in_off + i0,
+                          d_in_len + i0, d_out, d_out_off + i0, d_out_cap + i0, d_out_len + i0, d_status + i0,
+                          d_checksum ? d_checksum + i0 : nullptr, nullptr, 0);
+      if (rc != MD_OK) return rc;
+    }
+    return MD_OK;
+  }
   return deflate_launch(ctx, format, q.level, q.queue_len, q.driver, q.dynamic, q.matcher, q.gz_header, n, d_in, d_in_off,
                         d_in_len, d_out, d_out_off, d_out_cap, d_out_len, d_status, d_checksum, nullptr, q.total_in_bytes);
 }

@@ -136,6 +136,17 @@ int md_synchronize(md_ctx *ctx);
 /* Timing of the dominant kernel with HIP events recorded on the context's
  * stream: begin/end bracket any number of batch calls; end returns elapsed
  * milliseconds (synchronises). */
+/* Options of a context.  Keys:
+ *   "deflate_workspace_cap_mib"  value >= 0 (0 = none, the default).  The deflate kernels keep a per-position workspace of
+ *                                13 bytes per input byte; a md_deflate_batch_device call (with params->total_in_bytes given)
+ *                                whose workspace would be larger than the cap is taken in slices of consecutive streams.
+ *                                Same output; slower (fewer streams per launch than the kernels are laid out for).
+ *   "release_workspace"          (value ignored) waits for the context's stream and frees its grow-only device scratch
+ *                                (deflate workspaces, launch orders, decoder-piece buffers); it grows again on demand.
+ *   "inflate_waves"              1 or 2 (default): wavefronts per stream of the inflate kernel (2 = decoder + copier).
+ *   "profile"                    0 / 1: in-kernel phase profile of stream 0 (md_get_profile, a debugging aid).
+ * Unknown keys and values out of range: MD_E_INVALID_ARGUMENT. */
+int md_set_option(md_ctx *ctx, const char *key, int value);
 int md_timing_begin(md_ctx *ctx);
 int md_timing_end(md_ctx *ctx, float *ms);
 

@@ -386,3 +386,22 @@ def test_python_mirror(eng):
     assert de.Higher.uncompress(b"\x06", 10) == ("Error", "Invalid kind of block")
     assert zl.Higher.uncompress(b"\x79\x9c" + z[2:], len(data)) == ("Error", "Invalid Zlib header")
     assert zl.Higher.uncompress(z[:-1] + bytes([z[-1] ^ 1]), len(data)) == ("Error", "Invalid checksum")
+
+
+def test_workspace_cap_and_release(eng):
+    """md_set_option "deflate_workspace_cap_mib": a batch whose per-position workspace would exceed the cap goes in slices
+    of streams - same bytes; "release_workspace" gives the grow-only scratch back and the next call grows it again."""
+    import decompress_amd
+    from decompress_amd import workloads
+    bufs = [workloads.text(300 + i, 30000 + 2500 * i) for i in range(24)] + [b"", b"x"]
+    want = eng.deflate_many(bufs, fmt=decompress_amd.FORMAT_ZLIB, level=6)
+    eng.set_option("deflate_workspace_cap_mib", 1)
+    try:
+        assert eng.deflate_many(bufs, fmt=decompress_amd.FORMAT_ZLIB, level=6) == want
+        eng.set_option("release_workspace", 1)
+        assert eng.deflate_many(bufs, fmt=decompress_amd.FORMAT_ZLIB, level=6) == want
+    finally:
+        eng.set_option("deflate_workspace_cap_mib", 0)
+    eng.set_option("release_workspace", 1)
+    assert eng.deflate_many(bufs, fmt=decompress_amd.FORMAT_ZLIB, level=6) == want
+    assert all(st == 0 and zlib.decompress(z) == b for b, (st, z, _) in zip(bufs, want))
