@@ -867,6 +867,86 @@ int md_deflate_batch_device(md_ctx *ctx, int format, const md_deflate_params *pa
                         d_in_len, d_out, d_out_off, d_out_cap, d_out_len, d_status, d_checksum, nullptr, q.total_in_bytes);
 }
 
+// ---- device-side buffering for the encoder shim (stream_shim.cpp): not part of the public ABI -----------------------
+// md_def_src hands every piece of the input straight to a grow-only device buffer, md_def_encode runs the batch-of-one
+// deflate on it at the end of the input and serves the result from device memory one `Flush at a time: the HOST keeps
+// nothing of the stream (the device keeps all of it: the matcher's state does not cross launches).
+int md_i_dev_append(md_ctx *ctx, void **buf, size_t *cap, size_t used, const uint8_t *host, size_t len) {
+  if (!ctx || !buf || !cap || (!host && len)) return MD_E_INVALID_ARGUMENT;
+  MD_ON_DEVICE(ctx);
+  if (used + len + 16 > *cap) {
+    size_t ncap = *cap ? *cap : (size_t)1 << 20;
+    while (ncap < used + len + 16) ncap *= 2;
+    void *nb = nullptr;
+    if (hipMalloc(&nb, ncap) != hipSuccess) return fail(ctx, MD_E_OUT_OF_MEMORY, "hipMalloc(encoder input)");
+    if (*buf) {
+      HIP_TRY(ctx, hipMemcpyAsync(nb, *buf, used, hipMemcpyDeviceToDevice, ctx->stream));
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+      HIP_TRY(ctx, hipFree(*buf));
+    }
+    *buf = nb;
+    *cap = ncap;
+  }
+  if (len) {
+    HIP_TRY(ctx, hipMemcpyAsync((uint8_t *)*buf + used, host, len, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // (the caller's buffer is his again when src returns)
+  }
+  return MD_OK;
+}
+int md_i_dev_deflate_one(md_ctx *ctx, int format, const md_deflate_params *params, const void *d_in, size_t n, void **d_out,
+                         size_t *out_len, int *status, uint32_t *checksum) {
+  if (!ctx || !params || !d_out || !out_len || !status || !checksum) return MD_E_INVALID_ARGUMENT;
+  MD_ON_DEVICE(ctx);
+  uint64_t cap = (uint64_t)n + n / 4 + n / (uint64_t)params->queue_len * 16 + 4096;  // stored blocks of a queue fill each are the worst case
+  if (cap > MD_MAX_STREAM) cap = MD_MAX_STREAM;
+  DevBuf ddesc, dnone;
+  void *out = nullptr;
+  if (hipMalloc(&out, (size_t)cap) != hipSuccess || ddesc.alloc(5 * 8 + 8) != hipSuccess || dnone.alloc(16) != hipSuccess) {
+    if (out) hipFree(out);
+    return fail(ctx, MD_E_OUT_OF_MEMORY, "hipMalloc(encoder output)");
+  }
+  uint64_t h64[5] = {0, (uint64_t)n, 0, cap, 0};
+  uint64_t *d64 = (uint64_t *)ddesc.p;
+  int32_t *dst = (int32_t *)(d64 + 5);
+  uint32_t *dsum = (uint32_t *)(dst + 1);
+  md_deflate_params q = *params;
+  q.total_in_bytes = n ? n : 1;
+  int rc = MD_OK;
+  if (hipMemcpyAsync(d64, h64, sizeof h64, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = MD_E_HIP;
+  if (rc == MD_OK)
+    rc = md_deflate_batch_device(ctx, format, &q, 1, (const uint8_t *)(n ? d_in : dnone.p), d64 + 0, d64 + 1, (uint8_t *)out, d64 + 2,
+                                 d64 + 3, d64 + 4, dst, dsum);
+  uint64_t olen = 0;
+  int32_t st = 0;
+  uint32_t sum = 0;
+  if (rc == MD_OK && (hipMemcpyAsync(&olen, d64 + 4, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                      hipMemcpyAsync(&st, dst, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                      hipMemcpyAsync(&sum, dsum, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                      hipStreamSynchronize(ctx->stream) != hipSuccess))
+    rc = fail(ctx, MD_E_HIP, "encoder results");
+  if (rc != MD_OK) {
+    hipFree(out);
+    return rc;
+  }
+  *d_out = out;
+  *out_len = (size_t)olen;
+  *status = st;
+  *checksum = sum;
+  return MD_OK;
+}
+int md_i_dev_read(md_ctx *ctx, const void *d, size_t off, uint8_t *host, size_t len) {
+  if (!ctx || !d || (!host && len)) return MD_E_INVALID_ARGUMENT;
+  MD_ON_DEVICE(ctx);
+  if (len) HIP_TRY(ctx, hipMemcpy(host, (const uint8_t *)d + off, len, hipMemcpyDeviceToHost));
+  return MD_OK;
+}
+void md_i_dev_free(md_ctx *ctx, void *p) {
+  if (!ctx || !p) return;
+  DeviceGuard guard(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  hipFree(p);
+}
+
 int md_deflate_batch_host(md_ctx *ctx, int format, const md_deflate_params *params,
                           size_t n, const uint8_t *h_in, size_t in_bytes, const uint64_t *in_off,
                           const uint64_t *in_len, uint8_t *h_out, size_t out_bytes,

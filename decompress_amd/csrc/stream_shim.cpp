@@ -414,6 +414,14 @@ int md_inf_decode(md_inf_stream *s) {
 // ---- the encoder side: Zl.Def.encoder / Gz.Def.encoder / De.Higher's loop with `Manual src and dst ----
 }  // extern "C"
 
+// device-side buffering (capi.cpp): the host keeps nothing of the stream
+extern "C" {
+int md_i_dev_append(md_ctx *ctx, void **buf, size_t *cap, size_t used, const uint8_t *host, size_t len);
+int md_i_dev_deflate_one(md_ctx *ctx, int format, const md_deflate_params *params, const void *d_in, size_t n, void **d_out,
+                         size_t *out_len, int *status, uint32_t *checksum);
+int md_i_dev_read(md_ctx *ctx, const void *d, size_t off, uint8_t *host, size_t len);
+void md_i_dev_free(md_ctx *ctx, void *p);
+}
 struct md_def_stream {
   md_ctx *ctx;
   int format;
@@ -422,7 +430,8 @@ struct md_def_stream {
   std::vector<char> name, comment;
   uint8_t *o;
   size_t o_len, o_pos;
-  std::vector<uint8_t> in, out;
+  void *d_in, *d_out;          // the input so far / the whole result, in device memory
+  size_t in_cap, in_len, out_len;
   size_t served;
   bool eoi, ran;
   int status;
@@ -457,17 +466,29 @@ md_def_stream *md_def_encoder(md_ctx *ctx, int format, const md_deflate_params *
   s->o = o;
   s->o_len = o_len;
   s->o_pos = s->served = 0;
+  s->d_in = s->d_out = nullptr;
+  s->in_cap = s->in_len = s->out_len = 0;
   s->eoi = s->ran = false;
   s->status = MD_OK;
   s->checksum = 0;
   return s;
 }
-void md_def_free(md_def_stream *s) { delete s; }
+void md_def_free(md_def_stream *s) {
+  if (!s) return;
+  md_i_dev_free(s->ctx, s->d_in);
+  md_i_dev_free(s->ctx, s->d_out);
+  delete s;
+}
 int md_def_src(md_def_stream *s, const uint8_t *buf, size_t off, size_t len) {
   if (!s || (!buf && len) || s->eoi) return MD_E_INVALID_ARGUMENT;
-  if (len == 0) s->eoi = true;
-  else s->in.insert(s->in.end(), buf + off, buf + off + len);
-  return MD_OK;
+  if (len == 0) {
+    s->eoi = true;
+    return MD_OK;
+  }
+  if (len > MD_MAX_STREAM - s->in_len) return MD_E_INVALID_ARGUMENT;  // (32-bit cursors in the kernels, mdeflate.h)
+  const int rc = md_i_dev_append(s->ctx, &s->d_in, &s->in_cap, s->in_len, buf + off, len);
+  if (rc == MD_OK) s->in_len += len;
+  return rc;
 }
 void md_def_dst(md_def_stream *s, uint8_t *o, size_t o_len) {  // Zl.Def.dst: a fresh output buffer
   if (!s || !o || !o_len) return;
@@ -484,24 +505,23 @@ int md_def_encode(md_def_stream *s) {
   if (!s->eoi) return MD_AWAIT;
   if (!s->ran) {
     s->ran = true;
-    const uint64_t n = s->in.size();
-    uint64_t cap = n + n / 4 + n / s->params.queue_len * 16 + 4096;  // stored blocks of a queue fill each are the worst case
-    if (cap > MD_MAX_STREAM) cap = MD_MAX_STREAM;
-    s->out.resize((size_t)cap);
-    uint64_t in_off = 0, in_len = n, out_off = 0, out_cap = cap, out_len = 0;
-    int32_t st = 0;
-    static const uint8_t none = 0;
-    int rc = md_deflate_batch_host(s->ctx, s->format, &s->params, 1, n ? s->in.data() : &none, (size_t)n, &in_off, &in_len,
-                                   s->out.data(), (size_t)cap, &out_off, &out_cap, &out_len, &st, &s->checksum);
+    int st = 0;
+    const int rc = md_i_dev_deflate_one(s->ctx, s->format, &s->params, s->d_in, s->in_len, &s->d_out, &s->out_len, &st, &s->checksum);
     s->status = rc != MD_OK ? rc : st;
-    s->out.resize(s->status == MD_OK ? (size_t)out_len : 0);
+    if (s->status != MD_OK) s->out_len = 0;
+    md_i_dev_free(s->ctx, s->d_in);  // the input is not needed again
+    s->d_in = nullptr;
+    s->in_cap = 0;
   }
-  const size_t left = s->out.size() - s->served, room = s->o_len - s->o_pos;
+  const size_t left = s->out_len - s->served, room = s->o_len - s->o_pos;
   const size_t k = left < room ? left : room;
-  if (k) memcpy(s->o + s->o_pos, s->out.data() + s->served, k);
+  if (k && md_i_dev_read(s->ctx, s->d_out, s->served, s->o + s->o_pos, k) != MD_OK) {
+    s->status = MD_E_HIP;
+    return MD_MALFORMED;
+  }
   s->o_pos += k;
   s->served += k;
-  if (s->served < s->out.size()) return MD_FLUSH;
+  if (s->served < s->out_len) return MD_FLUSH;
   return s->status == MD_OK ? MD_END : MD_MALFORMED;
 }
 

@@ -357,8 +357,11 @@ int md_de_inf_continue_host(md_ctx *ctx, const uint8_t *src, size_t src_len, uns
  * with src (length 0 = end of input, as in the reference), calls decode / encode, and consumes its output buffer
  * whenever it gets MD_FLUSH (then md_inf_flush / md_def_dst), until MD_END or MD_MALFORMED (md_*_status gives
  * the MD_* status whose string is the reference's `Malformed message).  See csrc/stream_shim.cpp. */
-/* Memory: the encoder shim buffers the whole input until its end is signalled and holds the whole result until it has
- * been handed out — O(stream) host memory where the reference needs its window and one output buffer.  The decoder
+/* Memory: the encoder shim keeps nothing of the stream on the HOST - md_def_src sends every piece straight to a grow-only
+ * DEVICE buffer, md_def_encode runs the compressor once the end of the input is signalled and serves the result from
+ * device memory one `Flush at a time - but the device holds the whole input (plus the kernels' 13 bytes per input byte
+ * of workspace) and all of the output until it has been handed out, where the reference needs its window, its queue
+ * and one output buffer: no output before the end of the input.  The decoder
  * (DEFLATE, ZLIB, GZip) works in pieces: once md_inf_chunk_bytes (default 1 MiB) of input are buffered
  * it decodes up to the last block boundary inside them (md_de_inf_continue_host), hands that output out through
  * `Flush steps while input is still arriving, and keeps only the undecoded tail and the 32 KiB window; a stream that

@@ -1,6 +1,7 @@
 """Parity of the HIP deflate path (through the C ABI) with the CPU oracle: identical
 compressed bytes at the same level / queue / driver.  Needs an MI355X: `pytest -m gpu`."""
 import ctypes
+import os
 import random
 import zlib
 
@@ -334,6 +335,100 @@ def test_streaming_encoder_shim(eng, oracle):
     lib.md_def_free(s)
     assert bytes(out) == oracle.zl_deflate(data, 6)
     assert sigs.count(0) == 8 and sigs.count(1) >= 10
+
+
+def _rss_bytes():
+    with open("/proc/self/statm") as f:
+        return int(f.read().split()[1]) * os.sysconf("SC_PAGE_SIZE")
+
+
+def _push_through_encoder(eng, fmt, pieces, level, o_len=65536):
+    """pieces: an iterator of bytes -> (sha256 of the output, its length, checksum, peak growth of the resident set while
+    the pieces went through md_def_*)"""
+    import hashlib
+    lib = eng.lib
+    params = eng._params(level, 4096, 0, True)
+    o = ctypes.create_string_buffer(o_len)
+    s = lib.md_def_encoder(eng.ctx, fmt, ctypes.byref(params), o, len(o))
+    assert s
+    h, n_out, done = hashlib.sha256(), 0, False
+    rss0, peak = _rss_bytes(), 0
+    it = iter(pieces)
+    while True:
+        sig = lib.md_def_encode(s)
+        if sig == 0:  # `Await
+            chunk = next(it, b"")
+            assert lib.md_def_src(s, chunk, 0, len(chunk)) == 0
+            peak = max(peak, _rss_bytes() - rss0)
+        elif sig in (1, 2):  # `Flush / `End
+            k = len(o) - lib.md_def_dst_rem(s)
+            h.update(o.raw[:k])
+            n_out += k
+            if sig == 2:
+                break
+            lib.md_def_dst(s, o, len(o))
+        else:
+            raise AssertionError(lib.md_def_status(s))
+    peak = max(peak, _rss_bytes() - rss0)
+    status, checksum = lib.md_def_status(s), lib.md_def_checksum(s)
+    lib.md_def_free(s)
+    assert status == 0
+    return h.hexdigest(), n_out, checksum, peak
+
+
+def test_encoder_64mib_in_pieces_bounded_host_memory(eng, oracle):
+    """64 MiB pushed through md_def_* in 64 KiB pieces, zlib and gzip: the host keeps nothing of the stream (the pieces go
+    straight to device memory, the result is served from there one `Flush at a time) - its resident set grows by less
+    than 4 MiB - and the bytes are those of the one-shot oracle.  (The DEVICE still holds the whole stream: the matcher's
+    state does not cross launches)"""
+    import hashlib
+    import decompress_amd
+    from decompress_amd import workloads
+    piece, npieces = 65536, 1024
+    base = [workloads.text(0x600 + i, piece) for i in range(16)]  # (the stream: these 16 pieces, cycled)
+    for fmt in (decompress_amd.FORMAT_ZLIB, decompress_amd.FORMAT_GZIP):
+        digest, n_out, checksum, peak = _push_through_encoder(eng, fmt, (base[i % 16] for i in range(npieces)), 4)
+        assert peak < 4 << 20, peak
+        whole = b"".join(base[i % 16] for i in range(npieces))
+        want = oracle.zl_deflate(whole, 4) if fmt == decompress_amd.FORMAT_ZLIB else oracle.gz_deflate(whole, level=4)
+        assert (n_out, digest) == (len(want), hashlib.sha256(want).hexdigest())
+        assert checksum == (zlib.adler32(whole) if fmt == decompress_amd.FORMAT_ZLIB else zlib.crc32(whole))
+        del whole, want
+
+
+@pytest.mark.skipif(not os.environ.get("MD_SLOW"), reason="the reference's `Slow test: 4 GB through the encoder (set MD_SLOW=1)")
+def test_gzip_huge(eng):
+    """test/test.ml:1991-2014 'GZip with huge file': 4 000 055 296 zero bytes through Gz.Def at level 4 in io_buffer_size
+    pieces; here the result is also checked (gzip -t semantics: libz inflates it back to that many zeros)"""
+    import decompress_amd
+    zero = bytes(65536)
+    n = -(-4_000_000_000 // 65536)
+    lib = eng.lib
+    params = eng._params(4, 4096, 0, True)
+    o = ctypes.create_string_buffer(65536)
+    s = lib.md_def_encoder(eng.ctx, decompress_amd.FORMAT_GZIP, ctypes.byref(params), o, len(o))
+    d, total, fed = zlib.decompressobj(31), 0, 0
+    while True:
+        sig = lib.md_def_encode(s)
+        if sig == 0:
+            chunk = zero if fed < n else b""
+            fed += 1
+            assert lib.md_def_src(s, chunk, 0, len(chunk)) == 0
+        elif sig in (1, 2):
+            for off in range(0, len(o) - lib.md_def_dst_rem(s), 4096):  # (inflate in small steps: zeros expand 1000-fold)
+                blk = o.raw[off:min(off + 4096, len(o) - lib.md_def_dst_rem(s))]
+                while blk:
+                    out = d.decompress(blk, 1 << 24)
+                    assert not any(out[:: 4099])
+                    total += len(out)
+                    blk = d.unconsumed_tail
+            if sig == 2:
+                break
+            lib.md_def_dst(s, o, len(o))
+        else:
+            raise AssertionError(lib.md_def_status(s))
+    assert lib.md_def_status(s) == 0 and d.eof and total == n * 65536
+    lib.md_def_free(s)
 
 
 def test_encoder_params_checked_at_construction(eng):
