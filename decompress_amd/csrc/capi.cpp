@@ -41,7 +41,8 @@ extern "C" int md_launch_deflate(int format, int level, int qcap, int driver, in
                                  uint8_t *out, const uint64_t *out_off, const uint64_t *out_cap,
                                  uint64_t *out_len, int32_t *status, uint32_t *checksum, const md_front *fr, void *queue_ws,
                                  uint64_t *dbg, const uint8_t *gz_hdr, uint32_t gz_hdr_len,
-                                 const uint32_t *gz_crc, int matcher, uint32_t *hist, const uint32_t *order, hipStream_t stream);
+                                 const uint32_t *gz_crc, int matcher, uint32_t *hist, const uint32_t *order, const void *piece_ptrs,
+                                 hipStream_t stream);
 
 extern "C" int md_launch_gz_header(uint32_t n, const uint8_t *in, const uint64_t *in_off, const uint64_t *in_len,
                                    uint64_t *body_off, uint64_t *body_len, int32_t *hstatus, hipStream_t stream);
@@ -73,8 +74,9 @@ struct md_ctx {
   void *lzo_ws = nullptr;  // Lzo.compress dictionaries
   size_t lzo_ws_bytes = 0;
   int inflate_waves = 2;    // wavefronts per stream of the inflate kernel (md_set_option "inflate_waves": 1 = the one-wavefront form)
+  size_t piece_bytes = (size_t)1 << 20;  // md_set_option "encoder_piece_bytes": input the md_def_* encoder gathers before a launch
   size_t front_cap_bytes = 0;  // md_set_option "deflate_workspace_cap_mib": batches whose per-position workspace would be larger go in slices
-  int test_flags = 0;       // (kept for callers of md_set_option "deflate_test_flags": no effect since 0.3)
+  int test_flags = 0;       // md_set_option "deflate_test_flags": bit 4 = the md_def_* encoder moves its origin every 128 KiB (tests)
   uint64_t *dbg = nullptr;  // device buffer of the optional in-kernel profile (32 x u64)
   // deflate workspaces, grow-only: command queues (n x queue_len), the per-stream part of the front workspace
   // (slots, chunk starts: n-sized) and its per-position part (hash-chain links, look-ahead verdicts: 13 bytes per input byte)
@@ -303,6 +305,11 @@ int md_set_option(md_ctx *ctx, const char *key, int value) {
   if (!strcmp(key, "deflate_workspace_cap_mib")) {  // 0 = no cap (one launch per batch)
     if (value < 0) return fail(ctx, MD_E_INVALID_ARGUMENT, "deflate_workspace_cap_mib >= 0");
     ctx->front_cap_bytes = (size_t)value << 20;
+    return MD_OK;
+  }
+  if (!strcmp(key, "encoder_piece_bytes")) {
+    if (value < 1) return fail(ctx, MD_E_INVALID_ARGUMENT, "encoder_piece_bytes >= 1");
+    ctx->piece_bytes = (size_t)value;
     return MD_OK;
   }
   if (!strcmp(key, "release_workspace")) {  // give the grow-only scratch of this context back (it grows again on demand)
@@ -628,15 +635,25 @@ static int grow(md_ctx *ctx, void **buf, size_t *have, size_t need, const char *
   return MD_OK;
 }
 
+// One piece of one stream (md_i_piece_run below): device pointers of what differs from a batch of whole streams.
+struct PieceArgs {
+  const uint64_t *d_front_len;  // length of the text the launch holds, n - w0 (d_in_len is the absolute length n)
+  void *queue;                  // the stream's own command queue: it lives across launches
+  const void *ptrs[4];          // struct Piece of deflate_common.hpp: flags, state, pos, sum
+};
+
 // total_in: an upper bound of the sum of in_len when the caller knows one (md_deflate_params.total_in_bytes), else 0:
 // the front workspace is then sized from the totals the plan kernel computes, which costs one 16-byte read-back
 // (a synchronisation with the context's stream).
 static int deflate_launch(md_ctx *ctx, int format, int level, int queue_len, int driver, int dynamic, int matcher,
                           const md_gz_header *gz, size_t n, const uint8_t *d_in, const uint64_t *d_in_off,
                           const uint64_t *d_in_len, uint8_t *d_out, const uint64_t *d_out_off, const uint64_t *d_out_cap,
-                          uint64_t *d_out_len, int32_t *d_status, uint32_t *d_checksum, uint32_t *d_hist, size_t total_in) {
-  int grc_ = grow(ctx, &ctx->ws, &ctx->ws_bytes, md_deflate_queue_bytes((uint32_t)n, queue_len), "hipMalloc(deflate command queues)");
+                          uint64_t *d_out_len, int32_t *d_status, uint32_t *d_checksum, uint32_t *d_hist, size_t total_in,
+                          const PieceArgs *pa = nullptr) {
+  int grc_ = MD_OK;
+  if (!pa) grc_ = grow(ctx, &ctx->ws, &ctx->ws_bytes, md_deflate_queue_bytes((uint32_t)n, queue_len), "hipMalloc(deflate command queues)");
   if (grc_ != MD_OK) return grc_;
+  const uint64_t *d_front_len = pa ? pa->d_front_len : d_in_len;  // (a piece: the front kernels see [w0, n) as a stream)
   grc_ = grow(ctx, &ctx->fsmall, &ctx->fsmall_bytes, md_front_small_bytes((uint32_t)n), "hipMalloc(deflate plan)");
   if (grc_ != MD_OK) return grc_;
   md_front fr;
@@ -655,7 +672,7 @@ static int deflate_launch(md_ctx *ctx, int format, int level, int queue_len, int
     if (grc_ != MD_OK) return grc_;
   }
   md_front_carve(ctx->fsmall, ctx->fbig, (uint32_t)n, positions, &fr);
-  int prc = md_launch_deflate_plan((uint32_t)n, d_in_len, driver, matcher, level, positions, chunks, &fr, ctx->stream);
+  int prc = md_launch_deflate_plan((uint32_t)n, d_front_len, driver, matcher, level, positions, chunks, &fr, ctx->stream);
   if (prc != 0) return fail(ctx, MD_E_HIP, "deflate plan kernel launch", (hipError_t)prc);
   if (matcher_runs && total_in == 0) {
     uint64_t tot_pos = 0;
@@ -688,8 +705,10 @@ static int deflate_launch(md_ctx *ctx, int format, int level, int queue_len, int
       ctx->gz_hdr_valid = true;
     }
     gz_hdr = ctx->gz_hdr_dev;
-    int e = md_launch_crc32((uint32_t)n, d_in, d_in_off, d_in_len, gz_crc, ctx->stream);
-    if (e != 0) return fail(ctx, MD_E_HIP, "crc32 kernel launch", (hipError_t)e);
+    if (!pa) {  // (in pieces the CRC-32 is the caller's running one)
+      int e = md_launch_crc32((uint32_t)n, d_in, d_in_off, d_in_len, gz_crc, ctx->stream);
+      if (e != 0) return fail(ctx, MD_E_HIP, "crc32 kernel launch", (hipError_t)e);
+    }
   }
   // more streams than the link kernel (one per CU) or the sequential kernel (16 per CU) hold at once: longest first
   uint32_t *order = nullptr;
@@ -701,12 +720,12 @@ static int deflate_launch(md_ctx *ctx, int format, int level, int queue_len, int
     if (oe != 0) return fail(ctx, MD_E_HIP, "launch order kernel", (hipError_t)oe);
   }
   if (matcher_runs && chunks != 0) {
-    int frc = md_launch_deflate_front((uint32_t)n, chunks, d_in, d_in_off, d_in_len, matcher, max_chain, nice, &fr, order, ctx->stream);
+    int frc = md_launch_deflate_front((uint32_t)n, chunks, d_in, d_in_off, d_front_len, matcher, max_chain, nice, &fr, order, ctx->stream);
     if (frc != 0) return fail(ctx, MD_E_HIP, "deflate front kernel launch", (hipError_t)frc);
   }
   int rc = md_launch_deflate(format, level, queue_len, driver, dynamic, (uint32_t)n, d_in, d_in_off, d_in_len, d_out,
-                             d_out_off, d_out_cap, d_out_len, d_status, d_checksum, &fr, ctx->ws, ctx->dbg,
-                             gz_hdr, gz_hdr_len, gz_crc, matcher, d_hist, order, ctx->stream);
+                             d_out_off, d_out_cap, d_out_len, d_status, d_checksum, &fr, pa ? pa->queue : ctx->ws, ctx->dbg,
+                             gz_hdr, gz_hdr_len, gz_crc, matcher, d_hist, order, pa ? pa->ptrs : nullptr, ctx->stream);
   if (rc != 0) return fail(ctx, MD_E_HIP, "deflate kernel launch", (hipError_t)rc);
   return MD_OK;
 }
@@ -867,84 +886,90 @@ int md_deflate_batch_device(md_ctx *ctx, int format, const md_deflate_params *pa
                         d_in_len, d_out, d_out_off, d_out_cap, d_out_len, d_status, d_checksum, nullptr, q.total_in_bytes);
 }
 
-// ---- device-side buffering for the encoder shim (stream_shim.cpp): not part of the public ABI -----------------------
-// md_def_src hands every piece of the input straight to a grow-only device buffer, md_def_encode runs the batch-of-one
-// deflate on it at the end of the input and serves the result from device memory one `Flush at a time: the HOST keeps
-// nothing of the stream (the device keeps all of it: the matcher's state does not cross launches).
-int md_i_dev_append(md_ctx *ctx, void **buf, size_t *cap, size_t used, const uint8_t *host, size_t len) {
-  if (!ctx || !buf || !cap || (!host && len)) return MD_E_INVALID_ARGUMENT;
-  MD_ON_DEVICE(ctx);
-  if (used + len + 16 > *cap) {
-    size_t ncap = *cap ? *cap : (size_t)1 << 20;
-    while (ncap < used + len + 16) ncap *= 2;
-    void *nb = nullptr;
-    if (hipMalloc(&nb, ncap) != hipSuccess) return fail(ctx, MD_E_OUT_OF_MEMORY, "hipMalloc(encoder input)");
-    if (*buf) {
-      HIP_TRY(ctx, hipMemcpyAsync(nb, *buf, used, hipMemcpyDeviceToDevice, ctx->stream));
-      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-      HIP_TRY(ctx, hipFree(*buf));
-    }
-    *buf = nb;
-    *cap = ncap;
+// ---- the encoder shim's stream in pieces (stream_shim.cpp): not part of the public ABI ------------------------------
+// A launch takes the text [w0, n) of ONE stream - the last 64 KiB the launch before already saw plus what arrived since -
+// and goes on from the state that launch left in device memory (the two structs of the sequential kernel, 12 KiB, and
+// the stream's command queue): the matcher answers `Await at the end of the piece exactly where the reference's would
+// (deflate_kernel.hip, LZ_AWAIT), so the bytes are those of the reference fed the same pieces.  Neither side keeps
+// more of the stream than the window and the piece.
+struct md_piece {
+  void *d_text = nullptr, *d_out = nullptr, *d_state = nullptr, *d_queue = nullptr, *d_desc = nullptr;
+  size_t text_cap = 0, out_cap = 0;
+};
+size_t md_i_piece_bytes(const md_ctx *ctx) { return ctx ? ctx->piece_bytes : 0; }
+int md_i_test_flags(const md_ctx *ctx) { return ctx ? ctx->test_flags : 0; }
+static const size_t kPieceStateBytes = 12288;  // deflate_common.hpp kPieceState (checked against sizeof there)
+md_piece *md_i_piece_open(md_ctx *ctx, int queue_len) {
+  if (!ctx || queue_len < 4) return nullptr;
+  DeviceGuard guard(ctx->device);
+  md_piece *p = new md_piece();
+  if (hipMalloc(&p->d_state, kPieceStateBytes) != hipSuccess || hipMalloc(&p->d_queue, (size_t)queue_len * 4) != hipSuccess ||
+      hipMalloc(&p->d_desc, 128) != hipSuccess) {
+    hipFree(p->d_state);
+    hipFree(p->d_queue);
+    hipFree(p->d_desc);
+    delete p;
+    fail(ctx, MD_E_OUT_OF_MEMORY, "hipMalloc(encoder state)");
+    return nullptr;
   }
-  if (len) {
-    HIP_TRY(ctx, hipMemcpyAsync((uint8_t *)*buf + used, host, len, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // (the caller's buffer is his again when src returns)
-  }
-  return MD_OK;
+  return p;
 }
-int md_i_dev_deflate_one(md_ctx *ctx, int format, const md_deflate_params *params, const void *d_in, size_t n, void **d_out,
-                         size_t *out_len, int *status, uint32_t *checksum) {
-  if (!ctx || !params || !d_out || !out_len || !status || !checksum) return MD_E_INVALID_ARGUMENT;
-  MD_ON_DEVICE(ctx);
-  uint64_t cap = (uint64_t)n + n / 4 + n / (uint64_t)params->queue_len * 16 + 4096;  // stored blocks of a queue fill each are the worst case
-  if (cap > MD_MAX_STREAM) cap = MD_MAX_STREAM;
-  DevBuf ddesc, dnone;
-  void *out = nullptr;
-  if (hipMalloc(&out, (size_t)cap) != hipSuccess || ddesc.alloc(5 * 8 + 8) != hipSuccess || dnone.alloc(16) != hipSuccess) {
-    if (out) hipFree(out);
-    return fail(ctx, MD_E_OUT_OF_MEMORY, "hipMalloc(encoder output)");
-  }
-  uint64_t h64[5] = {0, (uint64_t)n, 0, cap, 0};
-  uint64_t *d64 = (uint64_t *)ddesc.p;
-  int32_t *dst = (int32_t *)(d64 + 5);
-  uint32_t *dsum = (uint32_t *)(dst + 1);
-  md_deflate_params q = *params;
-  q.total_in_bytes = n ? n : 1;
-  int rc = MD_OK;
-  if (hipMemcpyAsync(d64, h64, sizeof h64, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = MD_E_HIP;
-  if (rc == MD_OK)
-    rc = md_deflate_batch_device(ctx, format, &q, 1, (const uint8_t *)(n ? d_in : dnone.p), d64 + 0, d64 + 1, (uint8_t *)out, d64 + 2,
-                                 d64 + 3, d64 + 4, dst, dsum);
-  uint64_t olen = 0;
-  int32_t st = 0;
-  uint32_t sum = 0;
-  if (rc == MD_OK && (hipMemcpyAsync(&olen, d64 + 4, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-                      hipMemcpyAsync(&st, dst, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-                      hipMemcpyAsync(&sum, dsum, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-                      hipStreamSynchronize(ctx->stream) != hipSuccess))
-    rc = fail(ctx, MD_E_HIP, "encoder results");
-  if (rc != MD_OK) {
-    hipFree(out);
-    return rc;
-  }
-  *d_out = out;
-  *out_len = (size_t)olen;
-  *status = st;
-  *checksum = sum;
-  return MD_OK;
-}
-int md_i_dev_read(md_ctx *ctx, const void *d, size_t off, uint8_t *host, size_t len) {
-  if (!ctx || !d || (!host && len)) return MD_E_INVALID_ARGUMENT;
-  MD_ON_DEVICE(ctx);
-  if (len) HIP_TRY(ctx, hipMemcpy(host, (const uint8_t *)d + off, len, hipMemcpyDeviceToHost));
-  return MD_OK;
-}
-void md_i_dev_free(md_ctx *ctx, void *p) {
+void md_i_piece_close(md_ctx *ctx, md_piece *p) {
   if (!ctx || !p) return;
   DeviceGuard guard(ctx->device);
   hipStreamSynchronize(ctx->stream);
-  hipFree(p);
+  hipFree(p->d_text);
+  hipFree(p->d_out);
+  hipFree(p->d_state);
+  hipFree(p->d_queue);
+  hipFree(p->d_desc);
+  delete p;
+}
+// text: the bytes at positions [w0, w0 + text_len) (w0 a multiple of 64, at most 65536 - 64 behind the end of the piece
+// before).  Positions count from an origin the caller moves up now and then so that they stay below MD_MAX_STREAM:
+// rebase is how far it moved since the piece before (a multiple of 65536, at least 65536 below w0 as that piece counted
+// it).  sum / isize: Adler-32 (CRC-32 for gzip) and length mod 2^32 of the whole input so far.  The piece's output
+// stays in device memory (md_i_piece_out reads it); *status is MD_PIECE_AWAIT (1000) when the encoder waits for more.
+int md_i_piece_run(md_ctx *ctx, md_piece *p, int format, const md_deflate_params *params, const uint8_t *text, size_t text_len,
+                   uint64_t w0, uint64_t rebase, int first, int last, uint32_t sum, uint32_t isize, size_t out_cap,
+                   size_t *out_len, int *status) {
+  if (!ctx || !p || !params || !out_len || !status || (!text && text_len)) return MD_E_INVALID_ARGUMENT;
+  md_deflate_params q;
+  int rc = check_params(ctx, format, params, &q);
+  if (rc != MD_OK) return rc;
+  if (w0 + text_len > MD_MAX_STREAM) return fail(ctx, MD_E_INVALID_ARGUMENT, "piece beyond MD_MAX_STREAM");
+  MD_ON_DEVICE(ctx);
+  rc = grow(ctx, &p->d_text, &p->text_cap, text_len + 320, "hipMalloc(encoder text)");
+  if (rc == MD_OK) rc = grow(ctx, &p->d_out, &p->out_cap, out_cap ? out_cap : 16, "hipMalloc(encoder output)");
+  if (rc != MD_OK) return rc;
+  uint64_t h[12] = {0, (uint64_t)text_len, w0 + text_len, 0, (uint64_t)out_cap, 0, w0, rebase, 0, 0, 0, 0};
+  uint32_t *h32 = (uint32_t *)(h + 8);  // status, checksum, flags, -, sum, isize
+  h32[2] = (first ? 1u : 0u) | (last ? 2u : 0u);
+  h32[4] = sum;
+  h32[5] = isize;
+  uint64_t *d64 = (uint64_t *)p->d_desc;
+  uint32_t *d32 = (uint32_t *)(d64 + 8);
+  HIP_TRY(ctx, hipMemcpyAsync(d64, h, sizeof h, hipMemcpyHostToDevice, ctx->stream));
+  if (text_len) HIP_TRY(ctx, hipMemcpyAsync(p->d_text, text, text_len, hipMemcpyHostToDevice, ctx->stream));
+  PieceArgs pa{d64 + 1, p->d_queue, {d32 + 2, p->d_state, d64 + 6, d32 + 4}};
+  rc = deflate_launch(ctx, format, q.level, q.queue_len, q.driver, q.dynamic, q.matcher, q.gz_header, 1, (const uint8_t *)p->d_text,
+                      d64 + 0, d64 + 2, (uint8_t *)p->d_out, d64 + 3, d64 + 4, d64 + 5, (int32_t *)d32, d32 + 1, nullptr,
+                      text_len ? text_len : 1, &pa);
+  if (rc != MD_OK) return rc;
+  uint64_t olen = 0;
+  int32_t st = 0;
+  HIP_TRY(ctx, hipMemcpyAsync(&olen, d64 + 5, 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(&st, d32, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // (and the caller's text is his again)
+  *out_len = (size_t)olen;
+  *status = st;
+  return MD_OK;
+}
+int md_i_piece_out(md_ctx *ctx, const md_piece *p, size_t off, uint8_t *host, size_t len) {
+  if (!ctx || !p || (!host && len)) return MD_E_INVALID_ARGUMENT;
+  MD_ON_DEVICE(ctx);
+  if (len) HIP_TRY(ctx, hipMemcpy(host, (const uint8_t *)p->d_out + off, len, hipMemcpyDeviceToHost));
+  return MD_OK;
 }
 
 int md_deflate_batch_host(md_ctx *ctx, int format, const md_deflate_params *params,

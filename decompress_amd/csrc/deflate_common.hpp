@@ -45,6 +45,28 @@ struct Front {
   uint32_t *m, *mq;        // longest_match ahead over the full / quartered chain, valid where flg == FL_MATCH
 };
 
+// A stream compressed IN PIECES (the encoder of `Def.encode` while input is still arriving, lib/de.ml:4294-4349,
+// lib/zl.ml:523-555): the sequential kernel's state - two LDS structs - is written out when the matcher wants input the
+// piece does not hold, and read back when the next piece begins.  Every pointer null: whole streams (the batch path).
+//   flags[i]  bit 0: the stream's first piece, bit 1: its last one (the end of the input has been signalled)
+//   state     kPieceState bytes per stream
+//   pos[2i]   w0: position of the first byte the input buffer holds (in_off[i] points at it): the piece brings the
+//             32 KiB window (and a margin) along; in_len[i] is the length of the input so far, counted like w0
+//   pos[2i+1] rebase: positions are 32-bit, so a long stream's origin moves now and then - w0 and in_len count from the
+//             new origin, and this (a multiple of 64 KiB, at most the window base) is what the positions in the state
+//             the piece before left have to come down by
+//   sum[2i]   the checksum of the whole input so far (Adler-32 / CRC-32, computed by the host), [2i+1] its length mod 2^32
+//             (the trailer of the last piece)
+// status[i] = MD_PIECE_AWAIT when the piece ended with the matcher waiting for more input.
+struct Piece {
+  const uint32_t *flags;
+  uint8_t *state;
+  const uint64_t *pos;
+  const uint32_t *sum;
+};
+constexpr uint32_t kPieceState = 12288;
+constexpr int MD_PIECE_AWAIT = 1000;
+
 // hash of the string at a, from its little-endian first 4 bytes:
 //   De.Lz77  hash4, lib/de.ml:4067-4071: 4 bytes multiplied by 0x9e3779b1, top 15 bits;
 //   Lz       update_hash (lib/lz.ml:153-155, shift 5, 15 bits) rolled over 3 bytes by fill_window's

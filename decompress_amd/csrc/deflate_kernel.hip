@@ -23,6 +23,7 @@
 // The window is the input buffer itself: w[rel] = in[base + rel]; bytes the
 // reference reads beyond the data (H7) follow its 64 KiB sliding buffer exactly
 // (zero before the first slide, the byte 32 KiB earlier after it).  See DESIGN.md 4.
+#include <string.h>
 #include "deflate_common.hpp"
 
 namespace md {
@@ -61,7 +62,7 @@ enum { OP_FILL = 1, OP_BLOCK = 2, OP_FLUSH = 3, OP_SUCC_LITERAL = 4, OP_SUCC_LEN
 enum { K_FIRST_ENTRY, K_ENCODE, K_BLOCK, K_FLAT_DONE };
 enum { R_OK, R_BLOCK };
 enum { V_AWAIT, V_FLUSH, V_BLOCK };
-enum { LZ_FLUSH, LZ_END, LZ_NEED };
+enum { LZ_FLUSH, LZ_END, LZ_NEED, LZ_AWAIT };
 enum { LK_ENOUGH, LK_FILL };
 
 template <int N>
@@ -842,6 +843,7 @@ struct Lz {
   uint32_t match_start, prev_match;
   int match_length, prev_length, match_available;
   bool eoi;
+  bool more;              // a stream in pieces: input beyond n will come (`Await instead of the end of the input)
   int k;
   uint32_t prepared_end;  // positions < prepared_end have their hash_head in the LDS ring
   uint32_t p_end;         // positions < p_end (= n - 3; n - 2 for the Lz matcher) can be prepared ahead
@@ -1020,6 +1022,8 @@ __device__ __forceinline__ int lz_compress(DS *s, Enc *e, Lz *z, const Ws *ws) {
             } else if (z->matcher == MD_MATCHER_DE) e->q[e->qw++ & (e->qc - 1)] = Q_EOB;
             return LZ_END;
           }
+        } else if (z->more) {
+          return LZ_AWAIT;  // (a stream in pieces: the state is as the reference's when it answers `Await)
         } else {
           z->eoi = true;
           z->k = LK_FILL;
@@ -1031,7 +1035,7 @@ __device__ __forceinline__ int lz_compress(DS *s, Enc *e, Lz *z, const Ws *ws) {
         z->filled += len;
         z->lookahead += (int)len;
         if (z->lookahead < MIN_LOOKAHEAD) {
-          z->eoi = z->filled >= z->n;
+          z->eoi = !z->more && z->filled >= z->n;
           z->k = LK_FILL;
           continue;
         }
@@ -1063,7 +1067,7 @@ __device__ __forceinline__ int block_plan(int driver, int dynamic, int level, in
   return -TM_CHOOSE;
 }
 
-enum { ACT_PREP = 0, ACT_WRITE = 1, ACT_DONE = 2, ACT_TREES = 3 };
+enum { ACT_PREP = 0, ACT_WRITE = 1, ACT_DONE = 2, ACT_TREES = 3, ACT_AWAIT = 4 };
 enum { PH_LZ = 0, PH_FLUSH = 1, PH_END = 2, PH_TREES = 3, PH_TREES_END = 4, PH_SC_TREES = 5, PH_SC_WRITE = 6 };
 
 struct Run {  // the two state machines of one stream (lane 0's registers)
@@ -1116,6 +1120,7 @@ __device__ __forceinline__ void stream_begin(Run *r, const Ws *ws, const uint8_t
   z.match_length = z.prev_length = matcher == MD_MATCHER_LZ ? MIN_MATCH - 1 : 0;  // lib/lz.ml:563-566
   z.match_available = 0;
   z.eoi = n == 0;
+  z.more = false;
   z.k = LK_ENOUGH;
   z.prepared_end = 0;
   z.steps = 0;
@@ -1266,6 +1271,7 @@ __device__ __forceinline__ int stream_step(DS *s, const Ws *ws, Run *r, int driv
     {
       res = driver == DRV_ENCODE ? (int)LZ_END : lz_compress(s, &e, &z, ws);
       if (res == LZ_NEED) return ACT_PREP;
+      if (res == LZ_AWAIT) return ACT_AWAIT;
       if (driver == DRV_LZ77) {
         // `Flush (the queue is full) or `End: hand the queue's commands to the caller and empty it, as the
         // caller of De.Lz77.compress does before it calls again (lib/de.mli:453-524)
@@ -1380,7 +1386,7 @@ __global__ __launch_bounds__(kWave, 4) void deflate_kernel(
     const uint64_t *__restrict__ out_off, const uint64_t *__restrict__ out_cap,
     uint64_t *__restrict__ out_len, int32_t *__restrict__ status, uint32_t *__restrict__ checksum,
     Front fr, int *__restrict__ ws_queue, uint64_t *__restrict__ dbg, const uint8_t *__restrict__ gz_hdr, uint32_t gz_hdr_len,
-    const uint32_t *__restrict__ gz_crc, int matcher, uint32_t *__restrict__ hist, const uint32_t *__restrict__ order) {
+    const uint32_t *__restrict__ gz_crc, int matcher, uint32_t *__restrict__ hist, const uint32_t *__restrict__ order, Piece pcs) {
   __shared__ DS ds;
   // optional phase profile of stream 0 (md_set_option "profile"): [0] setup [1] look-ahead [2] bulk
   // literal runs [3] matcher/driver (lane 0) [4] bit packing [5] trees, in clock ticks; [8..] event counts
@@ -1396,7 +1402,13 @@ __global__ __launch_bounds__(kWave, 4) void deflate_kernel(
   const uint32_t lane = threadIdx.x;
   if (blockIdx.x >= n) return;
   const uint32_t sid = order ? order[blockIdx.x] : blockIdx.x;  // workgroups start in index order: longest streams first
-  const uint8_t *src = in + in_off[sid];
+  // a stream in pieces (struct Piece): in_off points at the byte of absolute position w0, in_len is the absolute length
+  // so far; positions stay absolute everywhere below, the text and the front workspace are addressed from w0
+  const bool piece = pcs.flags != nullptr;
+  const uint32_t pflags = piece ? pcs.flags[sid] : 3u;
+  const bool p_first = pflags & 1, p_last = (pflags & 2) != 0;
+  const uint32_t w0 = piece ? (uint32_t)pcs.pos[2 * sid] : 0u, rebase = piece ? (uint32_t)pcs.pos[2 * sid + 1] : 0u;
+  const uint8_t *src = in + in_off[sid] - w0;
   if (in_len[sid] > MD_MAX_STREAM || fr.flags[0]) {  // 32-bit cursors: the descriptor is out of range (mdeflate.h);
                                                        // or the batch is larger than md_deflate_params.total_in_bytes said
     if (lane == 0) {
@@ -1411,8 +1423,11 @@ __global__ __launch_bounds__(kWave, 4) void deflate_kernel(
   uint64_t cap64 = out_cap[sid];
   uint32_t cap = cap64 > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)cap64;  // more room than 32-bit cursors can use
   const uint64_t so = fr.slot[sid];
-  const uint32_t slot_len = (uint32_t)(fr.slot[sid + 1] - so);
-  Ws ws{fr.link + so, fr.flg + so, fr.m + so, fr.mq + so, ws_queue + (size_t)sid * qcap, fr.tail[2 * sid], fr.tail[2 * sid + 1]};
+  const uint32_t slot_len = (uint32_t)(fr.slot[sid + 1] - so) + w0;  // positions [w0, slot_len) have a cell
+  // (the front kernels saw the piece as a stream of its own beginning at w0: their positions - the tails - are relative)
+  const uint32_t tl0 = fr.tail[2 * sid], tl1 = fr.tail[2 * sid + 1];
+  Ws ws{fr.link + so - w0, fr.flg + so - w0, fr.m + so - w0, fr.mq + so - w0, ws_queue + (size_t)sid * qcap,
+        tl0 ? tl0 + w0 : 0u, tl1 ? tl1 + w0 : 0u};
 
   // ---- cooperative setup: histograms, code tables, Adler-32 of the input
   for (uint32_t i = lane; i < (uint32_t)L_CODES; i += kWave) ds.lits[i] = i == 256 ? 1 : 0;  // make_literals
@@ -1424,7 +1439,7 @@ __global__ __launch_bounds__(kWave, 4) void deflate_kernel(
     ds.t_bd[lane] = c_base_dist[lane];
   }
   uint32_t a = 1, b = 0;  // Lz77's update_crc (Adler-32 of the input), lib/de.ml:4217-4218
-  for (uint32_t ps = 0; ps < slen; ps += 1024) {
+  for (uint32_t ps = 0; ps < slen && !piece; ps += 1024) {
     const uint32_t b0 = ps + 1024 < slen ? ps + 1024 : slen;
     uint32_t s1 = 0, s2 = 0;
     for (uint32_t k = 0; k < 16; k++) {
@@ -1440,12 +1455,15 @@ __global__ __launch_bounds__(kWave, 4) void deflate_kernel(
     b = (b + (b0 - ps) * a + s2) % 65521u;
     a = (a + s1) % 65521u;
   }
-  const uint32_t adler = (b << 16) | a;
+  const uint32_t adler = piece ? pcs.sum[2 * sid] : (b << 16) | a;  // (in pieces: the host's running checksum)
+  const uint32_t isize = piece ? pcs.sum[2 * sid + 1] : slen;
   __threadfence_block();
   __syncthreads();
 
   uint32_t hdr = 0;
-  if (format == MD_FORMAT_ZLIB) {
+  if (!p_first) {
+    // (the frame's header went out with the first piece)
+  } else if (format == MD_FORMAT_ZLIB) {
     // Zl.Def header, lib/zl.ml:511-517 (FLEVEL map lib/zl.ml:580-581)
     int flevel = level == 0 ? 0 : level <= 5 ? 1 : level == 6 ? 2 : 3;
     unsigned h = (8 + ((15 - 8) << 4)) << 8;
@@ -1465,8 +1483,48 @@ __global__ __launch_bounds__(kWave, 4) void deflate_kernel(
   // VGPRs (a value only lane 0 uses still takes a whole vector register) and with them half of the occupancy
   __shared__ Run run;
   const bool room = cap >= hdr;
-  if (lane == 0) {
+  if (piece && !p_first) {
+    // the state the piece before left: the two structs as they were, then what belongs to this launch
+    static_assert(sizeof(DS) % 4 == 0 && sizeof(Run) % 4 == 0 && sizeof(DS) + sizeof(Run) <= kPieceState, "piece state");
+    const uint32_t *st = reinterpret_cast<const uint32_t *>(pcs.state + (size_t)sid * kPieceState);
+    __syncthreads();
+    for (uint32_t i = lane; i < sizeof(DS) / 4; i += kWave) reinterpret_cast<uint32_t *>(&ds)[i] = st[i];
+    for (uint32_t i = lane; i < sizeof(Run) / 4; i += kWave) reinterpret_cast<uint32_t *>(&run)[i] = st[sizeof(DS) / 4 + i];
+    __syncthreads();
+    if (lane == 0) {
+      run.e.o = dst;  // the encoder's output cursor counts within the piece
+      run.e.o_pos = 0;
+      run.e.o_cap = cap;
+      run.e.q = ws.queue;
+      // the origin of the positions moved (Lz's are absolute; differences of them are all that is ever used)
+      run.z.base -= rebase;
+      run.z.filled -= rebase;
+      run.z.strstart -= rebase;
+      run.z.match_start -= rebase;
+      run.z.prev_match -= rebase;
+      run.z.prepared_end -= rebase;
+      ds.zs.strstart -= rebase;
+      ds.zs.base -= rebase;
+      run.z.in = src;
+      run.z.n = slen;
+      run.z.p_end = matcher == MD_MATCHER_LZ ? (slen >= 3 ? slen - 2 : 0) : (run.z.level != 0 && slen >= 4) ? slen - 3 : 0;
+      run.z.more = !p_last;
+      ds.ctl[0] = run.z.strstart;
+      ds.ctl[1] = 0;
+      ds.ctl[2] = 0;
+      ds.ctl[3] = ACT_PREP;
+      ds.ring_dead = 1;  // the ring is loaded again, from the new front workspace
+      ds.w.o = run.e.o;
+      ds.w.q = run.e.q;
+      ds.w.o_pos = 0;
+      ds.w.o_cap = cap;
+    }
+  } else if (lane == 0) {
     if (room) stream_begin(&run, &ws, src, slen, dst + hdr, cap - hdr, level, qcap, driver, matcher);
+    if (room && piece && !p_last) {
+      run.z.more = true;
+      run.z.eoi = false;
+    }
     ds.ctl[0] = 0;
     ds.ctl[1] = room ? 0 : 1;
     ds.ctl[2] = 0;
@@ -1804,7 +1862,7 @@ __global__ __launch_bounds__(kWave, 4) void deflate_kernel(
       if (act == ACT_TREES) ds.ctl[4] = (uint32_t)run.mode;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // chain links / queue commands have landed
       ds.ctl[0] = run.z.strstart;
-      ds.ctl[1] = act == ACT_DONE ? 1 : 0;
+      ds.ctl[1] = act == ACT_DONE ? 1 : act == ACT_AWAIT ? 2 : 0;
       ds.ctl[2] = pe;
       ds.ctl[3] = (uint32_t)act;
       ds.zs.strstart = run.z.strstart;
@@ -1868,6 +1926,18 @@ __global__ __launch_bounds__(kWave, 4) void deflate_kernel(
     }
     return;
   }
+  if (piece && ds.ctl[1] == 2) {  // the matcher waits for input the piece does not hold: the state goes out, nothing else
+    uint32_t *st = reinterpret_cast<uint32_t *>(pcs.state + (size_t)sid * kPieceState);
+    __syncthreads();
+    for (uint32_t i = lane; i < sizeof(DS) / 4; i += kWave) st[i] = reinterpret_cast<const uint32_t *>(&ds)[i];
+    for (uint32_t i = lane; i < sizeof(Run) / 4; i += kWave) st[sizeof(DS) / 4 + i] = reinterpret_cast<const uint32_t *>(&run)[i];
+    if (lane == 0) {
+      out_len[sid] = hdr + run.e.o_pos;
+      status[sid] = run.e.overflow ? MD_UNEXPECTED_END_OF_OUTPUT : MD_PIECE_AWAIT;
+      if (checksum) checksum[sid] = adler;
+    }
+    return;
+  }
   if (lane == 0) {
     uint32_t body = room ? run.e.o_pos : 0;
     int st = !room || run.e.overflow ? MD_UNEXPECTED_END_OF_OUTPUT : MD_OK;
@@ -1889,14 +1959,14 @@ __global__ __launch_bounds__(kWave, 4) void deflate_kernel(
     }
     uint32_t sum = adler;
     if (format == MD_FORMAT_GZIP) {
-      sum = gz_crc[sid];
+      sum = piece ? adler : gz_crc[sid];  // (in pieces: the host's running CRC-32)
       if (st == MD_OK) {
         // Gz.Def checksum (lib/gz.ml:715-722): CRC-32, then the input size mod 2^32, little-endian
         if (cap - total < 8) st = MD_UNEXPECTED_END_OF_OUTPUT;
         else {
           for (int k = 0; k < 4; k++) {
             dst[total + k] = (uint8_t)(sum >> (8 * k));
-            dst[total + 4 + k] = (uint8_t)(slen >> (8 * k));
+            dst[total + 4 + k] = (uint8_t)(isize >> (8 * k));
           }
           total += 8;
         }
@@ -1919,17 +1989,20 @@ extern "C" int md_launch_deflate(int format, int level, int qcap, int driver, in
                                  uint8_t *out, const uint64_t *out_off, const uint64_t *out_cap,
                                  uint64_t *out_len, int32_t *status, uint32_t *checksum, const md::defl::Front *fr,
                                  void *queue_ws, uint64_t *dbg, const uint8_t *gz_hdr, uint32_t gz_hdr_len,
-                                 const uint32_t *gz_crc, int matcher, uint32_t *hist, const uint32_t *order, hipStream_t stream) {
+                                 const uint32_t *gz_crc, int matcher, uint32_t *hist, const uint32_t *order, const void *piece_ptrs,
+                                 hipStream_t stream) {
   if (n == 0) return 0;
   if (dbg) order = nullptr;  // (the profile is stream 0's)
+  md::defl::Piece pcs{};  // (four device pointers in the order of struct Piece, or null: whole streams)
+  if (piece_ptrs) memcpy(&pcs, piece_ptrs, sizeof pcs);
   if (dbg)
     hipLaunchKernelGGL(md::defl::deflate_kernel<true>, dim3(n), dim3(md::defl::kWave), 0, stream, format, level,
                        qcap, driver, dynamic, n, in, in_off, in_len, out, out_off, out_cap, out_len, status,
-                       checksum, *fr, (int *)queue_ws, dbg, gz_hdr, gz_hdr_len, gz_crc, matcher, hist, order);
+                       checksum, *fr, (int *)queue_ws, dbg, gz_hdr, gz_hdr_len, gz_crc, matcher, hist, order, pcs);
   else
     hipLaunchKernelGGL(md::defl::deflate_kernel<false>, dim3(n), dim3(md::defl::kWave), 0, stream, format, level,
                        qcap, driver, dynamic, n, in, in_off, in_len, out, out_off, out_cap, out_len, status,
-                       checksum, *fr, (int *)queue_ws, dbg, gz_hdr, gz_hdr_len, gz_crc, matcher, hist, order);
+                       checksum, *fr, (int *)queue_ws, dbg, gz_hdr, gz_hdr_len, gz_crc, matcher, hist, order, pcs);
   return (int)hipGetLastError();
 }
 

@@ -414,14 +414,68 @@ int md_inf_decode(md_inf_stream *s) {
 // ---- the encoder side: Zl.Def.encoder / Gz.Def.encoder / De.Higher's loop with `Manual src and dst ----
 }  // extern "C"
 
-// device-side buffering (capi.cpp): the host keeps nothing of the stream
+// The encoder takes its stream in pieces (capi.cpp, md_i_piece_*): the device goes on from the state the piece before
+// left, so neither side keeps more of the stream than the 64 KiB the matcher can reach back plus the piece in flight.
+struct md_piece;
 extern "C" {
-int md_i_dev_append(md_ctx *ctx, void **buf, size_t *cap, size_t used, const uint8_t *host, size_t len);
-int md_i_dev_deflate_one(md_ctx *ctx, int format, const md_deflate_params *params, const void *d_in, size_t n, void **d_out,
-                         size_t *out_len, int *status, uint32_t *checksum);
-int md_i_dev_read(md_ctx *ctx, const void *d, size_t off, uint8_t *host, size_t len);
-void md_i_dev_free(md_ctx *ctx, void *p);
+md_piece *md_i_piece_open(md_ctx *ctx, int queue_len);
+void md_i_piece_close(md_ctx *ctx, md_piece *p);
+int md_i_piece_run(md_ctx *ctx, md_piece *p, int format, const md_deflate_params *params, const uint8_t *text, size_t text_len,
+                   uint64_t w0, uint64_t rebase, int first, int last, uint32_t sum, uint32_t isize, size_t out_cap,
+                   size_t *out_len, int *status);
+int md_i_test_flags(const md_ctx *ctx);
+int md_i_piece_out(md_ctx *ctx, const md_piece *p, size_t off, uint8_t *host, size_t len);
+size_t md_i_piece_bytes(const md_ctx *ctx);
 }
+namespace {
+constexpr size_t kKeepBytes = 65536;             // text behind the end of a piece that the next launch sees again
+constexpr size_t kSrcMax = (size_t)1 << 30;      // most that one md_def_src hands over
+constexpr int kPieceAwait = 1000;                // MD_PIECE_AWAIT, deflate_common.hpp
+
+uint32_t adler32_update(uint32_t adler, const uint8_t *p, size_t n) {  // lib/de.ml:4217-4218 keeps it per fill; the sum is the same
+  uint32_t a = adler & 0xffff, b = adler >> 16;
+  while (n) {
+    size_t k = n < 5552 ? n : 5552;
+    n -= k;
+    while (k--) {
+      a += *p++;
+      b += a;
+    }
+    a %= 65521u;
+    b %= 65521u;
+  }
+  return (b << 16) | a;
+}
+struct Crc32Tables {
+  uint32_t t[8][256];
+  Crc32Tables() {
+    for (uint32_t i = 0; i < 256; i++) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; k++) c = (c >> 1) ^ (0xedb88320u & (0u - (c & 1)));
+      t[0][i] = c;
+    }
+    for (uint32_t i = 0; i < 256; i++)
+      for (int j = 1; j < 8; j++) t[j][i] = (t[j - 1][i] >> 8) ^ t[0][t[j - 1][i] & 0xff];
+  }
+};
+uint32_t crc32_update(uint32_t crc, const uint8_t *p, size_t n) {  // eight bytes a step
+  static const Crc32Tables T;
+  uint32_t c = ~crc;
+  while (n >= 8) {
+    uint32_t lo, hi;
+    memcpy(&lo, p, 4);
+    memcpy(&hi, p + 4, 4);
+    lo ^= c;
+    c = T.t[7][lo & 0xff] ^ T.t[6][(lo >> 8) & 0xff] ^ T.t[5][(lo >> 16) & 0xff] ^ T.t[4][lo >> 24] ^ T.t[3][hi & 0xff] ^
+        T.t[2][(hi >> 8) & 0xff] ^ T.t[1][(hi >> 16) & 0xff] ^ T.t[0][hi >> 24];
+    p += 8;
+    n -= 8;
+  }
+  while (n--) c = T.t[0][(c ^ *p++) & 0xff] ^ (c >> 8);
+  return ~c;
+}
+}  // namespace
+
 struct md_def_stream {
   md_ctx *ctx;
   int format;
@@ -430,10 +484,12 @@ struct md_def_stream {
   std::vector<char> name, comment;
   uint8_t *o;
   size_t o_len, o_pos;
-  void *d_in, *d_out;          // the input so far / the whole result, in device memory
-  size_t in_cap, in_len, out_len;
-  size_t served;
-  bool eoi, ran;
+  md_piece *dev;               // device side: text of the launch in flight, state, command queue, output of the piece
+  std::vector<uint8_t> text;   // the input at absolute positions [w0, w0 + text.size())
+  uint64_t w0, launched;       // ...of which [w0, launched) went through a launch already
+  uint64_t origin;             // what the device counts positions from (they are 32-bit there): it moves up as the stream grows
+  size_t out_len, served;      // output of the last launch (in device memory) / how much of it was handed out
+  bool eoi, first, done;
   int status;
   uint32_t checksum;
 };
@@ -447,6 +503,8 @@ md_def_stream *md_def_encoder(md_ctx *ctx, int format, const md_deflate_params *
   // format, level, queue (a power of two >= 4), driver, matcher, window: refused here (md_last_error_string says
   // why), not at the end of the input — Zl.Def.encoder raises Invalid_argument at construction too (lib/de.ml:2286-2288)
   if (md_validate_deflate_params(ctx, format, params) != MD_OK) return nullptr;
+  md_piece *dev = md_i_piece_open(ctx, params->queue_len);
+  if (!dev) return nullptr;
   md_def_stream *s = new md_def_stream();
   s->ctx = ctx;
   s->format = format;
@@ -465,18 +523,18 @@ md_def_stream *md_def_encoder(md_ctx *ctx, int format, const md_deflate_params *
   }
   s->o = o;
   s->o_len = o_len;
-  s->o_pos = s->served = 0;
-  s->d_in = s->d_out = nullptr;
-  s->in_cap = s->in_len = s->out_len = 0;
-  s->eoi = s->ran = false;
+  s->o_pos = s->served = s->out_len = 0;
+  s->dev = dev;
+  s->w0 = s->launched = s->origin = 0;
+  s->eoi = s->done = false;
+  s->first = true;
   s->status = MD_OK;
-  s->checksum = 0;
+  s->checksum = format == MD_FORMAT_GZIP ? 0u : 1u;
   return s;
 }
 void md_def_free(md_def_stream *s) {
   if (!s) return;
-  md_i_dev_free(s->ctx, s->d_in);
-  md_i_dev_free(s->ctx, s->d_out);
+  md_i_piece_close(s->ctx, s->dev);
   delete s;
 }
 int md_def_src(md_def_stream *s, const uint8_t *buf, size_t off, size_t len) {
@@ -485,10 +543,10 @@ int md_def_src(md_def_stream *s, const uint8_t *buf, size_t off, size_t len) {
     s->eoi = true;
     return MD_OK;
   }
-  if (len > MD_MAX_STREAM - s->in_len) return MD_E_INVALID_ARGUMENT;  // (32-bit cursors in the kernels, mdeflate.h)
-  const int rc = md_i_dev_append(s->ctx, &s->d_in, &s->in_cap, s->in_len, buf + off, len);
-  if (rc == MD_OK) s->in_len += len;
-  return rc;
+  if (len > kSrcMax) return MD_E_INVALID_ARGUMENT;  // (one launch takes what has arrived: positions within it are 32-bit)
+  s->text.insert(s->text.end(), buf + off, buf + off + len);
+  s->checksum = s->format == MD_FORMAT_GZIP ? crc32_update(s->checksum, buf + off, len) : adler32_update(s->checksum, buf + off, len);
+  return MD_OK;
 }
 void md_def_dst(md_def_stream *s, uint8_t *o, size_t o_len) {  // Zl.Def.dst: a fresh output buffer
   if (!s || !o || !o_len) return;
@@ -500,29 +558,67 @@ size_t md_def_dst_rem(const md_def_stream *s) { return s ? s->o_len - s->o_pos :
 int md_def_status(const md_def_stream *s) { return s ? s->status : MD_E_INVALID_ARGUMENT; }
 uint32_t md_def_checksum(const md_def_stream *s) { return s ? s->checksum : 0; }
 
+// one launch over what has arrived: its output waits in device memory for md_def_encode to hand it out
+static void def_launch(md_def_stream *s) {
+  const uint64_t end = s->w0 + s->text.size();
+  const size_t fresh = (size_t)(end - s->launched), ql = (size_t)s->params.queue_len;
+  // room: what the queue held back plus the fresh bytes as 2 bytes a command, a block header per queue fill, the frame
+  const size_t blocks = (fresh + ql) / ql + 2, per_block = ql >= 128 ? 320 : 24 + 4 * ql;
+  const size_t cap = 2048 + 2 * (fresh + ql) + blocks * per_block;
+  // the device's positions are 32-bit: once the text is 2 GiB from their origin the origin moves up to 64 KiB below it
+  // (deflate_test_flags bit 4: at 128 KiB already, so that a test of ordinary size goes through it)
+  const uint64_t far = (md_i_test_flags(s->ctx) & 16) ? (uint64_t)1 << 17 : (uint64_t)1 << 31;
+  uint64_t rebase = 0;
+  if (s->w0 - s->origin >= far) {
+    rebase = (s->w0 - s->origin - 65536) & ~(uint64_t)65535;
+    s->origin += rebase;
+  }
+  int st = 0;
+  const int rc = md_i_piece_run(s->ctx, s->dev, s->format, &s->params, s->text.data(), s->text.size(), s->w0 - s->origin, rebase,
+                                s->first, s->eoi, s->checksum, (uint32_t)end, cap, &s->out_len, &st);
+  s->first = false;
+  s->served = 0;
+  s->launched = end;
+  if (rc != MD_OK || (st != MD_OK && st != kPieceAwait)) {
+    s->status = rc != MD_OK ? rc : st;
+    s->out_len = 0;
+    s->done = true;
+    return;
+  }
+  if (st == MD_OK) s->done = true;  // (the last piece: trailer written)
+  // the next launch sees the last 64 KiB again (the matcher reaches 32 KiB - 262 behind a position it has yet to take,
+  // and those are less than 262 from the end): the text before goes
+  if (end > kKeepBytes) {
+    const uint64_t nw0 = (end - kKeepBytes) & ~(uint64_t)63;
+    if (nw0 > s->w0) {
+      s->text.erase(s->text.begin(), s->text.begin() + (size_t)(nw0 - s->w0));
+      s->w0 = nw0;
+    }
+  }
+}
+
 int md_def_encode(md_def_stream *s) {
   if (!s) return MD_MALFORMED;
-  if (!s->eoi) return MD_AWAIT;
-  if (!s->ran) {
-    s->ran = true;
-    int st = 0;
-    const int rc = md_i_dev_deflate_one(s->ctx, s->format, &s->params, s->d_in, s->in_len, &s->d_out, &s->out_len, &st, &s->checksum);
-    s->status = rc != MD_OK ? rc : st;
-    if (s->status != MD_OK) s->out_len = 0;
-    md_i_dev_free(s->ctx, s->d_in);  // the input is not needed again
-    s->d_in = nullptr;
-    s->in_cap = 0;
+  for (;;) {
+    if (s->served < s->out_len) {
+      const size_t left = s->out_len - s->served, room = s->o_len - s->o_pos;
+      const size_t k = left < room ? left : room;
+      if (k && md_i_piece_out(s->ctx, s->dev, s->served, s->o + s->o_pos, k) != MD_OK) {
+        s->status = MD_E_HIP;
+        s->done = true;
+        s->out_len = s->served = 0;
+        return MD_MALFORMED;
+      }
+      s->o_pos += k;
+      s->served += k;
+      if (s->served < s->out_len) return MD_FLUSH;
+    }
+    if (s->done) return s->status == MD_OK ? MD_END : MD_MALFORMED;
+    const size_t fresh = (size_t)(s->w0 + s->text.size() - s->launched);
+    // (a launch costs three kernels whatever it holds: input is gathered, 1 MiB unless md_set_option "encoder_piece_bytes")
+    if (!s->eoi && fresh < md_i_piece_bytes(s->ctx)) return MD_AWAIT;
+    def_launch(s);
   }
-  const size_t left = s->out_len - s->served, room = s->o_len - s->o_pos;
-  const size_t k = left < room ? left : room;
-  if (k && md_i_dev_read(s->ctx, s->d_out, s->served, s->o + s->o_pos, k) != MD_OK) {
-    s->status = MD_E_HIP;
-    return MD_MALFORMED;
-  }
-  s->o_pos += k;
-  s->served += k;
-  if (s->served < s->out_len) return MD_FLUSH;
-  return s->status == MD_OK ? MD_END : MD_MALFORMED;
 }
 
 }  // extern "C"

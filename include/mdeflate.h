@@ -141,6 +141,10 @@ int md_synchronize(md_ctx *ctx);
  *                                13 bytes per input byte; a md_deflate_batch_device call (with params->total_in_bytes given)
  *                                whose workspace would be larger than the cap is taken in slices of consecutive streams.
  *                                Same output; slower (fewer streams per launch than the kernels are laid out for).
+ *   "encoder_piece_bytes"        value >= 1 (default 1 MiB): how much input a md_def_* encoder gathers before it launches
+ *                                the kernels on it.  The bytes out are those of the reference handed the input in the
+ *                                same pieces (which are, but for corner cases at the very end of a stream, the same for
+ *                                any pieces).
  *   "release_workspace"          (value ignored) waits for the context's stream and frees its grow-only device scratch
  *                                (deflate workspaces, launch orders, decoder-piece buffers); it grows again on demand.
  *   "inflate_waves"              1 or 2 (default): wavefronts per stream of the inflate kernel (2 = decoder + copier).
@@ -357,11 +361,15 @@ int md_de_inf_continue_host(md_ctx *ctx, const uint8_t *src, size_t src_len, uns
  * with src (length 0 = end of input, as in the reference), calls decode / encode, and consumes its output buffer
  * whenever it gets MD_FLUSH (then md_inf_flush / md_def_dst), until MD_END or MD_MALFORMED (md_*_status gives
  * the MD_* status whose string is the reference's `Malformed message).  See csrc/stream_shim.cpp. */
-/* Memory: the encoder shim keeps nothing of the stream on the HOST - md_def_src sends every piece straight to a grow-only
- * DEVICE buffer, md_def_encode runs the compressor once the end of the input is signalled and serves the result from
- * device memory one `Flush at a time - but the device holds the whole input (plus the kernels' 13 bytes per input byte
- * of workspace) and all of the output until it has been handed out, where the reference needs its window, its queue
- * and one output buffer: no output before the end of the input.  The decoder
+/* Memory: the encoder works in pieces, like the reference's (whose state is its window, its queue and one output
+ * buffer).  md_def_src appends to a host buffer; once md_set_option "encoder_piece_bytes" (default 1 MiB) have gathered -
+ * or the end of the input is signalled - md_def_encode launches the kernels on them: they go on from the state the
+ * launch before left in device memory (12 KiB and the command queue), answer `Await inside the kernel exactly where
+ * De.Lz77 would (lookahead under 262 and nothing left of the piece), and the piece's output is handed out through
+ * `Flush steps while more input arrives.  Host and device each hold the last 64 KiB of the stream and the piece in
+ * flight; a stream may be of any length (positions are rebased inside, gzip's ISIZE wraps at 2^32 as lib/gz.ml's);
+ * one md_def_src call takes at most 1 GiB.  The bytes are those of the reference handed the input in the same pieces
+ * (fill_window's slide depends on how much each fill finds; for whole streams and for pieces the oracle agrees).  The decoder
  * (DEFLATE, ZLIB, GZip) works in pieces: once md_inf_chunk_bytes (default 1 MiB) of input are buffered
  * it decodes up to the last block boundary inside them (md_de_inf_continue_host), hands that output out through
  * `Flush steps while input is still arriving, and keeps only the undecoded tail and the 32 KiB window; a stream that

@@ -597,6 +597,7 @@ typedef struct {
   lzcfg_t cfg;
   const uint8_t *i;
   long i_pos, i_len; /* i_rem = i_len - i_pos + 1; EOI: i_len = LONG_MIN/2 */
+  long n_total, piece; /* the whole input; how much of it one `Await brings */
   int lits[LIT_FREQS], dsts[DST_FREQS];
   uint8_t w[2 * WSIZE + 320]; /* +320: the matcher may look 260 bytes past the 64 KiB window at end of input */
   int lookahead, strstart;
@@ -626,6 +627,17 @@ static long lz_rem(const lz_t *s) { return s->i_len - s->i_pos + 1; }
 static void lz_eoi(lz_t *s) {
   s->i_pos = 0;
   s->i_len = -(1L << 60);
+}
+/* The caller's answer to `Await: the next piece of the input (De.Lz77.src, lib/de.ml:4181-4188; `Manual refill :4200-4201), or the end of it.
+ * orc_set_src_piece(p) makes the drivers below hand the input over p bytes at a time (0: all of it at once), which is
+ * what decides how much fill_window finds each time it runs. */
+static size_t g_src_piece = 0;
+void orc_set_src_piece(size_t piece) { g_src_piece = piece; }
+static void lz_await(lz_t *s) {
+  if (s->i_len + 1 < s->n_total) {
+    long e = s->i_len + (long)s->piece;
+    s->i_len = e < s->n_total - 1 ? e : s->n_total - 1;
+  } else lz_eoi(s);
 }
 /* longest_match, lib/de.ml:4110-4174 */
 static int longest_match(lz_t *s, int cur_match) {
@@ -761,7 +773,7 @@ static int lz_compress(lz_t *s) {
           } else if (!s->matcher) q_push(s->q, Q_EOB); /* Lz.trailing pushes no EOB, lib/lz.ml:348-354 */
           return LZ_END;
         }
-        lz_eoi(s); /* `Await -> the driver signals end of input */
+        lz_await(s); /* `Await -> the driver hands over the next piece, or signals end of input */
         s->k = LK_FILL;
         continue;
       }
@@ -787,7 +799,7 @@ static int lz_compress(lz_t *s) {
         s->insert = ins;
       }
       if (!brk && s->lookahead < MIN_LOOKAHEAD && lz_rem(s) >= 0) {
-        if (lz_rem(s) == 0) lz_eoi(s);
+        if (lz_rem(s) == 0) lz_await(s);
         s->k = LK_FILL;
         continue;
       }
@@ -807,7 +819,9 @@ static lz_t *lz_new(int level, queue_t *q, const uint8_t *src, size_t n, int mat
   s->cfg = lz_levels[level];
   s->i = src;
   s->i_pos = 0;
-  s->i_len = (long)n - 1;
+  s->n_total = (long)n;
+  s->piece = g_src_piece && g_src_piece < n ? (long)g_src_piece : (long)n;
+  s->i_len = s->piece - 1;
   if (n == 0) lz_eoi(s);
   s->lits[256] = 1; /* make_literals, lib/de.ml:2333-2336 */
   s->q = q;

@@ -2,6 +2,7 @@
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use this.
 """
+import contextlib
 import ctypes
 import os
 import subprocess
@@ -180,6 +181,17 @@ class Oracle:
         out = ctypes.string_at(p, n)
         self.lib.orc_free(p)
         return out
+
+    @contextlib.contextmanager
+    def src_piece(self, piece):
+        """Inside the block the deflate drivers hand the input to De.Lz77 `piece` bytes per `Await (oracle.h)."""
+        self.lib.orc_set_src_piece.argtypes = [ctypes.c_size_t]
+        self.lib.orc_set_src_piece.restype = None
+        self.lib.orc_set_src_piece(piece)
+        try:
+            yield
+        finally:
+            self.lib.orc_set_src_piece(0)
 
     def deflate_raw(self, data, level=6, queue=4096, driver=0, dynamic=True, matcher=0):
         """De.Lz77 (matcher 0) or lib/lz.ml's Lz (matcher 1) + De.Def under one of the reference's

@@ -376,11 +376,106 @@ def _push_through_encoder(eng, fmt, pieces, level, o_len=65536):
     return h.hexdigest(), n_out, checksum, peak
 
 
+def _encode_in_pieces(eng, fmt, data, piece, level, queue=4096, o_len=4096):
+    """data through md_def_* `piece` bytes per `Await -> (output, number of `Flush answers before the last piece went in)"""
+    lib = eng.lib
+    params = eng._params(level, queue, 0, True)
+    o = ctypes.create_string_buffer(o_len)
+    s = lib.md_def_encoder(eng.ctx, fmt, ctypes.byref(params), o, len(o))
+    assert s
+    out, pos, early = bytearray(), 0, 0
+    while True:
+        sig = lib.md_def_encode(s)
+        if sig == 0:
+            chunk = data[pos:pos + piece]
+            pos += len(chunk)
+            assert lib.md_def_src(s, chunk, 0, len(chunk)) == 0
+        elif sig in (1, 2):
+            out += o.raw[:len(o) - lib.md_def_dst_rem(s)]
+            if sig == 2:
+                break
+            early += pos < len(data)
+            lib.md_def_dst(s, o, len(o))
+        else:
+            raise AssertionError(lib.md_def_status(s))
+    assert lib.md_def_status(s) == 0
+    lib.md_def_free(s)
+    return bytes(out), early
+
+
+@pytest.mark.parametrize("piece", [1000, 4096, 65536, 100000])
+def test_encoder_in_pieces_vs_oracle_in_pieces(eng, oracle, piece):
+    """The encoder goes on from device-resident state piece after piece (md_set_option "encoder_piece_bytes" = the piece:
+    every `Await is a launch): the bytes are those of the oracle handed the input in the same pieces (orc_set_src_piece),
+    and output comes out while input is still going in."""
+    import random
+    import decompress_amd
+    from decompress_amd import workloads
+    rng = random.Random(piece)
+    eng.set_option("encoder_piece_bytes", piece)
+    try:
+        for t in range(6):
+            n = rng.choice([0, 1, 262, 5000, 70000, 200000, 400000]) if t else 300000
+            kind = t % 3
+            data = (workloads.text(piece + t, n) if kind == 0 else bytes(rng.getrandbits(2) for _ in range(n)) if kind == 1
+                    else (workloads.text(t, 3000) * (n // 3000 + 1))[:n])
+            for level in (0, 1, 4, 6, 9):
+                if piece < 4096 and n > 100000 and level not in (4, 6):
+                    continue
+                with oracle.src_piece(piece):
+                    want_zl = oracle.zl_deflate(data, level)
+                    want_gz = oracle.gz_deflate(data, level=level) if level == 4 else None
+                got, early = _encode_in_pieces(eng, decompress_amd.FORMAT_ZLIB, data, piece, level)
+                assert got == want_zl, (t, n, level)
+                assert zlib.decompress(got) == data
+                if n >= 200000 and level and kind != 2:
+                    assert early > 0  # output before the end of the input
+                if want_gz is not None:
+                    got, _ = _encode_in_pieces(eng, decompress_amd.FORMAT_GZIP, data, piece, level)
+                    assert got == want_gz, (t, n, level)
+    finally:
+        eng.set_option("encoder_piece_bytes", 1 << 20)
+
+
+def test_encoder_origin_moves(eng, oracle):
+    """The device counts positions in 32 bits from an origin that moves up as the stream grows (every 2 GiB; with
+    deflate_test_flags bit 4 every 128 KiB): the bytes do not change, gzip's ISIZE is the whole length"""
+    import decompress_amd
+    from decompress_amd import workloads
+    data = workloads.text(91, 1_500_000)
+    eng.set_option("encoder_piece_bytes", 50000)
+    eng.set_option("deflate_test_flags", 16)
+    try:
+        with oracle.src_piece(50000):
+            want_zl, want_gz = oracle.zl_deflate(data, 6), oracle.gz_deflate(data, level=4)
+        got, _ = _encode_in_pieces(eng, decompress_amd.FORMAT_ZLIB, data, 50000, 6)
+        assert got == want_zl
+        got, _ = _encode_in_pieces(eng, decompress_amd.FORMAT_GZIP, data, 50000, 4)
+        assert got == want_gz and got[-4:] == len(data).to_bytes(4, "little")
+    finally:
+        eng.set_option("encoder_piece_bytes", 1 << 20)
+        eng.set_option("deflate_test_flags", 0)
+
+
+def test_encoder_small_queue_in_pieces(eng, oracle):
+    """a 16-command queue: a block every few commands, many of them per piece"""
+    import decompress_amd
+    from decompress_amd import workloads
+    data = workloads.text(77, 50000)
+    eng.set_option("encoder_piece_bytes", 3000)
+    try:
+        with oracle.src_piece(3000):
+            want = oracle.zl_deflate(data, 6, queue=16)
+        got, _ = _encode_in_pieces(eng, decompress_amd.FORMAT_ZLIB, data, 3000, 6, queue=16)
+        assert got == want and zlib.decompress(got) == data
+    finally:
+        eng.set_option("encoder_piece_bytes", 1 << 20)
+
+
 def test_encoder_64mib_in_pieces_bounded_host_memory(eng, oracle):
-    """64 MiB pushed through md_def_* in 64 KiB pieces, zlib and gzip: the host keeps nothing of the stream (the pieces go
-    straight to device memory, the result is served from there one `Flush at a time) - its resident set grows by less
-    than 4 MiB - and the bytes are those of the one-shot oracle.  (The DEVICE still holds the whole stream: the matcher's
-    state does not cross launches)"""
+    """64 MiB pushed through md_def_* in 64 KiB pieces, zlib and gzip: host and device keep the last 64 KiB and the
+    piece being gathered (1 MiB a launch) - the resident set grows by less than 4 MiB - and the bytes are those of the
+    oracle handed the input 1 MiB at a time (which are also those of the one-shot oracle here)."""
     import hashlib
     import decompress_amd
     from decompress_amd import workloads
@@ -390,7 +485,8 @@ def test_encoder_64mib_in_pieces_bounded_host_memory(eng, oracle):
         digest, n_out, checksum, peak = _push_through_encoder(eng, fmt, (base[i % 16] for i in range(npieces)), 4)
         assert peak < 4 << 20, peak
         whole = b"".join(base[i % 16] for i in range(npieces))
-        want = oracle.zl_deflate(whole, 4) if fmt == decompress_amd.FORMAT_ZLIB else oracle.gz_deflate(whole, level=4)
+        with oracle.src_piece(1 << 20):
+            want = oracle.zl_deflate(whole, 4) if fmt == decompress_amd.FORMAT_ZLIB else oracle.gz_deflate(whole, level=4)
         assert (n_out, digest) == (len(want), hashlib.sha256(want).hexdigest())
         assert checksum == (zlib.adler32(whole) if fmt == decompress_amd.FORMAT_ZLIB else zlib.crc32(whole))
         del whole, want

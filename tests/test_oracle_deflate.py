@@ -148,3 +148,20 @@ def test_encode_cases(oracle, case):
         if case["decoder"] == "ns":  # Ok (De.bigstring_length src, String.length expected)
             assert consumed == len(z)
         assert zlib.decompressobj(-15).decompress(z) == out
+
+
+def test_input_in_pieces(oracle):
+    """orc_set_src_piece: De.Lz77 handed the input p bytes per `Await (lib/de.ml:4181-4188, :4294-4342).  The stream stays
+    valid and - away from the corner where a candidate sits exactly at the window base when fill_window slides - the same
+    as for the whole input at once."""
+    import zlib
+    from decompress_amd import workloads
+    data = workloads.text(12, 150000)
+    whole = oracle.zl_deflate(data, 6)
+    for piece in (1, 263, 4096, 65536, 149999, 150000, 1 << 20):
+        with oracle.src_piece(piece):
+            got = oracle.zl_deflate(data, 6)
+            gz = oracle.gz_deflate(data, level=4)
+        assert zlib.decompress(got) == data and got == whole
+        assert zlib.decompress(gz, 31) == data
+    assert oracle.zl_deflate(data, 6) == whole  # (the setting does not outlive the block)
