@@ -30,7 +30,7 @@ extern "C" int md_launch_deflate_plan(uint32_t n, const uint64_t *in_len, int dr
                                       uint64_t cap_positions, uint32_t cap_chunks, const md_front *f, hipStream_t stream);
 extern "C" int md_launch_deflate_front(uint32_t n, uint32_t nchunks_max, const uint8_t *in, const uint64_t *in_off,
                                        const uint64_t *in_len, int matcher, uint32_t max_chain, uint32_t nice,
-                                       const md_front *f, const uint32_t *order, hipStream_t stream);
+                                       const md_front *f, const uint32_t *order, uint32_t match_skip, hipStream_t stream);
 extern "C" int md_launch_stream_order(uint32_t n, const uint64_t *in_len, uint32_t *order, hipStream_t stream);
 extern "C" void md_deflate_level_params(int driver, int matcher, int level, uint32_t *max_chain, uint32_t *nice);
 extern "C" int md_launch_def_ns(int format, int level, uint32_t n, uint32_t nchunks_max, const uint8_t *in, const uint64_t *in_off,
@@ -75,7 +75,8 @@ struct md_ctx {
   size_t lzo_ws_bytes = 0;
   int inflate_waves = 2;    // wavefronts per stream of the inflate kernel (md_set_option "inflate_waves": 1 = the one-wavefront form)
   size_t piece_bytes = (size_t)1 << 20;  // md_set_option "encoder_piece_bytes": input the md_def_* encoder gathers before a launch
-  size_t front_cap_bytes = 0;  // md_set_option "deflate_workspace_cap_mib": batches whose per-position workspace would be larger go in slices
+  size_t front_cap_bytes = 0;  // md_set_option "deflate_workspace_cap_mib" (md_create: a twelfth of the device's memory; 0 = none):
+                               // batches whose per-position workspace would be larger go in slices of positions
   int test_flags = 0;       // md_set_option "deflate_test_flags": bit 4 = the md_def_* encoder moves its origin every 128 KiB (tests)
   uint64_t *dbg = nullptr;  // device buffer of the optional in-kernel profile (32 x u64)
   // deflate workspaces, grow-only: command queues (n x queue_len), the per-stream part of the front workspace
@@ -85,6 +86,9 @@ struct md_ctx {
   // the decoder in pieces (md_de_inf_continue_host): input, output and descriptor scratch, grow-only
   void *cont_in = nullptr, *cont_out = nullptr, *cont_desc = nullptr;
   size_t cont_in_bytes = 0, cont_out_bytes = 0, cont_desc_bytes = 0;
+  // a deflate batch in slices of positions: descriptors of the slice and the streams' states between the slices, grow-only
+  void *slice_desc = nullptr, *slice_state = nullptr;
+  size_t slice_desc_bytes = 0, slice_state_bytes = 0;
   uint32_t *order = nullptr;  // inflate: launch order of a large batch (n words)
   size_t order_words = 0;
   std::string err;
@@ -239,6 +243,10 @@ md_ctx *md_create(int device, void *hip_stream) {
     fail(nullptr, MD_E_HIP, "hipEventCreate");
     return nullptr;
   }
+  {  // the deflate kernels' per-position workspace takes a twelfth of the device at most (24 GiB of 288) unless told otherwise
+    size_t mem_free = 0, mem_total = 0;
+    if (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess) ctx->front_cap_bytes = mem_total / 12;
+  }
   return ctx;
 }
 
@@ -254,6 +262,8 @@ void md_destroy(md_ctx *ctx) {
   if (ctx->cont_in) hipFree(ctx->cont_in);
   if (ctx->cont_out) hipFree(ctx->cont_out);
   if (ctx->cont_desc) hipFree(ctx->cont_desc);
+  if (ctx->slice_desc) hipFree(ctx->slice_desc);
+  if (ctx->slice_state) hipFree(ctx->slice_state);
   if (ctx->dbg) hipFree(ctx->dbg);
   if (ctx->gz_tmp) hipFree(ctx->gz_tmp);
   if (ctx->lzo_ws) hipFree(ctx->lzo_ws);
@@ -302,7 +312,7 @@ int md_set_option(md_ctx *ctx, const char *key, int value) {
     ctx->inflate_waves = value;
     return MD_OK;
   }
-  if (!strcmp(key, "deflate_workspace_cap_mib")) {  // 0 = no cap (one launch per batch)
+  if (!strcmp(key, "deflate_workspace_cap_mib")) {  // 0 = no cap (one launch of each kernel per batch whatever it takes)
     if (value < 0) return fail(ctx, MD_E_INVALID_ARGUMENT, "deflate_workspace_cap_mib >= 0");
     ctx->front_cap_bytes = (size_t)value << 20;
     return MD_OK;
@@ -315,9 +325,10 @@ int md_set_option(md_ctx *ctx, const char *key, int value) {
   if (!strcmp(key, "release_workspace")) {  // give the grow-only scratch of this context back (it grows again on demand)
     MD_ON_DEVICE(ctx);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    void **bufs[] = {&ctx->ws, &ctx->fsmall, &ctx->fbig, (void **)&ctx->order, &ctx->cont_in, &ctx->cont_out, &ctx->cont_desc};
+    void **bufs[] = {&ctx->ws, &ctx->fsmall, &ctx->fbig, (void **)&ctx->order, &ctx->cont_in, &ctx->cont_out, &ctx->cont_desc,
+                     &ctx->slice_desc, &ctx->slice_state};
     size_t *sizes[] = {&ctx->ws_bytes, &ctx->fsmall_bytes, &ctx->fbig_bytes, &ctx->order_words, &ctx->cont_in_bytes,
-                       &ctx->cont_out_bytes, &ctx->cont_desc_bytes};
+                       &ctx->cont_out_bytes, &ctx->cont_desc_bytes, &ctx->slice_desc_bytes, &ctx->slice_state_bytes};
     for (size_t i = 0; i < sizeof bufs / sizeof bufs[0]; i++) {
       if (*bufs[i]) hipFree(*bufs[i]);
       *bufs[i] = nullptr;
@@ -635,11 +646,13 @@ static int grow(md_ctx *ctx, void **buf, size_t *have, size_t need, const char *
   return MD_OK;
 }
 
+static const size_t kPieceStateBytes = 12288;  // deflate_common.hpp kPieceState (checked against sizeof there)
 // One piece of one stream (md_i_piece_run below): device pointers of what differs from a batch of whole streams.
 struct PieceArgs {
   const uint64_t *d_front_len;  // length of the text the launch holds, n - w0 (d_in_len is the absolute length n)
   void *queue;                  // the stream's own command queue: it lives across launches
   const void *ptrs[4];          // struct Piece of deflate_common.hpp: flags, state, pos, sum
+  uint32_t match_skip;          // leading positions of the text no stream of the launch will take (the window brought along)
 };
 
 // total_in: an upper bound of the sum of in_len when the caller knows one (md_deflate_params.total_in_bytes), else 0:
@@ -720,7 +733,7 @@ static int deflate_launch(md_ctx *ctx, int format, int level, int queue_len, int
     if (oe != 0) return fail(ctx, MD_E_HIP, "launch order kernel", (hipError_t)oe);
   }
   if (matcher_runs && chunks != 0) {
-    int frc = md_launch_deflate_front((uint32_t)n, chunks, d_in, d_in_off, d_front_len, matcher, max_chain, nice, &fr, order, ctx->stream);
+    int frc = md_launch_deflate_front((uint32_t)n, chunks, d_in, d_in_off, d_front_len, matcher, max_chain, nice, &fr, order, pa ? pa->match_skip : 0u, ctx->stream);
     if (frc != 0) return fail(ctx, MD_E_HIP, "deflate front kernel launch", (hipError_t)frc);
   }
   int rc = md_launch_deflate(format, level, queue_len, driver, dynamic, (uint32_t)n, d_in, d_in_off, d_in_len, d_out,
@@ -853,6 +866,188 @@ int md_validate_deflate_params(md_ctx *ctx, int format, const md_deflate_params 
   return check_params(ctx, format, params, &q);
 }
 
+// ---- a batch in slices of positions ----------------------------------------------------------------------------------
+// The per-position workspace is 13 bytes per input byte of what ONE launch covers.  With a cap set (md_set_option
+// "deflate_workspace_cap_mib") a batch that would need more goes through the kernels S positions of every stream at a
+// time: a launch covers [k*S - kSliceKeep, (k+1)*S) of each stream that reaches that far and goes on from the state
+// the launch before left (the machinery of the encoder in pieces, md_i_piece_run below).  S is a multiple of 32 KiB:
+// every fill of De.Lz77's window ends on such a boundary (lib/de.ml:4294-4342: more = 2 * wsize - lookahead - strstart
+// after a slide tops the window up, and the window's base moves 32 KiB at a time), so no fill ever finds less than it
+// would with the whole stream at hand and the bytes out are the same.  kSliceKeep: what a launch sees again of the
+// slice before - the matcher stopped less than 262 short of its end and reaches back 32 KiB - 262 from there.
+static const uint64_t kSliceKeep = 33792;
+static const uint64_t kSliceMin = 65536;
+
+static uint64_t slice_positions(const uint64_t *len, size_t n, uint64_t S) {  // most text one launch covers
+  uint64_t first = 0, second = 0;
+  for (size_t i = 0; i < n; i++) {
+    if (len[i] > MD_MAX_STREAM) continue;
+    first += len[i] < S ? len[i] : S;
+    if (len[i] > S) second += (len[i] - S < S ? len[i] - S : S) + kSliceKeep;
+  }
+  return (first > second ? first : second) + 319ull * n;
+}
+
+static int deflate_in_slices(md_ctx *ctx, int format, const md_deflate_params &q, size_t n, uint64_t S, const uint8_t *d_in,
+                             const uint64_t *h_in_off, const uint64_t *h_in_len, uint8_t *d_out, const uint64_t *h_out_off,
+                             const uint64_t *h_out_cap, uint64_t *h_out_len, int32_t *h_status, uint32_t *h_checksum,
+                             const uint32_t *h_crc) {
+  // state slots for the streams that do not end in the first slice
+  std::vector<uint64_t> slot(n, 0), used(n, 0);
+  std::vector<uint8_t> done(n, 0);
+  size_t n_long = 0;
+  uint64_t longest = 0;
+  for (size_t i = 0; i < n; i++) {
+    if (h_in_len[i] > MD_MAX_STREAM) {  // 32-bit cursors (mdeflate.h): refused as the kernel refuses it in a whole batch
+      done[i] = 1;
+      h_status[i] = MD_E_INVALID_ARGUMENT;
+      h_out_len[i] = 0;
+      h_checksum[i] = 0;
+      continue;
+    }
+    if (h_in_len[i] > S) slot[i] = n_long++;
+    if (h_in_len[i] > longest) longest = h_in_len[i];
+  }
+  int rc = grow(ctx, &ctx->slice_state, &ctx->slice_state_bytes, (n_long ? n_long : 1) * kPieceStateBytes, "hipMalloc(deflate slice states)");
+  if (rc != MD_OK) return rc;
+  rc = grow(ctx, &ctx->ws, &ctx->ws_bytes, md_deflate_queue_bytes((uint32_t)n, q.queue_len), "hipMalloc(deflate command queues)");
+  if (rc != MD_OK) return rc;
+  // descriptors of a slice: ten 64-bit and six 32-bit words per stream
+  const size_t desc_bytes = n * (10 * 8 + 6 * 4);
+  rc = grow(ctx, &ctx->slice_desc, &ctx->slice_desc_bytes, desc_bytes, "hipMalloc(deflate slice descriptors)");
+  if (rc != MD_OK) return rc;
+  std::vector<uint64_t> hbuf((desc_bytes + 7) / 8);
+  uint64_t *h64 = hbuf.data();
+  uint64_t *in_off = h64, *front_len = h64 + n, *abs_len = h64 + 2 * n, *out_off = h64 + 3 * n, *out_cap = h64 + 4 * n,
+           *out_len = h64 + 5 * n, *pos = h64 + 6 * n;
+  uint32_t *h32 = (uint32_t *)(h64 + 10 * n);
+  uint32_t *st = h32, *sum_out = h32 + n, *flags = h32 + 2 * n, *sums = h32 + 3 * n;  // (sums: 2 per stream)
+  uint64_t *d64 = (uint64_t *)ctx->slice_desc;
+  uint32_t *d32 = (uint32_t *)(d64 + 10 * n);
+  const uint64_t nslices = longest ? (longest + S - 1) / S : 1;
+  for (uint64_t k = 0; k < nslices; k++) {
+    uint64_t total = 0;
+    for (size_t i = 0; i < n; i++) {
+      const uint64_t len = h_in_len[i];
+      const uint64_t end = len < (k + 1) * S ? len : (k + 1) * S;
+      const uint64_t w0 = k == 0 ? 0 : k * S - kSliceKeep;
+      const bool idle = done[i] || (k > 0 && len <= k * S);
+      in_off[i] = h_in_off[i] + (idle ? 0 : w0);
+      front_len[i] = idle ? 0 : end - w0;
+      abs_len[i] = idle ? 0 : end;
+      out_off[i] = h_out_off[i] + used[i];
+      out_cap[i] = h_out_cap[i] - used[i];
+      out_len[i] = 0;
+      pos[4 * i] = idle ? 0 : w0;
+      pos[4 * i + 1] = 0;
+      pos[4 * i + 2] = slot[i];
+      pos[4 * i + 3] = i;
+      st[i] = 0;
+      sum_out[i] = 0;
+      flags[i] = idle ? 8u : (k == 0 ? 1u : 0u) | (end == len ? 2u : 0u) | 4u;
+      sums[2 * i] = h_crc ? h_crc[i] : 1u;
+      sums[2 * i + 1] = (uint32_t)len;
+      total += front_len[i];
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(d64, h64, desc_bytes, hipMemcpyHostToDevice, ctx->stream));
+    // (every stream of a later slice stopped less than 262 + 64 short of the slice before's end)
+    PieceArgs pa{d64 + n, ctx->ws, {d32 + 2 * n, ctx->slice_state, d64 + 6 * n, d32 + 3 * n}, k == 0 ? 0u : (uint32_t)kSliceKeep - 512u};
+    rc = deflate_launch(ctx, format, q.level, q.queue_len, q.driver, q.dynamic, q.matcher, q.gz_header, n, d_in, d64, d64 + 2 * n,
+                        d_out, d64 + 3 * n, d64 + 4 * n, d64 + 5 * n, (int32_t *)d32, d32 + n, nullptr, total ? total : 1, &pa);
+    if (rc != MD_OK) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(out_len, d64 + 5 * n, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(st, d32, 2 * n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < n; i++) {
+      if (flags[i] & 8) continue;
+      if ((int32_t)st[i] == 1000) {  // MD_PIECE_AWAIT: more of the stream to come
+        used[i] += out_len[i];
+        continue;
+      }
+      done[i] = 1;
+      h_status[i] = (int32_t)st[i];
+      h_checksum[i] = sum_out[i];
+      h_out_len[i] = (int32_t)st[i] == MD_OK ? used[i] + out_len[i] : 0;
+    }
+  }
+  for (size_t i = 0; i < n; i++)
+    if (!done[i]) return fail(ctx, MD_E_HIP, "deflate in slices: a stream did not end");
+  return MD_OK;
+}
+
+// the batch whose workspace is above the cap: lengths to the host, slices sized to the cap (in groups of streams if a
+// slice of every stream at once would still be too much), results back to the caller's device arrays
+static int deflate_capped(md_ctx *ctx, int format, const md_deflate_params &q, size_t n, const uint8_t *d_in, const uint64_t *d_in_off,
+                          const uint64_t *d_in_len, uint8_t *d_out, const uint64_t *d_out_off, const uint64_t *d_out_cap,
+                          uint64_t *d_out_len, int32_t *d_status, uint32_t *d_checksum, bool *whole) {
+  std::vector<uint64_t> h(4 * n);
+  uint64_t *in_off = h.data(), *in_len = in_off + n, *out_off = in_len + n, *out_cap = out_off + n;
+  HIP_TRY(ctx, hipMemcpyAsync(in_off, d_in_off, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(in_len, d_in_len, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(out_off, d_out_off, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(out_cap, d_out_cap, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  uint64_t total = 0, longest = 0;
+  for (size_t i = 0; i < n; i++) {
+    if (in_len[i] > MD_MAX_STREAM) in_len[i] = MD_MAX_STREAM + 1;  // (the kernel refuses it)
+    else total += in_len[i];
+    if (in_len[i] > longest) longest = in_len[i];
+  }
+  (void)longest;
+  *whole = md_front_big_bytes(total + 319ull * n) <= ctx->front_cap_bytes;
+  if (*whole) return MD_OK;  // (fits after all: the caller's one launch)
+  std::vector<uint64_t> r_len(n);
+  std::vector<int32_t> r_st(n);
+  std::vector<uint32_t> r_sum(n), crc;
+  if (format == MD_FORMAT_GZIP) {  // the CRC-32 of every stream, once
+    int grc = gz_scratch(ctx, n);
+    if (grc != MD_OK) return grc;
+    uint32_t *d_crc = (uint32_t *)((uint8_t *)ctx->gz_tmp + n * 20);
+    int e = md_launch_crc32((uint32_t)n, d_in, d_in_off, d_in_len, d_crc, ctx->stream);
+    if (e != 0) return fail(ctx, MD_E_HIP, "crc32 kernel launch", (hipError_t)e);
+    crc.resize(n);
+    HIP_TRY(ctx, hipMemcpyAsync(crc.data(), d_crc, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  // groups of consecutive streams, each with the largest slice that fits (at least kSliceMin)
+  for (size_t i0 = 0; i0 < n;) {
+    size_t k = n - i0;
+    uint64_t S = 0;
+    for (;;) {
+      uint64_t lo = kSliceMin / 32768, hi = 0;
+      uint64_t gl = 0;
+      for (size_t i = i0; i < i0 + k; i++) gl = in_len[i] <= MD_MAX_STREAM && in_len[i] > gl ? in_len[i] : gl;
+      hi = (gl + 32767) / 32768;
+      if (hi < lo) hi = lo;
+      if (md_front_big_bytes(slice_positions(in_len + i0, k, lo * 32768)) > ctx->front_cap_bytes && k > 1) {
+        k = (k + 1) / 2;  // too many streams for the smallest slice: fewer of them
+        continue;
+      }
+      while (lo < hi) {  // the largest S (in 32 KiB units) whose launches fit
+        const uint64_t mid = (lo + hi + 1) / 2;
+        if (md_front_big_bytes(slice_positions(in_len + i0, k, mid * 32768)) <= ctx->front_cap_bytes) lo = mid;
+        else hi = mid - 1;
+      }
+      S = lo * 32768;
+      if (gl > S) {  // as many slices as that takes, of even size
+        const uint64_t ns = (gl + S - 1) / S;
+        S = ((gl + ns - 1) / ns + 32767) / 32768 * 32768;
+      }
+      break;
+    }
+    int rc = deflate_in_slices(ctx, format, q, k, S, d_in, in_off + i0, in_len + i0, d_out, out_off + i0, out_cap + i0, r_len.data() + i0,
+                               r_st.data() + i0, r_sum.data() + i0, crc.empty() ? nullptr : crc.data() + i0);
+    if (rc != MD_OK) return rc;
+    i0 += k;
+  }
+  HIP_TRY(ctx, hipMemcpyAsync(d_out_len, r_len.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d_status, r_st.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (d_checksum) HIP_TRY(ctx, hipMemcpyAsync(d_checksum, r_sum.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // (the host vectors go out of scope)
+  *whole = false;
+  return MD_OK;
+}
+
 int md_deflate_batch_device(md_ctx *ctx, int format, const md_deflate_params *params, size_t n, const uint8_t *d_in,
                             const uint64_t *d_in_off, const uint64_t *d_in_len, uint8_t *d_out, const uint64_t *d_out_off,
                             const uint64_t *d_out_cap, uint64_t *d_out_len, int32_t *d_status, uint32_t *d_checksum) {
@@ -865,22 +1060,18 @@ int md_deflate_batch_device(md_ctx *ctx, int format, const md_deflate_params *pa
   if (!d_in_off || !d_in_len || !d_out_off || !d_out_cap || !d_out_len || !d_status)
     return fail(ctx, MD_E_INVALID_ARGUMENT, "null descriptor array");
   MD_ON_DEVICE(ctx);
-  // The per-position workspace is 13 bytes per input byte (md_front_big_bytes): with a cap set (md_set_option
-  // "deflate_workspace_cap_mib") a batch that would need more is taken in slices of consecutive streams, each sized
-  // from its own lengths (one read-back per slice).  Same bytes out; the sequential kernel then runs with fewer streams
-  // per CU than it is laid out for, so this trades time for memory.
-  if (ctx->front_cap_bytes && q.total_in_bytes && n > 1 && md_front_big_bytes((uint64_t)q.total_in_bytes + 319ull * n) > ctx->front_cap_bytes) {
-    size_t slices = (md_front_big_bytes((uint64_t)q.total_in_bytes + 319ull * n) + ctx->front_cap_bytes - 1) / ctx->front_cap_bytes;
-    if (slices > n) slices = n;
-    const size_t per = (n + slices - 1) / slices;
-    for (size_t i0 = 0; i0 < n; i0 += per) {
-      const size_t k = n - i0 < per ? n - i0 : per;
-      rc = deflate_launch(ctx, format, q.level, q.queue_len, q.driver, q.dynamic, q.matcher, q.gz_header, k, d_in, d_in_off + i0,
-                          d_in_len + i0, d_out, d_out_off + i0, d_out_cap + i0, d_out_len + i0, d_status + i0,
-                          d_checksum ? d_checksum + i0 : nullptr, nullptr, 0);
-      if (rc != MD_OK) return rc;
+  // The per-position workspace is 13 bytes per input byte of what one launch covers (md_front_big_bytes): with a cap set
+  // (md_set_option "deflate_workspace_cap_mib") a batch that would need more is taken in slices of positions - same bytes
+  // out (deflate_in_slices above).  Without params->total_in_bytes the lengths have to be read back to know.
+  {
+    uint32_t max_chain = 0, nice = 0;
+    md_deflate_level_params(q.driver, q.matcher, q.level, &max_chain, &nice);
+    if (ctx->front_cap_bytes && max_chain != 0 &&
+        (!q.total_in_bytes || md_front_big_bytes((uint64_t)q.total_in_bytes + 319ull * n) > ctx->front_cap_bytes)) {
+      bool whole = true;
+      rc = deflate_capped(ctx, format, q, n, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap, d_out_len, d_status, d_checksum, &whole);
+      if (rc != MD_OK || !whole) return rc;
     }
-    return MD_OK;
   }
   return deflate_launch(ctx, format, q.level, q.queue_len, q.driver, q.dynamic, q.matcher, q.gz_header, n, d_in, d_in_off,
                         d_in_len, d_out, d_out_off, d_out_cap, d_out_len, d_status, d_checksum, nullptr, q.total_in_bytes);
@@ -898,7 +1089,6 @@ struct md_piece {
 };
 size_t md_i_piece_bytes(const md_ctx *ctx) { return ctx ? ctx->piece_bytes : 0; }
 int md_i_test_flags(const md_ctx *ctx) { return ctx ? ctx->test_flags : 0; }
-static const size_t kPieceStateBytes = 12288;  // deflate_common.hpp kPieceState (checked against sizeof there)
 md_piece *md_i_piece_open(md_ctx *ctx, int queue_len) {
   if (!ctx || queue_len < 4) return nullptr;
   DeviceGuard guard(ctx->device);
@@ -926,12 +1116,12 @@ void md_i_piece_close(md_ctx *ctx, md_piece *p) {
   delete p;
 }
 // text: the bytes at positions [w0, w0 + text_len) (w0 a multiple of 64, at most 65536 - 64 behind the end of the piece
-// before).  Positions count from an origin the caller moves up now and then so that they stay below MD_MAX_STREAM:
+// before), of which the first `seen` went through the piece before already.  Positions count from an origin the caller moves up now and then so that they stay below MD_MAX_STREAM:
 // rebase is how far it moved since the piece before (a multiple of 65536, at least 65536 below w0 as that piece counted
 // it).  sum / isize: Adler-32 (CRC-32 for gzip) and length mod 2^32 of the whole input so far.  The piece's output
 // stays in device memory (md_i_piece_out reads it); *status is MD_PIECE_AWAIT (1000) when the encoder waits for more.
 int md_i_piece_run(md_ctx *ctx, md_piece *p, int format, const md_deflate_params *params, const uint8_t *text, size_t text_len,
-                   uint64_t w0, uint64_t rebase, int first, int last, uint32_t sum, uint32_t isize, size_t out_cap,
+                   size_t seen, uint64_t w0, uint64_t rebase, int first, int last, uint32_t sum, uint32_t isize, size_t out_cap,
                    size_t *out_len, int *status) {
   if (!ctx || !p || !params || !out_len || !status || (!text && text_len)) return MD_E_INVALID_ARGUMENT;
   md_deflate_params q;
@@ -942,16 +1132,16 @@ int md_i_piece_run(md_ctx *ctx, md_piece *p, int format, const md_deflate_params
   rc = grow(ctx, &p->d_text, &p->text_cap, text_len + 320, "hipMalloc(encoder text)");
   if (rc == MD_OK) rc = grow(ctx, &p->d_out, &p->out_cap, out_cap ? out_cap : 16, "hipMalloc(encoder output)");
   if (rc != MD_OK) return rc;
-  uint64_t h[12] = {0, (uint64_t)text_len, w0 + text_len, 0, (uint64_t)out_cap, 0, w0, rebase, 0, 0, 0, 0};
-  uint32_t *h32 = (uint32_t *)(h + 8);  // status, checksum, flags, -, sum, isize
+  uint64_t h[13] = {0, (uint64_t)text_len, w0 + text_len, 0, (uint64_t)out_cap, 0, w0, rebase, 0, 0, 0, 0, 0};  // ([8], [9]: state and queue slot)
+  uint32_t *h32 = (uint32_t *)(h + 10);  // status, checksum, flags, -, sum, isize
   h32[2] = (first ? 1u : 0u) | (last ? 2u : 0u);
   h32[4] = sum;
   h32[5] = isize;
   uint64_t *d64 = (uint64_t *)p->d_desc;
-  uint32_t *d32 = (uint32_t *)(d64 + 8);
+  uint32_t *d32 = (uint32_t *)(d64 + 10);
   HIP_TRY(ctx, hipMemcpyAsync(d64, h, sizeof h, hipMemcpyHostToDevice, ctx->stream));
   if (text_len) HIP_TRY(ctx, hipMemcpyAsync(p->d_text, text, text_len, hipMemcpyHostToDevice, ctx->stream));
-  PieceArgs pa{d64 + 1, p->d_queue, {d32 + 2, p->d_state, d64 + 6, d32 + 4}};
+  PieceArgs pa{d64 + 1, p->d_queue, {d32 + 2, p->d_state, d64 + 6, d32 + 4}, seen > 512 ? (uint32_t)(seen - 512) : 0u};
   rc = deflate_launch(ctx, format, q.level, q.queue_len, q.driver, q.dynamic, q.matcher, q.gz_header, 1, (const uint8_t *)p->d_text,
                       d64 + 0, d64 + 2, (uint8_t *)p->d_out, d64 + 3, d64 + 4, d64 + 5, (int32_t *)d32, d32 + 1, nullptr,
                       text_len ? text_len : 1, &pa);

@@ -48,15 +48,18 @@ struct Front {
 // A stream compressed IN PIECES (the encoder of `Def.encode` while input is still arriving, lib/de.ml:4294-4349,
 // lib/zl.ml:523-555): the sequential kernel's state - two LDS structs - is written out when the matcher wants input the
 // piece does not hold, and read back when the next piece begins.  Every pointer null: whole streams (the batch path).
-//   flags[i]  bit 0: the stream's first piece, bit 1: its last one (the end of the input has been signalled)
-//   state     kPieceState bytes per stream
-//   pos[2i]   w0: position of the first byte the input buffer holds (in_off[i] points at it): the piece brings the
+//   flags[i]  bit 0: the stream's first piece, bit 1: its last one (the end of the input has been signalled), bit 2: the
+//             Adler-32 is the kernel's own, carried in the state (else sum[2i] is the caller's running checksum), bit 3:
+//             nothing to do for this stream (it ended in an earlier launch of a batch in slices)
+//   state     kPieceState bytes per state slot
+//   pos[4i]   w0: position of the first byte the input buffer holds (in_off[i] points at it): the piece brings the
 //             32 KiB window (and a margin) along; in_len[i] is the length of the input so far, counted like w0
-//   pos[2i+1] rebase: positions are 32-bit, so a long stream's origin moves now and then - w0 and in_len count from the
+//   pos[4i+1] rebase: positions are 32-bit, so a long stream's origin moves now and then - w0 and in_len count from the
 //             new origin, and this (a multiple of 64 KiB, at most the window base) is what the positions in the state
 //             the piece before left have to come down by
-//   sum[2i]   the checksum of the whole input so far (Adler-32 / CRC-32, computed by the host), [2i+1] its length mod 2^32
-//             (the trailer of the last piece)
+//   pos[4i+2] the stream's state slot, pos[4i+3] its command queue's slot (whole streams: queue i)
+//   sum[2i]   the checksum of the whole input so far (Adler-32 / CRC-32; for gzip always the caller's), [2i+1] its length
+//             mod 2^32 (the trailer of the last piece)
 // status[i] = MD_PIECE_AWAIT when the piece ended with the matcher waiting for more input.
 struct Piece {
   const uint32_t *flags;

@@ -255,7 +255,7 @@ __global__ __launch_bounds__(kWave, 6) void deflate_match_kernel(uint32_t n, uin
                                                               const uint32_t *__restrict__ link, uint8_t *__restrict__ flg,
                                                               uint32_t *__restrict__ m, uint32_t *__restrict__ mq,
                                                               const uint32_t *__restrict__ flags, uint32_t max_chain,
-                                                              uint32_t nice) {
+                                                              uint32_t nice, uint32_t skip) {
   const uint32_t lane = threadIdx.x;
   if (flags[0]) return;
   // workgroup b runs on XCD b % 8: give every XCD one contiguous eighth of the chunks, so that the chunks that share
@@ -285,6 +285,9 @@ __global__ __launch_bounds__(kWave, 6) void deflate_match_kernel(uint32_t n, uin
   const uint32_t p_end = p_end_a[sid];
   const uint32_t pe = (c - chunk0[sid]) * kChunk;
   if (pe >= p_end) return;
+  // a stream in pieces: the first `skip` positions of the text are the window the piece brings along - the matcher is
+  // past them, they only have to be in the chains
+  if (pe + kChunk <= skip) return;
   const uint32_t slen = (uint32_t)in_len[sid];
   const uint8_t *src = in + in_off[sid];
   const uint64_t so = slot[sid];
@@ -451,14 +454,14 @@ extern "C" int md_launch_deflate_plan(uint32_t n, const uint64_t *in_len, int dr
 // link[] / tail[], then flg[] / m[] / mq[]: nchunks_max >= chunk0[n]
 extern "C" int md_launch_deflate_front(uint32_t n, uint32_t nchunks_max, const uint8_t *in, const uint64_t *in_off,
                                        const uint64_t *in_len, int matcher, uint32_t max_chain, uint32_t nice,
-                                       const md::defl::Front *f, const uint32_t *order, hipStream_t stream) {
+                                       const md::defl::Front *f, const uint32_t *order, uint32_t match_skip, hipStream_t stream) {
   using namespace md::defl;
   if (n == 0 || nchunks_max == 0) return 0;
   hipLaunchKernelGGL(deflate_link_kernel<false>, dim3(n), dim3(LW * kWave), 0, stream, n, in, in_off, in_len, f->p_end, f->slot,
                      f->link, (uint32_t *)f->tail, f->flags, matcher, order);
   const uint32_t per = (nchunks_max + 7) / 8;
   hipLaunchKernelGGL(deflate_match_kernel, dim3(per * 8), dim3(kWave), 0, stream, n, nchunks_max, in, in_off, in_len, f->p_end,
-                     f->slot, f->chunk0, f->link, f->flg, f->m, f->mq, f->flags, max_chain, nice);
+                     f->slot, f->chunk0, f->link, f->flg, f->m, f->mq, f->flags, max_chain, nice, match_skip);
   return (int)hipGetLastError();
 }
 

@@ -1407,7 +1407,9 @@ __global__ __launch_bounds__(kWave, 4) void deflate_kernel(
   const bool piece = pcs.flags != nullptr;
   const uint32_t pflags = piece ? pcs.flags[sid] : 3u;
   const bool p_first = pflags & 1, p_last = (pflags & 2) != 0;
-  const uint32_t w0 = piece ? (uint32_t)pcs.pos[2 * sid] : 0u, rebase = piece ? (uint32_t)pcs.pos[2 * sid + 1] : 0u;
+  if (pflags & 8) return;  // (a stream that ended in an earlier slice of the batch)
+  const uint32_t w0 = piece ? (uint32_t)pcs.pos[4 * sid] : 0u, rebase = piece ? (uint32_t)pcs.pos[4 * sid + 1] : 0u;
+  const size_t sslot = piece ? (size_t)pcs.pos[4 * sid + 2] : 0, qslot = piece ? (size_t)pcs.pos[4 * sid + 3] : sid;
   const uint8_t *src = in + in_off[sid] - w0;
   if (in_len[sid] > MD_MAX_STREAM || fr.flags[0]) {  // 32-bit cursors: the descriptor is out of range (mdeflate.h);
                                                        // or the batch is larger than md_deflate_params.total_in_bytes said
@@ -1426,7 +1428,7 @@ __global__ __launch_bounds__(kWave, 4) void deflate_kernel(
   const uint32_t slot_len = (uint32_t)(fr.slot[sid + 1] - so) + w0;  // positions [w0, slot_len) have a cell
   // (the front kernels saw the piece as a stream of its own beginning at w0: their positions - the tails - are relative)
   const uint32_t tl0 = fr.tail[2 * sid], tl1 = fr.tail[2 * sid + 1];
-  Ws ws{fr.link + so - w0, fr.flg + so - w0, fr.m + so - w0, fr.mq + so - w0, ws_queue + (size_t)sid * qcap,
+  Ws ws{fr.link + so - w0, fr.flg + so - w0, fr.m + so - w0, fr.mq + so - w0, ws_queue + qslot * qcap,
         tl0 ? tl0 + w0 : 0u, tl1 ? tl1 + w0 : 0u};
 
   // ---- cooperative setup: histograms, code tables, Adler-32 of the input
@@ -1438,24 +1440,30 @@ __global__ __launch_bounds__(kWave, 4) void deflate_kernel(
     ds.t_xd[lane] = c_extra_dbits[lane];
     ds.t_bd[lane] = c_base_dist[lane];
   }
-  uint32_t a = 1, b = 0;  // Lz77's update_crc (Adler-32 of the input), lib/de.ml:4217-4218
-  for (uint32_t ps = 0; ps < slen && !piece; ps += 1024) {
-    const uint32_t b0 = ps + 1024 < slen ? ps + 1024 : slen;
-    uint32_t s1 = 0, s2 = 0;
-    for (uint32_t k = 0; k < 16; k++) {
-      uint32_t x = ps + lane * 16 + k;
-      if (x < b0) {
-        uint32_t d = src[x];
-        s1 += d;
-        s2 += (b0 - x) * d;
+  // Lz77's update_crc (Adler-32 of the input), lib/de.ml:4217-4218: of [from, slen), continuing `seed`
+  auto adler_of = [&](uint32_t from, uint32_t seed) {
+    uint32_t a = seed & 0xffff, b = seed >> 16;
+    for (uint32_t ps = from; ps < slen; ps += 1024) {
+      const uint32_t b0 = ps + 1024 < slen ? ps + 1024 : slen;
+      uint32_t s1 = 0, s2 = 0;
+      for (uint32_t k = 0; k < 16; k++) {
+        uint32_t x = ps + lane * 16 + k;
+        if (x < b0) {
+          uint32_t d = src[x];
+          s1 += d;
+          s2 += (b0 - x) * d;
+        }
       }
+      s1 = wave_sum(s1);
+      s2 = wave_sum(s2);
+      b = (b + (b0 - ps) * a + s2) % 65521u;
+      a = (a + s1) % 65521u;
     }
-    s1 = wave_sum(s1);
-    s2 = wave_sum(s2);
-    b = (b + (b0 - ps) * a + s2) % 65521u;
-    a = (a + s1) % 65521u;
-  }
-  const uint32_t adler = piece ? pcs.sum[2 * sid] : (b << 16) | a;  // (in pieces: the host's running checksum)
+    return (b << 16) | a;
+  };
+  // in pieces: the host's running checksum, or (P_SUM: the batch in slices) ours, carried in the state
+  const bool own_sum = piece && (pflags & 4) && format != MD_FORMAT_GZIP;
+  uint32_t adler = !piece ? adler_of(0, 1u) : own_sum ? (p_first ? adler_of(0, 1u) : 1u) : pcs.sum[2 * sid];
   const uint32_t isize = piece ? pcs.sum[2 * sid + 1] : slen;
   __threadfence_block();
   __syncthreads();
@@ -1485,8 +1493,8 @@ __global__ __launch_bounds__(kWave, 4) void deflate_kernel(
   const bool room = cap >= hdr;
   if (piece && !p_first) {
     // the state the piece before left: the two structs as they were, then what belongs to this launch
-    static_assert(sizeof(DS) % 4 == 0 && sizeof(Run) % 4 == 0 && sizeof(DS) + sizeof(Run) <= kPieceState, "piece state");
-    const uint32_t *st = reinterpret_cast<const uint32_t *>(pcs.state + (size_t)sid * kPieceState);
+    static_assert(sizeof(DS) % 4 == 0 && sizeof(Run) % 4 == 0 && sizeof(DS) + sizeof(Run) + 4 <= kPieceState, "piece state");
+    const uint32_t *st = reinterpret_cast<const uint32_t *>(pcs.state + sslot * kPieceState);
     __syncthreads();
     for (uint32_t i = lane; i < sizeof(DS) / 4; i += kWave) reinterpret_cast<uint32_t *>(&ds)[i] = st[i];
     for (uint32_t i = lane; i < sizeof(Run) / 4; i += kWave) reinterpret_cast<uint32_t *>(&run)[i] = st[sizeof(DS) / 4 + i];
@@ -1518,6 +1526,11 @@ __global__ __launch_bounds__(kWave, 4) void deflate_kernel(
       ds.w.q = run.e.q;
       ds.w.o_pos = 0;
       ds.w.o_cap = cap;
+    }
+    if (own_sum) {  // the bytes that are new: from where the slice before ended (the matcher had filled up to there)
+      __syncthreads();
+      const uint32_t from = run.z.filled;
+      adler = adler_of(from < slen ? from : slen, st[(sizeof(DS) + sizeof(Run)) / 4]);
     }
   } else if (lane == 0) {
     if (room) stream_begin(&run, &ws, src, slen, dst + hdr, cap - hdr, level, qcap, driver, matcher);
@@ -1927,11 +1940,12 @@ __global__ __launch_bounds__(kWave, 4) void deflate_kernel(
     return;
   }
   if (piece && ds.ctl[1] == 2) {  // the matcher waits for input the piece does not hold: the state goes out, nothing else
-    uint32_t *st = reinterpret_cast<uint32_t *>(pcs.state + (size_t)sid * kPieceState);
+    uint32_t *st = reinterpret_cast<uint32_t *>(pcs.state + sslot * kPieceState);
     __syncthreads();
     for (uint32_t i = lane; i < sizeof(DS) / 4; i += kWave) st[i] = reinterpret_cast<const uint32_t *>(&ds)[i];
     for (uint32_t i = lane; i < sizeof(Run) / 4; i += kWave) st[sizeof(DS) / 4 + i] = reinterpret_cast<const uint32_t *>(&run)[i];
     if (lane == 0) {
+      st[(sizeof(DS) + sizeof(Run)) / 4] = adler;
       out_len[sid] = hdr + run.e.o_pos;
       status[sid] = run.e.overflow ? MD_UNEXPECTED_END_OF_OUTPUT : MD_PIECE_AWAIT;
       if (checksum) checksum[sid] = adler;

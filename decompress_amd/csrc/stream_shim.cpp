@@ -421,7 +421,7 @@ extern "C" {
 md_piece *md_i_piece_open(md_ctx *ctx, int queue_len);
 void md_i_piece_close(md_ctx *ctx, md_piece *p);
 int md_i_piece_run(md_ctx *ctx, md_piece *p, int format, const md_deflate_params *params, const uint8_t *text, size_t text_len,
-                   uint64_t w0, uint64_t rebase, int first, int last, uint32_t sum, uint32_t isize, size_t out_cap,
+                   size_t seen, uint64_t w0, uint64_t rebase, int first, int last, uint32_t sum, uint32_t isize, size_t out_cap,
                    size_t *out_len, int *status);
 int md_i_test_flags(const md_ctx *ctx);
 int md_i_piece_out(md_ctx *ctx, const md_piece *p, size_t off, uint8_t *host, size_t len);
@@ -574,7 +574,8 @@ static void def_launch(md_def_stream *s) {
     s->origin += rebase;
   }
   int st = 0;
-  const int rc = md_i_piece_run(s->ctx, s->dev, s->format, &s->params, s->text.data(), s->text.size(), s->w0 - s->origin, rebase,
+  const int rc = md_i_piece_run(s->ctx, s->dev, s->format, &s->params, s->text.data(), s->text.size(), (size_t)(s->launched - s->w0),
+                                s->w0 - s->origin, rebase,
                                 s->first, s->eoi, s->checksum, (uint32_t)end, cap, &s->out_len, &st);
   s->first = false;
   s->served = 0;

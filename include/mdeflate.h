@@ -137,10 +137,16 @@ int md_synchronize(md_ctx *ctx);
  * stream: begin/end bracket any number of batch calls; end returns elapsed
  * milliseconds (synchronises). */
 /* Options of a context.  Keys:
- *   "deflate_workspace_cap_mib"  value >= 0 (0 = none, the default).  The deflate kernels keep a per-position workspace of
- *                                13 bytes per input byte; a md_deflate_batch_device call (with params->total_in_bytes given)
- *                                whose workspace would be larger than the cap is taken in slices of consecutive streams.
- *                                Same output; slower (fewer streams per launch than the kernels are laid out for).
+ *   "deflate_workspace_cap_mib"  value >= 0 (default: a twelfth of the device's memory, 24 GiB on MI355X; 0 = none).  The
+ *                                deflate kernels keep a per-position workspace of 13 bytes per input byte of what one
+ *                                launch covers; a md_deflate_batch_device call whose workspace would be larger than the
+ *                                cap goes through the kernels in slices of positions - a multiple of 32 KiB of every
+ *                                stream per launch, going on from the state the launch before left - and in groups of
+ *                                streams if 64 KiB of every stream at once would still be too much.  Same bytes out
+ *                                (every fill of the reference's window ends on a 32 KiB boundary); a few per cent
+ *                                slower (4 096 x 1 MiB: 52 GiB and 141 ms whole, 3 slices, 19 GiB and 146 ms capped);
+ *                                the call then reads lengths and results back between the launches, i.e. it
+ *                                synchronises with the context's stream instead of only enqueueing.
  *   "encoder_piece_bytes"        value >= 1 (default 1 MiB): how much input a md_def_* encoder gathers before it launches
  *                                the kernels on it.  The bytes out are those of the reference handed the input in the
  *                                same pieces (which are, but for corner cases at the very end of a stream, the same for
@@ -217,7 +223,8 @@ typedef struct md_deflate_params {
   size_t total_in_bytes; /* batch calls with device descriptors: an upper bound of the sum of in_len[i], or 0 when the
                   * caller does not know it.  The engine sizes a per-position workspace (13 bytes per input byte
                   * plus 319 positions of padding per stream: hash-chain links, flags and two look-ahead verdicts;
-                  * grow-only for the life of the context - 52 GiB for 4 GiB of input) from it; with 0 it reads the sum back from the device first,
+                  * grow-only for the life of the context, and never above md_set_option "deflate_workspace_cap_mib": a batch
+                  * that would need more goes in slices of positions) from it; with 0 it reads the sum back from the device first,
                   * i.e. the call waits for the work already enqueued on the context's stream.  A batch whose descriptors
                   * add up to more than the hint gets status[i] = MD_E_INVALID_ARGUMENT for every stream. */
 } md_deflate_params;

@@ -580,8 +580,10 @@ def test_python_mirror(eng):
 
 
 def test_workspace_cap_and_release(eng):
-    """md_set_option "deflate_workspace_cap_mib": a batch whose per-position workspace would exceed the cap goes in slices
-    of streams - same bytes; "release_workspace" gives the grow-only scratch back and the next call grows it again."""
+    """md_set_option "deflate_workspace_cap_mib": a batch whose per-position workspace would exceed the cap goes through
+    the kernels in slices of positions (here 64 KiB of every stream per launch, 33 KiB seen again, in groups of streams
+    where even that is too much) - same bytes; "release_workspace" gives the grow-only scratch back and the next call
+    grows it again."""
     import decompress_amd
     from decompress_amd import workloads
     bufs = [workloads.text(300 + i, 30000 + 2500 * i) for i in range(24)] + [b"", b"x"]
@@ -596,3 +598,50 @@ def test_workspace_cap_and_release(eng):
     eng.set_option("release_workspace", 1)
     assert eng.deflate_many(bufs, fmt=decompress_amd.FORMAT_ZLIB, level=6) == want
     assert all(st == 0 and zlib.decompress(z) == b for b, (st, z, _) in zip(bufs, want))
+
+
+@pytest.mark.parametrize("cap_mib", [2, 8, 24])
+def test_batch_in_slices_of_positions(eng, oracle, cap_mib):
+    """streams of every length around the slice boundaries (32 KiB multiples) through a capped workspace: zlib, gzip and
+    raw DEFLATE under the three drivers, levels 1..9 - the bytes of the uncapped batch, which are the oracle's"""
+    import random
+    import decompress_amd
+    from decompress_amd import workloads
+    rng = random.Random(cap_mib)
+    lens = [0, 1, 262, 32768, 65535, 65536, 65537, 98304, 131072, 131073, 200000, 262144 + 5, 400000, 655360, 1 << 20, 1200001]
+    bufs = []
+    for i, n in enumerate(lens):
+        kind = i % 3
+        bufs.append(workloads.text(900 + i, n) if kind == 0 else bytes(rng.getrandbits(3) for _ in range(n)) if kind == 1
+                    else (workloads.text(i, 5000) * (n // 5000 + 1))[:n])
+    cases = [(decompress_amd.FORMAT_ZLIB, 6, decompress_amd.DRIVER_ZL), (decompress_amd.FORMAT_GZIP, 4, decompress_amd.DRIVER_ZL),
+             (decompress_amd.FORMAT_DEFLATE, 9, decompress_amd.DRIVER_HIGHER), (decompress_amd.FORMAT_DEFLATE, 1, decompress_amd.DRIVER_CLI),
+             (decompress_amd.FORMAT_ZLIB, 3, decompress_amd.DRIVER_ZL)]
+    for fmt, level, driver in cases:
+        want = eng.deflate_many(bufs, fmt=fmt, level=level, driver=driver)
+        eng.set_option("deflate_workspace_cap_mib", cap_mib)
+        try:
+            got = eng.deflate_many(bufs, fmt=fmt, level=level, driver=driver)
+        finally:
+            eng.set_option("deflate_workspace_cap_mib", 0)
+        for i, (w, g) in enumerate(zip(want, got)):
+            assert w == g, (fmt, level, driver, lens[i], w[0], g[0], len(w[1]), len(g[1]))
+        if fmt == decompress_amd.FORMAT_ZLIB and level == 6:
+            for b, (st, z, _) in zip(bufs, got):
+                assert st == 0 and z == oracle.zl_deflate(b, 6)
+
+
+def test_batch_in_slices_small_output_room(eng):
+    """a stream whose output room runs out in a later slice reports it like the whole batch does"""
+    import decompress_amd
+    from decompress_amd import workloads
+    bufs = [workloads.text(40 + i, 300000) for i in range(4)]
+    caps = [2 * 300000, 50000, 90000, 8]
+    want = eng.deflate_many(bufs, fmt=decompress_amd.FORMAT_ZLIB, level=4, caps=caps)
+    eng.set_option("deflate_workspace_cap_mib", 6)
+    try:
+        got = eng.deflate_many(bufs, fmt=decompress_amd.FORMAT_ZLIB, level=4, caps=caps)
+    finally:
+        eng.set_option("deflate_workspace_cap_mib", 0)
+    assert [(st, len(z)) for st, z, _ in got] == [(st, len(z)) for st, z, _ in want]
+    assert got[0] == want[0] and want[1][0] != 0
