@@ -200,6 +200,48 @@ __device__ void heap_down(DS *s, int hlen, int k) {
   }
   s->hk[k] = v;
 }
+// The merge loop's sifts by the whole wavefront.  Every node has a choice: the child that a sinking key meets
+// (pqdownheap's: the right one when it is not larger), the node itself for a leaf.  The choices of nodes 1 .. 63 live in
+// a register, lane = node (`row`), those of deeper nodes - a heap of 128 and more - in LDS (nx).  A sift is then: the
+// path from the root by lane reads of the register; its keys, one read by lane d = depth; where the key stops, one
+// ballot; the keys moving up, one write; and every lane makes its node's choice again from its children's keys.  Two
+// LDS round trips and some 60 instructions, where lane 0 walking down takes a round trip and 30 instructions per level:
+// a stream's wavefront is alone with its latencies (one stream per CU runs this kernel only 30 % faster than sixteen).
+// Returns the key at the root afterwards.
+__device__ __forceinline__ int heap_choice(const DS *s, int hlen, uint32_t j) {
+  const uint32_t c = j << 1;
+  if ((int)c > hlen || j == 0) return (int)j;
+  const u64x2 ab = *(const u64x2 *)&s->hk[c];
+  return (int)(((int)c < hlen && hsmaller(ab.y, ab.x)) ? c + 1 : c);
+}
+__device__ __forceinline__ uint64_t heap_sink_wave(DS *s, uint16_t *nx, int hlen, uint64_t v, uint32_t lane, int &row) {
+  int p = 1, myp = 1;
+#pragma unroll
+  for (int d = 1; d <= 6; d++) {
+    p = __builtin_amdgcn_readlane(row, p);  // (a leaf's choice is the leaf: p stays)
+    myp = (int)lane == d ? p : myp;
+  }
+  if (hlen >= 128) {
+    if (p >= 64) p = __builtin_amdgcn_readfirstlane((int)nx[p]);
+    myp = (int)lane == 7 ? p : myp;
+    if (p >= 64) p = __builtin_amdgcn_readfirstlane((int)nx[p]);
+    myp = (int)lane == 8 ? p : myp;
+  } else {
+    myp = (int)lane == 7 || (int)lane == 8 ? p : myp;
+  }
+  const int up = __builtin_amdgcn_update_dpp(0, myp, 0x111, 0xf, 0xf, false);  // row_shr:1: p of depth - 1
+  const uint64_t k = s->hk[myp];
+  const bool stop = lane >= 1 && lane <= 8 && (myp == up || hsmaller(v, k));
+  const uint64_t bm = __ballot(stop);
+  const uint32_t t = bm ? (uint32_t)__builtin_ctzll(bm) - 1u : 8u;  // v stops at depth t
+  const uint32_t klo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)k, 0x101, 0xf, 0xf, false);  // row_shl:1: the key below
+  const uint32_t khi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(k >> 32), 0x101, 0xf, 0xf, false);
+  if (lane <= t) s->hk[myp] = lane < t ? (((uint64_t)khi << 32) | klo) : v;
+  if (lane < t && myp >= 64) nx[myp] = (uint16_t)heap_choice(s, hlen, (uint32_t)myp);
+  row = heap_choice(s, hlen, lane);
+  const uint32_t r_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)k, 1), r_hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(k >> 32), 1);
+  return t == 0 ? v : (((uint64_t)r_hi << 32) | r_lo);
+}
 __device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -218,10 +260,8 @@ __device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
 template <bool TPROF>
 __device__ void tree_make_wave(DS *s, int length, int max_length, int *f, TreeRef t, uint32_t lane) {
   uint64_t t_prev = TPROF ? wall_clock64() : 0;
-  for (int n = (int)lane; n < HEAP_SIZE; n += kWave) {
-    s->tlen[n] = 0;
-    s->dads[n] = 0;
-  }
+  for (int n = (int)lane; n < HEAP_SIZE; n += kWave) s->dads[n] = 0;
+  uint16_t *nx = s->tlen;  // (the lengths' space until the merge is over)
   if (lane <= (uint32_t)MAX_BITS) s->bl_count[lane] = 0;
   int hlen = 0, max_code = -1;
   for (int base = 0; base < length; base += kWave) {
@@ -252,25 +292,37 @@ __device__ void tree_make_wave(DS *s, int length, int max_length, int *f, TreeRe
   // operations (ties are broken by heap position), by lane 0 on the LDS heap.  (A heap held in registers with
   // scalar-unit sifts was measured: no LDS round trips, but ~30 scalar instructions per level on the one scalar unit
   // the CU's 16 streams share — not faster.)
-  if (lane == 0) {
+  for (int j = 64 + (int)lane; j <= hlen; j += kWave) nx[j] = (uint16_t)heap_choice(s, hlen, (uint32_t)j);
+  __syncthreads();
+  {
     int hm = HEAP_SIZE, node = length;
+    int row = heap_choice(s, hlen, lane);
+    uint64_t root = s->hk[1];
     do {
-      const uint64_t n = s->hk[1];
-      s->hk[1] = s->hk[hlen--];
-      heap_down(s, hlen, 1);
-      const uint64_t m = s->hk[1];
+      const uint64_t n = root;
+      const uint64_t last = s->hk[hlen];
+      const int L = hlen--;
+      // the parent of the slot that went has one child left, or is a leaf now
+      const int q = L >> 1, qv = (L & 1) ? L - 1 : q;
+      row = (int)lane == q ? qv : row;
+      if (q >= 64 && lane == 0) nx[q] = (uint16_t)qv;
+      const uint64_t m = heap_sink_wave(s, nx, hlen, last, lane, row);
       const uint32_t ni = (uint32_t)n & 0xffff, mi = (uint32_t)m & 0xffff;
-      s->heap[--hm] = (uint16_t)ni;
-      s->heap[--hm] = (uint16_t)mi;
       const uint32_t fs = (uint32_t)(n >> 32) + (uint32_t)(m >> 32);
       const uint32_t dn = ((uint32_t)n >> 16), dm = ((uint32_t)m >> 16);
-      s->dads[ni] = s->dads[mi] = (uint16_t)node;
-      s->hk[1] = hkey(fs, (dn >= dm ? dn : dm) + 1, (uint32_t)node);
+      hm -= 2;
+      if (lane == 0) {
+        s->heap[hm + 1] = (uint16_t)ni;
+        s->heap[hm] = (uint16_t)mi;
+        s->dads[ni] = s->dads[mi] = (uint16_t)node;
+      }
+      root = heap_sink_wave(s, nx, hlen, hkey(fs, (dn >= dm ? dn : dm) + 1, (uint32_t)node), lane, row);
       node++;
-      heap_down(s, hlen, 1);
     } while (hlen >= 2);
-    s->heap[--hm] = (uint16_t)((uint32_t)s->hk[1] & 0xffff);
+    if (lane == 0) s->heap[--hm] = (uint16_t)((uint32_t)root & 0xffff);
   }
+  __syncthreads();
+  for (int n = (int)lane; n < HEAP_SIZE; n += kWave) s->tlen[n] = 0;
   __syncthreads();
   TP_MARK(1)
   // generate_lengths, lib/de.ml:1952-2009: a node's length is its depth below the root
