@@ -214,33 +214,63 @@ __device__ __forceinline__ int heap_choice(const DS *s, int hlen, uint32_t j) {
   const u64x2 ab = *(const u64x2 *)&s->hk[c];
   return (int)(((int)c < hlen && hsmaller(ab.y, ab.x)) ? c + 1 : c);
 }
-__device__ __forceinline__ uint64_t heap_sink_wave(DS *s, uint16_t *nx, int hlen, uint64_t v, uint32_t lane, int &row) {
-  int p = 1, myp = 1;
+// the same for node = lane, without branches: a lane beyond the heap reads the pair at the heap's end and drops it
+__device__ __forceinline__ int heap_choice_row(const DS *s, int hlen, uint32_t lane) {
+  const uint32_t c = lane << 1;
+  const bool leaf = (int)c > hlen || lane == 0;
+  const u64x2 ab = *(const u64x2 *)&s->hk[leaf ? 2u : c];
+  const uint32_t pick = ((int)c < hlen && hsmaller(ab.y, ab.x)) ? c + 1 : c;
+  return (int)(leaf ? lane : pick);
+}
+// hnext: the heap's length when the choices made at the end are used (the sift before a pop leaves them for the heap
+// without its last slot)
+template <bool DEEP>
+__device__ __forceinline__ uint64_t heap_sink_wave(DS *s, uint16_t *nx, int hlen, int hnext, uint64_t v, uint32_t lane, int &row) {
+  int p = 1;
 #pragma unroll
-  for (int d = 1; d <= 6; d++) {
-    p = __builtin_amdgcn_readlane(row, p);  // (a leaf's choice is the leaf: p stays)
-    myp = (int)lane == d ? p : myp;
-  }
-  if (hlen >= 128) {
+  for (int d = 1; d <= 6; d++) p = __builtin_amdgcn_readlane(row, p);  // (a leaf's choice is the leaf: p stays)
+  if (DEEP) {  // a heap of 128 and more
     if (p >= 64) p = __builtin_amdgcn_readfirstlane((int)nx[p]);
-    myp = (int)lane == 7 ? p : myp;
     if (p >= 64) p = __builtin_amdgcn_readfirstlane((int)nx[p]);
-    myp = (int)lane == 8 ? p : myp;
-  } else {
-    myp = (int)lane == 7 || (int)lane == 8 ? p : myp;
   }
+  // the path is the ancestors of where it ends: lane d takes the one of depth d (lanes beyond the end: the end again)
+  const int depth = 31 - __builtin_clz((unsigned)p);
+  const int sh = depth - (int)lane;
+  const int myp = p >> (sh > 0 ? sh : 0);
   const int up = __builtin_amdgcn_update_dpp(0, myp, 0x111, 0xf, 0xf, false);  // row_shr:1: p of depth - 1
   const uint64_t k = s->hk[myp];
   const bool stop = lane >= 1 && lane <= 8 && (myp == up || hsmaller(v, k));
-  const uint64_t bm = __ballot(stop);
+  const uint64_t bm = __builtin_amdgcn_ballot_w64(stop);
   const uint32_t t = bm ? (uint32_t)__builtin_ctzll(bm) - 1u : 8u;  // v stops at depth t
   const uint32_t klo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)k, 0x101, 0xf, 0xf, false);  // row_shl:1: the key below
   const uint32_t khi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(k >> 32), 0x101, 0xf, 0xf, false);
-  if (lane <= t) s->hk[myp] = lane < t ? (((uint64_t)khi << 32) | klo) : v;
-  if (lane < t && myp >= 64) nx[myp] = (uint16_t)heap_choice(s, hlen, (uint32_t)myp);
-  row = heap_choice(s, hlen, lane);
-  const uint32_t r_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)k, 1), r_hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(k >> 32), 1);
-  return t == 0 ? v : (((uint64_t)r_hi << 32) | r_lo);
+  const uint64_t w = lane < t ? (((uint64_t)khi << 32) | klo) : v;
+  if (lane <= t) s->hk[myp] = w;
+  if (DEEP && lane < t && myp >= 64) nx[myp] = (uint16_t)heap_choice(s, hlen, (uint32_t)myp);
+  row = heap_choice_row(s, hnext, lane);
+  // the key at the root now: what lane 0 wrote
+  return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(w >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)w);
+}
+// one step of the merge loop, lib/de.ml:2027-2049: the two smallest out, their parent in
+template <bool DEEP>
+__device__ __forceinline__ void merge_step(DS *s, uint16_t *nx, int &hlen, int &hm, int &node, uint64_t &root, int &row, uint32_t lane) {
+  const uint64_t n = root;
+  const uint64_t last = s->hk[hlen];
+  const int L = hlen--;
+  // the parent of the slot that went has one child left, or is a leaf now (the register's choices were made for that)
+  if (DEEP && (L >> 1) >= 64 && lane == 0) nx[L >> 1] = (uint16_t)((L & 1) ? L - 1 : (L >> 1));
+  const uint64_t m = heap_sink_wave<DEEP>(s, nx, hlen, hlen, last, lane, row);
+  const uint32_t ni = (uint32_t)n & 0xffff, mi = (uint32_t)m & 0xffff;
+  const uint32_t fs = (uint32_t)(n >> 32) + (uint32_t)(m >> 32);
+  const uint32_t dn = ((uint32_t)n >> 16), dm = ((uint32_t)m >> 16);
+  hm -= 2;
+  // (every lane writes the same values: no branch)
+  s->heap[hm] = (uint16_t)mi;
+  s->heap[hm + 1] = (uint16_t)ni;
+  s->dads[ni] = (uint16_t)node;
+  s->dads[mi] = (uint16_t)node;
+  root = heap_sink_wave<DEEP>(s, nx, hlen, hlen - 1, hkey(fs, (dn >= dm ? dn : dm) + 1, (uint32_t)node), lane, row);
+  node++;
 }
 __device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
 #pragma unroll
@@ -296,29 +326,11 @@ __device__ void tree_make_wave(DS *s, int length, int max_length, int *f, TreeRe
   __syncthreads();
   {
     int hm = HEAP_SIZE, node = length;
-    int row = heap_choice(s, hlen, lane);
+    hlen = __builtin_amdgcn_readfirstlane(hlen);  // (a count of ballots: the same on every lane)
+    int row = heap_choice_row(s, hlen - 1, lane);  // (for the heap after the first pop)
     uint64_t root = s->hk[1];
-    do {
-      const uint64_t n = root;
-      const uint64_t last = s->hk[hlen];
-      const int L = hlen--;
-      // the parent of the slot that went has one child left, or is a leaf now
-      const int q = L >> 1, qv = (L & 1) ? L - 1 : q;
-      row = (int)lane == q ? qv : row;
-      if (q >= 64 && lane == 0) nx[q] = (uint16_t)qv;
-      const uint64_t m = heap_sink_wave(s, nx, hlen, last, lane, row);
-      const uint32_t ni = (uint32_t)n & 0xffff, mi = (uint32_t)m & 0xffff;
-      const uint32_t fs = (uint32_t)(n >> 32) + (uint32_t)(m >> 32);
-      const uint32_t dn = ((uint32_t)n >> 16), dm = ((uint32_t)m >> 16);
-      hm -= 2;
-      if (lane == 0) {
-        s->heap[hm + 1] = (uint16_t)ni;
-        s->heap[hm] = (uint16_t)mi;
-        s->dads[ni] = s->dads[mi] = (uint16_t)node;
-      }
-      root = heap_sink_wave(s, nx, hlen, hkey(fs, (dn >= dm ? dn : dm) + 1, (uint32_t)node), lane, row);
-      node++;
-    } while (hlen >= 2);
+    while (hlen >= 128) merge_step<true>(s, nx, hlen, hm, node, root, row, lane);
+    while (hlen >= 2) merge_step<false>(s, nx, hlen, hm, node, root, row, lane);
     if (lane == 0) s->heap[--hm] = (uint16_t)((uint32_t)root & 0xffff);
   }
   __syncthreads();
@@ -1493,23 +1505,45 @@ __global__ __launch_bounds__(kWave, 4) void deflate_kernel(
     ds.t_bd[lane] = c_base_dist[lane];
   }
   // Lz77's update_crc (Adler-32 of the input), lib/de.ml:4217-4218: of [from, slen), continuing `seed`
+  // 4 KiB a step, 4 x 16 bytes per lane (the loads of the next step are under way while this one is summed: a stream's
+  // only wavefront would otherwise wait out an HBM round trip per step); sums by dot products: with k the index of a
+  // byte in its 16, sum (end - pos) * byte = (end - first) * sum(byte) - sum(k * byte)
+  auto adler_load = [&](uint32_t ps, v4u (&w)[4]) {
+#pragma unroll
+    for (uint32_t j = 0; j < 4; j++) {
+      const uint32_t x0 = ps + j * 1024 + lane * 16;
+      w[j] = v4u{0u, 0u, 0u, 0u};
+      if (x0 + 16 <= slen) __builtin_memcpy(&w[j], src + x0, 16);
+      else
+        for (uint32_t k = 0; x0 + k < slen && k < 16; k++) w[j][k >> 2] |= (uint32_t)src[x0 + k] << (8 * (k & 3));
+    }
+  };
   auto adler_of = [&](uint32_t from, uint32_t seed) {
     uint32_t a = seed & 0xffff, b = seed >> 16;
-    for (uint32_t ps = from; ps < slen; ps += 1024) {
-      const uint32_t b0 = ps + 1024 < slen ? ps + 1024 : slen;
+    v4u cur[4], nxt[4];
+    if (from < slen) adler_load(from, cur);
+    for (uint32_t ps = from; ps < slen; ps += 4096) {
+      const uint32_t b0 = ps + 4096 < slen ? ps + 4096 : slen;
+      if (b0 < slen) adler_load(b0, nxt);
       uint32_t s1 = 0, s2 = 0;
-      for (uint32_t k = 0; k < 16; k++) {
-        uint32_t x = ps + lane * 16 + k;
-        if (x < b0) {
-          uint32_t d = src[x];
-          s1 += d;
-          s2 += (b0 - x) * d;
+#pragma unroll
+      for (uint32_t j = 0; j < 4; j++) {
+        const uint32_t x0 = ps + j * 1024 + lane * 16;
+        uint32_t t1 = 0, tk = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) {
+          t1 = __builtin_amdgcn_udot4(cur[j][q], 0x01010101u, t1, false);
+          tk = __builtin_amdgcn_udot4(cur[j][q], 0x03020100u + 0x04040404u * q, tk, false);
         }
+        s1 += t1;
+        s2 += (b0 - x0) * t1 - tk;  // (nothing at or beyond the end: t1 = tk = 0)
       }
       s1 = wave_sum(s1);
       s2 = wave_sum(s2);
       b = (b + (b0 - ps) * a + s2) % 65521u;
       a = (a + s1) % 65521u;
+#pragma unroll
+      for (uint32_t j = 0; j < 4; j++) cur[j] = nxt[j];
     }
     return (b << 16) | a;
   };
