@@ -135,9 +135,9 @@ struct DS {
       // window of the parse step: what the look-ahead knows about positions s0 .. s0 + 79
       uint16_t pm_lf[80], pm_df[80], pm_lq[80], pm_dq[80];  // longest_match ahead: full / quartered chain
       uint8_t pm_k[80];      // bit 0: verdict known, bit 1: hash_head valid (lib/de.ml:4365-4369)
-      // bit buffer of one 64-command packing step (<= 15 + 64*48 bits): behind the ring (a queue fill is packed
+      // bit buffer of one 128-command packing step (<= 15 + 128*48 bits): behind the ring (a queue fill is packed
       // while the ring is alive) and behind `symbols` (a header is packed from them)
-      uint32_t bb[104];
+      uint32_t bb[200];
     };
   };
 };
@@ -751,20 +751,26 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
 // (One wavefront owns the bit buffer, and a wavefront's LDS operations execute in program order: the phases need no
 // barrier.  A workgroup barrier here also waits for the step's global stores to complete — a microsecond per step.)
 __device__ __forceinline__ void lds_order() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
-__device__ void pack_step(DS *s, uint32_t lane, uint64_t v, uint32_t nb, bool pad, Pack &p) {
-  const uint32_t incl = wave_incl_scan(nb);
+__device__ void pack_step(DS *s, uint32_t lane, uint64_t v, uint32_t nb, uint64_t v1, uint32_t nb1, bool pad, Pack &p) {
+  // (two items per lane, the second right behind the first: a step of the command loop takes 128 commands - what a step
+  // costs is its chain of dependent operations, hardly longer for two items than for one)
+  const uint32_t incl = wave_incl_scan(nb + nb1);
   const uint32_t total = p.bits + (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-  const uint32_t boff = p.bits + incl - nb;
+  const uint32_t boff = p.bits + incl - nb - nb1;
   const uint32_t nwords = (total + 31) / 32 + 1;
   for (uint32_t i = lane; i < nwords; i += kWave) s->bb[i] = i == 0 ? (uint32_t)p.hold : 0u;
   lds_order();
-  if (nb) {
-    const uint32_t w = boff >> 5, sh = boff & 31;
-    const uint64_t lo = v << sh;
-    atomicOr(&s->bb[w], (uint32_t)lo);
-    if ((lo >> 32) != 0) atomicOr(&s->bb[w + 1], (uint32_t)(lo >> 32));
-    if (sh + nb > 64) atomicOr(&s->bb[w + 2], (uint32_t)(v >> (64 - sh)));
-  }
+  auto put = [&](uint32_t at, uint64_t x, uint32_t n) {
+    if (n) {
+      const uint32_t w = at >> 5, sh = at & 31;
+      const uint64_t lo = x << sh;
+      atomicOr(&s->bb[w], (uint32_t)lo);
+      if ((lo >> 32) != 0) atomicOr(&s->bb[w + 1], (uint32_t)(lo >> 32));
+      if (sh + n > 64) atomicOr(&s->bb[w + 2], (uint32_t)(x >> (64 - sh)));
+    }
+  };
+  put(boff, v, nb);
+  put(boff + nb, v1, nb1);
   lds_order();
   uint32_t nbytes = total >> 3, rem = total & 7;
   if (pad) {
@@ -813,63 +819,81 @@ __device__ void enc_write_wave(DS *s, uint32_t lane) {
         v = sym & 0xff;
         nb = sym >> 8;
       }
-      pack_step(s, lane, v, nb, false, p);
+      pack_step(s, lane, v, nb, 0, 0, false, p);
     }
   }
   // the commands of the next step are on their way while this one is packed (the queue lives in HBM / L2; a ring
   // index is always inside it, so the load needs no guard)
-  int nxt = g_ldi(q + ((qr + lane) & (qc - 1)));
+  // two commands per lane: 2 * lane and 2 * lane + 1 of the step's 128
+  int nxt0 = g_ldi(q + ((qr + 2 * lane) & (qc - 1))), nxt1 = g_ldi(q + ((qr + 2 * lane + 1) & (qc - 1)));
+  struct Cmd {
+    bool act, is_eob, is_copy, ex;
+    int cmd, off, ml, lcode, dcode;
+  };
+  auto decode = [&](bool act, int raw) {
+    Cmd c;
+    c.act = act;
+    c.cmd = act ? raw : 0;
+    c.is_eob = act && c.cmd == Q_EOB;
+    c.is_copy = act && (c.cmd & Q_COPY) != 0;
+    c.off = c.cmd & 0xffff;
+    c.ml = (c.cmd >> 16) & 0x1ff;
+    c.lcode = c.is_copy ? length_code_of(c.ml + 3) : 0;
+    c.dcode = c.is_copy ? distance_code(s, c.off) : 0;
+    c.ex = true;  // Def.exists, lib/de.ml:2451-2463
+    if (act && kind == KIND_DYNAMIC && !c.is_eob)
+      c.ex = c.is_copy ? (s->lt.clen[257 + c.lcode] > 0 && s->dt.clen[c.dcode] > 0) : s->lt.clen[c.cmd & 0xff] > 0;
+    return c;
+  };
+  // the item of a command that is written: its codes and extra bits, or the end-of-block code where the step stops
+  auto item = [&](const Cmd &c, bool is_stop, uint64_t &v, uint32_t &nb) {
+    const int sym = is_stop ? 256 : c.is_copy ? 257 + c.lcode : c.cmd;
+    int l0, c0;
+    if (kind == KIND_DYNAMIC) {
+      l0 = s->lt.clen[sym];
+      c0 = s->lt.codes[sym];
+    } else static_lit(sym, &l0, &c0);
+    v = (uint64_t)(uint32_t)c0;
+    nb = (uint32_t)l0;
+    if (!is_stop && c.is_copy) {
+      const uint32_t l1 = s->t_xl[c.lcode], v1 = (uint32_t)(c.ml - s->t_bl[c.lcode & 0x1f]);
+      int l2, c2;
+      if (kind == KIND_DYNAMIC) {
+        l2 = s->dt.clen[c.dcode];
+        c2 = s->dt.codes[c.dcode];
+      } else {
+        l2 = 5;
+        c2 = (int)(__brev((unsigned)c.dcode) >> 27);
+      }
+      const uint32_t l3 = s->t_xd[c.dcode & 0x1f], v3 = (uint32_t)(c.off - s->t_bd[c.dcode]);
+      v |= (uint64_t)v1 << nb;
+      nb += l1;
+      v |= (uint64_t)(uint32_t)c2 << nb;
+      nb += (uint32_t)l2;
+      v |= (uint64_t)v3 << nb;
+      nb += l3;
+    }
+  };
+  constexpr uint32_t kStep = 2 * kWave;
   for (;;) {
     const uint32_t avail = qw - qr;
     if (avail == 0) break;
-    const bool act = lane < avail;
-    const int cmd = act ? nxt : 0;
-    nxt = g_ldi(q + ((qr + kWave + lane) & (qc - 1)));
-    const bool is_eob = act && cmd == Q_EOB;
-    const bool is_copy = act && (cmd & Q_COPY) != 0;
-    const int off = cmd & 0xffff, ml = (cmd >> 16) & 0x1ff;
-    const int lcode = is_copy ? length_code_of(ml + 3) : 0;
-    const int dcode = is_copy ? distance_code(s, off) : 0;
-    bool ex = true;  // Def.exists, lib/de.ml:2451-2463
-    if (act && kind == KIND_DYNAMIC && !is_eob)
-      ex = is_copy ? (s->lt.clen[257 + lcode] > 0 && s->dt.clen[dcode] > 0) : s->lt.clen[cmd & 0xff] > 0;
-    const uint64_t stopm = __ballot(act && (is_eob || !ex));
-    const uint32_t stopl = stopm ? (uint32_t)__builtin_ctzll(stopm) : 64u;
-    uint64_t v = 0;
-    uint32_t nb = 0;
-    if (act && lane <= stopl) {
-      const int sym = lane == stopl ? 256 : is_copy ? 257 + lcode : cmd;
-      int l0, c0;
-      if (kind == KIND_DYNAMIC) {
-        l0 = s->lt.clen[sym];
-        c0 = s->lt.codes[sym];
-      } else static_lit(sym, &l0, &c0);
-      v = (uint64_t)(uint32_t)c0;
-      nb = (uint32_t)l0;
-      if (lane < stopl && is_copy) {
-        const uint32_t l1 = s->t_xl[lcode], v1 = (uint32_t)(ml - s->t_bl[lcode & 0x1f]);
-        int l2, c2;
-        if (kind == KIND_DYNAMIC) {
-          l2 = s->dt.clen[dcode];
-          c2 = s->dt.codes[dcode];
-        } else {
-          l2 = 5;
-          c2 = (int)(__brev((unsigned)dcode) >> 27);
-        }
-        const uint32_t l3 = s->t_xd[dcode & 0x1f], v3 = (uint32_t)(off - s->t_bd[dcode]);
-        v |= (uint64_t)v1 << nb;
-        nb += l1;
-        v |= (uint64_t)(uint32_t)c2 << nb;
-        nb += (uint32_t)l2;
-        v |= (uint64_t)v3 << nb;
-        nb += l3;
-      }
-    }
-    const bool stop = stopl < 64;
-    // was the stopping command the end-of-block command (End) or one without a code (Leave)?
-    const bool end_cmd = stop && (__shfl((int)is_eob, (int)stopl) != 0);
-    pack_step(s, lane, v, nb, end_cmd && last, p);
-    qr += stop ? stopl + (end_cmd ? 1u : 0u) : (avail < (uint32_t)kWave ? avail : (uint32_t)kWave);
+    const Cmd a0 = decode(2 * lane < avail, nxt0), a1 = decode(2 * lane + 1 < avail, nxt1);
+    nxt0 = g_ldi(q + ((qr + kStep + 2 * lane) & (qc - 1)));
+    nxt1 = g_ldi(q + ((qr + kStep + 2 * lane + 1) & (qc - 1)));
+    // the step stops at the first command that is the end-of-block command (End) or has no code (Leave)
+    const uint64_t m0 = __builtin_amdgcn_ballot_w64(a0.act && (a0.is_eob || !a0.ex)), m1 = __builtin_amdgcn_ballot_w64(a1.act && (a1.is_eob || !a1.ex));
+    const uint32_t sp0 = m0 ? 2u * (uint32_t)__builtin_ctzll(m0) : kStep, sp1 = m1 ? 2u * (uint32_t)__builtin_ctzll(m1) + 1u : kStep;
+    const uint32_t sp = sp0 < sp1 ? sp0 : sp1;
+    uint64_t v0 = 0, v1 = 0;
+    uint32_t nb0 = 0, nb1 = 0;
+    if (a0.act && 2 * lane <= sp) item(a0, 2 * lane == sp, v0, nb0);
+    if (a1.act && 2 * lane + 1 <= sp) item(a1, 2 * lane + 1 == sp, v1, nb1);
+    const bool stop = sp < kStep;
+    const uint64_t e0 = __builtin_amdgcn_ballot_w64(a0.is_eob), e1 = __builtin_amdgcn_ballot_w64(a1.is_eob);
+    const bool end_cmd = stop && ((((sp & 1) ? e1 : e0) >> (sp >> 1)) & 1) != 0;
+    pack_step(s, lane, v0, nb0, v1, nb1, end_cmd && last, p);
+    qr += stop ? sp + (end_cmd ? 1u : 0u) : (avail < kStep ? avail : kStep);
     if (stop) {
       if (end_cmd && last) {
         rc = R_OK;
