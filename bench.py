@@ -121,6 +121,7 @@ def parse(argv=None):
     ap.add_argument("--deflate-steps", type=int, default=3)
     ap.add_argument("--gzip-members", type=int, default=32768, help="config 4: members of the ONE batch all ranks share")
     ap.add_argument("--inflate-waves", type=int, default=2, choices=[1, 2], help="wavefronts per stream of the inflate kernel (2 = decoder + copier, the default form)")
+    ap.add_argument("--deflate-cap-mib", type=int, default=None, help="md_set_option deflate_workspace_cap_mib (default: the library's, a sixth of the device; 0 = none)")
     ap.add_argument("--profile", action="store_true", help="print the in-kernel phase profile of stream 0 (stderr)")
     return ap.parse_args(argv)
 
@@ -536,6 +537,8 @@ def main():
     eng = decompress_amd.Engine(local_rank)
     if args.inflate_waves != 2:
         eng.set_option("inflate_waves", args.inflate_waves)
+    if args.deflate_cap_mib is not None:
+        eng.set_option("deflate_workspace_cap_mib", args.deflate_cap_mib)
     ranks_seen = 1
     if world > 1:
         t = torch.ones(1, dtype=torch.int64, device=dev)

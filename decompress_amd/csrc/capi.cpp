@@ -23,6 +23,11 @@ struct md_front {
   void *link, *flg, *m, *mq;
 };
 extern "C" size_t md_deflate_queue_bytes(uint32_t n, int qcap);
+// a stream's slot in the per-position workspace: its length + 64, rounded up to the match kernel's chunk (deflate_front.hip)
+#ifndef MD_PGM
+#define MD_PGM 4  // deflate_common.hpp
+#endif
+static const unsigned long long kSlotPad = 64 + (unsigned long long)(MD_PGM * 64) - 1;
 extern "C" size_t md_front_small_bytes(uint32_t n);
 extern "C" size_t md_front_big_bytes(uint64_t positions);
 extern "C" void md_front_carve(void *small_ws, void *big_ws, uint32_t n, uint64_t positions, md_front *f);
@@ -75,7 +80,7 @@ struct md_ctx {
   size_t lzo_ws_bytes = 0;
   int inflate_waves = 2;    // wavefronts per stream of the inflate kernel (md_set_option "inflate_waves": 1 = the one-wavefront form)
   size_t piece_bytes = (size_t)1 << 20;  // md_set_option "encoder_piece_bytes": input the md_def_* encoder gathers before a launch
-  size_t front_cap_bytes = 0;  // md_set_option "deflate_workspace_cap_mib" (md_create: a twelfth of the device's memory; 0 = none):
+  size_t front_cap_bytes = 0;  // md_set_option "deflate_workspace_cap_mib" (md_create: a sixth of the device's memory; 0 = none):
                                // batches whose per-position workspace would be larger go in slices of positions
   int test_flags = 0;       // md_set_option "deflate_test_flags": bit 4 = the md_def_* encoder moves its origin every 128 KiB (tests)
   uint64_t *dbg = nullptr;  // device buffer of the optional in-kernel profile (32 x u64)
@@ -243,9 +248,9 @@ md_ctx *md_create(int device, void *hip_stream) {
     fail(nullptr, MD_E_HIP, "hipEventCreate");
     return nullptr;
   }
-  {  // the deflate kernels' per-position workspace takes a twelfth of the device at most (24 GiB of 288) unless told otherwise
+  {  // the deflate kernels' per-position workspace takes a sixth of the device at most (48 GiB of 288) unless told otherwise
     size_t mem_free = 0, mem_total = 0;
-    if (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess) ctx->front_cap_bytes = mem_total / 12;
+    if (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess) ctx->front_cap_bytes = mem_total / 6;
   }
   return ctx;
 }
@@ -676,9 +681,9 @@ static int deflate_launch(md_ctx *ctx, int format, int level, int queue_len, int
   md_deflate_level_params(driver, matcher, level, &max_chain, &nice);
   const bool matcher_runs = max_chain != 0 && driver < 4;  // level 0 copies; De.Def.encode has no text
   if (matcher_runs && total_in != 0) {
-    // slot <= len + 64 + 255 positions and <= len / 256 + 1 chunks per stream
-    positions = (uint64_t)total_in + 319ull * n;
-    const uint64_t c64 = (uint64_t)total_in / 256 + n;
+    // slot <= len + 64 + (chunk - 1) positions and <= len / chunk + 2 chunks per stream
+    positions = (uint64_t)total_in + kSlotPad * n;
+    const uint64_t c64 = (uint64_t)total_in / (MD_PGM * 64) + 2ull * n;
     if (c64 > 0x7fffffffull) return fail(ctx, MD_E_INVALID_ARGUMENT, "batch too large for one launch");
     chunks = (uint32_t)c64;
     grc_ = grow(ctx, &ctx->fbig, &ctx->fbig_bytes, md_front_big_bytes(positions), "hipMalloc(deflate front workspace)");
@@ -755,8 +760,8 @@ static int def_ns_launch(md_ctx *ctx, int format, int level, size_t n, const uin
   uint32_t chunks = 0;
   const bool matcher_runs = level >= 1 && level <= 4;
   if (matcher_runs && total_in != 0) {
-    positions = (uint64_t)total_in + 319ull * n;
-    const uint64_t c64 = (uint64_t)total_in / 256 + n;
+    positions = (uint64_t)total_in + kSlotPad * n;
+    const uint64_t c64 = (uint64_t)total_in / (MD_PGM * 64) + 2ull * n;
     if (c64 > 0x7fffffffull) return fail(ctx, MD_E_INVALID_ARGUMENT, "batch too large for one launch");
     chunks = (uint32_t)c64;
     grc_ = grow(ctx, &ctx->fbig, &ctx->fbig_bytes, md_front_big_bytes(positions), "hipMalloc(deflate front workspace)");
@@ -885,7 +890,7 @@ static uint64_t slice_positions(const uint64_t *len, size_t n, uint64_t S) {  //
     first += len[i] < S ? len[i] : S;
     if (len[i] > S) second += (len[i] - S < S ? len[i] - S : S) + kSliceKeep;
   }
-  return (first > second ? first : second) + 319ull * n;
+  return (first > second ? first : second) + kSlotPad * n;
 }
 
 static int deflate_in_slices(md_ctx *ctx, int format, const md_deflate_params &q, size_t n, uint64_t S, const uint8_t *d_in,
@@ -994,7 +999,7 @@ static int deflate_capped(md_ctx *ctx, int format, const md_deflate_params &q, s
     if (in_len[i] > longest) longest = in_len[i];
   }
   (void)longest;
-  *whole = md_front_big_bytes(total + 319ull * n) <= ctx->front_cap_bytes;
+  *whole = md_front_big_bytes(total + kSlotPad * n) <= ctx->front_cap_bytes;
   if (*whole) return MD_OK;  // (fits after all: the caller's one launch)
   std::vector<uint64_t> r_len(n);
   std::vector<int32_t> r_st(n);
@@ -1009,9 +1014,17 @@ static int deflate_capped(md_ctx *ctx, int format, const md_deflate_params &q, s
     HIP_TRY(ctx, hipMemcpyAsync(crc.data(), d_crc, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   }
-  // groups of consecutive streams, each with the largest slice that fits (at least kSliceMin)
+  // First in groups of consecutive streams, as long as a group still fills the device several times over (16 streams
+  // per CU: 4 096 at a time - more streams than that take turns anyway; but a group lasts as long as its longest stream at
+  // least, so it has to bring enough work to cover that: four turns); then, within a group, in slices of positions, each
+  // group with the largest slice that fits (at least kSliceMin, else fewer streams)
+  const size_t kGeneration = 4 * 4096;
+  size_t groups = (size_t)((md_front_big_bytes(total + kSlotPad * n) + ctx->front_cap_bytes - 1) / ctx->front_cap_bytes);
+  if (groups > n / kGeneration) groups = n / kGeneration;
+  if (groups < 1) groups = 1;
+  const size_t per_group = (n + groups - 1) / groups;
   for (size_t i0 = 0; i0 < n;) {
-    size_t k = n - i0;
+    size_t k = n - i0 < per_group ? n - i0 : per_group;
     uint64_t S = 0;
     for (;;) {
       uint64_t lo = kSliceMin / 32768, hi = 0;
@@ -1067,7 +1080,7 @@ int md_deflate_batch_device(md_ctx *ctx, int format, const md_deflate_params *pa
     uint32_t max_chain = 0, nice = 0;
     md_deflate_level_params(q.driver, q.matcher, q.level, &max_chain, &nice);
     if (ctx->front_cap_bytes && max_chain != 0 &&
-        (!q.total_in_bytes || md_front_big_bytes((uint64_t)q.total_in_bytes + 319ull * n) > ctx->front_cap_bytes)) {
+        (!q.total_in_bytes || md_front_big_bytes((uint64_t)q.total_in_bytes + kSlotPad * n) > ctx->front_cap_bytes)) {
       bool whole = true;
       rc = deflate_capped(ctx, format, q, n, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap, d_out_len, d_status, d_checksum, &whole);
       if (rc != MD_OK || !whole) return rc;

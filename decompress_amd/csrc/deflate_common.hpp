@@ -29,7 +29,13 @@ constexpr int WSIZE = 1 << 15, WMASK = WSIZE - 1, MAX_DIST = WSIZE - MIN_LOOKAHE
 // (full / quartered chain, (length << 16) | distance), 0 the matcher has to look for itself
 enum { FL_ENDED = 2, FL_MATCH = 4 };
 constexpr int KSPEC = 128;  // chain links walked ahead per position at most (min(max_chain, KSPEC))
-constexpr int PGM = 4;      // steps of 64 positions one wavefront of the match kernel keeps in flight
+#ifndef MD_PGM
+#define MD_PGM 4
+#endif
+#ifndef MD_MATCH_WAVES
+#define MD_MATCH_WAVES 6
+#endif
+constexpr int PGM = MD_PGM;  // steps of 64 positions one wavefront of the match kernel keeps in flight
 constexpr uint32_t kChunk = PGM * kWave;
 
 // Position-indexed workspace of a batch.  Stream i owns positions [slot[i], slot[i + 1]) of link / flg / m / mq.

@@ -246,7 +246,7 @@ __global__ __launch_bounds__(LW *kWave) void deflate_link_kernel(uint32_t n, con
 // window limit is pos - MAX_DIST whatever the window base: before the first slide the base is 0, after a slide
 // strstart - base >= MAX_DIST.  The head candidate is admitted at distance == MAX_DIST, links only below it
 // (lib/de.ml:4367-4369 vs :4165).
-__global__ __launch_bounds__(kWave, 6) void deflate_match_kernel(uint32_t n, uint32_t nchunks_max, const uint8_t *__restrict__ in,
+__global__ __launch_bounds__(kWave, MD_MATCH_WAVES) void deflate_match_kernel(uint32_t n, uint32_t nchunks_max, const uint8_t *__restrict__ in,
                                                               const uint64_t *__restrict__ in_off,
                                                               const uint64_t *__restrict__ in_len,
                                                               const uint32_t *__restrict__ p_end_a,

@@ -137,15 +137,19 @@ int md_synchronize(md_ctx *ctx);
  * stream: begin/end bracket any number of batch calls; end returns elapsed
  * milliseconds (synchronises). */
 /* Options of a context.  Keys:
- *   "deflate_workspace_cap_mib"  value >= 0 (default: a twelfth of the device's memory, 24 GiB on MI355X; 0 = none).  The
+ *   "deflate_workspace_cap_mib"  value >= 0 (default: a sixth of the device's memory, 48 GiB on MI355X; 0 = none).  The
  *                                deflate kernels keep a per-position workspace of 13 bytes per input byte of what one
  *                                launch covers; a md_deflate_batch_device call whose workspace would be larger than the
  *                                cap goes through the kernels in slices of positions - a multiple of 32 KiB of every
  *                                stream per launch, going on from the state the launch before left - and in groups of
  *                                streams if 64 KiB of every stream at once would still be too much.  Same bytes out
- *                                (every fill of the reference's window ends on a 32 KiB boundary); a few per cent
- *                                slower (4 096 x 1 MiB: 52 GiB and 141 ms whole, 3 slices, 19 GiB and 146 ms capped);
- *                                the call then reads lengths and results back between the launches, i.e. it
+ *                                (every fill of the reference's window ends on a 32 KiB boundary).  Batches of
+ *                                more than four times 4 096 streams go in groups of streams first (no extra work).
+ *                                4 096 x 1 MiB: 52 GiB and 114.7 ms whole; 27.8 GiB (2 slices) 116.3 ms at the default;
+ *                                14.8 GiB (4 slices) 119.1 ms at 16 GiB; 6.7 GiB 127 ms at 8 GiB.  32 768 corpus files
+ *                                (7.1 GB, 93 GB whole): 573 ms whole, 576 ms at the default (two groups), 656 ms at
+ *                                29 GiB (two groups, each in slices: a slice lasts as long as its slowest stream).
+ *                                A capped call reads lengths and results back between the launches, i.e. it
  *                                synchronises with the context's stream instead of only enqueueing.
  *   "encoder_piece_bytes"        value >= 1 (default 1 MiB): how much input a md_def_* encoder gathers before it launches
  *                                the kernels on it.  The bytes out are those of the reference handed the input in the

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import torch
 import decompress_amd
 
-caps = [int(a) for a in sys.argv[1:]] or [0, 32768, 16384, 8192, 4096]
+caps = [int(a) for a in sys.argv[1:]] or [-1, 0, 29491, 16384, 8192]  # -1: the library default
 eng = decompress_amd.Engine(0)
 dev = eng.device
 n, nb = 4096, 1 << 20
@@ -21,7 +21,8 @@ d_ooff, d_cap = off * cap, torch.full((n,), cap, dtype=torch.int64, device=dev)
 ref = None
 for c in caps:
     eng.set_option("release_workspace", 1)
-    eng.set_option("deflate_workspace_cap_mib", c)
+    if c >= 0:
+        eng.set_option("deflate_workspace_cap_mib", c)
     d_out = torch.zeros(n * cap, dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
     free0 = torch.cuda.mem_get_info()[0]
