@@ -79,7 +79,7 @@ def _pmc_summary():
     return d if d.get("csrc_digest") == _csrc_digest() else None
 
 
-def pmc_traffic(names, is_default):
+def pmc_traffic(names, is_default, calls_key=None):
     """HBM bytes per launch from the COMMITTED rocprofv3 --pmc passes of this same command (tools/profile_gpu.sh on the
     default workload, profiles/<round>/pmc_summary.json) — not measured by this run: counters and timing cannot be
     collected in one process.  null when the workload differs or when a kernel source has changed since the profile
@@ -88,8 +88,11 @@ def pmc_traffic(names, is_default):
     if d is None:
         return None
     try:
-        return int(sum(d[k]["traffic_bytes_per_launch"] for k in names))
-    except (KeyError, ValueError, TypeError):
+        if calls_key is None:
+            return int(sum(d[k]["traffic_bytes_per_launch"] for k in names))
+        # a call may be several launches of a kernel (a deflate batch in slices): the dispatches' mean x launches per call
+        return int(sum(d[k]["traffic_bytes_per_launch"] * d[k]["launches"] / d[calls_key] for k in names))
+    except (KeyError, ValueError, TypeError, ZeroDivisionError):
         return None
 
 
@@ -300,9 +303,10 @@ def deflate_leg(args, eng, dev, rank, world, dist, fence):
                    "compressed_ratio": round(comp_all / (world * n * nb), 4)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 5),
-                     "traffic": pmc_traffic(("deflate_link_kernel", "deflate_match_kernel", "deflate_kernel"), is_default),
+                     "traffic": pmc_traffic(("deflate_link_kernel", "deflate_match_kernel", "deflate_kernel"), is_default, "deflate_calls"),
                      "traffic_source": pmc_source(),
-                     "kernel": "md::defl::deflate_link_kernel + deflate_match_kernel + deflate_kernel (one launch of each per step)",
+                     "kernel": "md::defl::deflate_link_kernel + deflate_match_kernel + deflate_kernel (per step one launch of each, or "
+                               "one per slice of positions where the workspace cap applies: 2 at the default cap)",
                      "kernel_ms": round(kernel_ms, 3),
                      "algorithmic_bytes_per_launch": algo},
     }

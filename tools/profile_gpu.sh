@@ -44,7 +44,7 @@ except Exception:  # the GPU box gets a snapshot without .git: the commit is lef
         commit = "?"
 sys.path.insert(0, os.path.dirname(out.rstrip("/")).rsplit("/gpurun_out", 1)[0])
 import bench as _bench
-summ = {"commit": commit, "csrc_digest": _bench._csrc_digest(), "command": cmd.replace(os.path.dirname(out.rstrip("/")).rsplit("/gpurun_out", 1)[0] + "/", ""),
+summ = {"commit": commit, "csrc_digest": _bench._csrc_digest(), "deflate_calls": (line.get("deflate") or {}).get("steps", 0) + 1, "command": cmd.replace(os.path.dirname(out.rstrip("/")).rsplit("/gpurun_out", 1)[0] + "/", ""),
         "note": "FETCH_SIZE / WRITE_SIZE are KiB per dispatch (rocprofv3, separate --pmc passes); means over the "
                 "dispatches of the run.  traffic_bytes_per_launch_raw = (FETCH + WRITE) x 1024.  On gfx950 FETCH_SIZE "
                 "counts a wide coalesced read (16 bytes per lane) at half its bytes (MI355X_MICROARCH.md, HBM); the "
