@@ -562,9 +562,10 @@ uint32_t md_def_checksum(const md_def_stream *s) { return s ? s->checksum : 0; }
 static void def_launch(md_def_stream *s) {
   const uint64_t end = s->w0 + s->text.size();
   const size_t fresh = (size_t)(end - s->launched), ql = (size_t)s->params.queue_len;
-  // room: what the queue held back plus the fresh bytes as 2 bytes a command, a block header per queue fill, the frame
+  // room: the commands the queue held back at 6 bytes each (a match: two codes of 15 bits, 5 + 13 extra bits), the fresh
+  // bytes at 2 bytes each (a literal is 15 bits at most, a match covers 3 bytes), a block header per queue fill, the frame
   const size_t blocks = (fresh + ql) / ql + 2, per_block = ql >= 128 ? 320 : 24 + 4 * ql;
-  const size_t cap = 2048 + 2 * (fresh + ql) + blocks * per_block;
+  const size_t cap = 2048 + 6 * ql + 2 * fresh + blocks * per_block;
   // the device's positions are 32-bit: once the text is 2 GiB from their origin the origin moves up to 64 KiB below it
   // (deflate_test_flags bit 4: at 128 KiB already, so that a test of ordinary size goes through it)
   const uint64_t far = (md_i_test_flags(s->ctx) & 16) ? (uint64_t)1 << 17 : (uint64_t)1 << 31;

@@ -457,6 +457,25 @@ def test_encoder_origin_moves(eng, oracle):
         eng.set_option("deflate_test_flags", 0)
 
 
+def test_encoder_pieces_flush_a_full_queue_of_matches(eng, oracle):
+    """a piece in which the queue fills flushes the 4 096 commands it held back - short far matches at 3-4 bytes of
+    output each: the room a piece gets counts them at their worst (6 bytes), not at a literal's (it was sized for
+    literals once: `Unexpected end of output` from the encoder)"""
+    import random
+    import decompress_amd
+    rng = random.Random(5)
+    grams = [bytes(rng.getrandbits(8) for _ in range(rng.randrange(3, 6))) for _ in range(50)]
+    data = b"".join(rng.choice(grams) for _ in range(50000))
+    eng.set_option("encoder_piece_bytes", 1000)
+    try:
+        with oracle.src_piece(1000):
+            want = oracle.zl_deflate(data, 6)
+        got, _ = _encode_in_pieces(eng, decompress_amd.FORMAT_ZLIB, data, 1000, 6)
+        assert got == want and zlib.decompress(got) == data
+    finally:
+        eng.set_option("encoder_piece_bytes", 1 << 20)
+
+
 def test_encoder_small_queue_in_pieces(eng, oracle):
     """a 16-command queue: a block every few commands, many of them per piece"""
     import decompress_amd
