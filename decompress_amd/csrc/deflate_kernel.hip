@@ -1866,55 +1866,65 @@ __global__ __launch_bounds__(kWave, 4) void deflate_kernel(
           }
         }
       }
-      const uint64_t special = __ballot(typ != 0);  // chain starts and unknowns
-      const uint64_t unknown = __ballot(typ == 2);
-      // ---- walk and emit (wave-uniform)
-      uint32_t cur = 0, pending = ds.zs.trivial == 1 ? 1u : 0u, cmds = 0;
-      const uint32_t cmax = qavail >= 3 ? qavail - 2 : 0;
-      bool stop = false;
-      while (!stop && cur < (uint32_t)kWave) {
-        const uint64_t rest = special >> cur;
-        const uint32_t x = rest ? cur + (uint32_t)__builtin_ctzll(rest) : (uint32_t)kWave;
-        if (x > cur) {  // literal steps cur .. x-1: the pending literal, then those of cur .. x-2
-          uint32_t nl = pending + (x - 1 - cur);
-          uint32_t xe = x;
-          if (cmds + nl > cmax) {  // queue: take what fits
-            const uint32_t fit = cmax - cmds;
-            if (fit < pending || fit == 0) break;
-            xe = cur + 1 + (fit - pending);
-            nl = fit;
-            stop = true;
+      // ---- the path from s0 through these chains, and its commands, by the whole wave.  The matcher arrives at a
+      //      position, and leaves it for the next one (no match there: its literal waits, `pending`) or for the end of
+      //      the chain's match.  Which positions it arrives at is a walk along these jumps from position 0: six rounds
+      //      of pointer doubling (a position's jump and the set of arrivals from it, over 1, 2, 4 ... jumps).  An arrival
+      //      writes the literal that waited (the position before was an arrival without a match) and, at a chain, the
+      //      chain's literals and its match; a prefix sum of these counts places them in the queue, and the arrivals that
+      //      fit the queue (an arrival's commands all or none) are the ones that happen.  (It was one wave-uniform loop
+      //      turn per literal run and per chain, ~80 dependent instructions each: three quarters of a text stream's time.)
+      const uint32_t nxt1 = typ == 2 ? 64u : typ == 1 ? lane + ck + cl : lane + 1;  // (>= 64: out of the window)
+      uint64_t arr = typ == 2 ? 0ull : 1ull << lane;
+      {
+        uint32_t J = nxt1 < 64u ? nxt1 : 64u;
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+          const int from = (int)(J & 63u);
+          const uint32_t alo = (uint32_t)__shfl((int)(uint32_t)arr, from), ahi = (uint32_t)__shfl((int)(uint32_t)(arr >> 32), from);
+          const uint32_t jn = (uint32_t)__shfl((int)J, from);
+          if (J < 64u) {
+            arr |= ((uint64_t)ahi << 32) | alo;
+            J = jn;
           }
-          if (lane < nl) {
-            const uint32_t q = s0 + cur - pending + lane;  // position of the literal
-            const uint32_t byte = ds.byt[q & (RING - 1)];
-            ws.queue[(qw + cmds + lane) & ((uint32_t)qcap - 1)] = (int)byte;
+        }
+      }
+      const uint64_t vis = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(arr >> 32)) << 32) |
+                           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)arr);  // the arrivals from position 0
+      const uint32_t pending0 = ds.zs.trivial == 1 ? 1u : 0u;
+      const uint64_t waits = vis & __builtin_amdgcn_ballot_w64(typ == 0);  // arrivals that leave their literal waiting
+      const bool here = (vis >> lane) & 1;
+      const uint32_t pend_in = lane ? (uint32_t)((waits >> (lane - 1)) & 1) : pending0;
+      const uint32_t mine = here ? pend_in + (typ == 1 ? ck + 1 : 0u) : 0u;
+      const uint32_t upto = wave_incl_scan(mine);
+      const uint32_t cmax = qavail >= 3 ? qavail - 2 : 0;
+      const bool happens = here && upto <= cmax;
+      const uint64_t hm = __builtin_amdgcn_ballot_w64(happens);
+      uint32_t cur = 0, pending = pending0, cmds = 0;
+      if (hm) {
+        const int last = 63 - __builtin_clzll(hm);
+        cmds = (uint32_t)__builtin_amdgcn_readlane((int)upto, last);
+        cur = (uint32_t)__builtin_amdgcn_readlane((int)nxt1, last);
+        pending = (uint32_t)((waits >> last) & 1);
+        if (happens) {
+          uint32_t at = qw + upto - mine;
+          if (pend_in) {
+            const uint32_t byte = ds.byt[(s0 + lane - 1) & (RING - 1)];
+            ws.queue[at++ & ((uint32_t)qcap - 1)] = (int)byte;
             atomicAdd(&ds.lits[byte], 1);
           }
-          cmds += nl;
-          pending = 1;
-          cur = xe;
-          if (stop) break;
+          if (typ == 1) {
+            for (uint32_t j = 0; j < ck; j++) {
+              const uint32_t byte = ds.byt[(s0 + lane + j) & (RING - 1)];
+              ws.queue[at++ & ((uint32_t)qcap - 1)] = (int)byte;
+              atomicAdd(&ds.lits[byte], 1);
+            }
+            // emit_match, lib/de.ml:4236-4245
+            ws.queue[at & ((uint32_t)qcap - 1)] = (int)(((cl - 3) << 16) | (cd - 1) | Q_COPY);
+            atomicAdd(&ds.lits[257 + length_code_of((int)cl)], 1);
+            atomicAdd(&ds.dsts[distance_code(&ds, (int)(cd - 1))], 1);
+          }
         }
-        if (cur >= (uint32_t)kWave || ((unknown >> cur) & 1)) break;
-        // the chain at cur: pending literal, ck literals, one match
-        const uint32_t k = (uint32_t)__shfl((int)ck, (int)cur), L = (uint32_t)__shfl((int)cl, (int)cur);
-        const uint32_t d = (uint32_t)__shfl((int)cd, (int)cur);
-        const uint32_t nl = pending + k;
-        if (cmds + nl + 1 > cmax) break;
-        if (lane < nl) {
-          const uint32_t q = s0 + cur - pending + lane;
-          const uint32_t byte = ds.byt[q & (RING - 1)];
-          ws.queue[(qw + cmds + lane) & ((uint32_t)qcap - 1)] = (int)byte;
-          atomicAdd(&ds.lits[byte], 1);
-        } else if (lane == nl) {  // emit_match, lib/de.ml:4236-4245
-          ws.queue[(qw + cmds + nl) & ((uint32_t)qcap - 1)] = (int)(((L - 3) << 16) | (d - 1) | Q_COPY);
-          atomicAdd(&ds.lits[257 + length_code_of((int)L)], 1);
-          atomicAdd(&ds.dsts[distance_code(&ds, (int)(d - 1))], 1);
-        }
-        cmds += nl + 1;
-        pending = 0;
-        cur += k + L;  // the match at cur + k covers L positions
       }
       if (lane == 0 && cur > 0) {
         ds.zs.strstart = s0 + cur;

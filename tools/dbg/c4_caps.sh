@@ -1,6 +1,6 @@
 #!/bin/bash
 cd "$(dirname "$0")/../.."
-for cap in "" "--deflate-cap-mib 0" "--deflate-cap-mib 29491"; do
+for cap in "--deflate-cap-mib 40800" "--deflate-cap-mib 36000"; do
   echo "== cap '$cap'"
   timeout 400 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-text-leg --no-deflate --no-verify $cap 2>/dev/null | python -c "
 import sys, json
