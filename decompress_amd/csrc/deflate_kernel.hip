@@ -1814,29 +1814,39 @@ __global__ __launch_bounds__(kWave, 4) void deflate_kernel(
         if (E > lim) E = lim;
       } else if (E > pe) E = pe;
       __syncthreads();
-      for (uint32_t j = lane; j < 80; j += kWave) {
-        const uint32_t q = s0 + j, r = q & (RING - 1);
-        uint32_t k = 0, lf = 2, df = 0, lq = 2, dq = 0;
-        if (q < E) {
-          const uint32_t f = ds.flg[r], l1v = ds.hl[r], c1v = l1v ? q - l1v : 0u;
-          if (f == FL_ENDED || f == FL_MATCH) k = 1;
-          if (c1v > base && q - c1v <= (uint32_t)MAX_DIST) k |= 2;
-          if (f == FL_MATCH) {
-            const uint32_t a = g_ld(ws.m + q), b = g_ld(ws.mq + q);
-            lf = a >> 16;
-            df = a & 0xffff;
-            lq = b >> 16;
-            dq = b & 0xffff;
+      {
+        // what the look-ahead knows about positions s0 .. s0 + 79: lane -> position s0 + lane, lanes 0 .. 15 also
+        // s0 + 64 + lane; the four loads of match results are issued before anything waits for them (no branch around
+        // them: a position without a match reads its cell and drops it)
+        const uint32_t q0 = s0 + lane, q1 = s0 + 64 + (lane & 15);
+        const uint32_t g0 = q0 < slot_len ? q0 : slot_len - 1, g1 = q1 < slot_len ? q1 : slot_len - 1;
+        const uint32_t ma0 = g_ld(ws.m + g0), mb0 = g_ld(ws.mq + g0), ma1 = g_ld(ws.m + g1), mb1 = g_ld(ws.mq + g1);
+        auto fill = [&](uint32_t j, uint32_t q, uint32_t a, uint32_t b) {
+          const uint32_t r = q & (RING - 1);
+          uint32_t k = 0, lf = 2, df = 0, lq = 2, dq = 0;
+          if (q < E) {
+            const uint32_t f = ds.flg[r], l1v = ds.hl[r], c1v = l1v ? q - l1v : 0u;
+            if (f == FL_ENDED || f == FL_MATCH) k = 1;
+            if (c1v > base && q - c1v <= (uint32_t)MAX_DIST) k |= 2;
+            if (f == FL_MATCH) {
+              lf = a >> 16;
+              df = a & 0xffff;
+              lq = b >> 16;
+              dq = b & 0xffff;
+            }
           }
-        }
-        ds.pm_k[j] = (uint8_t)k;
-        ds.pm_lf[j] = (uint16_t)lf;
-        ds.pm_df[j] = (uint16_t)df;
-        ds.pm_lq[j] = (uint16_t)lq;
-        ds.pm_dq[j] = (uint16_t)dq;
+          ds.pm_k[j] = (uint8_t)k;
+          ds.pm_lf[j] = (uint16_t)lf;
+          ds.pm_df[j] = (uint16_t)df;
+          ds.pm_lq[j] = (uint16_t)lq;
+          ds.pm_dq[j] = (uint16_t)dq;
+        };
+        fill(lane, q0, ma0, mb0);
+        if (lane < 16) fill(64 + lane, q1, ma1, mb1);
       }
       __syncthreads();
       // the lazy chain that starts at window position `lane`
+      const uint32_t lv_max_lazy = c_levels[eff_level][1], lv_good = c_levels[eff_level][2];
       uint32_t typ = 2, ck = 0, cl = 0, cd = 0;  // typ 0 literal, 1 match chain, 2 unknown
       {
         const uint32_t k0 = ds.pm_k[lane];
@@ -1852,8 +1862,8 @@ __global__ __launch_bounds__(kWave, 4) void deflate_kernel(
                 typ = 2;
                 break;
               }
-              if (L >= c_levels[eff_level][1]) break;  // prev_length >= max_lazy: no search
-              const bool quart = L >= c_levels[eff_level][2];
+              if (L >= lv_max_lazy) break;  // prev_length >= max_lazy: no search
+              const bool quart = L >= lv_good;
               const uint32_t m = (ds.pm_k[t] & 2) ? (quart ? ds.pm_lq[t] : ds.pm_lf[t]) : 2u;
               if (m <= L) break;
               d = quart ? ds.pm_dq[t] : ds.pm_df[t];
@@ -1887,6 +1897,7 @@ __global__ __launch_bounds__(kWave, 4) void deflate_kernel(
             arr |= ((uint64_t)ahi << 32) | alo;
             J = jn;
           }
+          if ((uint32_t)__builtin_amdgcn_readfirstlane((int)J) >= 64u) break;  // the walk from position 0 is complete
         }
       }
       const uint64_t vis = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(arr >> 32)) << 32) |
