@@ -2,7 +2,7 @@
 cd "$(dirname "$0")/../.."
 R=$PWD
 cd /tmp && export TMPDIR=/tmp
-for cap in "" "--deflate-cap-mib 0"; do
+for cap in ""; do
   rm -rf /tmp/c4p
   timeout 600 rocprofv3 --kernel-trace --stats -f csv -d /tmp/c4p -o t -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-text-leg --no-deflate --no-verify $cap > /dev/null 2>&1
   echo "== cap '$cap'"

@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/pmc_text; rm -rf $OUT; mkdir -p $OUT
-BENCH="python $REPO/tools/bench_deflate.py --streams 4096 --stream-kib 256 --level 6 --kind text --steps 2"
+BENCH="python $REPO/tools/bench_deflate.py --streams 4096 --stream-kib 256 --level ${LEVEL:-6} --kind text --steps 2"
 for C in "SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA"; do
   tag=$(echo $C | tr ' ' '_')
   timeout 600 rocprofv3 --kernel-trace --pmc $C -f csv -d $OUT/$tag -o pmc -- $BENCH > /dev/null 2> $OUT/$tag.log
