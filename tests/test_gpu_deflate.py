@@ -376,10 +376,10 @@ def _push_through_encoder(eng, fmt, pieces, level, o_len=65536):
     return h.hexdigest(), n_out, checksum, peak
 
 
-def _encode_in_pieces(eng, fmt, data, piece, level, queue=4096, o_len=4096):
+def _encode_in_pieces(eng, fmt, data, piece, level, queue=4096, o_len=4096, driver=0, matcher=None):
     """data through md_def_* `piece` bytes per `Await -> (output, number of `Flush answers before the last piece went in)"""
     lib = eng.lib
-    params = eng._params(level, queue, 0, True)
+    params = eng._params(level, queue, driver, True, matcher=matcher)
     o = ctypes.create_string_buffer(o_len)
     s = lib.md_def_encoder(eng.ctx, fmt, ctypes.byref(params), o, len(o))
     assert s
@@ -472,6 +472,24 @@ def test_encoder_pieces_flush_a_full_queue_of_matches(eng, oracle):
             want = oracle.zl_deflate(data, 6)
         got, _ = _encode_in_pieces(eng, decompress_amd.FORMAT_ZLIB, data, 1000, 6)
         assert got == want and zlib.decompress(got) == data
+    finally:
+        eng.set_option("encoder_piece_bytes", 1 << 20)
+
+
+def test_encoder_in_pieces_other_drivers_and_matcher(eng, oracle):
+    """De.Higher's driver, the CLI's, and lib/lz.ml's matcher (its fill_window is De.Lz77's, lib/lz.ml:382-426) through
+    the encoder in pieces: raw DEFLATE equal to the oracle handed the same pieces"""
+    import decompress_amd
+    from decompress_amd import workloads
+    data = workloads.text(314, 260000)
+    eng.set_option("encoder_piece_bytes", 40000)
+    try:
+        for driver, matcher, level in ((1, 0, 4), (2, 0, 6), (0, 1, 6), (0, 1, 2)):
+            with oracle.src_piece(40000):
+                want, _ = oracle.deflate_raw(data, level=level, queue=4096, driver=driver, dynamic=True, matcher=matcher)
+            got, _ = _encode_in_pieces(eng, decompress_amd.FORMAT_DEFLATE, data, 40000, level, driver=driver, matcher=matcher)
+            assert got == want, (driver, matcher, level, len(got), len(want))
+            assert zlib.decompressobj(-15).decompress(got) == data
     finally:
         eng.set_option("encoder_piece_bytes", 1 << 20)
 
@@ -635,12 +653,15 @@ def test_batch_in_slices_of_positions(eng, oracle, cap_mib):
                     else (workloads.text(i, 5000) * (n // 5000 + 1))[:n])
     cases = [(decompress_amd.FORMAT_ZLIB, 6, decompress_amd.DRIVER_ZL), (decompress_amd.FORMAT_GZIP, 4, decompress_amd.DRIVER_ZL),
              (decompress_amd.FORMAT_DEFLATE, 9, decompress_amd.DRIVER_HIGHER), (decompress_amd.FORMAT_DEFLATE, 1, decompress_amd.DRIVER_CLI),
-             (decompress_amd.FORMAT_ZLIB, 3, decompress_amd.DRIVER_ZL)]
+             (decompress_amd.FORMAT_ZLIB, 3, decompress_amd.DRIVER_ZL), (decompress_amd.FORMAT_DEFLATE, 7, -1)]
     for fmt, level, driver in cases:
-        want = eng.deflate_many(bufs, fmt=fmt, level=level, driver=driver)
+        matcher = None
+        if driver < 0:  # lib/lz.ml's matcher under the Zl driver
+            driver, matcher = decompress_amd.DRIVER_ZL, 1
+        want = eng.deflate_many(bufs, fmt=fmt, level=level, driver=driver, matcher=matcher)
         eng.set_option("deflate_workspace_cap_mib", cap_mib)
         try:
-            got = eng.deflate_many(bufs, fmt=fmt, level=level, driver=driver)
+            got = eng.deflate_many(bufs, fmt=fmt, level=level, driver=driver, matcher=matcher)
         finally:
             eng.set_option("deflate_workspace_cap_mib", 0)
         for i, (w, g) in enumerate(zip(want, got)):
