@@ -329,14 +329,16 @@ __global__ __launch_bounds__(kWave, MD_MATCH_WAVES) void deflate_match_kernel(ui
   for (uint32_t lv = 0; lv < kspec; lv++) {
     bool act[PGM];
     bool any = false;
+    // the candidate is in reach: the head at distance <= MAX_DIST, a link below it (pos - MAX_DIST < candidate; a
+    // position that close to the start reaches everything before it) - one comparison, no branches
+    const uint32_t lim = (uint32_t)MAX_DIST + (lv == 0 ? 1u : 0u);
 #pragma unroll
     for (int g = 0; g < PGM; g++) {
       const uint32_t pos = pe + g * kWave + lane;
-      const uint32_t lower = pos > (uint32_t)MAX_DIST ? pos - MAX_DIST : 0;
-      act[g] = pos < p_end && (fc[g] & 15u) == 0 && (lv == 0 ? (cw[g] != 0 && pos - cw[g] <= (uint32_t)MAX_DIST) : cw[g] > lower);
-      any = any || act[g];
+      act[g] = (pos < p_end) & ((fc[g] & 15u) == 0) & (cw[g] != 0) & (pos - cw[g] < lim);
+      any = any | act[g];
     }
-    if (__ballot(any) == 0) break;
+    if (__builtin_amdgcn_ballot_w64(any) == 0) break;
     uint32_t rec[PGM], nx[PGM];
 #pragma unroll
     for (int g = 0; g < PGM; g++) {
@@ -347,8 +349,8 @@ __global__ __launch_bounds__(kWave, MD_MATCH_WAVES) void deflate_match_kernel(ui
     }
 #pragma unroll
     for (int g = 0; g < PGM; g++) {
-      bool hit = act[g] && (rec[g] >> 16) == fp16(w4[g]);  // the candidate's 3 bytes may be ours: look at them
-      if (__ballot(hit)) {
+      const bool hit = act[g] & ((rec[g] >> 16) == fp16(w4[g]));  // the candidate's 3 bytes may be ours: look at them
+      if (__builtin_amdgcn_ballot_w64(hit)) {
         const uint32_t pos = pe + g * kWave + lane;
         if (hit && pos + MIN_LOOKAHEAD > slen) {  // too close to the end to compare ahead: the matcher's job, if the 3 bytes are there
           uint32_t v;
