@@ -300,7 +300,9 @@ def deflate_leg(args, eng, dev, rank, world, dist, fence):
         "steps": args.deflate_steps, "ms_per_step": round(elapsed / args.deflate_steps * 1e3, 3), "parity_ok": ok,
         "config": {"workload": "C3: %d x %d KiB printable-ASCII buffers per GPU, De.Lz77 + De.Def level 6, queue 4096, "
                                "Zl driver, dynamic blocks" % (n, args.deflate_kib),
-                   "compressed_ratio": round(comp_all / (world * n * nb), 4)},
+                   "compressed_ratio": round(comp_all / (world * n * nb), 4),
+                   "workspace_cap_mib": ("library default: device memory / 6 (a batch above it goes in slices of positions, same bytes)"
+                                         if args.deflate_cap_mib is None else args.deflate_cap_mib)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 5),
                      "traffic": pmc_traffic(("deflate_link_kernel", "deflate_match_kernel", "deflate_kernel"), is_default, "deflate_calls"),
