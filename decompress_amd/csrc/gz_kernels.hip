@@ -133,13 +133,35 @@ __device__ __forceinline__ uint32_t crc_word(const CrcTab *tb, uint32_t c, uint3
 }
 // standard CRC-32 (init and final xor ~0) of buf[0, len), whole wave; result on every lane
 __device__ uint32_t crc32_wave(const CrcTab *tb, const uint8_t *buf, uint64_t len, uint32_t lane) {
-  const uint64_t seg = ((len + kWave - 1) / kWave + 15) & ~(uint64_t)15;
+  // (segments of whole 64-byte lines: a lane takes a line at a time, four 16-byte loads issued together - with one 16-byte
+  // load per step the 64 lines a step touches were back in L2 before their other three quarters were asked for: the
+  // 32 wavefronts of a CU hold 128 KiB of such lines against 16 KiB of L1, and the kernel ran at a fifth of HBM's rate)
+  const uint64_t seg = ((len + kWave - 1) / kWave + 63) & ~(uint64_t)63;
   uint64_t a = (uint64_t)lane * seg, b = a + seg;
   if (a > len) a = len;
   if (b > len) b = len;
   uint32_t c = 0xffffffffu;
   const uint8_t *q = buf + a, *e = buf + b;
-  while (q < e && ((uintptr_t)q & 15) != 0) c = tb->t[0][(c ^ *q++) & 0xff] ^ (c >> 8);
+  while (q < e && ((uintptr_t)q & 63) != 0) c = tb->t[0][(c ^ *q++) & 0xff] ^ (c >> 8);
+  for (; q + 64 <= e; q += 64) {
+    const uint4 v0 = *(const uint4 *)q, v1 = *(const uint4 *)(q + 16), v2 = *(const uint4 *)(q + 32), v3 = *(const uint4 *)(q + 48);
+    c = crc_word(tb, c, v0.x);
+    c = crc_word(tb, c, v0.y);
+    c = crc_word(tb, c, v0.z);
+    c = crc_word(tb, c, v0.w);
+    c = crc_word(tb, c, v1.x);
+    c = crc_word(tb, c, v1.y);
+    c = crc_word(tb, c, v1.z);
+    c = crc_word(tb, c, v1.w);
+    c = crc_word(tb, c, v2.x);
+    c = crc_word(tb, c, v2.y);
+    c = crc_word(tb, c, v2.z);
+    c = crc_word(tb, c, v2.w);
+    c = crc_word(tb, c, v3.x);
+    c = crc_word(tb, c, v3.y);
+    c = crc_word(tb, c, v3.z);
+    c = crc_word(tb, c, v3.w);
+  }
   for (; q + 16 <= e; q += 16) {
     const uint4 v = *(const uint4 *)q;
     c = crc_word(tb, c, v.x);
