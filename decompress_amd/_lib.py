@@ -7,7 +7,8 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO = os.path.join(HERE, "libmdeflate.so")
+# MD_LIBMDEFLATE: another build of the same library (measurement builds of tools/dbg; there is still no fallback)
+SO = os.environ.get("MD_LIBMDEFLATE") or os.path.join(HERE, "libmdeflate.so")
 
 c_sz = ctypes.c_size_t
 c_u8p = ctypes.c_void_p

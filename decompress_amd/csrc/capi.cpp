@@ -36,6 +36,8 @@ extern "C" int md_launch_deflate_plan(uint32_t n, const uint64_t *in_len, int dr
 extern "C" int md_launch_deflate_front(uint32_t n, uint32_t nchunks_max, const uint8_t *in, const uint64_t *in_off,
                                        const uint64_t *in_len, int matcher, uint32_t max_chain, uint32_t nice,
                                        const md_front *f, const uint32_t *order, uint32_t match_skip, hipStream_t stream);
+extern "C" int md_i_debug_inflate_lds_pad(uint32_t bytes);
+extern "C" int md_i_debug_known_bounds(int mode, uint32_t nstreams);
 extern "C" int md_launch_stream_order(uint32_t n, const uint64_t *in_len, uint32_t *order, hipStream_t stream);
 extern "C" void md_deflate_level_params(int driver, int matcher, int level, uint32_t *max_chain, uint32_t *nice);
 extern "C" int md_launch_def_ns(int format, int level, uint32_t n, uint32_t nchunks_max, const uint8_t *in, const uint64_t *in_off,
@@ -343,6 +345,17 @@ int md_set_option(md_ctx *ctx, const char *key, int value) {
   }
   if (!strcmp(key, "deflate_test_flags")) {
     ctx->test_flags = value;
+    return MD_OK;
+  }
+  if (!strcmp(key, "debug_known_bounds")) {  // measurement builds only (-DMD_DEBUG_KNOWN_BOUNDS): mode | streams << 4
+    MD_ON_DEVICE(ctx);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (value < 0 || md_i_debug_known_bounds(value & 15, (uint32_t)value >> 4)) return fail(ctx, MD_E_INVALID_ARGUMENT, "debug_known_bounds: not a measurement build");
+    return MD_OK;
+  }
+  if (!strcmp(key, "debug_inflate_lds_pad")) {  // measurement only: unused LDS per stream, i.e. fewer streams per CU
+    MD_ON_DEVICE(ctx);
+    if (value < 0 || md_i_debug_inflate_lds_pad((uint32_t)value)) return fail(ctx, MD_E_INVALID_ARGUMENT, "debug_inflate_lds_pad");
     return MD_OK;
   }
   return fail(ctx, MD_E_INVALID_ARGUMENT, "unknown option");

@@ -43,6 +43,7 @@
 // blocks (lib/de.ml:1613-1627) and the zlib frame (lib/zl.ml:400-417) run between rounds.  The first
 // failing token in stream order decides the status and everything before it is written
 // (oracle/de_inflate.c).
+#include <stdlib.h>
 #include <string.h>
 #include "inflate_util.hpp"
 
@@ -127,6 +128,16 @@ __device__ __forceinline__ lds_hscratch *hscratch_of(lds_smem *sm) {
   return reinterpret_cast<lds_hscratch *>(reinterpret_cast<lds_u8 *>(sm->win) + kHScratchAt);
 }
 
+#ifdef MD_DEBUG_KNOWN_BOUNDS
+// Measurement build only (tools/dbg/build_known_bounds.sh): mode & 3 == 1 records what the sync
+// passes of every round found (start, end, stop, counts per lane), == 2 replays the record instead of walking - the
+// time of that launch is what a PERFECT sync would leave of the kernel.  mode & 4: the copier skips the matches (far and
+// near) and only flushes; mode & 8: the copier does nothing at all (the decoder's time alone).  Results are only right in
+// modes 0..2.
+constexpr uint32_t KB_ROUNDS = 512;
+__device__ uint4 *g_kb_buf;
+__device__ int g_kb_mode;
+#endif
 __device__ __forceinline__ uint32_t mk_entry(uint32_t n, uint32_t xb, uint32_t val8, uint32_t nbits, uint32_t tb) {
   return n | (xb << 5) | (val8 << 9) | (nbits << 17) | (tb << 21);
 }
@@ -168,6 +179,9 @@ __device__ __forceinline__ uint32_t dist_value(uint32_t m, uint32_t xb, uint32_t
 struct Window {
   uint32_t w[8], wx;
   uint32_t base;  // of the fetched words; 0xffffffff = nothing fetched
+#ifdef MD_DEBUG_KNOWN_BOUNDS
+  uint32_t kb_round, kb_sid;
+#endif
   __device__ __forceinline__ void fetch(const uint8_t *__restrict__ body, uint32_t nbytes, uint32_t b, uint32_t lane) {
     base = b;
     const uint32_t off = b + lane * 32;
@@ -1114,6 +1128,19 @@ __device__ __forceinline__ void copy_round(lds_smem *sm, Sink &sk, uint32_t lane
   lds_u16 *list = (lds_u16 *)sm->list;
   const uint32_t R0 = sk.pos, rb = sk.sbase();
   uint32_t nnear = 0;
+#ifdef MD_DEBUG_KNOWN_BOUNDS
+  {
+    const int kbm = __builtin_amdgcn_readfirstlane(g_kb_mode);
+    if (kbm & 8) {
+      sk.pos += total;
+      return;
+    }
+    if (kbm & 4) {
+      sk.flush(total);
+      return;
+    }
+  }
+#endif
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // earlier rounds' flushes have landed
   if (R0 + 40 > sk.cap) {
     copy_far_guarded<PF>(mrec, mpos, pend, list, sk.stage, sk.g, R0, rb, sk.cap, lane, nrec, &nnear);
@@ -1182,9 +1209,23 @@ __device__ __forceinline__ int inflate_block(lds_smem *sm, const uint8_t *__rest
     // walk again in passes 2+, which cost a full pass each for a handful of lanes (the pass without counts is the
     // cheap one: 24 instructions a step against 34)
     const uint32_t runin = lane ? (zs * RUNIN_NUM) / RUNIN_DEN : 0u;
+    bool counted = false;
+#ifdef MD_DEBUG_KNOWN_BOUNDS
+    const int kbm = __builtin_amdgcn_readfirstlane(g_kb_mode);
+    const bool kb_can = wnd.kb_round < KB_ROUNDS;
+    uint4 *kbp = g_kb_buf + ((size_t)wnd.kb_sid * KB_ROUNDS + wnd.kb_round) * kWave + lane;
+    wnd.kb_round++;
+    if ((kbm & 3) == 2 && kb_can) {
+      const uint4 v = *kbp;
+      start = v.x;
+      end = v.y;
+      stop = v.z & 0xffffu;
+      counted = (v.z >> 16) != 0;
+      nb = v.w;
+    } else {
+#endif
     sync_pass<false, BUDGET>(win, lut, lroot, true, start - runin, limit, end, stop, nb);
     pf.tick(P_DECODE1);
-    bool counted = false;
     const uint32_t passes = zs * PASSES >= PASS_BITS ? PASSES : PASS_BITS / zs > PASSES_MAX ? PASSES_MAX : PASS_BITS / zs;
     for (uint32_t it = 0; it < passes; it++) {
       const uint32_t pe = __shfl_up(end, 1), ps = __shfl_up(stop, 1);
@@ -1195,6 +1236,10 @@ __device__ __forceinline__ int inflate_block(lds_smem *sm, const uint8_t *__rest
       sync_pass<true, BUDGET>(win, lut, lroot, redo, start, limit, end, stop, nb);
       counted = counted || redo;
     }
+#ifdef MD_DEBUG_KNOWN_BOUNDS
+      if ((kbm & 3) == 1 && kb_can) *kbp = make_uint4(start, end, stop | (counted ? 0x10000u : 0u), nb);
+    }
+#endif
     pf.tick(P_DECODE2);
     uint32_t nvalid;
     {
@@ -1416,6 +1461,10 @@ __global__ __launch_bounds__(PAIR ? 2 * kWave : kWave, PAIR ? 4 : 2) void inflat
   uint32_t fixed_lroot = 0;  // != 0: the tables in LDS are the fixed ones (and this is their root width)
   Window wnd;
   wnd.base = 0xffffffffu;
+#ifdef MD_DEBUG_KNOWN_BOUNDS
+  wnd.kb_round = 0;
+  wnd.kb_sid = sid;
+#endif
   if (cont.resume_bits && lane == 0) {  // no block complete yet
     cont.resume_bits[sid] = bp;
     cont.resume_out[sid] = sk.pos;
@@ -1620,6 +1669,36 @@ extern "C" int md_launch_stream_order(uint32_t n, const uint64_t *in_len, uint32
   return (int)hipGetLastError();
 }
 
+// measurement only (md_set_option "debug_inflate_lds_pad", tools/dbg/inflate_occupancy.py): bytes of unused dynamic LDS
+// per workgroup, which lowers the number of streams a CU holds at once
+static uint32_t g_debug_lds_pad = 0;
+extern "C" int md_i_debug_inflate_lds_pad(uint32_t bytes) {
+  using namespace md::wv;
+  if (bytes + sizeof(Smem) > 160u * 1024u) return 1;
+  hipError_t e = hipFuncSetAttribute((const void *)inflate_wave_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void *)inflate_wave_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return (int)e;
+  g_debug_lds_pad = bytes;
+  return 0;
+}
+
+extern "C" int md_i_debug_known_bounds(int mode, uint32_t nstreams) {
+#ifdef MD_DEBUG_KNOWN_BOUNDS
+  static uint4 *buf = nullptr;
+  static uint32_t cap = 0;
+  if (nstreams > cap) {
+    if (buf) hipFree(buf);
+    if (hipMalloc((void **)&buf, (size_t)nstreams * md::wv::KB_ROUNDS * 64 * sizeof(uint4)) != hipSuccess) return 2;
+    cap = nstreams;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(md::wv::g_kb_buf), &buf, sizeof buf) != hipSuccess) return 3;
+  }
+  return hipMemcpyToSymbol(HIP_SYMBOL(md::wv::g_kb_mode), &mode, sizeof mode) == hipSuccess ? 0 : 4;
+#else
+  (void)mode, (void)nstreams;
+  return 1;  // not a measurement build
+#endif
+}
+
 // `order` = n words of device scratch, or null for index order; waves = wavefronts per stream (2, or 1)
 extern "C" int md_launch_inflate_wave(int format, uint32_t n, const uint8_t *in, const uint64_t *in_off,
                                       const uint64_t *in_len, uint8_t *out, const uint64_t *out_off,
@@ -1634,8 +1713,9 @@ extern "C" int md_launch_inflate_wave(int format, uint32_t n, const uint8_t *in,
   const uint32_t *ord = dbg ? nullptr : order;
   Cont cont{};  // (seven device pointers in the order of struct Cont, or null)
   if (cont_ptrs) memcpy(&cont, cont_ptrs, sizeof cont);
+  const uint32_t lds_pad = g_debug_lds_pad;
 #define MD_LAUNCH_INFLATE(P, Q)                                                                                          \
-  hipLaunchKernelGGL((inflate_wave_kernel<P, Q>), grid, block, 0, stream, format, n, in, in_off, in_len, out, out_off, \
+  hipLaunchKernelGGL((inflate_wave_kernel<P, Q>), grid, block, (P) ? 0u : lds_pad, stream, format, n, in, in_off, in_len, out, out_off, \
                      out_cap, out_len, consumed, status, checksum, dbg, ord, cont)
   if (dbg) {
     if (single) MD_LAUNCH_INFLATE(true, false);

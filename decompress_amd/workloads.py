@@ -4,7 +4,8 @@ tests/golden/corpus.tar.xz = the reference's test/corpus, packed by tests/golden
 C1  one 64 KiB stream of stored blocks (65535 + 1 bytes)
 C2  N x 256 KiB zlib streams, dynamic Huffman (libz level 6)      [headline]
     plaintext i: even i = the 256 KiB of the concatenated corpus that start at offset i * 4099 (mod its length),
-    odd i = seeded Zipf-distributed word text (zlib ratio ~0.38, full range of match distances)
+    odd i = order-2 Markov text over a 64-symbol ASCII alphabet, seed 0xC2 + i (markov_text: zlib-6 ratio 0.40);
+    rounds 1-4 used seeded Zipf word text there (text(): still BENCH's `r01_workload` leg)
 C3  N x 1 MiB uniform printable-ASCII buffers (deflate input)
 C4  the 15 corpus files, file[i mod 15], as gzip members
 """
@@ -98,7 +99,7 @@ def corpus_slice(i, nbytes):
 
 def c2_plain(i, nbytes, seed0=0xC2):
     """plaintext of C2's stream i"""
-    return corpus_slice(i, nbytes) if i % 2 == 0 else text(seed0 + i, nbytes)
+    return corpus_slice(i, nbytes) if i % 2 == 0 else markov_text(seed0 + i, nbytes)
 
 
 def ascii_uniform(seed, nbytes):
@@ -152,3 +153,38 @@ def pack(streams, align=16):
     for s, o in zip(streams, offs):
         blob[o:o + len(s)] = np.frombuffer(s, dtype=np.uint8)
     return blob, offs, lens
+
+
+# ---- C2's odd streams as SURVEY §8(d) defines them: order-2 Markov ASCII text --------------------------------------
+_MARKOV_ALPHABET = (b" \netaoinshrdlcumwfgypbvkjxqz" b"ETAOINSHRDLCUMWFGYPBVKJXQZ" b".,;:'-!?()")
+assert len(_MARKOV_ALPHABET) == 64 and len(set(_MARKOV_ALPHABET)) == 64
+_MARKOV_THETA = 0.288  # geometric decay of a state's next-symbol probabilities: tuned so that zlib level 6 gives ~0.40
+_markov_cache = None
+
+
+def _markov_table():
+    """4096 states (the last two symbols) x 256 slots -> the next STATE for a uniform random byte, as one flat list.
+    Every state has its own order of the 64 symbols (fixed seed), the k-th of them with probability ~ theta^k, quantised
+    to 1/256."""
+    global _markov_cache
+    if _markov_cache is None:
+        rng = np.random.default_rng(0xC2C2)
+        p = _MARKOV_THETA ** np.arange(64)
+        p /= p.sum()
+        edges = np.minimum(255, np.floor(np.cumsum(p) * 256).astype(np.int64))  # slot r belongs to the first k with r <= edges[k]
+        rank_of_slot = np.searchsorted(edges, np.arange(256), side="left")
+        perm = np.argsort(rng.random((4096, 64)), axis=1)
+        nxt_sym = perm[:, rank_of_slot]                                      # [4096, 256]
+        nxt_state = ((np.arange(4096)[:, None] & 63) << 6) | nxt_sym
+        _markov_cache = nxt_state.reshape(-1).tolist()
+    return _markov_cache
+
+
+def markov_text(seed, nbytes):
+    """nbytes of order-2 Markov text over a 64-symbol ASCII alphabet (one chain per stream, seeded)."""
+    flat = _markov_table()
+    r = np.random.default_rng(seed).integers(0, 256, size=nbytes, dtype=np.uint8).tobytes()
+    st = seed & 4095
+    states = [st := flat[(st << 8) | x] for x in r]
+    sym = (np.array(states, dtype=np.uint16) & 63).astype(np.uint8)
+    return np.frombuffer(_MARKOV_ALPHABET, dtype=np.uint8)[sym].tobytes()
