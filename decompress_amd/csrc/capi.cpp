@@ -23,11 +23,12 @@ struct md_front {
   void *link, *flg, *m, *mq;
 };
 extern "C" size_t md_deflate_queue_bytes(uint32_t n, int qcap);
-// a stream's slot in the per-position workspace: its length + 64, rounded up to the match kernel's chunk (deflate_front.hip)
-#ifndef MD_PGM
-#define MD_PGM 4  // deflate_common.hpp
-#endif
-static const unsigned long long kSlotPad = 64 + (unsigned long long)(MD_PGM * 64) - 1;
+// a stream's slot in the per-position workspace: its length + 64, rounded up to the match kernel's chunk; the chunk and
+// the size of a stream's state slot are the kernels' constants (deflate_common.hpp), asked for, not copied
+extern "C" uint32_t md_front_chunk();
+extern "C" uint32_t md_piece_state_bytes();
+static const unsigned long long kChunkPositions = md_front_chunk();
+static const unsigned long long kSlotPad = 64 + kChunkPositions - 1;
 extern "C" size_t md_front_small_bytes(uint32_t n);
 extern "C" size_t md_front_big_bytes(uint64_t positions);
 extern "C" void md_front_carve(void *small_ws, void *big_ws, uint32_t n, uint64_t positions, md_front *f);
@@ -664,7 +665,7 @@ static int grow(md_ctx *ctx, void **buf, size_t *have, size_t need, const char *
   return MD_OK;
 }
 
-static const size_t kPieceStateBytes = 12288;  // deflate_common.hpp kPieceState (checked against sizeof there)
+static const size_t kPieceStateBytes = md_piece_state_bytes();  // deflate_common.hpp kPieceState (checked against sizeof there)
 // One piece of one stream (md_i_piece_run below): device pointers of what differs from a batch of whole streams.
 struct PieceArgs {
   const uint64_t *d_front_len;  // length of the text the launch holds, n - w0 (d_in_len is the absolute length n)
@@ -682,6 +683,8 @@ static int deflate_launch(md_ctx *ctx, int format, int level, int queue_len, int
                           uint64_t *d_out_len, int32_t *d_status, uint32_t *d_checksum, uint32_t *d_hist, size_t total_in,
                           const PieceArgs *pa = nullptr) {
   int grc_ = MD_OK;
+  // (the Lz77-alone / encode-alone / scripted drivers leave the kernel before it saves a piece's state)
+  if (pa && driver >= 3) return fail(ctx, MD_E_INVALID_ARGUMENT, "a stream in pieces needs one of the three public drivers");
   if (!pa) grc_ = grow(ctx, &ctx->ws, &ctx->ws_bytes, md_deflate_queue_bytes((uint32_t)n, queue_len), "hipMalloc(deflate command queues)");
   if (grc_ != MD_OK) return grc_;
   const uint64_t *d_front_len = pa ? pa->d_front_len : d_in_len;  // (a piece: the front kernels see [w0, n) as a stream)
@@ -696,7 +699,7 @@ static int deflate_launch(md_ctx *ctx, int format, int level, int queue_len, int
   if (matcher_runs && total_in != 0) {
     // slot <= len + 64 + (chunk - 1) positions and <= len / chunk + 2 chunks per stream
     positions = (uint64_t)total_in + kSlotPad * n;
-    const uint64_t c64 = (uint64_t)total_in / (MD_PGM * 64) + 2ull * n;
+    const uint64_t c64 = (uint64_t)total_in / kChunkPositions + 2ull * n;
     if (c64 > 0x7fffffffull) return fail(ctx, MD_E_INVALID_ARGUMENT, "batch too large for one launch");
     chunks = (uint32_t)c64;
     grc_ = grow(ctx, &ctx->fbig, &ctx->fbig_bytes, md_front_big_bytes(positions), "hipMalloc(deflate front workspace)");
@@ -747,7 +750,8 @@ static int deflate_launch(md_ctx *ctx, int format, int level, int queue_len, int
     const int orc = order_scratch(ctx, n);
     if (orc != MD_OK) return orc;
     order = ctx->order;
-    int oe = md_launch_stream_order((uint32_t)n, d_in_len, order, ctx->stream);
+    // (a slice of a batch: by what the slice brings, not by the absolute length so far - idle streams bring nothing)
+    int oe = md_launch_stream_order((uint32_t)n, d_front_len, order, ctx->stream);
     if (oe != 0) return fail(ctx, MD_E_HIP, "launch order kernel", (hipError_t)oe);
   }
   if (matcher_runs && chunks != 0) {
@@ -774,7 +778,7 @@ static int def_ns_launch(md_ctx *ctx, int format, int level, size_t n, const uin
   const bool matcher_runs = level >= 1 && level <= 4;
   if (matcher_runs && total_in != 0) {
     positions = (uint64_t)total_in + kSlotPad * n;
-    const uint64_t c64 = (uint64_t)total_in / (MD_PGM * 64) + 2ull * n;
+    const uint64_t c64 = (uint64_t)total_in / kChunkPositions + 2ull * n;
     if (c64 > 0x7fffffffull) return fail(ctx, MD_E_INVALID_ARGUMENT, "batch too large for one launch");
     chunks = (uint32_t)c64;
     grc_ = grow(ctx, &ctx->fbig, &ctx->fbig_bytes, md_front_big_bytes(positions), "hipMalloc(deflate front workspace)");
@@ -997,7 +1001,7 @@ static int deflate_in_slices(md_ctx *ctx, int format, const md_deflate_params &q
 // slice of every stream at once would still be too much), results back to the caller's device arrays
 static int deflate_capped(md_ctx *ctx, int format, const md_deflate_params &q, size_t n, const uint8_t *d_in, const uint64_t *d_in_off,
                           const uint64_t *d_in_len, uint8_t *d_out, const uint64_t *d_out_off, const uint64_t *d_out_cap,
-                          uint64_t *d_out_len, int32_t *d_status, uint32_t *d_checksum, bool *whole) {
+                          uint64_t *d_out_len, int32_t *d_status, uint32_t *d_checksum, bool *whole, uint64_t *total_out) {
   std::vector<uint64_t> h(4 * n);
   uint64_t *in_off = h.data(), *in_len = in_off + n, *out_off = in_len + n, *out_cap = out_off + n;
   HIP_TRY(ctx, hipMemcpyAsync(in_off, d_in_off, n * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -1012,6 +1016,7 @@ static int deflate_capped(md_ctx *ctx, int format, const md_deflate_params &q, s
     if (in_len[i] > longest) longest = in_len[i];
   }
   (void)longest;
+  *total_out = total ? total : 1;  // what the lengths add up to: the one launch sizes its workspace from this, not from the hint
   *whole = md_front_big_bytes(total + kSlotPad * n) <= ctx->front_cap_bytes;
   if (*whole) return MD_OK;  // (fits after all: the caller's one launch)
   std::vector<uint64_t> r_len(n);
@@ -1095,8 +1100,12 @@ int md_deflate_batch_device(md_ctx *ctx, int format, const md_deflate_params *pa
     if (ctx->front_cap_bytes && max_chain != 0 &&
         (!q.total_in_bytes || md_front_big_bytes((uint64_t)q.total_in_bytes + kSlotPad * n) > ctx->front_cap_bytes)) {
       bool whole = true;
-      rc = deflate_capped(ctx, format, q, n, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap, d_out_len, d_status, d_checksum, &whole);
+      uint64_t total = 0;
+      rc = deflate_capped(ctx, format, q, n, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap, d_out_len, d_status, d_checksum, &whole, &total);
       if (rc != MD_OK || !whole) return rc;
+      // the batch fits the cap after all: one launch, sized from the sum just read back (no second read-back in
+      // deflate_launch, and a loose hint cannot make the workspace grow above the cap)
+      q.total_in_bytes = (size_t)total;
     }
   }
   return deflate_launch(ctx, format, q.level, q.queue_len, q.driver, q.dynamic, q.matcher, q.gz_header, n, d_in, d_in_off,

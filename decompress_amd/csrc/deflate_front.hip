@@ -420,6 +420,9 @@ extern "C" size_t md_front_small_bytes(uint32_t n) {
   const size_t k = n;
   return up256((k + 1) * 8) + up256((k + 1) * 4) + up256(k * 4) + up256(k * 8) + 256;
 }
+// the kernels' constants the host glue sizes its buffers with (capi.cpp has no copy of them)
+extern "C" uint32_t md_front_chunk() { return md::defl::kChunk; }              // positions per wavefront of the match kernel
+extern "C" uint32_t md_piece_state_bytes() { return md::defl::kPieceState; }   // bytes of a stream's state slot (struct Piece)
 extern "C" size_t md_front_big_bytes(uint64_t positions) {
   const size_t np = (size_t)positions;
   return up256(np * 4) + up256(np) + 2 * up256(np * 4);

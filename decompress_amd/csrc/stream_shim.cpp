@@ -544,6 +544,9 @@ int md_def_src(md_def_stream *s, const uint8_t *buf, size_t off, size_t len) {
     return MD_OK;
   }
   if (len > kSrcMax) return MD_E_INVALID_ARGUMENT;  // (one launch takes what has arrived: positions within it are 32-bit)
+  // ... and so is the text that waits for md_def_encode: src calls without an encode in between must not pile up more than
+  // one launch can take (mdeflate.h: call md_def_encode between sources; it launches what has arrived)
+  if ((s->w0 + s->text.size()) - s->launched + len > kSrcMax) return MD_E_INVALID_ARGUMENT;
   s->text.insert(s->text.end(), buf + off, buf + off + len);
   s->checksum = s->format == MD_FORMAT_GZIP ? crc32_update(s->checksum, buf + off, len) : adler32_update(s->checksum, buf + off, len);
   return MD_OK;

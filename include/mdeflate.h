@@ -379,7 +379,8 @@ int md_de_inf_continue_host(md_ctx *ctx, const uint8_t *src, size_t src_len, uns
  * De.Lz77 would (lookahead under 262 and nothing left of the piece), and the piece's output is handed out through
  * `Flush steps while more input arrives.  Host and device each hold the last 64 KiB of the stream and the piece in
  * flight; a stream may be of any length (positions are rebased inside, gzip's ISIZE wraps at 2^32 as lib/gz.ml's);
- * one md_def_src call takes at most 1 GiB.  The bytes are those of the reference handed the input in the same pieces
+ * one md_def_src call takes at most 1 GiB, and so does what md_def_src calls have handed over since the last md_def_encode
+ * (MD_E_INVALID_ARGUMENT beyond that: call md_def_encode between sources - it launches what has arrived).  The bytes are those of the reference handed the input in the same pieces
  * (fill_window's slide depends on how much each fill finds; for whole streams and for pieces the oracle agrees).  The decoder
  * (DEFLATE, ZLIB, GZip) works in pieces: once md_inf_chunk_bytes (default 1 MiB) of input are buffered
  * it decodes up to the last block boundary inside them (md_de_inf_continue_host), hands that output out through
