@@ -119,6 +119,7 @@ def parse(argv=None):
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-deflate", action="store_true", help="skip the deflate leg (config 3)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the gzip (config 4) and LZO (config 5) legs")
+    ap.add_argument("--no-host-path", action="store_true", help="skip the host-buffer legs (md_*_batch_host end to end, H2D / D2H alone)")
     ap.add_argument("--no-text-leg", action="store_true", help="skip the extra inflate measurement on round 1's workload")
     ap.add_argument("--deflate-streams", type=int, default=4096)
     ap.add_argument("--deflate-kib", type=int, default=1024)
@@ -240,6 +241,91 @@ def cpu_baseline_deflate(bufs, level, budget_s):
                       "thread on %d threads%s" % (level, done >> 20, len(bufs), cores, quota)}
 
 
+def _copy_ms(torch, dst, src, dev, reps=3):
+    """milliseconds of one dst.copy_(src) between a pinned host tensor and a device tensor (HIP events, best of reps)"""
+    best = None
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(dev)
+        e0.record()
+        dst.copy_(src, non_blocking=True)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        ms = e0.elapsed_time(e1)
+        best = ms if best is None or ms < best else best
+    return best
+
+
+def host_path_inflate(eng, dev, blob, in_off, in_len, out_off, out_cap, out_bytes, d_out_ref, kernel_ms, reps=3):
+    """the caller with HOST buffers (the reference's are bigarrays, lib/de.mli:93-106) - md_inflate_batch_host
+    end to end on pinned buffers, beside the copies and the kernel timed alone.  d_out_ref: the device result of the
+    resident path, to compare with."""
+    import torch
+    import decompress_amd
+    h_in = eng.host_buffer(blob.nbytes)
+    h_in[:] = blob
+    h_out = eng.host_buffer(out_bytes)
+    t_in, t_out = torch.from_numpy(h_in), torch.from_numpy(h_out)   # (pinned: md_host_alloc)
+    d_a = torch.empty(blob.nbytes, dtype=torch.uint8, device=dev)
+    h2d_ms = _copy_ms(torch, d_a, t_in, dev)
+    d2h_ms = _copy_ms(torch, t_out, d_out_ref[:out_bytes], dev)
+    del d_a
+    h_out[:] = 0
+    best, res = None, None
+    for _ in range(reps + 1):   # (the first call grows the context's device copies)
+        t0 = time.perf_counter()
+        res = eng.inflate_batch_host(decompress_amd.FORMAT_ZLIB, h_in, in_off, in_len, h_out, out_off, out_cap)
+        dt = (time.perf_counter() - t0) * 1e3
+        best = dt if best is None or dt < best else best
+    ok = bool((res[2] == 0).all()) and bool(torch.equal(torch.from_numpy(h_out).to(dev), d_out_ref[:out_bytes]))
+    eng.set_option("host_pipeline_slices", 1)
+    t0 = time.perf_counter()
+    eng.inflate_batch_host(decompress_amd.FORMAT_ZLIB, h_in, in_off, in_len, h_out, out_off, out_cap)
+    serial = (time.perf_counter() - t0) * 1e3
+    eng.set_option("host_pipeline_slices", 16)
+    eng.set_option("release_workspace", 0)
+    return {"entry_point": "md_inflate_batch_host, pinned host buffers (md_host_alloc), slices of streams pipelined on three HIP streams",
+            "end_to_end_ms": round(best, 3), "h2d_ms": round(h2d_ms, 3), "kernel_ms": round(kernel_ms, 3), "d2h_ms": round(d2h_ms, 3),
+            "over_max_copy": round(best / max(h2d_ms, d2h_ms), 3), "one_slice_ms": round(serial, 3),
+            "h2d_gbs": round(blob.nbytes / h2d_ms / 1e6, 1), "d2h_gbs": round(out_bytes / d2h_ms / 1e6, 1),
+            "mib_per_s": round(out_bytes / 2**20 / (best * 1e-3), 1), "parity_ok": ok}
+
+
+
+def host_path_deflate(eng, dev, d_in, n, nb, kernel_ms, d_out_ref, ref_len, ref_cap):
+    """md_deflate_batch_host on pinned buffers for the C3 batch, beside the copies alone.  Output room per buffer: the
+    input size + 8 KiB (the batch compresses to 0.83), so that the copy-out moves about what was produced."""
+    import torch
+    import decompress_amd
+    cap = nb + 8192
+    h_in = eng.host_buffer(n * nb)
+    t_in = torch.from_numpy(h_in)
+    t_in.copy_(d_in)
+    h_out = eng.host_buffer(n * cap)
+    t_out = torch.from_numpy(h_out)
+    d_a = torch.empty(n * nb, dtype=torch.uint8, device=dev)
+    h2d_ms = _copy_ms(torch, d_a, t_in, dev, reps=2)
+    d2h_ms = _copy_ms(torch, t_out, d_a[: min(n * nb, n * cap)], dev, reps=2) * (n * cap) / min(n * nb, n * cap)
+    del d_a
+    off = np.arange(n, dtype=np.uint64)
+    best, res = None, None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        res = eng.deflate_batch_host(decompress_amd.FORMAT_ZLIB, h_in, off * nb, np.full(n, nb, dtype=np.uint64), h_out, off * cap,
+                                     np.full(n, cap, dtype=np.uint64), level=6, queue=4096)
+        dt = (time.perf_counter() - t0) * 1e3
+        best = dt if best is None or dt < best else best
+    ok = bool((res[1] == 0).all()) and bool((res[0] == ref_len.cpu().numpy().astype(np.uint64)).all())
+    for k in range(0, n, max(1, n // 16)):  # bytes against the resident path's
+        m = int(res[0][k])
+        ok = ok and bool(torch.equal(torch.from_numpy(h_out[k * cap:k * cap + m].copy()).to(dev), d_out_ref[k * ref_cap:k * ref_cap + m]))
+    eng.set_option("release_workspace", 0)
+    return {"entry_point": "md_deflate_batch_host, pinned host buffers, output room = input + 8 KiB per buffer",
+            "end_to_end_ms": round(best, 3), "h2d_ms": round(h2d_ms, 3), "kernel_ms": round(kernel_ms, 3), "d2h_ms": round(d2h_ms, 3),
+            "sum_ms": round(h2d_ms + kernel_ms + d2h_ms, 3), "mib_per_s": round(n * nb / 2**20 / (best * 1e-3), 1), "parity_ok": ok}
+
+
+
 def deflate_leg(args, eng, dev, rank, world, dist, fence):
     """BASELINE config 3: n x 1 MiB printable-ASCII buffers, level 6, queue 4096, Zl driver."""
     import torch
@@ -324,6 +410,11 @@ def deflate_leg(args, eng, dev, rank, world, dist, fence):
                      "kernel_ms": round(kernel_ms, 3),
                      "algorithmic_bytes_per_launch": algo},
     }
+    if world == 1 and not args.no_host_path:
+        try:
+            leg["host_path"] = host_path_deflate(eng, dev, d_in, n, nb, kernel_ms, d_out, out_len, cap)
+        except (MemoryError, RuntimeError) as e:
+            leg["host_path"] = {"error": str(e)[:200]}
     if world == 1 and not args.no_cpu_baseline and sample:
         leg["cpu_baseline"] = cpu_baseline_deflate(sample, 6, args.cpu_seconds)
     return leg
@@ -684,6 +775,12 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_inflate(streams, nbytes, args.cpu_seconds)
+    if world == 1 and not args.no_host_path:
+        # the same batch from HOST buffers (outside the timed region of `value`, which stays the resident-buffer figure)
+        try:
+            line["host_path"] = host_path_inflate(eng, dev, blob, in_off, in_len, out_off, out_cap, n * nbytes, d_out, kernel_ms)
+        except (MemoryError, RuntimeError) as e:
+            line["host_path"] = {"error": str(e)[:200]}
     if not args.no_text_leg and world == 1 and (n, nbytes) == (4096, 262144):
         # the same kernel on round 1's stand-in workload (every stream seeded word text, 512 distinct), so that
         # BENCH_r01's 10.99 ms/step has a like-for-like successor; outside the timed region of `value`

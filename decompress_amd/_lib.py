@@ -48,6 +48,8 @@ SYMBOLS = [
     ("md_destroy", None, [c_vp]),
     ("md_synchronize", ctypes.c_int, [c_vp]),
     ("md_set_option", ctypes.c_int, [c_vp, ctypes.c_char_p, ctypes.c_int]),
+    ("md_host_alloc", c_vp, [c_vp, c_sz]),
+    ("md_host_free", None, [c_vp, c_vp]),
     ("md_timing_begin", ctypes.c_int, [c_vp]),
     ("md_timing_end", ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_float)]),
     ("md_inflate_batch_device", ctypes.c_int,

@@ -99,6 +99,13 @@ struct md_ctx {
   size_t slice_desc_bytes = 0, slice_state_bytes = 0;
   uint32_t *order = nullptr;  // inflate: launch order of a large batch (n words)
   size_t order_words = 0;
+  // the host-buffer entry points (md_*_batch_host): device copies of the caller's blobs and descriptors, grow-only, and
+  // the two copy streams that run next to the context's stream (copy-in of slice k + 1 and copy-out of slice k - 1 under
+  // the kernels of slice k)
+  void *host_in = nullptr, *host_out = nullptr, *host_desc = nullptr;
+  size_t host_in_bytes = 0, host_out_bytes = 0, host_desc_bytes = 0;
+  hipStream_t s_in = nullptr, s_out = nullptr;
+  int host_slices_max = 16;  // md_set_option "host_pipeline_slices": 1 = copy-in / kernels / copy-out one after the other
   std::string err;
 };
 
@@ -276,6 +283,11 @@ void md_destroy(md_ctx *ctx) {
   if (ctx->gz_tmp) hipFree(ctx->gz_tmp);
   if (ctx->lzo_ws) hipFree(ctx->lzo_ws);
   if (ctx->gz_hdr_dev) hipFree(ctx->gz_hdr_dev);
+  if (ctx->host_in) hipFree(ctx->host_in);
+  if (ctx->host_out) hipFree(ctx->host_out);
+  if (ctx->host_desc) hipFree(ctx->host_desc);
+  if (ctx->s_in) hipStreamDestroy(ctx->s_in);
+  if (ctx->s_out) hipStreamDestroy(ctx->s_out);
   if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -301,6 +313,22 @@ int md_timing_end(md_ctx *ctx, float *ms) {
   HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
   HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
   return MD_OK;
+}
+
+void *md_host_alloc(md_ctx *ctx, size_t bytes) {
+  if (!ctx) return nullptr;
+  DeviceGuard guard(ctx->device);
+  void *p = nullptr;
+  if (!guard.ok || hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+    fail(ctx, MD_E_OUT_OF_MEMORY, "hipHostMalloc");
+    return nullptr;
+  }
+  return p;
+}
+void md_host_free(md_ctx *ctx, void *p) {
+  if (!ctx || !p) return;
+  DeviceGuard guard(ctx->device);
+  hipHostFree(p);
 }
 
 int md_set_option(md_ctx *ctx, const char *key, int value) {
@@ -334,9 +362,10 @@ int md_set_option(md_ctx *ctx, const char *key, int value) {
     MD_ON_DEVICE(ctx);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     void **bufs[] = {&ctx->ws, &ctx->fsmall, &ctx->fbig, (void **)&ctx->order, &ctx->cont_in, &ctx->cont_out, &ctx->cont_desc,
-                     &ctx->slice_desc, &ctx->slice_state};
+                     &ctx->slice_desc, &ctx->slice_state, &ctx->host_in, &ctx->host_out, &ctx->host_desc};
     size_t *sizes[] = {&ctx->ws_bytes, &ctx->fsmall_bytes, &ctx->fbig_bytes, &ctx->order_words, &ctx->cont_in_bytes,
-                       &ctx->cont_out_bytes, &ctx->cont_desc_bytes, &ctx->slice_desc_bytes, &ctx->slice_state_bytes};
+                       &ctx->cont_out_bytes, &ctx->cont_desc_bytes, &ctx->slice_desc_bytes, &ctx->slice_state_bytes,
+                       &ctx->host_in_bytes, &ctx->host_out_bytes, &ctx->host_desc_bytes};
     for (size_t i = 0; i < sizeof bufs / sizeof bufs[0]; i++) {
       if (*bufs[i]) hipFree(*bufs[i]);
       *bufs[i] = nullptr;
@@ -346,6 +375,11 @@ int md_set_option(md_ctx *ctx, const char *key, int value) {
   }
   if (!strcmp(key, "deflate_test_flags")) {
     ctx->test_flags = value;
+    return MD_OK;
+  }
+  if (!strcmp(key, "host_pipeline_slices")) {  // md_*_batch_host: slices of streams in flight (1 = no overlap of copies and kernels)
+    if (value < 1 || value > 64) return fail(ctx, MD_E_INVALID_ARGUMENT, "host_pipeline_slices is 1 .. 64");
+    ctx->host_slices_max = value;
     return MD_OK;
   }
   if (!strcmp(key, "debug_known_bounds")) {  // measurement builds only (-DMD_DEBUG_KNOWN_BOUNDS): mode | streams << 4
@@ -454,6 +488,114 @@ struct DevBuf {
 };
 }  // namespace
 
+// ---- host buffers in, host buffers out (the reference's callers own host bigarrays, lib/de.mli:93-106) ----------------
+// The batch goes through the device in SLICES of consecutive streams: the copy-in of slice k + 1 (stream s_in) and the
+// copy-out of slice k - 1 (stream s_out) run under the kernels of slice k (the context's stream); events order the three.
+// A slice copies the byte range its streams span in the caller's blob (ranges of different slices may overlap or lie in
+// any order: a byte copied twice is copied with the same value, and an output range is final when its slice's kernels
+// are).  With pinned host buffers (hipHostMalloc / hipHostRegister) the copies are DMA transfers and really overlap;
+// pageable buffers go through the runtime's staging and mostly do not.  The device copies of the blobs are the context's,
+// grow-only (md_set_option "release_workspace" gives them back).
+static int grow(md_ctx *ctx, void **buf, size_t *have, size_t need, const char *what);
+namespace {
+struct HostSlice {
+  size_t i0, i1;
+  uint64_t in_lo, in_hi, out_lo, out_hi;
+};
+// slices of about equal bytes (input + output room), at least min_streams streams each, at most max_slices
+std::vector<HostSlice> host_slices(size_t n, const uint64_t *in_off, const uint64_t *in_len, const uint64_t *out_off,
+                                   const uint64_t *out_cap, size_t min_streams, size_t max_slices, uint64_t in_bytes, uint64_t out_bytes) {
+  uint64_t total = 0;
+  for (size_t i = 0; i < n; i++) total += in_len[i] + out_cap[i];
+  size_t want = (size_t)(total / ((uint64_t)64 << 20));
+  if (want > max_slices) want = max_slices;
+  if (min_streams && want > n / min_streams) want = n / min_streams;
+  if (want < 1) want = 1;
+  std::vector<HostSlice> v;
+  uint64_t acc = 0, span = 0;
+  size_t i0 = 0;
+  for (size_t k = 0; k < want; k++) {
+    const uint64_t upto = total / want * (k + 1);
+    size_t i1 = i0;
+    while (i1 < n && (k + 1 == want || acc < upto)) {
+      acc += in_len[i1] + out_cap[i1];
+      i1++;
+    }
+    if (i1 == i0) continue;
+    HostSlice sl{i0, i1, ~0ull, 0, ~0ull, 0};
+    for (size_t i = i0; i < i1; i++) {
+      if (in_len[i]) {
+        sl.in_lo = in_off[i] < sl.in_lo ? in_off[i] : sl.in_lo;
+        sl.in_hi = in_off[i] + in_len[i] > sl.in_hi ? in_off[i] + in_len[i] : sl.in_hi;
+      }
+      if (out_cap[i]) {
+        sl.out_lo = out_off[i] < sl.out_lo ? out_off[i] : sl.out_lo;
+        sl.out_hi = out_off[i] + out_cap[i] > sl.out_hi ? out_off[i] + out_cap[i] : sl.out_hi;
+      }
+    }
+    if (sl.in_hi <= sl.in_lo) sl.in_lo = sl.in_hi = 0;
+    if (sl.out_hi <= sl.out_lo) sl.out_lo = sl.out_hi = 0;
+    span += (sl.in_hi - sl.in_lo) + (sl.out_hi - sl.out_lo);
+    v.push_back(sl);
+    i0 = i1;
+  }
+  // a layout whose slices span much more than the blobs hold (streams scattered across the blob): one slice, whole blobs
+  if (v.size() <= 1 || span > in_bytes + out_bytes + (in_bytes + out_bytes) / 4) {
+    v.clear();
+    v.push_back(HostSlice{0, n, 0, in_bytes, 0, out_bytes});
+  }
+  return v;
+}
+struct EventList {
+  std::vector<hipEvent_t> ev;
+  ~EventList() {
+    for (hipEvent_t e : ev) hipEventDestroy(e);
+  }
+  hipEvent_t make() {
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    ev.push_back(e);
+    return e;
+  }
+};
+}  // namespace
+
+// `launch(i0, count)` enqueues the device entry point for streams [i0, i0 + count) on ctx->stream
+extern "C++" {
+template <class Launch>
+static int host_pipeline(md_ctx *ctx, const std::vector<HostSlice> &sl, const uint8_t *h_in, uint8_t *d_in, uint8_t *h_out, uint8_t *d_out,
+                         Launch launch) {
+  if (!ctx->s_in && hipStreamCreateWithFlags(&ctx->s_in, hipStreamNonBlocking) != hipSuccess) return fail(ctx, MD_E_HIP, "hipStreamCreate");
+  if (!ctx->s_out && hipStreamCreateWithFlags(&ctx->s_out, hipStreamNonBlocking) != hipSuccess) return fail(ctx, MD_E_HIP, "hipStreamCreate");
+  EventList evs;
+  // (whatever the caller queued on the context's stream before this call comes first, also for the copy streams)
+  hipEvent_t e0 = evs.make();
+  if (!e0) return fail(ctx, MD_E_HIP, "hipEventCreate");
+  HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
+  HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_in, e0, 0));
+  int rc = MD_OK;
+  for (size_t k = 0; k < sl.size() && rc == MD_OK; k++) {
+    hipEvent_t e_in = evs.make(), e_k = evs.make();
+    if (!e_in || !e_k) return fail(ctx, MD_E_HIP, "hipEventCreate");
+    if (sl[k].in_hi > sl[k].in_lo)
+      HIP_TRY(ctx, hipMemcpyAsync(d_in + sl[k].in_lo, h_in + sl[k].in_lo, sl[k].in_hi - sl[k].in_lo, hipMemcpyHostToDevice, ctx->s_in));
+    HIP_TRY(ctx, hipEventRecord(e_in, ctx->s_in));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, e_in, 0));
+    rc = launch(sl[k].i0, sl[k].i1 - sl[k].i0);
+    if (rc != MD_OK) break;
+    HIP_TRY(ctx, hipEventRecord(e_k, ctx->stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_out, e_k, 0));
+    if (sl[k].out_hi > sl[k].out_lo)
+      HIP_TRY(ctx, hipMemcpyAsync(h_out + sl[k].out_lo, d_out + sl[k].out_lo, sl[k].out_hi - sl[k].out_lo, hipMemcpyDeviceToHost, ctx->s_out));
+  }
+  // everything in flight ends before the call returns (also after an error: the buffers are the caller's)
+  hipError_t a = hipStreamSynchronize(ctx->s_in), b2 = hipStreamSynchronize(ctx->stream), c = hipStreamSynchronize(ctx->s_out);
+  if (rc != MD_OK) return rc;
+  if (a != hipSuccess || b2 != hipSuccess || c != hipSuccess) return fail(ctx, MD_E_HIP, "host pipeline", a != hipSuccess ? a : b2 != hipSuccess ? b2 : c);
+  return MD_OK;
+}
+}  // extern "C++"
+
 int md_inflate_batch_host(md_ctx *ctx, int format, size_t n, const uint8_t *h_in, size_t in_bytes,
                           const uint64_t *in_off, const uint64_t *in_len, uint8_t *h_out,
                           size_t out_bytes, const uint64_t *out_off, const uint64_t *out_cap,
@@ -471,25 +613,27 @@ int md_inflate_batch_host(md_ctx *ctx, int format, size_t n, const uint8_t *h_in
       return fail(ctx, MD_E_INVALID_ARGUMENT, "output range out of bounds");
   }
   MD_ON_DEVICE(ctx);
-  DevBuf din, dout, ddesc;
   const size_t desc_words = 6 * n;  // in_off in_len out_off out_cap out_len consumed
-  if (din.alloc(in_bytes + 8) != hipSuccess || dout.alloc(out_bytes) != hipSuccess ||
-      ddesc.alloc(desc_words * 8 + n * 8) != hipSuccess)
-    return fail(ctx, MD_E_OUT_OF_MEMORY, "hipMalloc");
-  uint64_t *d64 = (uint64_t *)ddesc.p;
+  int grc_ = grow(ctx, &ctx->host_in, &ctx->host_in_bytes, in_bytes + 64, "hipMalloc(host path input)");
+  if (grc_ == MD_OK) grc_ = grow(ctx, &ctx->host_out, &ctx->host_out_bytes, out_bytes + 64, "hipMalloc(host path output)");
+  if (grc_ == MD_OK) grc_ = grow(ctx, &ctx->host_desc, &ctx->host_desc_bytes, desc_words * 8 + n * 8, "hipMalloc(host path descriptors)");
+  if (grc_ != MD_OK) return grc_;
+  uint8_t *din = (uint8_t *)ctx->host_in, *dout = (uint8_t *)ctx->host_out;
+  uint64_t *d64 = (uint64_t *)ctx->host_desc;
   int32_t *dstatus = (int32_t *)(d64 + desc_words);
   uint32_t *dsum = (uint32_t *)(dstatus + n);
   hipStream_t st = ctx->stream;
-  HIP_TRY(ctx, hipMemcpyAsync(din.p, h_in, in_bytes, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(d64 + 0 * n, in_off, n * 8, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(d64 + 1 * n, in_len, n * 8, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(d64 + 2 * n, out_off, n * 8, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(d64 + 3 * n, out_cap, n * 8, hipMemcpyHostToDevice, st));
-  int rc = md_inflate_batch_device(ctx, format, n, (const uint8_t *)din.p, d64, d64 + n,
-                                   (uint8_t *)dout.p, d64 + 2 * n, d64 + 3 * n, d64 + 4 * n,
-                                   d64 + 5 * n, dstatus, dsum);
+  // a slice should still fill the chip once (8 streams per CU): 2 048 streams at least
+  const std::vector<HostSlice> sl = host_slices(n, in_off, in_len, out_off, out_cap, 2048, (size_t)ctx->host_slices_max, in_bytes, out_bytes);
+  int rc = host_pipeline(ctx, sl, h_in, din, h_out, dout, [&](size_t i0, size_t cnt) {
+    return md_inflate_batch_device(ctx, format, cnt, din, d64 + i0, d64 + n + i0, dout, d64 + 2 * n + i0, d64 + 3 * n + i0,
+                                   d64 + 4 * n + i0, d64 + 5 * n + i0, dstatus + i0, dsum + i0);
+  });
   if (rc != MD_OK) return rc;
-  HIP_TRY(ctx, hipMemcpyAsync(h_out, dout.p, out_bytes, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipMemcpyAsync(out_len, d64 + 4 * n, n * 8, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipMemcpyAsync(consumed, d64 + 5 * n, n * 8, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipMemcpyAsync(status, dstatus, n * 4, hipMemcpyDeviceToHost, st));
@@ -528,8 +672,6 @@ int md_inflate_continue_batch_device(md_ctx *ctx, size_t n, const uint8_t *d_in,
 // One piece of a raw DEFLATE stream that is decoded as it arrives (mdeflate.h): the inflate kernel on one stream with
 // a starting bit, the window in front of the output buffer and the checksum state handed in, and the last block
 // boundary inside the piece handed back.
-static int grow(md_ctx *ctx, void **buf, size_t *have, size_t need, const char *what);
-
 int md_de_inf_continue_host(md_ctx *ctx, const uint8_t *src, size_t src_len, unsigned start_bit, uint8_t *dst, size_t hist_len,
                             size_t dst_cap, uint32_t adler_in, unsigned flags, size_t *dst_len, int *status,
                             md_inf_resume *resume) {
@@ -1214,27 +1356,31 @@ int md_deflate_batch_host(md_ctx *ctx, int format, const md_deflate_params *para
       return fail(ctx, MD_E_INVALID_ARGUMENT, "output range out of bounds");
   }
   MD_ON_DEVICE(ctx);
-  DevBuf din, dout, ddesc;
-  if (din.alloc(in_bytes + 8) != hipSuccess || dout.alloc(out_bytes) != hipSuccess ||
-      ddesc.alloc(5 * n * 8 + n * 8) != hipSuccess)
-    return fail(ctx, MD_E_OUT_OF_MEMORY, "hipMalloc");
-  uint64_t *d64 = (uint64_t *)ddesc.p;
+  int grc_ = grow(ctx, &ctx->host_in, &ctx->host_in_bytes, in_bytes + 64, "hipMalloc(host path input)");
+  if (grc_ == MD_OK) grc_ = grow(ctx, &ctx->host_out, &ctx->host_out_bytes, out_bytes + 64, "hipMalloc(host path output)");
+  if (grc_ == MD_OK) grc_ = grow(ctx, &ctx->host_desc, &ctx->host_desc_bytes, 5 * n * 8 + n * 8, "hipMalloc(host path descriptors)");
+  if (grc_ != MD_OK) return grc_;
+  uint8_t *din = (uint8_t *)ctx->host_in, *dout = (uint8_t *)ctx->host_out;
+  uint64_t *d64 = (uint64_t *)ctx->host_desc;
   int32_t *dstatus = (int32_t *)(d64 + 5 * n);
   uint32_t *dsum = (uint32_t *)(dstatus + n);
   hipStream_t st = ctx->stream;
-  HIP_TRY(ctx, hipMemcpyAsync(din.p, h_in, in_bytes, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(d64 + 0 * n, in_off, n * 8, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(d64 + 1 * n, in_len, n * 8, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(d64 + 2 * n, out_off, n * 8, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(d64 + 3 * n, out_cap, n * 8, hipMemcpyHostToDevice, st));
-  md_deflate_params hp = *params;
-  hp.total_in_bytes = 0;
-  for (size_t i = 0; i < n; i++) hp.total_in_bytes += (size_t)in_len[i];
-  if (hp.total_in_bytes == 0) hp.total_in_bytes = 1;  // all empty: still no read-back
-  int rc = md_deflate_batch_device(ctx, format, &hp, n, (const uint8_t *)din.p, d64, d64 + n, (uint8_t *)dout.p,
-                                   d64 + 2 * n, d64 + 3 * n, d64 + 4 * n, dstatus, dsum);
+  // the sequential kernel holds 16 streams per CU: a slice of fewer than 4 096 streams leaves the chip part empty for as
+  // long as a stream takes, so a batch is only cut where every slice still has that many
+  const std::vector<HostSlice> sl = host_slices(n, in_off, in_len, out_off, out_cap, 4096, (size_t)ctx->host_slices_max, in_bytes, out_bytes);
+  int rc = host_pipeline(ctx, sl, h_in, din, h_out, dout, [&](size_t i0, size_t cnt) {
+    md_deflate_params hp = *params;
+    hp.total_in_bytes = 0;
+    for (size_t i = i0; i < i0 + cnt; i++) hp.total_in_bytes += (size_t)in_len[i];
+    if (hp.total_in_bytes == 0) hp.total_in_bytes = 1;  // all empty: still no read-back
+    return md_deflate_batch_device(ctx, format, &hp, cnt, din, d64 + i0, d64 + n + i0, dout, d64 + 2 * n + i0, d64 + 3 * n + i0,
+                                   d64 + 4 * n + i0, dstatus + i0, dsum + i0);
+  });
   if (rc != MD_OK) return rc;
-  HIP_TRY(ctx, hipMemcpyAsync(h_out, dout.p, out_bytes, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipMemcpyAsync(out_len, d64 + 4 * n, n * 8, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipMemcpyAsync(status, dstatus, n * 4, hipMemcpyDeviceToHost, st));
   if (checksum) HIP_TRY(ctx, hipMemcpyAsync(checksum, dsum, n * 4, hipMemcpyDeviceToHost, st));

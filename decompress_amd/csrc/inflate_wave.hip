@@ -108,7 +108,6 @@ struct Smem {  // the kernel's only LDS object: it sits at LDS address 0
   uint32_t mrec[RMAX];                     // the round's match records in stream order
   uint16_t mpos[RMAX];                     // their staging positions
   alignas(16) uint8_t stage[STAGE + 16];   // one round of output; header scratch while a header is parsed
-  uint32_t pend[STAGE / 32 + 2];           // bit per staging byte: still to be produced by a near match
   uint16_t list[RMAX];                     // the round's near matches (indices into mrec), in stream order
   Mail mail;
 };
@@ -624,6 +623,46 @@ __device__ __forceinline__ void sync_pass(const lds_u32 *win, const lds_u32 *lut
   }
 }
 
+// The speculative pass of a round (round 5): lane i walks from a run-in ahead of its zone - somewhere inside a token, most
+// likely - to the first token boundary at or beyond the zone's end, like sync_pass; on the way it notes `mid`, the first
+// token boundary at or beyond the zone's START (what lane i - 1's walk will report as its end if both walks are on the
+// stream's real chain of tokens), and counts what the tokens from there on produce.  A lane whose `mid` equals its left
+// neighbour's end needs no second walk: from the same boundary the decode is the same.  So the counting pass that every
+// lane went through after the speculative one is gone; only the lanes that had not synchronised by their zone's start
+// (5-13 % of them) walk again.  (0xffffffff = the walk ended before it saw such a boundary.)  `known`: the walk starts on
+// a boundary that is known to be real (lane 0).
+__device__ __forceinline__ void sync_pass_mid(const lds_u32 *win, const lds_u32 *lut, uint32_t lroot, uint32_t start, uint32_t zstart,
+                                              uint32_t limit, bool known, uint32_t &mid, uint32_t &end, uint32_t &stop, uint32_t &nb) {
+  uint32_t p = start, e = e_root(lroot), cnt = 0, m = known ? start : 0xffffffffu;
+  bool live = known;
+  if (p < limit) {
+    const uint32_t thr = (kLitB << 21) | limit;
+    uint32_t key;
+    Cursor c;
+    c.init(win, start);
+    do {
+      const uint32_t w = c.peek(p);
+      const uint32_t en = lut_step(lut, e, w);
+      const uint32_t n = e_n(en), xb = e_xb(en);
+      const bool root = e_tb(en) == kLitB;
+      const uint32_t len1 = e_val(en) + __builtin_amdgcn_ubfe(w, n - xb, xb) + (kCountMatch + 2);  // length - 1, and a match
+      const uint32_t add = (root ? 1u : 0u) + (e_tb(en) == kDistB ? len1 : 0u);
+      cnt += live ? add : 0u;  // (the token that ends on `mid` is the left neighbour's)
+      p += n;
+      const bool cross = root && !live && p >= zstart;
+      m = cross ? p : m;
+      live = live || cross;
+      c.seek(win, p);
+      e = en;
+      key = (en & kTbMask) | p;
+    } while (key < thr);
+  }
+  mid = m;
+  end = p;
+  stop = e_tb(e) >= kStopEobI ? e_tb(e) : 0u;
+  nb = cnt;
+}
+
 struct LaneOut {
   uint32_t endp;   // bit after the last token taken (a token boundary)
   uint32_t stopc;  // 0 = zone done, kStEob, kStTrunc (round capacity), else MD_* status of the failing token
@@ -805,44 +844,6 @@ struct Sink {
   }
 };
 
-// ---- the pending map: one bit per staging byte that a near match has still to produce -------------
-// masks of bits [a, a + n) in the words a >> 5 and (a >> 5) + 1; returns the end bit relative to the first word
-__device__ __forceinline__ uint32_t pend_masks(uint32_t a, uint32_t n, uint32_t &m0, uint32_t &m1) {
-  const uint32_t e = (a & 31) + n;
-  m0 = 0xffffffffu << (a & 31);
-  if (e <= 32) {
-    m0 &= 0xffffffffu >> (32 - e);
-    m1 = 0;
-  } else {
-    m1 = e >= 64 ? 0xffffffffu : ~(0xffffffffu << (e - 32));
-  }
-  return e;
-}
-__device__ __forceinline__ bool pend_any(const lds_u32 *pend, uint32_t a, uint32_t b) {  // b > a
-  uint32_t m0, m1;
-  const uint32_t w0 = a >> 5, e = pend_masks(a, b - a, m0, m1);
-  uint32_t any = (pend[w0] & m0) | (pend[w0 + 1] & m1);
-  for (uint32_t w = w0 + 2, r = e; r > 64; w++, r -= 32) any |= pend[w] & (r >= 96 ? 0xffffffffu : ~(0xffffffffu << (r - 64)));
-  return any != 0;
-}
-template <bool SET>
-__device__ __forceinline__ void pend_update(lds_u32 *pend, uint32_t a, uint32_t b) {  // b > a
-  uint32_t m0, m1;
-  const uint32_t w0 = a >> 5, e = pend_masks(a, b - a, m0, m1);
-  if (SET) {
-    __hip_atomic_fetch_or(&pend[w0], m0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    __hip_atomic_fetch_or(&pend[w0 + 1], m1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  } else {
-    __hip_atomic_fetch_and(&pend[w0], ~m0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    __hip_atomic_fetch_and(&pend[w0 + 1], ~m1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  }
-  for (uint32_t w = w0 + 2, r = e; r > 64; w++, r -= 32) {
-    const uint32_t m = r >= 96 ? 0xffffffffu : ~(0xffffffffu << (r - 64));
-    if (SET) __hip_atomic_fetch_or(&pend[w], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    else __hip_atomic_fetch_and(&pend[w], ~m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  }
-}
-
 // exact store of the low n (1..8) bytes of v at an arbitrary LDS address: two overlapping 4-byte (or 1 + 2-byte) stores
 __device__ __forceinline__ void lds_put(lds_u8 *p, uint64_t v, uint32_t n) {
   const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
@@ -862,7 +863,7 @@ __device__ __forceinline__ void lds_put(lds_u8 *p, uint64_t v, uint32_t n) {
 // in stream order, one per lane and row of 64.  FIRST the loads of ALL rows are started - 2 LDS reads per record, one
 // unaligned 16-byte load each: the source lies in L2 or beyond, two microseconds away on a busy chip, and a round
 // should wait for that once, not once per group of rows (three sets of four rows, two of them in flight, spent more
-// time waiting than working) - and while they are in flight the near matches are marked in the pending map and listed,
+// time waiting than working) - and while they are in flight the near matches are listed,
 // in stream order, for copy_near_all (*nnear_out of them).  THEN the rows are gone through again as their data
 // arrives: the record is read once more (cheaper than keeping three more registers per row) and its bytes are stored
 // with exact-length LDS stores; bytes 16 .. 31 of the longer records follow in a second batch of the same kind, and
@@ -890,7 +891,7 @@ __device__ __forceinline__ FarRow far_row(const lds_u32 *mrec, const lds_u16 *mp
   return f;
 }
 template <class PF>
-__device__ __forceinline__ void copy_far(const lds_u32 *mrec, const lds_u16 *mpos, lds_u32 *pend, lds_u16 *list, const Sink &sk,
+__device__ __forceinline__ void copy_far(const lds_u32 *mrec, const lds_u16 *mpos, lds_u16 *list, const Sink &sk,
                                          uint32_t lane, uint32_t nrec, uint32_t *nnear_out, PF &pf) {
   lds_u8 *stage = sk.stage;
   const uint32_t R0 = sk.pos, rb = sk.sbase();
@@ -914,10 +915,7 @@ __device__ __forceinline__ void copy_far(const lds_u32 *mrec, const lds_u16 *mpo
   for (uint32_t c0 = 0; c0 < nrec; c0 += kWave) {
     const FarRow f = far_row(mrec, mpos, c0 + lane, nrec, rb, R0);
     const uint64_t nb = __ballot(f.near);
-    if (f.near) {
-      list[nnear + lane_rank(nb)] = (uint16_t)(c0 + lane);
-      pend_update<true>(pend, f.qs, f.qs + f.ml);
-    }
+    if (f.near) list[nnear + lane_rank(nb)] = (uint16_t)(c0 + lane);
     nnear += (uint32_t)__builtin_popcountll(nb);
     const uint64_t lb = __ballot(f.n > 16);
     const uint32_t lc = (uint32_t)__builtin_popcountll(lb);
@@ -998,7 +996,7 @@ __device__ __forceinline__ void copy_far(const lds_u32 *mrec, const lds_u16 *mpo
 }
 // the same for the last rounds of a stream, where an 8-byte load could reach past the output buffer: guarded loads
 template <class PF>
-__device__ __noinline__ void copy_far_guarded(const lds_u32 *mrec, const lds_u16 *mpos, lds_u32 *pend, lds_u16 *list,
+__device__ __noinline__ void copy_far_guarded(const lds_u32 *mrec, const lds_u16 *mpos, lds_u16 *list,
                                               lds_u8 *stage, const uint8_t *g, uint32_t R0, uint32_t rb, uint32_t cap,
                                               uint32_t lane, uint32_t nrec, uint32_t *nnear_out) {
   uint32_t nnear = 0;
@@ -1013,7 +1011,6 @@ __device__ __noinline__ void copy_far_guarded(const lds_u32 *mrec, const lds_u16
     const uint64_t nb = __ballot(near);
     if (near) {
       list[nnear + lane_rank(nb)] = (uint16_t)r;
-      pend_update<true>(pend, qs, qs + ml);
       n = s < R0 ? R0 - s : 0u;
     }
     nnear += (uint32_t)__builtin_popcountll(nb);
@@ -1060,12 +1057,14 @@ __device__ __forceinline__ void wave_copy(lds_u8 *stage, uint32_t dd, uint32_t s
 
 // Near matches: the source reaches into this round's staging buffer.  copy_far listed them in stream order; they
 // are taken 64 at a time, one per lane, whatever lane decoded them.  Everything a record of a group can depend on is
-// an earlier group (done) or the group itself, so a group is repeated until it is done; a record is copied in the
-// pass in which none of its source bytes is pending any more.  The earliest record left in a group never waits:
-// every pass makes progress.  `list` lives in the input window's space, which is not needed again before the next
-// round loads it.
+// an earlier group (done) or the group itself.  Inside a group the records' destinations are disjoint and ascending
+// with the lane, so the records whose output a lane's source range [sa, sb) touches are a RANGE of lower lanes: found
+// once per group by two binary searches over the lanes (ds_bpermute), kept as a 64-bit mask.  A record is copied in the
+// pass in which all of them are done (a wave-uniform mask of finished lanes); the lowest lane left never waits, so every
+// pass makes progress.  (Until round 5 this was a bitmap of pending staging bytes in LDS: two atomics to set, two loads
+// to test and two atomics to clear per record and pass.)
 template <class PF>
-__device__ __forceinline__ void copy_near_all(const lds_u32 *mrec, const lds_u16 *mpos, lds_u32 *pend, const lds_u16 *list,
+__device__ __forceinline__ void copy_near_all(const lds_u32 *mrec, const lds_u16 *mpos, const lds_u16 *list,
                                               const Sink &sk, uint32_t lane, uint32_t count, bool *stuck, PF &pf) {
   lds_u8 *stage = sk.stage;
   const uint32_t head = sk.pos - sk.sbase();  // staging index of the round start
@@ -1080,6 +1079,19 @@ __device__ __forceinline__ void copy_near_all(const lds_u32 *mrec, const lds_u16
     const uint32_t sa = (uint32_t)(s0 + (int32_t)skip), sb = d < ml ? qs : (uint32_t)s0 + ml;
     const uint32_t n = ml - skip;         // skip < ml: a near match reaches into the round
     const bool fast = d >= n && n <= 32;  // the usual case: source and destination do not overlap
+    // what the lanes of this group still have to produce: [qb, qe), ascending with the lane (idle lanes: nothing, on top)
+    const uint32_t qb = todo ? qs + skip : 0xffffffffu, qe = todo ? qs + ml : 0xffffffffu;
+    uint32_t jlo = 0, jhi = 0;  // lanes [jlo, jhi): qe > sa and qb < sb
+#pragma unroll
+    for (uint32_t st = 32; st > 0; st >>= 1) {
+      const uint32_t ve = __shfl(qe, jlo + st - 1), vb = __shfl(qb, jhi + st - 1);
+      jlo = ve <= sa ? jlo + st : jlo;
+      jhi = vb < sb ? jhi + st : jhi;
+    }
+    jhi = jhi < lane ? jhi : lane;  // (lower lanes only: a record's own output is not its source)
+    uint64_t need = 0;
+    if (sa < sb && jlo < jhi) need = ((jhi >= 64 ? 0ull : (1ull << jhi)) - 1ull) & ~((1ull << jlo) - 1ull);
+    uint64_t done = 0;  // wave-uniform: lanes of this group that are copied
     pf.tick_lds(P_NEAR_LOAD);
     for (uint32_t guard = 0; __ballot(todo) != 0; guard++) {
       if (guard > kWave) {  // cannot happen
@@ -1087,7 +1099,7 @@ __device__ __forceinline__ void copy_near_all(const lds_u32 *mrec, const lds_u16
         return;
       }
       pf.count(C_NEAR_IT);
-      const bool ready = todo && (sa >= sb || !pend_any(pend, sa, sb));
+      const bool ready = todo && (need & ~done) == 0;
       if constexpr (PF::on) {
         if (__ballot(ready && !fast)) pf.count(C_LONG_NEAR);
       }
@@ -1109,10 +1121,8 @@ __device__ __forceinline__ void copy_near_all(const lds_u32 *mrec, const lds_u16
         wave_copy(stage, rdlane(qs + skip, l), rdlane(sa, l), rdlane(n, l), rdlane(d, l), lane);
       }
       pf.tick_lds(P_NEAR_SLOW);
-      if (ready) {
-        pend_update<false>(pend, qs, qs + ml);
-        todo = false;
-      }
+      done |= __ballot(ready);
+      todo = todo && !ready;
       pf.tick_lds(P_NEAR_UPD);
     }
   }
@@ -1124,7 +1134,6 @@ template <class PF>
 __device__ __forceinline__ void copy_round(lds_smem *sm, Sink &sk, uint32_t lane, uint32_t total, uint32_t nrec, bool *stuck, PF &pf) {
   const lds_u32 *mrec = (const lds_u32 *)sm->mrec;
   const lds_u16 *mpos = (const lds_u16 *)sm->mpos;
-  lds_u32 *pend = (lds_u32 *)sm->pend;
   lds_u16 *list = (lds_u16 *)sm->list;
   const uint32_t R0 = sk.pos, rb = sk.sbase();
   uint32_t nnear = 0;
@@ -1143,12 +1152,12 @@ __device__ __forceinline__ void copy_round(lds_smem *sm, Sink &sk, uint32_t lane
 #endif
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // earlier rounds' flushes have landed
   if (R0 + 40 > sk.cap) {
-    copy_far_guarded<PF>(mrec, mpos, pend, list, sk.stage, sk.g, R0, rb, sk.cap, lane, nrec, &nnear);
+    copy_far_guarded<PF>(mrec, mpos, list, sk.stage, sk.g, R0, rb, sk.cap, lane, nrec, &nnear);
     pf.tick(P_FAR);
   } else {
-    copy_far(mrec, mpos, pend, list, sk, lane, nrec, &nnear, pf);
+    copy_far(mrec, mpos, list, sk, lane, nrec, &nnear, pf);
   }
-  copy_near_all(mrec, mpos, pend, list, sk, lane, nnear, stuck, pf);
+  copy_near_all(mrec, mpos, list, sk, lane, nnear, stuck, pf);
   sk.flush(total);
   pf.tick(P_ADLER);
 }
@@ -1224,7 +1233,14 @@ __device__ __forceinline__ int inflate_block(lds_smem *sm, const uint8_t *__rest
       nb = v.w;
     } else {
 #endif
-    sync_pass<false, BUDGET>(win, lut, lroot, true, start - runin, limit, end, stop, nb);
+    if constexpr (BUDGET) {  // (a walk limited to KMAX steps ends where its start decides: the old order of passes)
+      sync_pass<false, BUDGET>(win, lut, lroot, true, start - runin, limit, end, stop, nb);
+    } else {
+      uint32_t mid;
+      sync_pass_mid(win, lut, lroot, start - runin, start, limit, lane == 0, mid, end, stop, nb);
+      counted = mid != 0xffffffffu;
+      start = counted ? mid : start;
+    }
     pf.tick(P_DECODE1);
     const uint32_t passes = zs * PASSES >= PASS_BITS ? PASSES : PASS_BITS / zs > PASSES_MAX ? PASSES_MAX : PASS_BITS / zs;
     for (uint32_t it = 0; it < passes; it++) {
@@ -1435,7 +1451,6 @@ __global__ __launch_bounds__(PAIR ? 2 * kWave : kWave, PAIR ? 4 : 2) void inflat
   sk.want_adler = (checksum != nullptr) || format == MD_FORMAT_ZLIB || cont.resume_adler != nullptr;
 
   if (threadIdx.x < 4) sm->lut[kStopEobI + threadIdx.x] = mk_entry(0, 0, 0, 0, kStopEobI + (threadIdx.x & 2));  // the self-looping STOP entries
-  for (uint32_t i = threadIdx.x; i < STAGE / 32 + 2; i += blockDim.x) sm->pend[i] = 0;
   if constexpr (PAIR) {
     if (threadIdx.x < sizeof(Mail) / 4) ((lds_u32 *)&sm->mail)[threadIdx.x] = threadIdx.x == 6 ? sk.a : threadIdx.x == 7 ? sk.b : 0u;
     __syncthreads();

@@ -179,6 +179,62 @@ class Engine:
             _ptr(out_cap), _ptr(out_len), _ptr(consumed), _ptr(status), _ptr(checksum)))
         return results
 
+    # ------------------------------------------------------------------ host buffers (md_*_batch_host)
+    def host_buffer(self, nbytes):
+        """A pinned host buffer of nbytes (md_host_alloc) as a numpy uint8 array; the array owns it (freed with it)."""
+        import numpy as np
+
+        p = self.lib.md_host_alloc(self.ctx, nbytes)
+        if not p:
+            raise MemoryError("md_host_alloc(%d)" % nbytes)
+        lib, ctx = self.lib, self.ctx
+
+        class _Owner:
+            def __init__(self):
+                self.buf = (ctypes.c_uint8 * max(1, nbytes)).from_address(p)
+
+            def __del__(self):
+                lib.md_host_free(ctx, p)
+
+        owner = _Owner()
+        a = np.frombuffer(owner.buf, dtype=np.uint8, count=nbytes)
+        self._host_owners = getattr(self, "_host_owners", [])
+        self._host_owners.append(owner)
+        return a
+
+    def inflate_batch_host(self, fmt, h_in, in_off, in_len, h_out, out_off, out_cap):
+        """md_inflate_batch_host: numpy uint8 blobs (pinned ones overlap copies and kernels) and uint64 descriptor arrays.
+        Returns (out_len, consumed, status, checksum) numpy arrays.  Synchronous."""
+        import numpy as np
+
+        n = len(in_off)
+        u64 = lambda a: np.ascontiguousarray(a, dtype=np.uint64)
+        in_off, in_len, out_off, out_cap = u64(in_off), u64(in_len), u64(out_off), u64(out_cap)
+        out_len, consumed = np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint64)
+        status, checksum = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.uint32)
+        self._check(self.lib.md_inflate_batch_host(
+            self.ctx, fmt, n, h_in.ctypes.data, h_in.nbytes, in_off.ctypes.data, in_len.ctypes.data, h_out.ctypes.data,
+            h_out.nbytes, out_off.ctypes.data, out_cap.ctypes.data, out_len.ctypes.data, consumed.ctypes.data,
+            status.ctypes.data, checksum.ctypes.data))
+        return out_len, consumed, status, checksum
+
+    def deflate_batch_host(self, fmt, h_in, in_off, in_len, h_out, out_off, out_cap, level=6, queue=4096, driver=DRIVER_ZL,
+                           dynamic=True, matcher=None, header=None):
+        """md_deflate_batch_host, as inflate_batch_host.  Returns (out_len, status, checksum of the input)."""
+        import numpy as np
+
+        n = len(in_off)
+        u64 = lambda a: np.ascontiguousarray(a, dtype=np.uint64)
+        in_off, in_len, out_off, out_cap = u64(in_off), u64(in_len), u64(out_off), u64(out_cap)
+        out_len = np.zeros(n, dtype=np.uint64)
+        status, checksum = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.uint32)
+        params = self._params(level, queue, driver, dynamic, matcher, header, 0)
+        self._check(self.lib.md_deflate_batch_host(
+            self.ctx, fmt, ctypes.byref(params), n, h_in.ctypes.data, h_in.nbytes, in_off.ctypes.data, in_len.ctypes.data,
+            h_out.ctypes.data, h_out.nbytes, out_off.ctypes.data, out_cap.ctypes.data, out_len.ctypes.data,
+            status.ctypes.data, checksum.ctypes.data))
+        return out_len, status, checksum
+
     def inflate_many(self, streams, caps, fmt=FORMAT_DEFLATE):
         """Convenience for tests: list of bytes -> list of (status, consumed, bytes, adler)."""
         import numpy as np

@@ -156,11 +156,19 @@ int md_synchronize(md_ctx *ctx);
  *                                same pieces (which are, but for corner cases at the very end of a stream, the same for
  *                                any pieces).
  *   "release_workspace"          (value ignored) waits for the context's stream and frees its grow-only device scratch
- *                                (deflate workspaces, launch orders, decoder-piece buffers); it grows again on demand.
+ *                                (deflate workspaces, launch orders, decoder-piece buffers, the host entry points' device copies); it grows again on demand.
+ *   "host_pipeline_slices"       1 .. 64 (default 16): most slices of streams a md_*_batch_host call cuts a batch into so that
+ *                                its copies overlap with its kernels (1: copy-in, kernels, copy-out one after the other).
  *   "inflate_waves"              1 or 2 (default): wavefronts per stream of the inflate kernel (2 = decoder + copier).
+ *   "debug_inflate_lds_pad", "debug_known_bounds"   measurement aids of tools/dbg (occupancy curve, known-boundaries floor).
  *   "profile"                    0 / 1: in-kernel phase profile of stream 0 (md_get_profile, a debugging aid).
  * Unknown keys and values out of range: MD_E_INVALID_ARGUMENT. */
 int md_set_option(md_ctx *ctx, const char *key, int value);
+/* Pinned (page-locked) host memory for the buffers handed to the md_*_host entry points: copies from and to it are DMA
+ * transfers that overlap with the kernels.  NULL when the allocation fails.  (An OCaml caller wraps it in a Bigarray with
+ * caml_ba_alloc and frees it from the custom block's finaliser: INTEGRATION.md.) */
+void *md_host_alloc(md_ctx *ctx, size_t bytes);
+void md_host_free(md_ctx *ctx, void *p);
 int md_timing_begin(md_ctx *ctx);
 int md_timing_end(md_ctx *ctx, float *ms);
 
@@ -182,8 +190,14 @@ int md_inflate_batch_device(md_ctx *ctx, int format, size_t n,
                             uint64_t *d_out_len, uint64_t *d_consumed,
                             int32_t *d_status, uint32_t *d_checksum);
 
-/* Same with HOST pointers: copies inputs H2D, runs the kernels, copies results
- * D2H and synchronises.  h_in/h_out are the packed buffers the offsets index. */
+/* Same with HOST pointers (the reference's callers own host bigarrays, lib/de.mli:93-106): copies inputs H2D, runs the
+ * kernels, copies results D2H and synchronises.  h_in/h_out are the packed buffers the offsets index.  A batch of many
+ * streams goes through in slices of consecutive streams (md_set_option "host_pipeline_slices", default up to 16; a slice
+ * keeps enough streams to fill the device), the copy-in of the next slice and the copy-out of the one before running
+ * under the kernels of the current one - which they only do when h_in / h_out are PINNED host memory (md_host_alloc
+ * below, or the caller's own hipHostMalloc / hipHostRegister); pageable buffers give the same results, copied one
+ * after the other.  The device copies of the blobs belong to the context and are kept between calls
+ * (md_set_option "release_workspace" frees them). */
 int md_inflate_batch_host(md_ctx *ctx, int format, size_t n, const uint8_t *h_in,
                           size_t in_bytes, const uint64_t *in_off,
                           const uint64_t *in_len, uint8_t *h_out, size_t out_bytes,

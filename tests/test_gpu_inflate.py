@@ -696,3 +696,82 @@ def test_two_contexts_in_two_threads(oracle):
     for t in range(2):
         for p, z, (st, used, o, adler) in zip(plains[t], srcs[t], out[t]):
             assert (st, used, o, adler) == (0, len(z), p, zlib.adler32(p))
+
+
+@pytest.mark.parametrize("pinned", [True, False], ids=["pinned", "pageable"])
+def test_host_entry_points_in_slices(eng, pinned):
+    """md_inflate_batch_host / md_deflate_batch_host with a batch large enough to go through in pipelined slices of
+    streams (copies under kernels on three HIP streams): results equal the one-slice form's and the oracle's, whatever the
+    layout of the blobs (ascending here; scattered: a reversed order of the streams in the blob)."""
+    import decompress_amd
+    from tests import oracle_lib
+    from decompress_amd import workloads
+    orc = oracle_lib.load()
+    rng = random.Random(5)
+    n, nb = 4400, 24576
+    plains = [workloads.text(1000 + (i % 64), nb)[: nb - (i % 7) * 100] for i in range(n)]
+    zs = [zlib.compress(p, 6) for p in plains[:64]]
+    streams = [zs[i % 64] if (i % 7) == 0 else None for i in range(n)]
+    for i in range(n):
+        if streams[i] is None:
+            streams[i] = zlib.compress(plains[i], 1 + i % 9)
+    bad = rng.randrange(n)
+    streams[bad] = streams[bad][:-9]  # one truncated stream somewhere: its status, nobody else's
+    for order in ("ascending", "reversed"):
+        lens = np.array([len(z) for z in streams], dtype=np.uint64)
+        idx = list(range(n)) if order == "ascending" else list(range(n - 1, -1, -1))
+        in_off = np.zeros(n, dtype=np.uint64)
+        pos = 0
+        for i in idx:
+            in_off[i] = pos
+            pos += (len(streams[i]) + 15) // 16 * 16
+        cap = 32768
+        out_off = np.zeros(n, dtype=np.uint64)
+        for k, i in enumerate(idx):
+            out_off[i] = k * cap
+        mk = eng.host_buffer if pinned else (lambda m: np.zeros(m, dtype=np.uint8))
+        h_in, h_out = mk(pos + 64), mk(n * cap)
+        for i in range(n):
+            h_in[int(in_off[i]):int(in_off[i]) + len(streams[i])] = np.frombuffer(streams[i], dtype=np.uint8)
+        got = {}
+        for slices in (16, 1):
+            eng.set_option("host_pipeline_slices", slices)
+            h_out[:] = 0
+            res = eng.inflate_batch_host(decompress_amd.FORMAT_ZLIB, h_in, in_off, lens, h_out, out_off, np.full(n, cap, dtype=np.uint64))
+            got[slices] = (tuple(a.copy() for a in res), h_out.copy())
+        eng.set_option("host_pipeline_slices", 16)
+        for a, b in zip(got[16][0], got[1][0]):
+            assert (a == b).all(), order
+        assert (got[16][1] == got[1][1]).all(), order
+        out_len, consumed, status, checksum = got[16][0]
+        for i in range(0, n, 37):
+            rc, used, out = orc.zl_inflate(streams[i], cap)
+            assert status[i] == rc, (order, i)
+            if rc == 0:
+                assert (int(out_len[i]), int(consumed[i])) == (len(out), used) and checksum[i] == zlib.adler32(out)
+                assert got[16][1][int(out_off[i]):int(out_off[i]) + len(out)].tobytes() == out, (order, i)
+        assert status[bad] != 0 and (np.delete(status, bad) == 0).all()
+        # ... and back: the deflate entry point on the plaintexts (4 400 >= 4 096 streams: still one slice; 8 800: two)
+        if order == "ascending":
+            pl = plains + plains
+            m = len(pl)
+            p_len = np.array([len(p) for p in pl], dtype=np.uint64)
+            p_off = np.arange(m, dtype=np.uint64) * nb
+            h_p = mk(m * nb)
+            for i, p in enumerate(pl):
+                h_p[i * nb:i * nb + len(p)] = np.frombuffer(p, dtype=np.uint8)
+            h_c = mk(m * cap)
+            dres = {}
+            for slices in (16, 1):
+                eng.set_option("host_pipeline_slices", slices)
+                h_c[:] = 0
+                r = eng.deflate_batch_host(decompress_amd.FORMAT_ZLIB, h_p, p_off, p_len, h_c, np.arange(m, dtype=np.uint64) * cap,
+                                           np.full(m, cap, dtype=np.uint64), level=4, queue=1024)
+                dres[slices] = (tuple(a.copy() for a in r), h_c.copy())
+            eng.set_option("host_pipeline_slices", 16)
+            assert all((a == b).all() for a, b in zip(dres[16][0], dres[1][0])) and (dres[16][1] == dres[1][1]).all()
+            assert (dres[16][0][1] == 0).all()
+            for i in range(0, m, 211):
+                z = dres[16][1][i * cap:i * cap + int(dres[16][0][0][i])].tobytes()
+                assert zlib.decompress(z) == pl[i] and z == orc.zl_deflate(pl[i], 4, queue=1024), i
+    eng.set_option("release_workspace", 0)
