@@ -305,7 +305,8 @@ def host_path_deflate(eng, dev, d_in, n, nb, kernel_ms, d_out_ref, ref_len, ref_
     t_out = torch.from_numpy(h_out)
     d_a = torch.empty(n * nb, dtype=torch.uint8, device=dev)
     h2d_ms = _copy_ms(torch, d_a, t_in, dev, reps=2)
-    d2h_ms = _copy_ms(torch, t_out, d_a[: min(n * nb, n * cap)], dev, reps=2) * (n * cap) / min(n * nb, n * cap)
+    m = min(n * nb, n * cap)
+    d2h_ms = _copy_ms(torch, t_out[:m], d_a[:m], dev, reps=2) * (n * cap) / m
     del d_a
     off = np.arange(n, dtype=np.uint64)
     best, res = None, None

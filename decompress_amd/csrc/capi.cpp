@@ -627,8 +627,9 @@ int md_inflate_batch_host(md_ctx *ctx, int format, size_t n, const uint8_t *h_in
   HIP_TRY(ctx, hipMemcpyAsync(d64 + 1 * n, in_len, n * 8, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(d64 + 2 * n, out_off, n * 8, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(d64 + 3 * n, out_cap, n * 8, hipMemcpyHostToDevice, st));
-  // a slice should still fill the chip once (8 streams per CU): 2 048 streams at least
-  const std::vector<HostSlice> sl = host_slices(n, in_off, in_len, out_off, out_cap, 2048, (size_t)ctx->host_slices_max, in_bytes, out_bytes);
+  // a slice of 1 024 streams (4 per CU) runs at half the batch's rate per stream - still several times what the link to
+  // the host moves (57 GB/s each way measured), so the copies stay the longer leg and more slices hide more of the kernels
+  const std::vector<HostSlice> sl = host_slices(n, in_off, in_len, out_off, out_cap, 1024, (size_t)ctx->host_slices_max, in_bytes, out_bytes);
   int rc = host_pipeline(ctx, sl, h_in, din, h_out, dout, [&](size_t i0, size_t cnt) {
     return md_inflate_batch_device(ctx, format, cnt, din, d64 + i0, d64 + n + i0, dout, d64 + 2 * n + i0, d64 + 3 * n + i0,
                                    d64 + 4 * n + i0, d64 + 5 * n + i0, dstatus + i0, dsum + i0);

@@ -56,7 +56,11 @@ constexpr uint32_t SMIN = 48;      // ... and at least: where the data expands s
                                    // staging buffer, the zones shrink so that all 64 lanes still have work (cost then
                                    // follows the output, not the number of zones thrown away)
 constexpr uint32_t KMAX = 64;      // walk steps per lane per pass
-constexpr uint32_t RUNIN_NUM = 1, RUNIN_DEN = 2;  // run-in of the speculative pass, as a fraction of the zone
+#ifndef MD_RUNIN_NUM
+#define MD_RUNIN_NUM 1
+#define MD_RUNIN_DEN 2
+#endif
+constexpr uint32_t RUNIN_NUM = MD_RUNIN_NUM, RUNIN_DEN = MD_RUNIN_DEN;  // run-in of the speculative pass, as a fraction of the zone
 constexpr uint32_t PASSES = 5;     // walks after the first one: at least this many are allowed, more when the zones are small
 constexpr uint32_t PASS_BITS = 1600, PASSES_MAX = 16;  // (a walk costs in proportion to the zone size)
 constexpr uint32_t RMAX = 768;     // match records per round, all lanes together (in stream order)
@@ -1217,7 +1221,7 @@ __device__ __forceinline__ int inflate_block(lds_smem *sm, const uint8_t *__rest
     // boundary at the zone's END, and the longer the walk, the likelier that it has synchronised by then - fewer lanes
     // walk again in passes 2+, which cost a full pass each for a handful of lanes (the pass without counts is the
     // cheap one: 24 instructions a step against 34)
-    const uint32_t runin = lane ? (zs * RUNIN_NUM) / RUNIN_DEN : 0u;
+    const uint32_t runin_ = (zs * RUNIN_NUM) / RUNIN_DEN, runin = runin_ < lane * zs ? runin_ : lane * zs;  // (not before the round's start)
     bool counted = false;
 #ifdef MD_DEBUG_KNOWN_BOUNDS
     const int kbm = __builtin_amdgcn_readfirstlane(g_kb_mode);
