@@ -48,6 +48,15 @@ SYMBOLS = [
     ("md_destroy", None, [c_vp]),
     ("md_synchronize", ctypes.c_int, [c_vp]),
     ("md_set_option", ctypes.c_int, [c_vp, ctypes.c_char_p, ctypes.c_int]),
+    ("md_def_batch_open", c_vp, [c_vp, ctypes.c_int, c_pp, c_sz]),
+    ("md_def_batch_src", ctypes.c_int, [c_vp, c_sz, c_vp, c_sz]),
+    ("md_def_batch_encode", ctypes.c_int, [c_vp]),
+    ("md_def_batch_pending", c_sz, [c_vp, c_sz]),
+    ("md_def_batch_out", c_sz, [c_vp, c_sz, c_vp, c_sz]),
+    ("md_def_batch_status", ctypes.c_int, [c_vp, c_sz]),
+    ("md_def_batch_error", ctypes.c_int, [c_vp, c_sz]),
+    ("md_def_batch_checksum", ctypes.c_uint32, [c_vp, c_sz]),
+    ("md_def_batch_close", None, [c_vp]),
     ("md_host_alloc", c_vp, [c_vp, c_sz]),
     ("md_host_free", None, [c_vp, c_vp]),
     ("md_timing_begin", ctypes.c_int, [c_vp]),

@@ -1333,6 +1333,66 @@ int md_i_piece_run(md_ctx *ctx, md_piece *p, int format, const md_deflate_params
   *status = st;
   return MD_OK;
 }
+// One piece of each of n streams in ONE launch of the kernels (md_def_batch, stream_shim.cpp): texts, outputs, states
+// and queues are the caller's device buffers, the descriptors host arrays of n entries.  flags as struct Piece's (bit 3:
+// the stream takes no part in this launch).  Synchronous: the results are read back.
+struct md_pieces_io {
+  const uint64_t *text_off, *text_len, *abs_len, *out_off, *out_cap, *w0, *rebase;
+  const uint32_t *flags, *sum, *isize;
+  uint64_t *out_len;
+  int32_t *status;
+};
+int md_i_pieces_run(md_ctx *ctx, int format, const md_deflate_params *params, size_t n, const uint8_t *d_text, uint8_t *d_out,
+                    void *d_state, void *d_queue, void **d_desc, size_t *d_desc_bytes, const md_pieces_io *io, uint32_t match_skip) {
+  if (!ctx || !params || !io || n == 0) return MD_E_INVALID_ARGUMENT;
+  md_deflate_params q;
+  int rc = check_params(ctx, format, params, &q);
+  if (rc != MD_OK) return rc;
+  MD_ON_DEVICE(ctx);
+  const size_t desc_bytes = n * (10 * 8 + 6 * 4);
+  rc = grow(ctx, d_desc, d_desc_bytes, desc_bytes, "hipMalloc(encoder batch descriptors)");
+  if (rc != MD_OK) return rc;
+  std::vector<uint64_t> hbuf((desc_bytes + 7) / 8);
+  uint64_t *h64 = hbuf.data();
+  uint64_t *in_off = h64, *front_len = h64 + n, *abs_len = h64 + 2 * n, *out_off = h64 + 3 * n, *out_cap = h64 + 4 * n,
+           *out_len = h64 + 5 * n, *pos = h64 + 6 * n;
+  uint32_t *h32 = (uint32_t *)(h64 + 10 * n);
+  uint32_t *st = h32, *flags = h32 + 2 * n, *sums = h32 + 3 * n;
+  uint64_t total = 0;
+  for (size_t i = 0; i < n; i++) {
+    const bool idle = (io->flags[i] & 8u) != 0;
+    if (!idle && io->abs_len[i] > MD_MAX_STREAM) return fail(ctx, MD_E_INVALID_ARGUMENT, "piece beyond MD_MAX_STREAM");
+    in_off[i] = io->text_off[i];
+    front_len[i] = idle ? 0 : io->text_len[i];
+    abs_len[i] = idle ? 0 : io->abs_len[i];
+    out_off[i] = io->out_off[i];
+    out_cap[i] = io->out_cap[i];
+    out_len[i] = 0;
+    pos[4 * i] = idle ? 0 : io->w0[i];
+    pos[4 * i + 1] = idle ? 0 : io->rebase[i];
+    pos[4 * i + 2] = i;
+    pos[4 * i + 3] = i;
+    st[i] = 0;
+    h32[n + i] = 0;
+    flags[i] = io->flags[i];
+    sums[2 * i] = io->sum[i];
+    sums[2 * i + 1] = io->isize[i];
+    total += front_len[i];
+  }
+  uint64_t *d64 = (uint64_t *)*d_desc;
+  uint32_t *d32 = (uint32_t *)(d64 + 10 * n);
+  HIP_TRY(ctx, hipMemcpyAsync(d64, h64, desc_bytes, hipMemcpyHostToDevice, ctx->stream));
+  PieceArgs pa{d64 + n, d_queue, {d32 + 2 * n, d_state, d64 + 6 * n, d32 + 3 * n}, match_skip};
+  rc = deflate_launch(ctx, format, q.level, q.queue_len, q.driver, q.dynamic, q.matcher, q.gz_header, n, d_text, d64, d64 + 2 * n,
+                      d_out, d64 + 3 * n, d64 + 4 * n, d64 + 5 * n, (int32_t *)d32, d32 + n, nullptr, total ? total : 1, &pa);
+  if (rc != MD_OK) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(io->out_len, d64 + 5 * n, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(io->status, d32, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return MD_OK;
+}
+hipStream_t md_i_stream(md_ctx *ctx) { return ctx->stream; }
+int md_i_device(md_ctx *ctx) { return ctx->device; }
 int md_i_piece_out(md_ctx *ctx, const md_piece *p, size_t off, uint8_t *host, size_t len) {
   if (!ctx || !p || (!host && len)) return MD_E_INVALID_ARGUMENT;
   MD_ON_DEVICE(ctx);

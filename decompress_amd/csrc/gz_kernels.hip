@@ -229,6 +229,24 @@ __global__ __launch_bounds__(kWave) void gz_finish_kernel(
   }
 }
 
+
+// The text of n streaming encoders for their next launch (md_def_batch, stream_shim.cpp): stream i's region of the new
+// blob is the tail of its region in the old one (the window the matcher can still reach) followed by the bytes that
+// arrived since (packed in `fresh`).  d[6 i ..]: old offset of the tail, its length, offset in `fresh`, fresh length,
+// new offset (unused).  One workgroup per stream, 16 bytes per thread and step where the alignments allow.
+__global__ __launch_bounds__(256) void piece_gather_kernel(uint32_t n, const uint8_t *__restrict__ old_blob, const uint8_t *__restrict__ fresh,
+                                                           uint8_t *__restrict__ new_blob, const uint64_t *__restrict__ d) {
+  const uint32_t i = blockIdx.x;
+  if (i >= n) return;
+  const uint64_t toff = d[6 * i], tlen = d[6 * i + 1], foff = d[6 * i + 2], flen = d[6 * i + 3], noff = d[6 * i + 4];
+  const uint8_t *a = old_blob + toff;
+  uint8_t *o = new_blob + noff;
+  for (uint64_t k = threadIdx.x; k < tlen; k += 256) o[k] = a[k];
+  const uint8_t *b = fresh + foff;
+  o += tlen;
+  for (uint64_t k = threadIdx.x; k < flen; k += 256) o[k] = b[k];
+}
+
 }  // namespace gz
 }  // namespace md
 
@@ -252,5 +270,11 @@ extern "C" int md_launch_gz_finish(uint32_t n, const uint8_t *in, const uint64_t
   if (n == 0) return 0;
   hipLaunchKernelGGL(md::gz::gz_finish_kernel, dim3(n), dim3(md::gz::kWave), 0, stream, n, in, in_off, in_len,
                      body_off, hstatus, out, out_off, out_len, consumed, status, checksum);
+  return (int)hipGetLastError();
+}
+extern "C" int md_launch_piece_gather(uint32_t n, const uint8_t *old_blob, const uint8_t *fresh, uint8_t *new_blob, const uint64_t *d,
+                                      hipStream_t stream) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(md::gz::piece_gather_kernel, dim3(n), dim3(256), 0, stream, n, old_blob, fresh, new_blob, d);
   return (int)hipGetLastError();
 }

@@ -15,6 +15,7 @@
 // Divergence (documented): the kernels have De.Inf.Ns's whole-buffer end-of-input rule; the
 // streaming rule of lib/de.ml:941-944 (a final end-of-block code shorter than the longest code is accepted at the
 // end of the input) gives the same result on every stream a compressor emits.
+#include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -426,6 +427,18 @@ int md_i_piece_run(md_ctx *ctx, md_piece *p, int format, const md_deflate_params
 int md_i_test_flags(const md_ctx *ctx);
 int md_i_piece_out(md_ctx *ctx, const md_piece *p, size_t off, uint8_t *host, size_t len);
 size_t md_i_piece_bytes(const md_ctx *ctx);
+struct md_pieces_io {
+  const uint64_t *text_off, *text_len, *abs_len, *out_off, *out_cap, *w0, *rebase;
+  const uint32_t *flags, *sum, *isize;
+  uint64_t *out_len;
+  int32_t *status;
+};
+int md_i_pieces_run(md_ctx *ctx, int format, const md_deflate_params *params, size_t n, const uint8_t *d_text, uint8_t *d_out,
+                    void *d_state, void *d_queue, void **d_desc, size_t *d_desc_bytes, const md_pieces_io *io, uint32_t match_skip);
+hipStream_t md_i_stream(md_ctx *ctx);
+int md_i_device(md_ctx *ctx);
+uint32_t md_piece_state_bytes();
+int md_launch_piece_gather(uint32_t n, const uint8_t *old_blob, const uint8_t *fresh, uint8_t *new_blob, const uint64_t *d, hipStream_t stream);
 }
 namespace {
 constexpr size_t kKeepBytes = 65536;             // text behind the end of a piece that the next launch sees again
@@ -624,6 +637,276 @@ int md_def_encode(md_def_stream *s) {
     if (!s->eoi && fresh < md_i_piece_bytes(s->ctx)) return MD_AWAIT;
     def_launch(s);
   }
+}
+
+
+// ---- many streaming encoders at once (md_def_batch_*, mdeflate.h) ------------------------------------------------------
+// n independent Zl.Def / Gz.Def / De.Def encoders (lib/zl.ml:509-555) with the same parameters whose pieces go through the
+// kernels TOGETHER: one launch of the three kernels per md_def_batch_encode whatever n is (md_def_* is one launch per
+// encoder and piece), and an encoder's window - the last 64 KiB of its text - STAYS in device memory: only the bytes that
+// arrived since the launch before cross the link, packed into one copy.  The text of launch k + 1 is gathered on the device
+// from the tail of launch k's and the fresh bytes (piece_gather_kernel); state, queue, rebasing and the `Await protocol
+// are the single encoder's (def_launch above, struct Piece), so the bytes of every encoder are those of md_def_* - and of
+// the reference - handed the same pieces.
+struct md_def_batch {
+  md_ctx *ctx = nullptr;
+  int format = 0;
+  md_deflate_params params{};
+  md_gz_header gz{};
+  std::vector<char> name, comment;
+  size_t n = 0;
+  struct Enc {
+    std::vector<uint8_t> fresh;   // input handed over since the last launch
+    uint64_t w0 = 0, end = 0;     // the device holds the text of absolute positions [w0, end) ...
+    uint64_t text_off = 0;        // ... at this offset of the current text blob
+    uint64_t origin = 0;          // what the device counts this stream's positions from (32-bit there)
+    bool eoi = false, first = true, done = false, launched_eoi = false;
+    int status = MD_OK;
+    uint32_t checksum = 0;
+    uint64_t out_off = 0, out_len = 0, served = 0;  // output of the last launch in the device's output blob
+    std::vector<uint8_t> held;    // output of earlier launches that was not fetched before the next one
+  };
+  std::vector<Enc> e;
+  void *d_text[2] = {nullptr, nullptr};
+  size_t text_cap[2] = {0, 0};
+  int cur = 0;
+  void *d_fresh = nullptr, *d_out = nullptr, *d_state = nullptr, *d_queue = nullptr, *d_desc = nullptr, *d_gdesc = nullptr;
+  size_t fresh_cap = 0, out_cap = 0, desc_bytes = 0, gdesc_cap = 0;
+  uint8_t *h_stage = nullptr;     // pinned: the fresh bytes of a launch, packed
+  size_t stage_cap = 0;
+};
+namespace {
+struct DevGuard {
+  int prev = -1;
+  explicit DevGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) hipSetDevice(dev);
+  }
+  ~DevGuard() {
+    if (prev >= 0) hipSetDevice(prev);
+  }
+};
+bool regrow(void **p, size_t *cap, size_t need) {
+  if (need <= *cap) return true;
+  if (*p) hipFree(*p);
+  *p = nullptr;
+  *cap = 0;
+  const size_t want = need + need / 4 + 4096;
+  if (hipMalloc(p, want) != hipSuccess) return false;
+  *cap = want;
+  return true;
+}
+}  // namespace
+
+md_def_batch *md_def_batch_open(md_ctx *ctx, int format, const md_deflate_params *params, size_t n) {
+  if (!ctx || !params || n == 0 || n > 0x7fffffffu) return nullptr;
+  if (md_validate_deflate_params(ctx, format, params) != MD_OK) return nullptr;
+  DevGuard guard(md_i_device(ctx));
+  md_def_batch *b = new md_def_batch();
+  b->ctx = ctx;
+  b->format = format;
+  b->params = *params;
+  if (params->gz_header) {
+    b->gz = *params->gz_header;
+    if (b->gz.filename) {
+      b->name.assign(b->gz.filename, b->gz.filename + strlen(b->gz.filename) + 1);
+      b->gz.filename = b->name.data();
+    }
+    if (b->gz.comment) {
+      b->comment.assign(b->gz.comment, b->gz.comment + strlen(b->gz.comment) + 1);
+      b->gz.comment = b->comment.data();
+    }
+    b->params.gz_header = &b->gz;
+  }
+  b->n = n;
+  b->e.resize(n);
+  for (auto &x : b->e) x.checksum = format == MD_FORMAT_GZIP ? 0u : 1u;
+  if (hipMalloc(&b->d_state, n * (size_t)md_piece_state_bytes()) != hipSuccess ||
+      hipMalloc(&b->d_queue, n * (size_t)params->queue_len * 4) != hipSuccess) {
+    hipFree(b->d_state);
+    hipFree(b->d_queue);
+    delete b;
+    return nullptr;
+  }
+  return b;
+}
+void md_def_batch_close(md_def_batch *b) {
+  if (!b) return;
+  DevGuard guard(md_i_device(b->ctx));
+  hipStreamSynchronize(md_i_stream(b->ctx));
+  void *bufs[] = {b->d_text[0], b->d_text[1], b->d_fresh, b->d_out, b->d_state, b->d_queue, b->d_desc, b->d_gdesc};
+  for (void *p : bufs)
+    if (p) hipFree(p);
+  if (b->h_stage) hipHostFree(b->h_stage);
+  delete b;
+}
+int md_def_batch_src(md_def_batch *b, size_t i, const uint8_t *buf, size_t len) {
+  if (!b || i >= b->n || (!buf && len)) return MD_E_INVALID_ARGUMENT;
+  md_def_batch::Enc &x = b->e[i];
+  if (x.eoi) return MD_E_INVALID_ARGUMENT;
+  if (len == 0) {
+    x.eoi = true;
+    return MD_OK;
+  }
+  if (x.fresh.size() + len > kSrcMax) return MD_E_INVALID_ARGUMENT;  // (what one launch takes: call md_def_batch_encode in between)
+  x.fresh.insert(x.fresh.end(), buf, buf + len);
+  x.checksum = b->format == MD_FORMAT_GZIP ? crc32_update(x.checksum, buf, len) : adler32_update(x.checksum, buf, len);
+  return MD_OK;
+}
+size_t md_def_batch_pending(const md_def_batch *b, size_t i) {
+  if (!b || i >= b->n) return 0;
+  const md_def_batch::Enc &x = b->e[i];
+  return x.held.size() + (size_t)(x.out_len - x.served);
+}
+int md_def_batch_status(const md_def_batch *b, size_t i) {  // the signal md_def_encode would give
+  if (!b || i >= b->n) return MD_MALFORMED;
+  const md_def_batch::Enc &x = b->e[i];
+  if (x.done) return x.status == MD_OK ? MD_END : MD_MALFORMED;
+  return MD_AWAIT;
+}
+int md_def_batch_error(const md_def_batch *b, size_t i) {  // the MD_* status behind MD_MALFORMED (MD_OK otherwise)
+  if (!b || i >= b->n) return MD_E_INVALID_ARGUMENT;
+  return b->e[i].status;
+}
+uint32_t md_def_batch_checksum(const md_def_batch *b, size_t i) { return b && i < b->n ? b->e[i].checksum : 0; }
+size_t md_def_batch_out(md_def_batch *b, size_t i, uint8_t *dst, size_t cap) {
+  if (!b || i >= b->n || (!dst && cap)) return 0;
+  md_def_batch::Enc &x = b->e[i];
+  size_t got = 0;
+  if (!x.held.empty()) {
+    const size_t k = x.held.size() < cap ? x.held.size() : cap;
+    memcpy(dst, x.held.data(), k);
+    x.held.erase(x.held.begin(), x.held.begin() + k);
+    got = k;
+  }
+  if (got < cap && x.served < x.out_len) {
+    DevGuard guard(md_i_device(b->ctx));
+    const size_t left = (size_t)(x.out_len - x.served), k = left < cap - got ? left : cap - got;
+    if (hipMemcpy(dst + got, (const uint8_t *)b->d_out + x.out_off + x.served, k, hipMemcpyDeviceToHost) != hipSuccess) return got;
+    x.served += k;
+    got += k;
+  }
+  return got;
+}
+// One launch over what has arrived for every encoder since the last one.  Encoders without new input (and whose end of
+// input has not been signalled since) sit the launch out.  MD_OK, or the call-level error.
+int md_def_batch_encode(md_def_batch *b) {
+  if (!b) return MD_E_INVALID_ARGUMENT;
+  DevGuard guard(md_i_device(b->ctx));
+  hipStream_t st = md_i_stream(b->ctx);
+  const size_t n = b->n, ql = (size_t)b->params.queue_len;
+  // output that was not fetched yet moves to the host: the launch writes a new output blob
+  for (size_t i = 0; i < n; i++) {
+    md_def_batch::Enc &x = b->e[i];
+    if (x.served < x.out_len) {
+      const size_t k = (size_t)(x.out_len - x.served), at = x.held.size();
+      x.held.resize(at + k);
+      if (hipMemcpy(x.held.data() + at, (const uint8_t *)b->d_out + x.out_off + x.served, k, hipMemcpyDeviceToHost) != hipSuccess) return MD_E_HIP;
+    }
+    x.out_len = x.served = 0;
+  }
+  std::vector<uint64_t> text_off(n), text_len(n), abs_len(n), out_off(n), out_cap(n), w0(n), rebase(n, 0), out_len(n, 0), g(6 * n);
+  std::vector<uint32_t> flags(n), sum(n), isize(n);
+  std::vector<int32_t> status(n, 0);
+  const uint64_t far = (md_i_test_flags(b->ctx) & 16) ? (uint64_t)1 << 17 : (uint64_t)1 << 31;
+  uint64_t tpos = 0, fpos = 0, opos = 0;
+  uint32_t skip = 0xffffffffu;
+  size_t active = 0;
+  for (size_t i = 0; i < n; i++) {
+    md_def_batch::Enc &x = b->e[i];
+    const bool act = !x.done && (!x.fresh.empty() || (x.eoi && !x.launched_eoi));
+    const uint64_t keep = x.end - x.w0, fresh = act ? x.fresh.size() : 0;
+    g[6 * i] = x.text_off;
+    g[6 * i + 1] = x.done ? 0 : keep;
+    g[6 * i + 2] = fpos;
+    g[6 * i + 3] = fresh;
+    g[6 * i + 4] = tpos;
+    g[6 * i + 5] = 0;
+    fpos += (fresh + 15) & ~(uint64_t)15;
+    if (act) {
+      if (x.w0 - x.origin >= far) {  // 32-bit positions on the device: the origin moves up (def_launch above)
+        rebase[i] = (x.w0 - x.origin - 65536) & ~(uint64_t)65535;
+        x.origin += rebase[i];
+      }
+      const uint64_t end = x.end + fresh;
+      const size_t blocks = (fresh + ql) / ql + 2, per_block = ql >= 128 ? 320 : 24 + 4 * ql;
+      out_cap[i] = 2048 + 6 * ql + 2 * fresh + blocks * per_block;
+      flags[i] = (x.first ? 1u : 0u) | (x.eoi ? 2u : 0u);
+      abs_len[i] = end - x.origin;
+      w0[i] = x.w0 - x.origin;
+      isize[i] = (uint32_t)end;
+      const uint64_t seen = keep;
+      const uint32_t sk = seen > 512 ? (uint32_t)(seen - 512) : 0u;
+      skip = sk < skip ? sk : skip;
+      active++;
+    } else {
+      flags[i] = 8u;
+      out_cap[i] = 16;
+      abs_len[i] = w0[i] = 0;
+      isize[i] = 0;
+    }
+    sum[i] = x.checksum;
+    text_off[i] = tpos;
+    text_len[i] = (x.done ? 0 : keep) + fresh;
+    out_off[i] = opos;
+    tpos += ((x.done ? 0 : keep) + fresh + 320 + 63) & ~(uint64_t)63;
+    opos += (out_cap[i] + 63) & ~(uint64_t)63;
+  }
+  if (active == 0) return MD_OK;
+  const int nxt = b->cur ^ 1;
+  if (!regrow(&b->d_text[nxt], &b->text_cap[nxt], (size_t)tpos + 64) || !regrow(&b->d_fresh, &b->fresh_cap, (size_t)fpos + 64) ||
+      !regrow(&b->d_out, &b->out_cap, (size_t)opos + 64) || !regrow(&b->d_gdesc, &b->gdesc_cap, 6 * n * 8))
+    return MD_E_OUT_OF_MEMORY;
+  if (fpos + 64 > b->stage_cap) {
+    if (b->h_stage) hipHostFree(b->h_stage);
+    b->h_stage = nullptr;
+    b->stage_cap = 0;
+    const size_t want = (size_t)fpos + (size_t)fpos / 4 + 4096;
+    if (hipHostMalloc((void **)&b->h_stage, want, hipHostMallocDefault) != hipSuccess) return MD_E_OUT_OF_MEMORY;
+    b->stage_cap = want;
+  }
+  for (size_t i = 0; i < n; i++)
+    if (g[6 * i + 3]) memcpy(b->h_stage + g[6 * i + 2], b->e[i].fresh.data(), (size_t)g[6 * i + 3]);
+  if (fpos && hipMemcpyAsync(b->d_fresh, b->h_stage, (size_t)fpos, hipMemcpyHostToDevice, st) != hipSuccess) return MD_E_HIP;
+  if (hipMemcpyAsync(b->d_gdesc, g.data(), 6 * n * 8, hipMemcpyHostToDevice, st) != hipSuccess) return MD_E_HIP;
+  if (md_launch_piece_gather((uint32_t)n, (const uint8_t *)b->d_text[b->cur], (const uint8_t *)b->d_fresh, (uint8_t *)b->d_text[nxt],
+                             (const uint64_t *)b->d_gdesc, st) != 0)
+    return MD_E_HIP;
+  md_pieces_io io{text_off.data(), text_len.data(), abs_len.data(), out_off.data(), out_cap.data(), w0.data(), rebase.data(),
+                  flags.data(), sum.data(), isize.data(), out_len.data(), status.data()};
+  const int rc = md_i_pieces_run(b->ctx, b->format, &b->params, n, (const uint8_t *)b->d_text[nxt], (uint8_t *)b->d_out, b->d_state,
+                                 b->d_queue, &b->d_desc, &b->desc_bytes, &io, skip == 0xffffffffu ? 0u : skip);
+  if (rc != MD_OK) return rc;
+  b->cur = nxt;
+  for (size_t i = 0; i < n; i++) {
+    md_def_batch::Enc &x = b->e[i];
+    x.text_off = text_off[i];
+    if (flags[i] & 8u) continue;
+    x.end += x.fresh.size();
+    x.fresh.clear();
+    x.first = false;
+    if (x.eoi) x.launched_eoi = true;
+    if (status[i] != MD_OK && status[i] != kPieceAwait) {
+      x.status = status[i];
+      x.done = true;
+      continue;
+    }
+    x.out_off = out_off[i];
+    x.out_len = out_len[i];
+    x.served = 0;
+    if (status[i] == MD_OK) x.done = true;  // (the last piece: trailer written)
+  }
+  // the next launch sees the last 64 KiB of every text again; what lies before goes (the gather takes the tail only)
+  for (size_t i = 0; i < n; i++) {
+    md_def_batch::Enc &x = b->e[i];
+    if (x.done || x.end <= kKeepBytes) continue;
+    const uint64_t nw0 = (x.end - kKeepBytes) & ~(uint64_t)63;
+    if (nw0 > x.w0) {
+      x.text_off += nw0 - x.w0;
+      x.w0 = nw0;
+    }
+  }
+  return MD_OK;
 }
 
 }  // extern "C"

@@ -428,6 +428,28 @@ int md_def_status(const md_def_stream *s);
 uint32_t md_def_checksum(const md_def_stream *s);
 void md_def_free(md_def_stream *s);
 
+/* ---- many streaming encoders at once ----
+ * n independent Zl.Def / Gz.Def / De.Def encoders (lib/zl.ml:509-555: every `Zl.Def.encoder` is its own state machine) with
+ * the same parameters, advanced TOGETHER: md_def_batch_src hands input to encoder i (host memory, copied; length 0 = the
+ * end of its input, as in the reference), md_def_batch_encode is ONE launch of the kernels over what has arrived for all
+ * of them since the last one - whatever n is - and leaves every encoder's output of that launch in device memory, from
+ * where md_def_batch_out copies it out (md_def_batch_pending says how much waits; what is not fetched before the next
+ * encode is kept on the host side).  md_def_batch_status: MD_AWAIT (more input wanted), MD_END (the trailer is written:
+ * the stream is complete once its pending output is fetched) or MD_MALFORMED (md_def_batch_error: that stream's MD_* status).  An encoder's window
+ * (the last 64 KiB of its text), its state and its queue stay in device memory between launches: only new bytes cross the
+ * link, in one copy per launch.  The bytes of every encoder are those of md_def_* - and of the reference - handed the same
+ * pieces (a piece = what arrived between two md_def_batch_encode calls).  One md_def_batch_src hands over 1 GiB at most. */
+typedef struct md_def_batch md_def_batch;
+md_def_batch *md_def_batch_open(md_ctx *ctx, int format, const md_deflate_params *params, size_t n);
+int md_def_batch_src(md_def_batch *b, size_t i, const uint8_t *buf, size_t len);
+int md_def_batch_encode(md_def_batch *b);
+size_t md_def_batch_pending(const md_def_batch *b, size_t i);
+size_t md_def_batch_out(md_def_batch *b, size_t i, uint8_t *dst, size_t cap);
+int md_def_batch_status(const md_def_batch *b, size_t i);
+int md_def_batch_error(const md_def_batch *b, size_t i);
+uint32_t md_def_batch_checksum(const md_def_batch *b, size_t i);
+void md_def_batch_close(md_def_batch *b);
+
 /* ---- GZip (lib/gz.ml) ---- */
 
 /* What Gz.Inf.filename / comment / os / extra report (lib/gz.ml:612-633): offsets into src. */

@@ -688,3 +688,82 @@ def test_batch_in_slices_small_output_room(eng):
         eng.set_option("deflate_workspace_cap_mib", 0)
     assert [(st, len(z)) for st, z, _ in got] == [(st, len(z)) for st, z, _ in want]
     assert got[0] == want[0] and want[1][0] != 0
+
+
+@pytest.mark.parametrize("piece", [3000, 65536, 200000])
+def test_many_encoders_at_once(eng, oracle, piece):
+    """md_def_batch_*: n streaming encoders advanced together, one launch of the kernels per round of pieces, windows kept in
+    device memory.  Every encoder's bytes are the oracle's handed the same pieces (and md_def_*'s); output is there before
+    the inputs end; streams of different lengths end in different rounds, empty ones at once; not fetching the output of a
+    round does not lose it."""
+    import random
+    import decompress_amd
+    from decompress_amd import workloads
+    lib = eng.lib
+    rng = random.Random(piece)
+    lens = [0, 1, 5, 262, 4095, 4096, 40000, 65536, 65537, 100000, 131072, 300000, 70000, 33000, 98500, 250000]
+    lens += [rng.randrange(0, 220000) for _ in range(24)]
+    datas = []
+    for k, n in enumerate(lens):
+        kind = k % 4
+        datas.append(workloads.text(500 + k, n) if kind == 0 else workloads.ascii_uniform(600 + k, n) if kind == 1
+                     else bytes(rng.getrandbits(2) for _ in range(n)) if kind == 2 else (workloads.text(k, 2000) * (n // 2000 + 1))[:n])
+    for fmt, level, queue in ((decompress_amd.FORMAT_ZLIB, 6, 4096), (decompress_amd.FORMAT_GZIP, 4, 4096), (decompress_amd.FORMAT_ZLIB, 1, 64),
+                              (decompress_amd.FORMAT_DEFLATE, 9, 1024)):
+        if piece < 65536 and level == 9:
+            continue
+        params = eng._params(level, queue, 0, True)
+        n = len(datas)
+        b = lib.md_def_batch_open(eng.ctx, fmt, ctypes.byref(params), n)
+        assert b
+        outs = [bytearray() for _ in range(n)]
+        pos = [0] * n
+        sent_end = [False] * n
+        early = 0
+        buf = ctypes.create_string_buffer(1 << 20)
+        rounds = 0
+        while not all(lib.md_def_batch_status(b, i) == 2 for i in range(n)):  # MD_END
+            rounds += 1
+            assert rounds < 400
+            for i in range(n):
+                if sent_end[i]:
+                    continue
+                chunk = datas[i][pos[i]:pos[i] + piece]
+                pos[i] += len(chunk)
+                assert lib.md_def_batch_src(b, i, chunk, len(chunk)) == 0
+                if len(chunk) == 0:
+                    sent_end[i] = True
+            assert lib.md_def_batch_encode(b) == 0
+            for i in range(n):
+                st = lib.md_def_batch_status(b, i)
+                assert st in (0, 2), (i, st)  # MD_AWAIT / MD_END
+                if rounds % 3 == 0 and st != 2:
+                    continue  # (left for later: the next encode keeps it)
+                while lib.md_def_batch_pending(b, i):
+                    k = lib.md_def_batch_out(b, i, buf, rng.choice((len(buf), 100, 4096)))
+                    assert k > 0
+                    outs[i] += buf.raw[:k]
+                    early += not sent_end[i]
+        if piece <= 65536:
+            assert early > 0  # output before the end of the input
+        for i in range(n):
+            assert lib.md_def_batch_pending(b, i) == 0
+            with oracle.src_piece(piece):
+                if fmt == decompress_amd.FORMAT_ZLIB:
+                    want = oracle.zl_deflate(datas[i], level, queue)
+                elif fmt == decompress_amd.FORMAT_GZIP:
+                    want = oracle.gz_deflate(datas[i], level=level)
+                else:
+                    want = oracle.deflate_raw(datas[i], level, queue)[0]
+            assert bytes(outs[i]) == want, (fmt, level, i, len(datas[i]), len(outs[i]), len(want))
+            if fmt == decompress_amd.FORMAT_ZLIB:
+                assert zlib.decompress(bytes(outs[i])) == datas[i]
+                assert lib.md_def_batch_checksum(b, i) == zlib.adler32(datas[i])
+        # after the end: more input is refused, another encode is a no-op
+        assert lib.md_def_batch_src(b, 0, b"x", 1) < 0
+        assert lib.md_def_batch_encode(b) == 0
+        lib.md_def_batch_close(b)
+    # ... and the single encoder gives the same bytes for the same pieces
+    got, _ = _encode_in_pieces(eng, decompress_amd.FORMAT_ZLIB, datas[11], piece, 6)
+    with oracle.src_piece(piece):
+        assert got == oracle.zl_deflate(datas[11], 6)
