@@ -136,6 +136,7 @@ struct DeviceGuard {
   explicit DeviceGuard(int dev) {
     if (hipGetDevice(&prev) != hipSuccess) prev = -1;
     if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    if (!ok) (void)hipGetLastError();  // (the call reports the failure itself: no stale error for whoever asks next)
   }
   ~DeviceGuard() {
     if (prev >= 0) (void)hipSetDevice(prev);
@@ -326,9 +327,8 @@ void *md_host_alloc(md_ctx *ctx, size_t bytes) {
   return p;
 }
 void md_host_free(md_ctx *ctx, void *p) {
-  if (!ctx || !p) return;
-  DeviceGuard guard(ctx->device);
-  hipHostFree(p);
+  (void)ctx;  // (pinned memory is freed whatever the current device is - and a buffer may outlive its context)
+  if (p) hipHostFree(p);
 }
 
 int md_set_option(md_ctx *ctx, const char *key, int value) {
@@ -382,10 +382,10 @@ int md_set_option(md_ctx *ctx, const char *key, int value) {
     ctx->host_slices_max = value;
     return MD_OK;
   }
-  if (!strcmp(key, "debug_known_bounds")) {  // measurement builds only (-DMD_DEBUG_KNOWN_BOUNDS): mode | streams << 4
+  if (!strcmp(key, "debug_known_bounds")) {  // measurement builds only (-DMD_DEBUG_KNOWN_BOUNDS): mode | streams << 5
     MD_ON_DEVICE(ctx);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (value < 0 || md_i_debug_known_bounds(value & 15, (uint32_t)value >> 4)) return fail(ctx, MD_E_INVALID_ARGUMENT, "debug_known_bounds: not a measurement build");
+    if (value < 0 || md_i_debug_known_bounds(value & 31, (uint32_t)value >> 5)) return fail(ctx, MD_E_INVALID_ARGUMENT, "debug_known_bounds: not a measurement build");
     return MD_OK;
   }
   if (!strcmp(key, "debug_inflate_lds_pad")) {  // measurement only: unused LDS per stream, i.e. fewer streams per CU

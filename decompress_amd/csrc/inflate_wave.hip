@@ -57,7 +57,7 @@ constexpr uint32_t SMIN = 48;      // ... and at least: where the data expands s
                                    // follows the output, not the number of zones thrown away)
 constexpr uint32_t KMAX = 64;      // walk steps per lane per pass
 #ifndef MD_RUNIN_NUM
-#define MD_RUNIN_NUM 1
+#define MD_RUNIN_NUM 3
 #define MD_RUNIN_DEN 2
 #endif
 constexpr uint32_t RUNIN_NUM = MD_RUNIN_NUM, RUNIN_DEN = MD_RUNIN_DEN;  // run-in of the speculative pass, as a fraction of the zone
@@ -625,46 +625,6 @@ __device__ __forceinline__ void sync_pass(const lds_u32 *win, const lds_u32 *lut
     stop = e_tb(e) >= kStopEobI ? e_tb(e) : 0u;
     if (COUNT) nb = cnt;
   }
-}
-
-// The speculative pass of a round (round 5): lane i walks from a run-in ahead of its zone - somewhere inside a token, most
-// likely - to the first token boundary at or beyond the zone's end, like sync_pass; on the way it notes `mid`, the first
-// token boundary at or beyond the zone's START (what lane i - 1's walk will report as its end if both walks are on the
-// stream's real chain of tokens), and counts what the tokens from there on produce.  A lane whose `mid` equals its left
-// neighbour's end needs no second walk: from the same boundary the decode is the same.  So the counting pass that every
-// lane went through after the speculative one is gone; only the lanes that had not synchronised by their zone's start
-// (5-13 % of them) walk again.  (0xffffffff = the walk ended before it saw such a boundary.)  `known`: the walk starts on
-// a boundary that is known to be real (lane 0).
-__device__ __forceinline__ void sync_pass_mid(const lds_u32 *win, const lds_u32 *lut, uint32_t lroot, uint32_t start, uint32_t zstart,
-                                              uint32_t limit, bool known, uint32_t &mid, uint32_t &end, uint32_t &stop, uint32_t &nb) {
-  uint32_t p = start, e = e_root(lroot), cnt = 0, m = known ? start : 0xffffffffu;
-  bool live = known;
-  if (p < limit) {
-    const uint32_t thr = (kLitB << 21) | limit;
-    uint32_t key;
-    Cursor c;
-    c.init(win, start);
-    do {
-      const uint32_t w = c.peek(p);
-      const uint32_t en = lut_step(lut, e, w);
-      const uint32_t n = e_n(en), xb = e_xb(en);
-      const bool root = e_tb(en) == kLitB;
-      const uint32_t len1 = e_val(en) + __builtin_amdgcn_ubfe(w, n - xb, xb) + (kCountMatch + 2);  // length - 1, and a match
-      const uint32_t add = (root ? 1u : 0u) + (e_tb(en) == kDistB ? len1 : 0u);
-      cnt += live ? add : 0u;  // (the token that ends on `mid` is the left neighbour's)
-      p += n;
-      const bool cross = root && !live && p >= zstart;
-      m = cross ? p : m;
-      live = live || cross;
-      c.seek(win, p);
-      e = en;
-      key = (en & kTbMask) | p;
-    } while (key < thr);
-  }
-  mid = m;
-  end = p;
-  stop = e_tb(e) >= kStopEobI ? e_tb(e) : 0u;
-  nb = cnt;
 }
 
 struct LaneOut {
@@ -1237,14 +1197,7 @@ __device__ __forceinline__ int inflate_block(lds_smem *sm, const uint8_t *__rest
       nb = v.w;
     } else {
 #endif
-    if constexpr (BUDGET) {  // (a walk limited to KMAX steps ends where its start decides: the old order of passes)
-      sync_pass<false, BUDGET>(win, lut, lroot, true, start - runin, limit, end, stop, nb);
-    } else {
-      uint32_t mid;
-      sync_pass_mid(win, lut, lroot, start - runin, start, limit, lane == 0, mid, end, stop, nb);
-      counted = mid != 0xffffffffu;
-      start = counted ? mid : start;
-    }
+    sync_pass<false, BUDGET>(win, lut, lroot, true, start - runin, limit, end, stop, nb);
     pf.tick(P_DECODE1);
     const uint32_t passes = zs * PASSES >= PASS_BITS ? PASSES : PASS_BITS / zs > PASSES_MAX ? PASSES_MAX : PASS_BITS / zs;
     for (uint32_t it = 0; it < passes; it++) {

@@ -2,6 +2,8 @@
 allocator / stream provider here; the work is done by libmdeflate.so)."""
 import ctypes
 
+import numpy as _np
+
 from . import _lib
 
 FORMAT_DEFLATE = 0
@@ -25,6 +27,13 @@ STATUS_CODES = {v: k for k, v in STATUS_NAMES.items()}
 
 class Error(RuntimeError):
     """Call-level failure (the reference raises Invalid_argument / Failure)."""
+
+
+class _HostArray(_np.ndarray):
+    """numpy view of a pinned block of md_host_alloc; carries the owner that frees it"""
+
+    def __array_finalize__(self, obj):
+        self._md_owner = getattr(obj, "_md_owner", None)
 
 
 def _ptr(t):
@@ -194,12 +203,12 @@ class Engine:
                 self.buf = (ctypes.c_uint8 * max(1, nbytes)).from_address(p)
 
             def __del__(self):
-                lib.md_host_free(ctx, p)
+                lib.md_host_free(None, p)  # (the context may be gone by now: md_host_free does not use it)
 
         owner = _Owner()
         a = np.frombuffer(owner.buf, dtype=np.uint8, count=nbytes)
-        self._host_owners = getattr(self, "_host_owners", [])
-        self._host_owners.append(owner)
+        a = a.view(_HostArray)
+        a._md_owner = owner  # the array (and every view of it) keeps the pinned block alive; it goes when they do
         return a
 
     def inflate_batch_host(self, fmt, h_in, in_off, in_len, h_out, out_off, out_cap):

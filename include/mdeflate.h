@@ -168,7 +168,7 @@ int md_set_option(md_ctx *ctx, const char *key, int value);
  * transfers that overlap with the kernels.  NULL when the allocation fails.  (An OCaml caller wraps it in a Bigarray with
  * caml_ba_alloc and frees it from the custom block's finaliser: INTEGRATION.md.) */
 void *md_host_alloc(md_ctx *ctx, size_t bytes);
-void md_host_free(md_ctx *ctx, void *p);
+void md_host_free(md_ctx *ctx, void *p); /* (ctx may be NULL, or already destroyed: it is not used) */
 int md_timing_begin(md_ctx *ctx);
 int md_timing_end(md_ctx *ctx, float *ms);
 

@@ -52,7 +52,7 @@ for waves in (2, 1):
         args = setup(sub)
         ref = None
         for name, mode in (("normal", 0), ("record", 1), ("replay", 2), ("replay+nomatch", 2 | 4), ("replay+nocopy", 2 | 8), ("nomatch", 4), ("nocopy", 8), ("normal again", 0)):
-            eng.set_option("debug_known_bounds", mode | (n << 4))
+            eng.set_option("debug_known_bounds", mode | (n << 5))
             ms, bad = timed(args)
             same = None
             if mode in (0, 1, 2):
@@ -64,7 +64,7 @@ for waves in (2, 1):
             rows.append({"waves": waves, "streams": n, "mode": name, "ms": round(ms, 4), "bad_status": bad, "same_bytes": same})
             print(rows[-1], flush=True)
         del args, ref
-eng.set_option("debug_known_bounds", 0 | (1 << 4))
+eng.set_option("debug_known_bounds", 0 | (1 << 5))
 os.makedirs(os.path.dirname(out_path), exist_ok=True)
 with open(out_path, "w") as f:
     json.dump(rows, f, indent=1)

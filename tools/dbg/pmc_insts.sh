@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/pmc_insts
 mkdir -p $OUT
-BENCH="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-verify --no-secondary --unique 256 $*"
+BENCH="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-verify --no-secondary --no-host-path --unique 256 $*"
 for C in "SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_VALU" "SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS"; do
   tag=$(echo $C | tr ' ' '_')
   rocprofv3 --kernel-trace --pmc $C -f csv -d $OUT/$tag -o pmc -- $BENCH > /dev/null 2> $OUT/$tag.log

@@ -8,7 +8,7 @@ REPO=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-text-leg --no-secondary $*"
+BENCH="python $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-text-leg --no-secondary --no-host-path --no-verify $*"
 echo "== kernel trace: $BENCH"
 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/trace" -o trace -- $BENCH > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.log"
 tail -1 "$OUT/bench_under_rocprof.json" | cut -c1-400
