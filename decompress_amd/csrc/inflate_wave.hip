@@ -862,24 +862,22 @@ __device__ __forceinline__ void copy_far(const lds_u32 *mrec, const lds_u16 *mpo
   const uint8_t *g = sk.g;
   uint32_t nnear = 0;
   uint64_t v0[FR], v1[FR];
-  // (straight-line: a load behind a branch makes the compiler wait for it at the join; a row beyond the last record
-  // reads g[0..15] with every lane, one cache line)
+  // ONE pass over the records' rows: the loads of a row are started, the row's near matches and long records are listed
+  // while they fly, and what the stores will need - staging position and byte count - stays in a register per row, so
+  // that a record is read from LDS once, not three times (rounds 3-4: a pass to start the loads, one to list, one to store;
+  // the same time within noise, seven registers fewer).  Straight-line: a load behind a branch makes the compiler wait
+  // for it at the join; a row beyond the last record reads g[0..15] with every lane, one cache line
+  uint32_t pk[FR];
+  uint32_t nlong = 0;
+  bool spill = false;
 #pragma unroll
   for (int u = 0; u < FR; u++) {
     const FarRow f = far_row(mrec, mpos, u * kWave + lane, nrec, rb, R0);
     v0[u] = out_ld64(g + f.src);
     v1[u] = out_ld64(g + f.src + 8);
-  }
-  pf.tick_lds(P_FAR_REC);
-  // while the loads are on their way: the near matches are listed (from the bottom of `list`) and marked, and so are
-  // the records that take more than 16 bytes from the old output (from the top of `list`; should the two lists meet,
-  // the near matches keep their places and the long records are copied by the slow loop at the end)
-  uint32_t nlong = 0;
-  bool spill = false;
-  for (uint32_t c0 = 0; c0 < nrec; c0 += kWave) {
-    const FarRow f = far_row(mrec, mpos, c0 + lane, nrec, rb, R0);
+    pk[u] = f.qs | (f.n << 16);
     const uint64_t nb = __ballot(f.near);
-    if (f.near) list[nnear + lane_rank(nb)] = (uint16_t)(c0 + lane);
+    if (f.near) list[nnear + lane_rank(nb)] = (uint16_t)(u * kWave + lane);
     nnear += (uint32_t)__builtin_popcountll(nb);
     const uint64_t lb = __ballot(f.n > 16);
     const uint32_t lc = (uint32_t)__builtin_popcountll(lb);
@@ -888,25 +886,25 @@ __device__ __forceinline__ void copy_far(const lds_u32 *mrec, const lds_u16 *mpo
       nlong = 0;
     }
     if (lb && !spill) {
-      if (f.n > 16) list[RMAX - 1 - (nlong + lane_rank(lb))] = (uint16_t)(c0 + lane);
+      if (f.n > 16) list[RMAX - 1 - (nlong + lane_rank(lb))] = (uint16_t)(u * kWave + lane);
       nlong += lc;
     }
   }
-  pf.tick_lds(P_FAR);
+  pf.tick_lds(P_FAR_REC);
 #pragma unroll
   for (int u = 0; u < FR; u++) {
     if ((uint32_t)u * kWave < nrec) {
-      const FarRow f = far_row(mrec, mpos, u * kWave + lane, nrec, rb, R0);
+      const uint32_t qs = pk[u] & 0xffffu, n = pk[u] >> 16;
       if constexpr (PF::on) {
         if (u == 0) {
           asm volatile("" ::"v"(v0[u]), "v"(v1[u]));
           pf.tick_all(P_FAR_LOAD);
         }
       }
-      if (f.n) {
-        lds_u8 *dd = stage + f.qs;
-        lds_put(dd, v0[u], f.n < 8 ? f.n : 8);
-        if (f.n > 8) lds_put(dd + 8, v1[u], f.n < 16 ? f.n - 8 : 8);
+      if (n) {
+        lds_u8 *dd = stage + qs;
+        lds_put(dd, v0[u], n < 8 ? n : 8);
+        if (n > 8) lds_put(dd + 8, v1[u], n < 16 ? n - 8 : 8);
       }
     }
   }
