@@ -56,6 +56,16 @@ constexpr uint32_t SMIN = 48;      // ... and at least: where the data expands s
                                    // staging buffer, the zones shrink so that all 64 lanes still have work (cost then
                                    // follows the output, not the number of zones thrown away)
 constexpr uint32_t KMAX = 64;      // walk steps per lane per pass
+#ifndef MD_EMIT_SPLIT
+#define MD_EMIT_SPLIT 1  // the two wavefronts of a stream emit a round together, each one half of every zone (inflate_block)
+#endif
+#if defined(MD_DEBUG_KNOWN_BOUNDS)
+#undef MD_EMIT_SPLIT
+#define MD_EMIT_SPLIT 0  // (the replayed sync results carry no mid-zone boundaries)
+#endif
+#ifndef MD_SPLIT_B
+#define MD_SPLIT_B 4  // eighths of a zone that the copier emits
+#endif
 #ifndef MD_RUNIN_NUM
 #define MD_RUNIN_NUM 3
 #define MD_RUNIN_DEN 2
@@ -99,13 +109,17 @@ constexpr uint32_t kNearBit = 0x8000u;            // match record: len-3[23:16] 
 struct Mail {
   uint32_t emitted;  // jobs posted by the decoder
   uint32_t copied;   // jobs finished by the copier: staging buffer and records are free again
-  uint32_t kind;     // kJobRound | kJobStored | kJobQuit
+  uint32_t kind;     // kJobRound | kJobStored | kJobQuit | kJobEmit
   uint32_t total;    // bytes the job produces
   uint32_t x;        // match records of the round | body offset of the stored bytes
   uint32_t stuck;    // the copier's defensive verdict
   uint32_t a, b;     // Adler-32 state after job `copied`
 };
-constexpr uint32_t kJobRound = 0, kJobStored = 1, kJobQuit = 2;
+constexpr uint32_t kJobRound = 0, kJobStored = 1, kJobQuit = 2, kJobEmit = 3;
+// kJobEmit: the copier emits the second halves of the round's zones while the decoder emits the first ones.  What it needs
+// lies in `list` (the copier's own array, idle between two rounds): four words per lane - start, limit, output position,
+// first record (0xffffffff: nothing to do) -, then six wave-uniform words; the lanes' results come back in the same place.
+constexpr uint32_t kHxUni = 4 * 64;  // word index of the uniform part: lroot, tot, rb, R0, cap, checked
 struct Smem {  // the kernel's only LDS object: it sits at LDS address 0
   uint32_t win[WIN_WORDS];
   uint32_t lut[kLutWords];
@@ -595,11 +609,21 @@ __device__ __forceinline__ uint32_t lut_step(const lds_u32 *lut, uint32_t e, uin
 // while `key` < `thr` (see the table layout); every step of a complete code consumes a bit, so it ends.  BUDGET: the
 // block has an incomplete code (allowed when the only code is 1 bit long, lib/de.ml:549-550), whose unused slot
 // consumes nothing (lib/de.ml:521: a zero entry is "0 bits, symbol 0"): the walk is then limited to KMAX steps.
-template <bool COUNT, bool BUDGET>
+// MID (counting passes): also the first token boundary at or beyond `mthr` (the middle of the zone) and what the tokens
+// before it produce - where the zone is cut when the stream's two wavefronts emit it together (0xffffffff: none, the zone's
+// tokens end before the middle or the walk stopped there).
+template <bool COUNT, bool BUDGET, bool MID = false>
 __device__ __forceinline__ void sync_pass(const lds_u32 *win, const lds_u32 *lut, uint32_t lroot, bool go, uint32_t start,
-                                          uint32_t limit, uint32_t &end, uint32_t &stop, uint32_t &nb) {
+                                          uint32_t limit, uint32_t &end, uint32_t &stop, uint32_t &nb, uint32_t mthr = 0,
+                                          uint32_t *midp = nullptr, uint32_t *midcnt = nullptr) {
   if (go) {
     uint32_t p = start, e = e_root(lroot), cnt = 0;
+    uint32_t mp = 0xffffffffu, mc = 0;
+    bool got = false;
+    if (MID && start >= mthr) {  // (the token before reached beyond the middle: everything is the second half's)
+      mp = start;
+      got = true;
+    }
     if (p < limit) {
       const uint32_t thr = (kLitB << 21) | limit;
       uint32_t slot = 0, key;
@@ -615,6 +639,12 @@ __device__ __forceinline__ void sync_pass(const lds_u32 *win, const lds_u32 *lut
           cnt += (e_tb(en) == kLitB ? 1u : 0u) + (e_tb(en) == kDistB ? len1 : 0u);
         }
         p += n;
+        if (MID) {
+          const bool cross = (e_tb(en) == kLitB) & !got & (p >= mthr);
+          mp = cross ? p : mp;
+          mc = cross ? cnt : mc;
+          got = got | cross;
+        }
         c.seek(win, p);
         e = en;
         key = (en & kTbMask) | p;
@@ -624,6 +654,10 @@ __device__ __forceinline__ void sync_pass(const lds_u32 *win, const lds_u32 *lut
     end = p;
     stop = e_tb(e) >= kStopEobI ? e_tb(e) : 0u;
     if (COUNT) nb = cnt;
+    if (MID) {
+      *midp = mp;
+      *midcnt = mc;
+    }
   }
 }
 
@@ -1166,6 +1200,7 @@ __device__ __forceinline__ int inflate_block(lds_smem *sm, const uint8_t *__rest
   lds_u16 *mpos = (lds_u16 *)sm->mpos;
   const uint32_t total_bits = body_len * 8;
   uint32_t zs = *zone_io;  // zone size of this round (wave-uniform), adapted to the expansion of the last one
+  constexpr bool kSplit = PAIR && !BUDGET && MD_EMIT_SPLIT != 0;
   for (;;) {
     const uint32_t base = (bp >> 5) << 2;  // window start (byte of the body, multiple of 4)
     wnd.ensure(win, body, body_len, base, lane);
@@ -1174,6 +1209,7 @@ __device__ __forceinline__ int inflate_block(lds_smem *sm, const uint8_t *__rest
     pf.count(C_ROUNDS);
     pf.count(C_PASSES);
     uint32_t start = rbp + lane * zs, end = 0, stop = 0, nb = 0;
+    uint32_t midp = 0xffffffffu, midcnt = 0;  // (kSplit) where the zone is cut in two, and what its first half produces
     const uint32_t limit = rbp + (lane + 1) * zs;
     // the speculative pass starts a RUN-IN ahead of the zone (inside the zone before): all it has to deliver is the
     // boundary at the zone's END, and the longer the walk, the likelier that it has synchronised by then - fewer lanes
@@ -1204,7 +1240,8 @@ __device__ __forceinline__ int inflate_block(lds_smem *sm, const uint8_t *__rest
       if (__ballot(redo) == 0) break;
       if (redo && lane > 0) start = pe;
       pf.count(C_PASSES);
-      sync_pass<true, BUDGET>(win, lut, lroot, redo, start, limit, end, stop, nb);
+      if constexpr (kSplit) sync_pass<true, BUDGET, true>(win, lut, lroot, redo, start, limit, end, stop, nb, limit - (zs * MD_SPLIT_B) / 8, &midp, &midcnt);
+      else sync_pass<true, BUDGET>(win, lut, lroot, redo, start, limit, end, stop, nb);
       counted = counted || redo;
     }
 #ifdef MD_DEBUG_KNOWN_BOUNDS
@@ -1246,11 +1283,57 @@ __device__ __forceinline__ int inflate_block(lds_smem *sm, const uint8_t *__rest
       if (!mail_wait_idle(sm, sent)) return MD_E_HIP;
       pf.tick(P_WAIT_DEC);
     }
+    // Two wavefronts, one round: the copier has nothing to do until the round is emitted, so it emits the second half of
+    // every zone while this wavefront emits the first (the counting pass left the boundary in the middle and what lies
+    // before it: the halves' output positions and records are known) - the emit pass is half as long.  Small zones are
+    // not worth the hand-over.
+    bool split = false;
+    uint32_t bq = 0, br = 0;  // the second half's bytes | records before it, relative to the lane's
+    LaneOut lob;
+    lob.endp = 0, lob.stopc = 0, lob.bytes = 0, lob.nm = 0;
+    bool gob = false;
+    if constexpr (kSplit) split = zs >= 128;
     {
       const uint32_t all = rdlane(off + mynb, nvalid - 1) & (kCountMatch - 1);  // bytes the round will produce
       const bool plain = tot >= rbp + kWave * zs + 64 && R0 >= 32768u && all <= sk.cap - R0 && (R0 - rb) + all <= STAGE - 16;
-      if (plain && !BUDGET) emit_pass<false, false>(win, lut, lroot, mrec, mpos, sk.stage, roff, tot, mine, start, limit, q0, rb, R0, sk.cap, lo);
-      else emit_pass<true, BUDGET>(win, lut, lroot, mrec, mpos, sk.stage, roff, tot, mine, start, limit, q0, rb, R0, sk.cap, lo);
+      uint32_t alimit = limit;
+      if constexpr (kSplit) {
+        if (split) {
+          gob = mine && midp != 0xffffffffu && midp < limit && midp >= start;
+          bq = midcnt & (kCountMatch - 1);
+          br = midcnt >> 20;
+          lds_u32 *hx = reinterpret_cast<lds_u32 *>(sm->list);
+          hx[4 * lane + 0] = gob ? midp : 0xffffffffu;
+          hx[4 * lane + 1] = limit;
+          hx[4 * lane + 2] = q0 + bq;
+          hx[4 * lane + 3] = roff + br;
+          if (lane < 6) hx[kHxUni + lane] = lane == 0 ? lroot : lane == 1 ? tot : lane == 2 ? rb : lane == 3 ? R0 : lane == 4 ? sk.cap : (plain ? 0u : 1u);
+          mail_post(sm, lane, kJobEmit, 0, 0, sent);
+          alimit = gob ? midp : limit;
+        }
+      }
+      if (plain && !BUDGET) emit_pass<false, false>(win, lut, lroot, mrec, mpos, sk.stage, roff, tot, mine, start, alimit, q0, rb, R0, sk.cap, lo);
+      else emit_pass<true, BUDGET>(win, lut, lroot, mrec, mpos, sk.stage, roff, tot, mine, start, alimit, q0, rb, R0, sk.cap, lo);
+      if constexpr (kSplit) {
+        if (split) {
+          if (!mail_wait_idle(sm, sent)) return MD_E_HIP;
+          const lds_u32 *hx = reinterpret_cast<const lds_u32 *>(sm->list);
+          if (gob) {
+            lob.endp = hx[4 * lane + 0];
+            lob.stopc = hx[4 * lane + 1];
+            lob.bytes = hx[4 * lane + 2];
+            lob.nm = hx[4 * lane + 3];
+          }
+          // a lane's verdict: its first half's if that stopped, else its second half's
+          const bool sa = lo.stopc != 0;
+          if (!sa && gob) {
+            lo.endp = lob.endp;
+            lo.stopc = lob.stopc;
+            lo.bytes = bq + lob.bytes;
+            lo.nm = br + lob.nm;
+          }
+        }
+      }
     }
     pf.tick(P_EMIT_A);
     // the first stopped lane (stream order) ends the round
@@ -1323,7 +1406,25 @@ __device__ __forceinline__ void copier_main(lds_smem *sm, const uint8_t *__restr
     if (kind == kJobQuit) break;
     bool stuck = false;
     if (kind == kJobRound) copy_round(sm, sk, lane, total, x, &stuck, pf);
-    else copy_stored(sk, body, x, total, lane);
+    else if (kind == kJobEmit) {
+      if constexpr (MD_EMIT_SPLIT != 0) {
+        lds_u32 *hx = reinterpret_cast<lds_u32 *>(sm->list);
+        const uint32_t bstart = hx[4 * lane + 0], blimit = hx[4 * lane + 1], bq0 = hx[4 * lane + 2], brec = hx[4 * lane + 3];
+        const uint32_t lroot = uni(hx[kHxUni + 0]), tot = uni(hx[kHxUni + 1]), rb = uni(hx[kHxUni + 2]), R0 = uni(hx[kHxUni + 3]),
+                       cap = uni(hx[kHxUni + 4]), checked = uni(hx[kHxUni + 5]);
+        const bool go = bstart != 0xffffffffu;
+        LaneOut lo;
+        lo.endp = bstart, lo.stopc = 0, lo.bytes = 0, lo.nm = 0;
+        const lds_u32 *win = (const lds_u32 *)sm->win;
+        const lds_u32 *lut = (const lds_u32 *)sm->lut;
+        if (checked) emit_pass<true, false>(win, lut, lroot, (lds_u32 *)sm->mrec, (lds_u16 *)sm->mpos, sk.stage, brec, tot, go, go ? bstart : 0u, blimit, bq0, rb, R0, cap, lo);
+        else emit_pass<false, false>(win, lut, lroot, (lds_u32 *)sm->mrec, (lds_u16 *)sm->mpos, sk.stage, brec, tot, go, go ? bstart : 0u, blimit, bq0, rb, R0, cap, lo);
+        hx[4 * lane + 0] = lo.endp;
+        hx[4 * lane + 1] = lo.stopc;
+        hx[4 * lane + 2] = lo.bytes;
+        hx[4 * lane + 3] = lo.nm;
+      }
+    } else copy_stored(sk, body, x, total, lane);
     if (lane == 0) {
       sm->mail.a = sk.a;
       sm->mail.b = sk.b;

@@ -32,3 +32,4 @@ for k, v in cat:
     p = (catb + catb)[offs[k]:offs[k] + nb]
     run(k, p)
 run("zipf", workloads.text(0xC3, nb))
+run("markov", workloads.markov_text(0xC3, nb))
