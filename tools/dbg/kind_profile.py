@@ -40,3 +40,4 @@ names = sys.argv[1:] or ["book1", "geo", "obj2", "paper2", "pic", "progl"]
 for k in names:
     run(k, (catb + catb)[offs[k]:offs[k] + nb])
 run("zipf", workloads.text(0xC3, nb))
+run("markov", workloads.markov_text(0xC3, nb))
