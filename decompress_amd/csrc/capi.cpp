@@ -517,7 +517,7 @@ std::vector<HostSlice> host_slices(size_t n, const uint64_t *in_off, const uint6
   for (size_t k = 0; k < want; k++) {
     const uint64_t upto = total / want * (k + 1);
     size_t i1 = i0;
-    while (i1 < n && (k + 1 == want || acc < upto)) {
+    while (i1 < n && (k + 1 == want || acc < upto || i1 - i0 < min_streams)) {  // (never fewer than min_streams, whatever the sizes: ADVICE r5)
       acc += in_len[i1] + out_cap[i1];
       i1++;
     }
@@ -568,29 +568,49 @@ static int host_pipeline(md_ctx *ctx, const std::vector<HostSlice> &sl, const ui
   if (!ctx->s_in && hipStreamCreateWithFlags(&ctx->s_in, hipStreamNonBlocking) != hipSuccess) return fail(ctx, MD_E_HIP, "hipStreamCreate");
   if (!ctx->s_out && hipStreamCreateWithFlags(&ctx->s_out, hipStreamNonBlocking) != hipSuccess) return fail(ctx, MD_E_HIP, "hipStreamCreate");
   EventList evs;
+  // From the first enqueue on there is NO early return: an error is recorded, the loop is left, and the three streams are
+  // synchronised before the call returns - the copies read and write the caller's h_in / h_out, and the context's device
+  // blobs may be grown (freed) by the next call.
+  int rc = MD_OK;
+  hipError_t herr = hipSuccess;
+  const char *hwhat = nullptr;
+#define MD_PIPE_TRY(expr)                       \
+  if (rc == MD_OK && herr == hipSuccess) {      \
+    const hipError_t e_ = (expr);               \
+    if (e_ != hipSuccess) {                     \
+      herr = e_;                                \
+      hwhat = #expr;                            \
+    }                                           \
+  }
   // (whatever the caller queued on the context's stream before this call comes first, also for the copy streams)
   hipEvent_t e0 = evs.make();
-  if (!e0) return fail(ctx, MD_E_HIP, "hipEventCreate");
-  HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
-  HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_in, e0, 0));
-  int rc = MD_OK;
-  for (size_t k = 0; k < sl.size() && rc == MD_OK; k++) {
+  if (!e0) return fail(ctx, MD_E_HIP, "hipEventCreate");  // (nothing enqueued yet)
+  MD_PIPE_TRY(hipEventRecord(e0, ctx->stream));
+  MD_PIPE_TRY(hipStreamWaitEvent(ctx->s_in, e0, 0));
+  for (size_t k = 0; k < sl.size() && rc == MD_OK && herr == hipSuccess; k++) {
     hipEvent_t e_in = evs.make(), e_k = evs.make();
-    if (!e_in || !e_k) return fail(ctx, MD_E_HIP, "hipEventCreate");
+    if (!e_in || !e_k) {
+      herr = hipErrorOutOfMemory;
+      hwhat = "hipEventCreate";
+      break;
+    }
     if (sl[k].in_hi > sl[k].in_lo)
-      HIP_TRY(ctx, hipMemcpyAsync(d_in + sl[k].in_lo, h_in + sl[k].in_lo, sl[k].in_hi - sl[k].in_lo, hipMemcpyHostToDevice, ctx->s_in));
-    HIP_TRY(ctx, hipEventRecord(e_in, ctx->s_in));
-    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, e_in, 0));
+      MD_PIPE_TRY(hipMemcpyAsync(d_in + sl[k].in_lo, h_in + sl[k].in_lo, sl[k].in_hi - sl[k].in_lo, hipMemcpyHostToDevice, ctx->s_in));
+    MD_PIPE_TRY(hipEventRecord(e_in, ctx->s_in));
+    MD_PIPE_TRY(hipStreamWaitEvent(ctx->stream, e_in, 0));
+    if (herr != hipSuccess) break;
     rc = launch(sl[k].i0, sl[k].i1 - sl[k].i0);
     if (rc != MD_OK) break;
-    HIP_TRY(ctx, hipEventRecord(e_k, ctx->stream));
-    HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_out, e_k, 0));
+    MD_PIPE_TRY(hipEventRecord(e_k, ctx->stream));
+    MD_PIPE_TRY(hipStreamWaitEvent(ctx->s_out, e_k, 0));
     if (sl[k].out_hi > sl[k].out_lo)
-      HIP_TRY(ctx, hipMemcpyAsync(h_out + sl[k].out_lo, d_out + sl[k].out_lo, sl[k].out_hi - sl[k].out_lo, hipMemcpyDeviceToHost, ctx->s_out));
+      MD_PIPE_TRY(hipMemcpyAsync(h_out + sl[k].out_lo, d_out + sl[k].out_lo, sl[k].out_hi - sl[k].out_lo, hipMemcpyDeviceToHost, ctx->s_out));
   }
+#undef MD_PIPE_TRY
   // everything in flight ends before the call returns (also after an error: the buffers are the caller's)
   hipError_t a = hipStreamSynchronize(ctx->s_in), b2 = hipStreamSynchronize(ctx->stream), c = hipStreamSynchronize(ctx->s_out);
   if (rc != MD_OK) return rc;
+  if (herr != hipSuccess) return fail(ctx, MD_E_HIP, hwhat, herr);
   if (a != hipSuccess || b2 != hipSuccess || c != hipSuccess) return fail(ctx, MD_E_HIP, "host pipeline", a != hipSuccess ? a : b2 != hipSuccess ? b2 : c);
   return MD_OK;
 }

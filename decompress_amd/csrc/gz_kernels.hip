@@ -233,18 +233,38 @@ __global__ __launch_bounds__(kWave) void gz_finish_kernel(
 // The text of n streaming encoders for their next launch (md_def_batch, stream_shim.cpp): stream i's region of the new
 // blob is the tail of its region in the old one (the window the matcher can still reach) followed by the bytes that
 // arrived since (packed in `fresh`).  d[6 i ..]: old offset of the tail, its length, offset in `fresh`, fresh length,
-// new offset (unused).  One workgroup per stream, 16 bytes per thread and step where the alignments allow.
+// new offset (unused).  Grid = (chunks of 64 KiB, stream): a thread copies 16 destination-aligned bytes per step (the
+// source is read with unaligned 16-byte loads), the few bytes in front of the first and behind the last aligned chunk of a
+// part one by one (it was one byte per thread and step, one workgroup per stream).
+constexpr uint32_t kGatherChunk = 65536;
+__device__ __forceinline__ void gather_part(uint8_t *__restrict__ o, const uint8_t *__restrict__ a, uint64_t len, uint64_t c0, uint64_t c1) {
+  // bytes [c0, c1) of the part (c0, c1 within [0, len]); 16-byte steps on o's alignment
+  if (c0 >= c1) return;
+  const uint64_t head = (16 - ((uintptr_t)(o + c0) & 15)) & 15;
+  const uint64_t h1 = c0 + head < c1 ? c0 + head : c1;
+  for (uint64_t k = c0 + threadIdx.x; k < h1; k += 256) o[k] = a[k];
+  const uint64_t body = (c1 - h1) & ~(uint64_t)15;
+  for (uint64_t k = h1 + (uint64_t)threadIdx.x * 16; k < h1 + body; k += 256 * 16) {
+    uint4 v;
+    __builtin_memcpy(&v, a + k, 16);
+    *reinterpret_cast<uint4 *>(o + k) = v;
+  }
+  for (uint64_t k = h1 + body + threadIdx.x; k < c1; k += 256) o[k] = a[k];
+  (void)len;
+}
 __global__ __launch_bounds__(256) void piece_gather_kernel(uint32_t n, const uint8_t *__restrict__ old_blob, const uint8_t *__restrict__ fresh,
                                                            uint8_t *__restrict__ new_blob, const uint64_t *__restrict__ d) {
-  const uint32_t i = blockIdx.x;
-  if (i >= n) return;
-  const uint64_t toff = d[6 * i], tlen = d[6 * i + 1], foff = d[6 * i + 2], flen = d[6 * i + 3], noff = d[6 * i + 4];
-  const uint8_t *a = old_blob + toff;
-  uint8_t *o = new_blob + noff;
-  for (uint64_t k = threadIdx.x; k < tlen; k += 256) o[k] = a[k];
-  const uint8_t *b = fresh + foff;
-  o += tlen;
-  for (uint64_t k = threadIdx.x; k < flen; k += 256) o[k] = b[k];
+  for (uint32_t i = blockIdx.y; i < n; i += gridDim.y) {
+    const uint64_t toff = d[6 * i], tlen = d[6 * i + 1], foff = d[6 * i + 2], flen = d[6 * i + 3], noff = d[6 * i + 4];
+    uint8_t *o = new_blob + noff;
+    // the stream's new text is [0, tlen) from the old blob, then [tlen, tlen + flen) from `fresh`; this workgroup takes the
+    // chunks blockIdx.x, blockIdx.x + gridDim.x, ... of it
+    for (uint64_t c0 = (uint64_t)blockIdx.x * kGatherChunk; c0 < tlen + flen; c0 += (uint64_t)gridDim.x * kGatherChunk) {
+      const uint64_t c1 = c0 + kGatherChunk < tlen + flen ? c0 + kGatherChunk : tlen + flen;
+      if (c0 < tlen) gather_part(o, old_blob + toff, tlen, c0, c1 < tlen ? c1 : tlen);
+      if (c1 > tlen) gather_part(o + tlen, fresh + foff, flen, (c0 > tlen ? c0 : tlen) - tlen, c1 - tlen);
+    }
+  }
 }
 
 }  // namespace gz
@@ -275,6 +295,6 @@ extern "C" int md_launch_gz_finish(uint32_t n, const uint8_t *in, const uint64_t
 extern "C" int md_launch_piece_gather(uint32_t n, const uint8_t *old_blob, const uint8_t *fresh, uint8_t *new_blob, const uint64_t *d,
                                       hipStream_t stream) {
   if (n == 0) return 0;
-  hipLaunchKernelGGL(md::gz::piece_gather_kernel, dim3(n), dim3(256), 0, stream, n, old_blob, fresh, new_blob, d);
+  hipLaunchKernelGGL(md::gz::piece_gather_kernel, dim3(16, n < 65535u ? n : 65535u), dim3(256), 0, stream, n, old_blob, fresh, new_blob, d);
   return (int)hipGetLastError();
 }

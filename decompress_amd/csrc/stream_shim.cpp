@@ -552,6 +552,7 @@ void md_def_free(md_def_stream *s) {
 }
 int md_def_src(md_def_stream *s, const uint8_t *buf, size_t off, size_t len) {
   if (!s || (!buf && len) || s->eoi) return MD_E_INVALID_ARGUMENT;
+  if (s->done && s->status != MD_OK) return MD_E_INVALID_ARGUMENT;  // (an encoder that ended with an error takes no more input)
   if (len == 0) {
     s->eoi = true;
     return MD_OK;
@@ -743,7 +744,7 @@ void md_def_batch_close(md_def_batch *b) {
 int md_def_batch_src(md_def_batch *b, size_t i, const uint8_t *buf, size_t len) {
   if (!b || i >= b->n || (!buf && len)) return MD_E_INVALID_ARGUMENT;
   md_def_batch::Enc &x = b->e[i];
-  if (x.eoi) return MD_E_INVALID_ARGUMENT;
+  if (x.eoi || x.done) return MD_E_INVALID_ARGUMENT;  // (an encoder that ended, also with an error, takes no more input)
   if (len == 0) {
     x.eoi = true;
     return MD_OK;
@@ -825,15 +826,15 @@ int md_def_batch_encode(md_def_batch *b) {
     fpos += (fresh + 15) & ~(uint64_t)15;
     if (act) {
       if (x.w0 - x.origin >= far) {  // 32-bit positions on the device: the origin moves up (def_launch above)
-        rebase[i] = (x.w0 - x.origin - 65536) & ~(uint64_t)65535;
-        x.origin += rebase[i];
-      }
+        rebase[i] = (x.w0 - x.origin - 65536) & ~(uint64_t)65535;  // (committed to x.origin only once the launch has succeeded:
+      }                                                             //  a call that fails before it leaves every encoder retryable)
+      const uint64_t origin = x.origin + rebase[i];
       const uint64_t end = x.end + fresh;
       const size_t blocks = (fresh + ql) / ql + 2, per_block = ql >= 128 ? 320 : 24 + 4 * ql;
       out_cap[i] = 2048 + 6 * ql + 2 * fresh + blocks * per_block;
       flags[i] = (x.first ? 1u : 0u) | (x.eoi ? 2u : 0u);
-      abs_len[i] = end - x.origin;
-      w0[i] = x.w0 - x.origin;
+      abs_len[i] = end - origin;
+      w0[i] = x.w0 - origin;
       isize[i] = (uint32_t)end;
       const uint64_t seen = keep;
       const uint32_t sk = seen > 512 ? (uint32_t)(seen - 512) : 0u;
@@ -882,6 +883,7 @@ int md_def_batch_encode(md_def_batch *b) {
     md_def_batch::Enc &x = b->e[i];
     x.text_off = text_off[i];
     if (flags[i] & 8u) continue;
+    x.origin += rebase[i];
     x.end += x.fresh.size();
     x.fresh.clear();
     x.first = false;

@@ -36,6 +36,13 @@ class _HostArray(_np.ndarray):
         self._md_owner = getattr(obj, "_md_owner", None)
 
 
+def _check_blob(a, name):
+    """The host entry points take the blob's address and byte count: it has to be a C-contiguous uint8 array (a strided
+    view or another dtype would hand the library a wrong extent)."""
+    if not isinstance(a, _np.ndarray) or a.dtype != _np.uint8 or not a.flags["C_CONTIGUOUS"]:
+        raise TypeError("%s must be a C-contiguous numpy uint8 array" % name)
+
+
 def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
@@ -217,6 +224,7 @@ class Engine:
         import numpy as np
 
         n = len(in_off)
+        _check_blob(h_in, "h_in"), _check_blob(h_out, "h_out")
         u64 = lambda a: np.ascontiguousarray(a, dtype=np.uint64)
         in_off, in_len, out_off, out_cap = u64(in_off), u64(in_len), u64(out_off), u64(out_cap)
         out_len, consumed = np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint64)
@@ -233,6 +241,7 @@ class Engine:
         import numpy as np
 
         n = len(in_off)
+        _check_blob(h_in, "h_in"), _check_blob(h_out, "h_out")
         u64 = lambda a: np.ascontiguousarray(a, dtype=np.uint64)
         in_off, in_len, out_off, out_cap = u64(in_off), u64(in_len), u64(out_off), u64(out_cap)
         out_len = np.zeros(n, dtype=np.uint64)
