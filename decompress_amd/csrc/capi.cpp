@@ -497,6 +497,7 @@ struct DevBuf {
 // pageable buffers go through the runtime's staging and mostly do not.  The device copies of the blobs are the context's,
 // grow-only (md_set_option "release_workspace" gives them back).
 static int grow(md_ctx *ctx, void **buf, size_t *have, size_t need, const char *what);
+extern "C++" {
 namespace {
 struct HostSlice {
   size_t i0, i1;
@@ -559,6 +560,7 @@ struct EventList {
   }
 };
 }  // namespace
+}  // extern "C++"
 
 // `launch(i0, count)` enqueues the device entry point for streams [i0, i0 + count) on ctx->stream
 extern "C++" {

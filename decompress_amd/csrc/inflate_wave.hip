@@ -842,20 +842,6 @@ struct Sink {
   }
 };
 
-// exact store of the low n (1..8) bytes of v at an arbitrary LDS address: two overlapping 4-byte (or 1 + 2-byte) stores
-__device__ __forceinline__ void lds_put(lds_u8 *p, uint64_t v, uint32_t n) {
-  const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
-  if (n >= 4) {
-    const uint32_t k = n - 4;  // 0..4
-    const uint32_t t = k >= 4 ? hi : __builtin_amdgcn_alignbyte(hi, lo, k);
-    *reinterpret_cast<MD_LDS u32_u *>(p) = lo;
-    *reinterpret_cast<MD_LDS u32_u *>(p + k) = t;
-  } else {
-    *p = (uint8_t)lo;
-    if (n > 1) *reinterpret_cast<MD_LDS u16_u *>(p + n - 2) = (uint16_t)(lo >> (8 * (n - 2)));
-  }
-}
-
 // Far matches (the whole source is older than this round: final in HBM/L2 once the flush of earlier rounds has
 // been waited for; d >= ml) and the heads of matches that straddle the round start.  The round's records are taken
 // in stream order, one per lane and row of 64.  FIRST the loads of ALL rows are started - 2 LDS reads per record, one

@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "inflate_util.hpp"
 #include "mdeflate.h"
 
 namespace md {
@@ -29,6 +30,11 @@ constexpr int kWave = 64;
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ uint8_t ld_nt8(const uint8_t *p) { return __builtin_nontemporal_load(p); }
+// Workgroup -> stream: consecutive workgroups go to the 8 XCDs in turn, so with sid = blockIdx.x a batch whose cheap and
+// expensive streams alternate (C5: text, noise, text, ...) puts all the expensive ones on four XCDs - measured: 8 192 mixed
+// streams took twice as long as their 4 096 text streams alone.  XCD x takes the contiguous eighth x of the batch instead.
+__device__ __forceinline__ uint32_t xcd_stream(uint32_t b, uint32_t n) { return (b & 7u) * ((n + 7u) / 8u) + (b >> 3); }
+__host__ inline uint32_t xcd_grid(uint32_t n) { return 8u * ((n + 7u) / 8u); }
 
 // 256-byte window of the input in registers: lane l holds bytes [wbase + 4l, wbase + 4l + 4)
 struct Win {
@@ -60,10 +66,26 @@ struct Dec {
   int state;
 };
 
-// transmit (lib/lzo.ml:188-192) with blit's bounds (:81-89)
+// transmit (lib/lzo.ml:188-192) with blit's bounds (:81-89).  Long runs (incompressible input is ONE literal run) go 16
+// bytes per lane and step: unaligned loads, stores on the destination's alignment.
 __device__ __forceinline__ int transmit(Dec &d, uint32_t len) {
   if (d.i_pos > d.in.n || len > d.in.n - d.i_pos || len > d.cap - d.o_pos) return MD_LZO_OUT_OF_BOUND;
-  for (uint32_t k = d.lane; k < len; k += kWave) d.dst[d.o_pos + k] = d.in.src[d.i_pos + k];
+  const uint8_t *s = d.in.src + d.i_pos;
+  uint8_t *o = d.dst + d.o_pos;
+  if (len < 256) {
+    for (uint32_t k = d.lane; k < len; k += kWave) o[k] = s[k];
+  } else {
+    const uint32_t head = (16u - (uint32_t)((uintptr_t)o & 15)) & 15u;
+    const uint32_t body = (len - head) & ~15u;
+    if (d.lane < head) o[d.lane] = s[d.lane];
+    for (uint32_t k = head + d.lane * 16; k < head + body; k += kWave * 16) {
+      uint4 v;
+      __builtin_memcpy(&v, s + k, 16);
+      *reinterpret_cast<uint4 *>(o + k) = v;
+    }
+    const uint32_t k = head + body + d.lane;
+    if (k < len) o[k] = s[k];
+  }
   d.i_pos += len;
   d.o_pos += len;
   return MD_OK;
@@ -101,7 +123,205 @@ __device__ __forceinline__ int count(Dec &d, uint32_t *out) {
     if (rc_) return rc_;      \
   }
 
-__device__ int uncompress_stream(Dec &d) {
+// ONE instruction of `fiber` (lib/lzo.ml:315-369) with every check in the reference's order, straight on the output
+// buffer: the interpreter of rounds 2-5, now the slow path - what the batched decoder below does not take (an instruction
+// near the end of the input, a length that goes on over zero bytes, the end marker, anything that fails) comes here, so
+// the error cases and their order are the reference's by construction.  *end: the end-of-stream instruction.
+__device__ __noinline__ int fiber_step(Dec &d, bool *end) {
+  LZ_EOI()
+  uint32_t chr = d.in.byte(d.i_pos++);
+  const int st = d.state & 3;  // -1 land 3 = 3
+  uint32_t len, off, cnt;
+  int nstate;
+  if (chr < 16 && st == 0) {
+    if (chr == 0) {
+      LZ_EOI()
+      LZ_TRY(count(d, &cnt))
+      len = 3 + 15 + cnt;
+    } else len = chr + 3;
+    d.state = -1;
+    LZ_EOI()
+    LZ_TRY(transmit(d, len))
+    return MD_OK;
+  }
+  if (chr < 16) {
+    LZ_EOI()
+    const uint32_t h = d.in.byte(d.i_pos++);
+    off = (h << 2) + (chr >> 2) + 1;
+    len = 0;
+    nstate = (int)(chr & 3);
+  } else if (chr < 32) {
+    len = chr & 7;
+    if (len == 0) {
+      LZ_EOI()
+      LZ_TRY(count(d, &cnt))
+      len = 7 + cnt;
+    }
+    LZ_EOI()
+    if (d.i_pos + 2 > d.in.n) return MD_LZO_OUT_OF_BOUND;
+    const uint32_t s = d.in.byte(d.i_pos) | (d.in.byte(d.i_pos + 1) << 8);
+    d.i_pos += 2;
+    off = 16384 + (((chr & 8) >> 3) << 14) + (s >> 2);
+    nstate = (int)(s & 0xff);
+    if (off == 16384) {  // end_of_lzo
+      *end = true;
+      return MD_OK;
+    }
+  } else if (chr < 64) {
+    len = chr & 31;
+    if (len == 0) {
+      LZ_EOI()
+      LZ_TRY(count(d, &cnt))
+      len = 31 + cnt;
+    }
+    LZ_EOI()
+    if (d.i_pos + 2 > d.in.n) return MD_LZO_OUT_OF_BOUND;
+    const uint32_t s = d.in.byte(d.i_pos) | (d.in.byte(d.i_pos + 1) << 8);
+    d.i_pos += 2;
+    nstate = (int)(s & 0xff);
+    off = (s >> 2) + 1;
+  } else {
+    nstate = (int)chr;
+    len = (chr >> 5) - 1;
+    LZ_EOI()
+    const uint32_t h = d.in.byte(d.i_pos++);
+    off = (h << 3) + ((chr >> 2) & 7) + 1;
+  }
+  // Copy (lib/lzo.ml:283-288): len + 2 bytes, then copy_done = transmit (state land 3)
+  LZ_EOI()
+  d.state = nstate;
+  LZ_TRY(copy(d, off, len + 2))
+  LZ_TRY(transmit(d, (uint32_t)(nstate & 3)))
+  return MD_OK;
+}
+
+// ---- the batched decoder (round 6) ---------------------------------------------------------------------------------
+// LZO's instruction stream is byte-aligned, and what an instruction DOES (copy `len` bytes from `off` back, then 0..3
+// literals; or a run of literals) is independent of its neighbours once its first byte and the decoder's state (zero /
+// not zero, lib/lzo.ml:322-336) are known.  So a BATCH of the stream is taken in three steps:
+//   decode  lane l decodes the instruction that WOULD start at input byte base + l, in both states (they differ only for
+//           opcodes below 16) - opcode length, offset, lengths, the state it leaves - and packs "bytes to advance, bytes
+//           produced, state left, not for the fast path" into one word per state;
+//   walk    the scalar unit follows the chain from lane 0 (base IS an instruction start): one v_readlane and a dozen
+//           scalar instructions per instruction, marking the lanes that really are instructions, until the chain leaves
+//           the 64 bytes, the batch's output is full, or it meets an instruction the fast path does not take;
+//   copy    the marked lanes know their output position from a prefix sum.  Literals go from the input window in LDS to
+//           a staging buffer in LDS; matches whose source is older than the batch are read from the output buffer (all
+//           lanes at once, unaligned 8-byte loads); matches that reach into the batch itself are taken in stream order
+//           by the whole wave, byte j from staging or the output buffer; then the batch leaves in 16-byte chunks.
+// Everything else is fiber_step's: one instruction, the reference's checks in the reference's order.  An instruction is
+// taken by the fast path only if all of its opcode bytes and literals lie inside the input AND one more byte follows
+// (the EOI guard before Copy), its lengths need no zero-byte continuation, it is not the end marker, and - checked after
+// the prefix sum - its offset and its bytes fit the output: what the fast path takes cannot fail.
+constexpr uint32_t kInRing = 2048, kInBlk = 1024;  // input window: a ring of two 1 KiB blocks, the next one on its way
+constexpr uint32_t kStage = 3072;                  // staging: one batch of output, 16-byte aligned with the output buffer
+constexpr uint32_t kBatchMax = kStage - 16;        // bytes a batch may produce
+constexpr uint32_t kExotic = 1u << 20, kNextZero = 1u << 21;
+struct LSmem {
+  alignas(16) uint8_t in[kInRing + 32];  // (+ the ring's first bytes again: an access may run over the end)
+  alignas(16) uint8_t stage[kStage + 32];
+};
+typedef wv::lds_u8 lds_u8;
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));  // (HIP's uint4 has no assignment in address space 3)
+using wv::lds_ld64;
+using wv::lds_put;
+using wv::out_ld8;
+using wv::out_ld_guard;
+
+struct InRing {
+  lds_u8 *ring;
+  const uint8_t *src;
+  uint32_t n, lane;
+  uint32_t lo;   // blocks lo and lo + 1 are in the ring (slot = block & 1); 0xffffffff: nothing
+  uint4 ahead;   // this lane's 16 bytes of block lo + 2
+  __device__ __forceinline__ uint4 load(uint32_t blk) const {
+    const uint64_t a = (uint64_t)blk * kInBlk + lane * 16;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (a + 16 <= n) __builtin_memcpy(&v, src + a, 16);
+    else if (a < n) {
+      uint32_t w[4] = {0, 0, 0, 0};
+      for (uint32_t k = 0; a + k < n; k++) w[k >> 2] |= (uint32_t)src[a + k] << (8 * (k & 3));
+      v = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    return v;
+  }
+  __device__ __forceinline__ void put(uint32_t blk, const uint4 &v) {
+    const uint32_t slot = (blk & 1) * kInBlk;
+    const v4u x = {v.x, v.y, v.z, v.w};
+    *reinterpret_cast<MD_LDS v4u *>(ring + slot + lane * 16) = x;
+    if (slot == 0 && lane < 2) *reinterpret_cast<MD_LDS v4u *>(ring + kInRing + lane * 16) = x;
+  }
+  // input bytes [pos, pos + 1 KiB) readable from the ring
+  __device__ __forceinline__ void ensure(uint32_t pos) {
+    const uint32_t need = pos / kInBlk;
+    if (need == lo) return;
+    if (need == lo + 1) {
+      put(lo + 2, ahead);
+      lo = need;
+    } else {
+      put(need, load(need));
+      put(need + 1, load(need + 1));
+      lo = need;
+    }
+    ahead = load(lo + 2);
+  }
+  __device__ __forceinline__ const lds_u8 *at(uint32_t pos) const { return ring + (pos & (kInRing - 1)); }
+};
+
+__device__ __forceinline__ uint32_t rdl(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+
+// the instruction that would start with the bytes b (b0 = opcode) in state zero (ZERO) / not zero
+struct Ins {
+  uint32_t k, off, mlen, lit;  // opcode bytes, offset, match bytes (0: none), literals that follow
+  bool exotic;
+};
+template <bool ZERO>
+__device__ __forceinline__ Ins decode_ins(uint32_t b) {
+  const uint32_t chr = b & 0xff, b1 = (b >> 8) & 0xff;
+  Ins r;
+  r.exotic = false;
+  if (chr >= 64) {
+    r.k = 2;
+    r.off = (b1 << 3) + ((chr >> 2) & 7) + 1;
+    r.mlen = (chr >> 5) + 1;
+    r.lit = chr & 3;
+  } else if (chr >= 16) {
+    const bool m3 = chr >= 32;
+    uint32_t L = m3 ? chr & 31 : chr & 7;
+    const bool ext = L == 0;
+    r.exotic = ext && b1 == 0;  // the length goes on over zero bytes
+    if (ext) L = (m3 ? 31u : 7u) + b1;
+    const uint32_t s = ext ? b >> 16 : (b >> 8) & 0xffff;
+    r.k = ext ? 4 : 3;
+    r.off = m3 ? (s >> 2) + 1 : 16384 + ((chr & 8) << 11) + (s >> 2);
+    r.exotic = r.exotic || r.off == 16384;  // the end marker
+    r.mlen = L + 2;
+    r.lit = s & 3;
+  } else if (ZERO) {
+    const bool ext = chr == 0;
+    r.exotic = ext && b1 == 0;
+    r.k = ext ? 2 : 1;
+    r.off = 0;
+    r.mlen = 0;
+    r.lit = ext ? 18 + b1 : chr + 3;
+  } else {
+    r.k = 2;
+    r.off = (b1 << 2) + (chr >> 2) + 1;
+    r.mlen = 2;
+    r.lit = chr & 3;
+  }
+  return r;
+}
+template <bool ZERO>
+__device__ __forceinline__ uint32_t pack_ins(uint32_t b, uint32_t p, uint32_t n) {
+  const Ins r = decode_ins<ZERO>(b);
+  const bool inside = p < n && p + r.k < n && p + r.k + r.lit <= n;
+  // a run of literals leaves the state -1 (not zero), a match the number of its literals (lib/lzo.ml:283-288, :322-336)
+  const bool next_zero = r.mlen != 0 && r.lit == 0;
+  return (r.k + r.lit) | ((r.mlen + r.lit) << 10) | ((r.exotic || !inside) ? kExotic : 0u) | (next_zero ? kNextZero : 0u);
+}
+
+__device__ int uncompress_stream(Dec &d, LSmem MD_LDS *sm) {
   LZ_EOI()
   uint32_t chr = d.in.byte(0);
   if (chr == 16) return MD_LZO_NO_DICTIONARY;
@@ -111,77 +331,137 @@ __device__ int uncompress_stream(Dec &d) {
     LZ_EOI()
     LZ_TRY(transmit(d, chr - 17))
   }
-  for (;;) {  // fiber, lib/lzo.ml:315-369
-    LZ_EOI()
-    chr = d.in.byte(d.i_pos++);
-    const int st = d.state & 3;  // -1 land 3 = 3
-    uint32_t len, off, cnt;
-    int nstate;
-    if (chr < 16 && st == 0) {
-      if (chr == 0) {
-        LZ_EOI()
-        LZ_TRY(count(d, &cnt))
-        len = 3 + 15 + cnt;
-      } else len = chr + 3;
-      d.state = -1;
-      LZ_EOI()
-      LZ_TRY(transmit(d, len))
+  const uint32_t lane = d.lane;
+  lds_u8 *stage = (lds_u8 *)sm->stage;
+  InRing ir;
+  ir.ring = (lds_u8 *)sm->in;
+  ir.src = d.in.src;
+  ir.n = d.in.n;
+  ir.lane = lane;
+  ir.lo = 0xfffffff0u;
+  bool slow = false;
+  for (;;) {
+    if (slow) {
+      bool end = false;
+      LZ_TRY(fiber_step(d, &end))
+      if (end) return MD_OK;
+      slow = false;
       continue;
     }
-    if (chr < 16) {
-      LZ_EOI()
-      const uint32_t h = d.in.byte(d.i_pos++);
-      off = (h << 2) + (chr >> 2) + 1;
-      len = 0;
-      nstate = (int)(chr & 3);
-    } else if (chr < 32) {
-      len = chr & 7;
-      if (len == 0) {
-        LZ_EOI()
-        LZ_TRY(count(d, &cnt))
-        len = 7 + cnt;
+    // ---- decode: the 64 instructions that would start at base .. base + 63
+    const uint32_t base = d.i_pos, n = d.in.n;
+    ir.ensure(base);
+    const uint32_t p = base + lane;
+    const uint32_t b = *reinterpret_cast<const MD_LDS wv::u32_u *>(ir.at(p));
+    const uint32_t wz = pack_ins<true>(b, p, n), wn = pack_ins<false>(b, p, n);
+    // ---- walk (wave-uniform)
+    uint32_t cur = 0, zero = (d.state & 3) == 0 ? 1u : 0u, osum = 0;
+    uint64_t taken = 0, zmask = 0;
+    while (cur < 64) {
+      const uint32_t w = zero ? rdl(wz, cur) : rdl(wn, cur);
+      if (w & kExotic) {
+        slow = true;
+        break;
       }
-      LZ_EOI()
-      if (d.i_pos + 2 > d.in.n) return MD_LZO_OUT_OF_BOUND;
-      const uint32_t s = d.in.byte(d.i_pos) | (d.in.byte(d.i_pos + 1) << 8);
-      d.i_pos += 2;
-      off = 16384 + (((chr & 8) >> 3) << 14) + (s >> 2);
-      nstate = (int)(s & 0xff);
-      if (off == 16384) break;  // end_of_lzo
-    } else if (chr < 64) {
-      len = chr & 31;
-      if (len == 0) {
-        LZ_EOI()
-        LZ_TRY(count(d, &cnt))
-        len = 31 + cnt;
-      }
-      LZ_EOI()
-      if (d.i_pos + 2 > d.in.n) return MD_LZO_OUT_OF_BOUND;
-      const uint32_t s = d.in.byte(d.i_pos) | (d.in.byte(d.i_pos + 1) << 8);
-      d.i_pos += 2;
-      nstate = (int)(s & 0xff);
-      off = (s >> 2) + 1;
-    } else {
-      nstate = (int)chr;
-      len = (chr >> 5) - 1;
-      LZ_EOI()
-      const uint32_t h = d.in.byte(d.i_pos++);
-      off = (h << 3) + ((chr >> 2) & 7) + 1;
+      const uint32_t ob = (w >> 10) & 1023;
+      if (osum + ob > kBatchMax) break;
+      taken |= 1ull << cur;
+      zmask |= (uint64_t)zero << cur;
+      osum += ob;
+      cur += w & 1023;
+      zero = (w >> 21) & 1;
     }
-    // Copy (lib/lzo.ml:283-288): len + 2 bytes, then copy_done = transmit (state land 3)
-    LZ_EOI()
-    d.state = nstate;
-    LZ_TRY(copy(d, off, len + 2))
-    LZ_TRY(transmit(d, (uint32_t)(nstate & 3)))
+    // ---- the marked lanes: their instruction, their place in the output
+    bool mine = (taken >> lane) & 1;
+    const bool mz = (zmask >> lane) & 1;
+    const Ins rz = decode_ins<true>(b), rn = decode_ins<false>(b);
+    const uint32_t k = mz ? rz.k : rn.k, off = mz ? rz.off : rn.off, mlen = mz ? rz.mlen : rn.mlen, lit = mz ? rz.lit : rn.lit;
+    const uint32_t o0 = d.o_pos, rb = o0 & ~15u;
+    const uint32_t orel = wv::wave_excl_scan(mine ? mlen + lit : 0u, lane);
+    const uint32_t oabs = o0 + orel;
+    {  // what does not fit the output is the slow path's (it fails there, with the reference's error)
+      const uint64_t bad = __ballot(mine && ((mlen != 0 && off > oabs) || mlen + lit > d.cap - oabs || oabs > d.cap));
+      if (bad) {
+        const uint32_t fb = (uint32_t)__builtin_ctzll(bad);
+        taken &= (1ull << fb) - 1;
+        mine = (taken >> lane) & 1;
+        osum = rdl(orel, fb);
+        cur = fb;
+        zero = (uint32_t)((zmask >> fb) & 1);
+        slow = true;
+      }
+    }
+    if (taken) {
+      const uint32_t sidx = oabs - rb;  // staging index of this lane's first byte
+      // literals: input window -> staging
+      {
+        const uint32_t lsrc = p + k, ldst = sidx + mlen;
+        const bool shortl = mine && lit != 0 && lit <= 16;
+        if (shortl) {
+          const uint64_t v0 = lds_ld64(ir.at(lsrc));
+          lds_put(stage + ldst, v0, lit < 8 ? lit : 8);
+          if (lit > 8) lds_put(stage + ldst + 8, lds_ld64(ir.at(lsrc + 8)), lit - 8);
+        }
+        for (uint64_t lm = __ballot(mine && lit > 16); lm; lm &= lm - 1) {  // a long run: by the whole wave (<= 273 bytes)
+          const uint32_t l = (uint32_t)__builtin_ctzll(lm);
+          const uint32_t s = rdl(lsrc, l), t = rdl(ldst, l), c = rdl(lit, l), j = lane * 8;
+          if (j < c) lds_put(stage + t + j, lds_ld64(ir.at(s + j)), c - j < 8 ? c - j : 8);
+        }
+      }
+      // matches
+      const uint32_t sabs = oabs - off;  // (mlen != 0)
+      const bool far = mine && mlen != 0 && sabs + mlen <= o0;
+      const bool near = mine && mlen != 0 && !far;
+      if (__ballot(mine && mlen != 0 && sabs < o0)) {  // some source byte lies in the output buffer
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // earlier batches' bytes have landed
+        if (far) {
+          for (uint32_t j = 0; j < mlen; j += 8)
+            lds_put(stage + sidx + j, out_ld_guard(d.dst, sabs + j, mlen - j, d.cap), mlen - j < 8 ? mlen - j : 8);
+        }
+      }
+      for (uint64_t nm = __ballot(near); nm; nm &= nm - 1) {  // in stream order; byte j = source byte j mod off
+        const uint32_t l = (uint32_t)__builtin_ctzll(nm);
+        const uint32_t s = rdl(sabs, l), t = rdl(sidx, l), c = rdl(mlen, l), f = rdl(off, l);
+        const float inv = 1.0f / (float)f;
+        for (uint32_t j = lane; j < c; j += kWave) {
+          uint32_t r = j;
+          if (f < c) {
+            r = j - (uint32_t)((float)j * inv) * f;  // j mod f, the quotient may be one off either way
+            r = (int32_t)r < 0 ? r + f : r;
+            r = r >= f ? r - f : r;
+          }
+          const uint32_t x = s + r;
+          stage[t + j] = x >= o0 ? stage[x - rb] : (uint8_t)out_ld8(d.dst + x);
+        }
+      }
+      // the batch leaves: whole 16-byte chunks one per lane, the bytes in front of the first and behind the last one by one
+      {
+        const uint32_t endp = o0 + osum;
+        const uint32_t full0 = (o0 + 15) & ~15u, full1 = endp & ~15u;
+        for (uint32_t ps = full0; ps < full1; ps += kWave * 16) {
+          const uint32_t c = ps + lane * 16;
+          if (c < full1) {  // (16-byte aligned offset; the buffer itself may start anywhere)
+            const v4u v = *reinterpret_cast<const MD_LDS v4u *>(stage + (c - rb));
+            __builtin_memcpy(d.dst + c, &v, 16);
+          }
+        }
+        const uint32_t head1 = full0 < endp ? full0 : endp, tail0 = full1 > head1 ? full1 : head1;
+        const uint32_t x = lane < 16 ? o0 + lane : tail0 + (lane - 16);
+        if (lane < 16 ? x < head1 : (lane < 32 && x < endp)) d.dst[x] = stage[x - rb];
+        d.o_pos = endp;
+      }
+    }
+    d.i_pos = base + cur;
+    d.state = zero ? 0 : 1;
   }
-  return MD_OK;
 }
 
 __global__ __launch_bounds__(kWave) void lzo_uncompress_kernel(
     uint32_t n, const uint8_t *__restrict__ in, const uint64_t *__restrict__ in_off,
     const uint64_t *__restrict__ in_len, uint8_t *__restrict__ out, const uint64_t *__restrict__ out_off,
     const uint64_t *__restrict__ out_cap, uint64_t *__restrict__ out_len, int32_t *__restrict__ status) {
-  const uint32_t lane = threadIdx.x, sid = blockIdx.x;
+  __shared__ LSmem smem;
+  const uint32_t lane = threadIdx.x, sid = xcd_stream(blockIdx.x, n);
   if (sid >= n) return;
   Dec d;
   d.in.src = in + in_off[sid];
@@ -201,7 +481,7 @@ __global__ __launch_bounds__(kWave) void lzo_uncompress_kernel(
   d.i_pos = d.o_pos = 0;
   d.lane = lane;
   d.state = 0;
-  const int st = uncompress_stream(d);
+  const int st = uncompress_stream(d, (LSmem MD_LDS *)&smem);
   if (lane == 0) {
     status[sid] = st;
     out_len[sid] = st == MD_OK ? d.o_pos : 0;
@@ -418,7 +698,7 @@ __global__ __launch_bounds__(kWave, 8) void lzo_compress_kernel(
     const uint64_t *__restrict__ in_len, uint8_t *__restrict__ out, const uint64_t *__restrict__ out_off,
     const uint64_t *__restrict__ out_cap, uint64_t *__restrict__ out_len, int32_t *__restrict__ status,
     uint16_t *__restrict__ ws_dict) {
-  const uint32_t lane = threadIdx.x, sid = blockIdx.x;
+  const uint32_t lane = threadIdx.x, sid = xcd_stream(blockIdx.x, n);
   if (sid >= n) return;
   // make_wrkmem (lib/lzo.ml:645-646): 16 K u16 entries per stream in an HBM workspace — in LDS the
   // 32 KiB would hold residency to 5 wavefronts per CU, and the probe loop lives on occupancy
@@ -466,7 +746,7 @@ extern "C" int md_launch_lzo_uncompress(uint32_t n, const uint8_t *in, const uin
                                         uint8_t *out, const uint64_t *out_off, const uint64_t *out_cap,
                                         uint64_t *out_len, int32_t *status, hipStream_t stream) {
   if (n == 0) return 0;
-  hipLaunchKernelGGL(md::lzo::lzo_uncompress_kernel, dim3(n), dim3(md::lzo::kWave), 0, stream, n, in, in_off, in_len,
+  hipLaunchKernelGGL(md::lzo::lzo_uncompress_kernel, dim3(md::lzo::xcd_grid(n)), dim3(md::lzo::kWave), 0, stream, n, in, in_off, in_len,
                      out, out_off, out_cap, out_len, status);
   return (int)hipGetLastError();
 }
@@ -475,7 +755,7 @@ extern "C" int md_launch_lzo_compress(uint32_t n, const uint8_t *in, const uint6
                                       uint8_t *out, const uint64_t *out_off, const uint64_t *out_cap,
                                       uint64_t *out_len, int32_t *status, uint16_t *ws_dict, hipStream_t stream) {
   if (n == 0) return 0;
-  hipLaunchKernelGGL(md::lzo::lzo_compress_kernel, dim3(n), dim3(md::lzo::kWave), 0, stream, n, in, in_off, in_len, out,
+  hipLaunchKernelGGL(md::lzo::lzo_compress_kernel, dim3(md::lzo::xcd_grid(n)), dim3(md::lzo::kWave), 0, stream, n, in, in_off, in_len, out,
                      out_off, out_cap, out_len, status, ws_dict);
   return (int)hipGetLastError();
 }

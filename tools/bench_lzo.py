@@ -14,6 +14,7 @@ def main():
     ap.add_argument("--streams", type=int, default=8192)
     ap.add_argument("--stream-kib", type=int, default=128)
     ap.add_argument("--unique", type=int, default=128)
+    ap.add_argument("--kind", default="mix", help="mix (C5: half text, half ASCII noise) | text | ascii")
     args = ap.parse_args()
     import torch
     import decompress_amd
@@ -22,7 +23,8 @@ def main():
     dev = torch.device("cuda", 0)
     eng = decompress_amd.Engine(0)
     n, nb = args.streams, args.stream_kib * 1024
-    uniq = [(workloads.text if i % 2 == 0 else workloads.ascii_uniform)(0xC5 + i, nb) for i in range(min(args.unique, n))]
+    pick = lambda i: workloads.text if (args.kind == 'text' or (args.kind == 'mix' and i % 2 == 0)) else workloads.ascii_uniform
+    uniq = [pick(i)(0xC5 + i, nb) for i in range(min(args.unique, n))]
     bufs = [uniq[i % len(uniq)] for i in range(n)]
     blob, off, ln = workloads.pack(bufs, align=32)
     cap = np.full(n, lzo.max_compressed_length(nb), dtype=np.int64)
