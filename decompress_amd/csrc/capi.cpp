@@ -63,10 +63,11 @@ extern "C" int md_launch_gz_finish(uint32_t n, const uint8_t *in, const uint64_t
 
 extern "C" int md_launch_lzo_uncompress(uint32_t n, const uint8_t *in, const uint64_t *in_off, const uint64_t *in_len,
                                         uint8_t *out, const uint64_t *out_off, const uint64_t *out_cap,
-                                        uint64_t *out_len, int32_t *status, hipStream_t stream);
+                                        uint64_t *out_len, int32_t *status, uint32_t *counter, uint32_t slots, hipStream_t stream);
 extern "C" int md_launch_lzo_compress(uint32_t n, const uint8_t *in, const uint64_t *in_off, const uint64_t *in_len,
                                       uint8_t *out, const uint64_t *out_off, const uint64_t *out_cap,
-                                      uint64_t *out_len, int32_t *status, uint16_t *ws_dict, hipStream_t stream);
+                                      uint64_t *out_len, int32_t *status, uint16_t *ws_dict, uint32_t *counter, uint32_t slots,
+                                      hipStream_t stream);
 
 struct md_ctx {
   int device = 0;
@@ -81,6 +82,8 @@ struct md_ctx {
   bool gz_hdr_valid = false;
   void *lzo_ws = nullptr;  // Lzo.compress dictionaries
   size_t lzo_ws_bytes = 0;
+  uint32_t *counters = nullptr;  // work counters of the kernels with persistent workgroups (zeroed in front of a launch)
+  int cus = 256;                 // compute units of the device
   int inflate_waves = 2;    // wavefronts per stream of the inflate kernel (md_set_option "inflate_waves": 1 = the one-wavefront form)
   size_t piece_bytes = (size_t)1 << 20;  // md_set_option "encoder_piece_bytes": input the md_def_* encoder gathers before a launch
   size_t front_cap_bytes = 0;  // md_set_option "deflate_workspace_cap_mib" (md_create: a sixth of the device's memory; 0 = none):
@@ -259,6 +262,15 @@ md_ctx *md_create(int device, void *hip_stream) {
     fail(nullptr, MD_E_HIP, "hipEventCreate");
     return nullptr;
   }
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) ctx->cus = cus;
+    if (hipMalloc((void **)&ctx->counters, 256) != hipSuccess) {
+      md_destroy(ctx);
+      fail(nullptr, MD_E_OUT_OF_MEMORY, "hipMalloc(counters)");
+      return nullptr;
+    }
+  }
   {  // the deflate kernels' per-position workspace takes a sixth of the device at most (48 GiB of 288) unless told otherwise
     size_t mem_free = 0, mem_total = 0;
     if (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess) ctx->front_cap_bytes = mem_total / 6;
@@ -283,6 +295,7 @@ void md_destroy(md_ctx *ctx) {
   if (ctx->dbg) hipFree(ctx->dbg);
   if (ctx->gz_tmp) hipFree(ctx->gz_tmp);
   if (ctx->lzo_ws) hipFree(ctx->lzo_ws);
+  if (ctx->counters) hipFree(ctx->counters);
   if (ctx->gz_hdr_dev) hipFree(ctx->gz_hdr_dev);
   if (ctx->host_in) hipFree(ctx->host_in);
   if (ctx->host_out) hipFree(ctx->host_out);
@@ -1675,8 +1688,12 @@ static int lzo_batch_device(md_ctx *ctx, bool compress, size_t n, const uint8_t 
   if (!d_in_off || !d_in_len || !d_out_off || !d_out_cap || !d_out_len || !d_status)
     return fail(ctx, MD_E_INVALID_ARGUMENT, "null descriptor array");
   MD_ON_DEVICE(ctx);
-  if (compress) {  // Lzo's wrkmem: 16 K u16 entries per stream
-    const size_t need = n * (size_t)(1u << 15);
+  // persistent workgroups (lzo_kernels.hip): as many as the chip holds at once - 30 per CU by the decoder's 5 KiB of LDS,
+  // 32 by the compressor's 8 wavefronts per SIMD - drawing streams from a counter
+  const uint32_t slots = (uint32_t)ctx->cus * (compress ? 32u : 30u);
+  const size_t wgs = n < slots ? n : slots;
+  if (compress) {  // Lzo's wrkmem: 16 K u16 entries per workgroup
+    const size_t need = wgs * (size_t)(1u << 15);
     if (need > ctx->lzo_ws_bytes) {
       if (ctx->lzo_ws) {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1688,10 +1705,11 @@ static int lzo_batch_device(md_ctx *ctx, bool compress, size_t n, const uint8_t 
       ctx->lzo_ws_bytes = need;
     }
   }
+  HIP_TRY(ctx, hipMemsetAsync(ctx->counters, 0, 4, ctx->stream));
   const int e = compress ? md_launch_lzo_compress((uint32_t)n, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap,
-                                                  d_out_len, d_status, (uint16_t *)ctx->lzo_ws, ctx->stream)
+                                                  d_out_len, d_status, (uint16_t *)ctx->lzo_ws, ctx->counters, slots, ctx->stream)
                          : md_launch_lzo_uncompress((uint32_t)n, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap,
-                                                    d_out_len, d_status, ctx->stream);
+                                                    d_out_len, d_status, ctx->counters, slots, ctx->stream);
   if (e != 0) return fail(ctx, MD_E_HIP, "lzo kernel launch", (hipError_t)e);
   return MD_OK;
 }

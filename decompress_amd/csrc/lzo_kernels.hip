@@ -30,11 +30,15 @@ constexpr int kWave = 64;
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ uint8_t ld_nt8(const uint8_t *p) { return __builtin_nontemporal_load(p); }
-// Workgroup -> stream: consecutive workgroups go to the 8 XCDs in turn, so with sid = blockIdx.x a batch whose cheap and
-// expensive streams alternate (C5: text, noise, text, ...) puts all the expensive ones on four XCDs - measured: 8 192 mixed
-// streams took twice as long as their 4 096 text streams alone.  XCD x takes the contiguous eighth x of the batch instead.
-__device__ __forceinline__ uint32_t xcd_stream(uint32_t b, uint32_t n) { return (b & 7u) * ((n + 7u) / 8u) + (b >> 3); }
-__host__ inline uint32_t xcd_grid(uint32_t n) { return 8u * ((n + 7u) / 8u); }
+// Workgroup -> stream: PERSISTENT workgroups draw streams from a counter in device memory.  With one workgroup per
+// stream a batch whose cheap and expensive streams alternate (C5: text, noise, text, ...) ended up with all its expensive
+// streams on some of the CUs - a slot freed by a stream that ends at once is refilled at once, by the next workgroup in
+// line: 8 192 mixed streams took as long as 8 192 text streams, twice their 4 096 text streams alone.
+__device__ __forceinline__ uint32_t next_stream(uint32_t *counter, uint32_t lane) {
+  uint32_t v = 0;
+  if (lane == 0) v = atomicAdd(counter, 1u);
+  return uni(v);
+}
 
 // 256-byte window of the input in registers: lane l holds bytes [wbase + 4l, wbase + 4l + 4)
 struct Win {
@@ -459,32 +463,35 @@ __device__ int uncompress_stream(Dec &d, LSmem MD_LDS *sm) {
 __global__ __launch_bounds__(kWave) void lzo_uncompress_kernel(
     uint32_t n, const uint8_t *__restrict__ in, const uint64_t *__restrict__ in_off,
     const uint64_t *__restrict__ in_len, uint8_t *__restrict__ out, const uint64_t *__restrict__ out_off,
-    const uint64_t *__restrict__ out_cap, uint64_t *__restrict__ out_len, int32_t *__restrict__ status) {
+    const uint64_t *__restrict__ out_cap, uint64_t *__restrict__ out_len, int32_t *__restrict__ status, uint32_t *counter) {
   __shared__ LSmem smem;
-  const uint32_t lane = threadIdx.x, sid = xcd_stream(blockIdx.x, n);
-  if (sid >= n) return;
-  Dec d;
-  d.in.src = in + in_off[sid];
-  const uint64_t l64 = in_len[sid], c64 = out_cap[sid];
-  if (l64 > MD_MAX_STREAM) {  // 32-bit cursors: the descriptor is out of range (mdeflate.h)
-    if (lane == 0) {
-      status[sid] = MD_E_INVALID_ARGUMENT;
-      out_len[sid] = 0;
+  const uint32_t lane = threadIdx.x;
+  for (;;) {
+    const uint32_t sid = next_stream(counter, lane);
+    if (sid >= n) return;
+    Dec d;
+    d.in.src = in + in_off[sid];
+    const uint64_t l64 = in_len[sid], c64 = out_cap[sid];
+    if (l64 > MD_MAX_STREAM) {  // 32-bit cursors: the descriptor is out of range (mdeflate.h)
+      if (lane == 0) {
+        status[sid] = MD_E_INVALID_ARGUMENT;
+        out_len[sid] = 0;
+      }
+      continue;
     }
-    return;
-  }
-  d.in.n = (uint32_t)l64;
-  d.in.lane = lane;
-  d.in.fill(0);
-  d.dst = out + out_off[sid];
-  d.cap = c64 > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)c64;
-  d.i_pos = d.o_pos = 0;
-  d.lane = lane;
-  d.state = 0;
-  const int st = uncompress_stream(d, (LSmem MD_LDS *)&smem);
-  if (lane == 0) {
-    status[sid] = st;
-    out_len[sid] = st == MD_OK ? d.o_pos : 0;
+    d.in.n = (uint32_t)l64;
+    d.in.lane = lane;
+    d.in.fill(0);
+    d.dst = out + out_off[sid];
+    d.cap = c64 > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)c64;
+    d.i_pos = d.o_pos = 0;
+    d.lane = lane;
+    d.state = 0;
+    const int st = uncompress_stream(d, (LSmem MD_LDS *)&smem);
+    if (lane == 0) {
+      status[sid] = st;
+      out_len[sid] = st == MD_OK ? d.o_pos : 0;
+    }
   }
 }
 
@@ -697,65 +704,70 @@ __global__ __launch_bounds__(kWave, 8) void lzo_compress_kernel(
     uint32_t n, const uint8_t *__restrict__ in, const uint64_t *__restrict__ in_off,
     const uint64_t *__restrict__ in_len, uint8_t *__restrict__ out, const uint64_t *__restrict__ out_off,
     const uint64_t *__restrict__ out_cap, uint64_t *__restrict__ out_len, int32_t *__restrict__ status,
-    uint16_t *__restrict__ ws_dict) {
-  const uint32_t lane = threadIdx.x, sid = xcd_stream(blockIdx.x, n);
-  if (sid >= n) return;
-  // make_wrkmem (lib/lzo.ml:645-646): 16 K u16 entries per stream in an HBM workspace — in LDS the
+    uint16_t *__restrict__ ws_dict, uint32_t *counter) {
+  const uint32_t lane = threadIdx.x;
+  // make_wrkmem (lib/lzo.ml:645-646): 16 K u16 entries per (persistent) workgroup in an HBM workspace — in LDS the
   // 32 KiB would hold residency to 5 wavefronts per CU, and the probe loop lives on occupancy
-  uint16_t *dict = ws_dict + (size_t)sid * (1u << 14);
-  Cmp c;
-  c.src = in + in_off[sid];
-  const uint64_t l64 = in_len[sid], c64 = out_cap[sid];
-  if (l64 > MD_MAX_STREAM) {  // 32-bit cursors: the descriptor is out of range (mdeflate.h)
-    if (lane == 0) {
-      status[sid] = MD_E_INVALID_ARGUMENT;
-      out_len[sid] = 0;
+  uint16_t *dict = ws_dict + (size_t)blockIdx.x * (1u << 14);
+  for (;;) {
+    const uint32_t sid = next_stream(counter, lane);
+    if (sid >= n) return;
+    Cmp c;
+    c.src = in + in_off[sid];
+    const uint64_t l64 = in_len[sid], c64 = out_cap[sid];
+    if (l64 > MD_MAX_STREAM) {  // 32-bit cursors: the descriptor is out of range (mdeflate.h)
+      if (lane == 0) {
+        status[sid] = MD_E_INVALID_ARGUMENT;
+        out_len[sid] = 0;
+      }
+      continue;
     }
-    return;
-  }
-  c.n = (uint32_t)l64;
-  c.dst = out + out_off[sid];
-  c.cap = c64 > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)c64;
-  c.lane = lane;
-  c.op = 0;
-  c.oob = false;
-  c.patch = 0;
-  // Lzo.compress, lib/lzo.ml:648-660
-  uint32_t idx = 0, len = c.n, t = 0;
-  while (len > 20) {
-    const uint32_t ll = len < 49152u ? len : 49152u;
-    if (((t + ll) >> 5) == 0) break;
-    for (uint32_t i = lane; i < (1u << 11); i += kWave) reinterpret_cast<uint4 *>(dict)[i] = make_uint4(0, 0, 0, 0);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    t = compress_chunk(c, dict, idx, ll, t);
-    idx += ll;
-    len -= ll;
-  }
-  t += len;
-  record_trailer(c, c.n - t, t);
-  if (lane == 0) {
-    status[sid] = c.oob ? MD_LZO_OUT_OF_BOUND : MD_OK;
-    out_len[sid] = c.oob ? 0 : c.op;
+    c.n = (uint32_t)l64;
+    c.dst = out + out_off[sid];
+    c.cap = c64 > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)c64;
+    c.lane = lane;
+    c.op = 0;
+    c.oob = false;
+    c.patch = 0;
+    // Lzo.compress, lib/lzo.ml:648-660
+    uint32_t idx = 0, len = c.n, t = 0;
+    while (len > 20) {
+      const uint32_t ll = len < 49152u ? len : 49152u;
+      if (((t + ll) >> 5) == 0) break;
+      for (uint32_t i = lane; i < (1u << 11); i += kWave) reinterpret_cast<uint4 *>(dict)[i] = make_uint4(0, 0, 0, 0);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      t = compress_chunk(c, dict, idx, ll, t);
+      idx += ll;
+      len -= ll;
+    }
+    t += len;
+    record_trailer(c, c.n - t, t);
+    if (lane == 0) {
+      status[sid] = c.oob ? MD_LZO_OUT_OF_BOUND : MD_OK;
+      out_len[sid] = c.oob ? 0 : c.op;
+    }
   }
 }
 
 }  // namespace lzo
 }  // namespace md
 
+// grid: `slots` persistent workgroups (what the chip holds at once; the caller knows the device), never more than streams
 extern "C" int md_launch_lzo_uncompress(uint32_t n, const uint8_t *in, const uint64_t *in_off, const uint64_t *in_len,
                                         uint8_t *out, const uint64_t *out_off, const uint64_t *out_cap,
-                                        uint64_t *out_len, int32_t *status, hipStream_t stream) {
+                                        uint64_t *out_len, int32_t *status, uint32_t *counter, uint32_t slots, hipStream_t stream) {
   if (n == 0) return 0;
-  hipLaunchKernelGGL(md::lzo::lzo_uncompress_kernel, dim3(md::lzo::xcd_grid(n)), dim3(md::lzo::kWave), 0, stream, n, in, in_off, in_len,
-                     out, out_off, out_cap, out_len, status);
+  hipLaunchKernelGGL(md::lzo::lzo_uncompress_kernel, dim3(n < slots ? n : slots), dim3(md::lzo::kWave), 0, stream, n, in, in_off, in_len,
+                     out, out_off, out_cap, out_len, status, counter);
   return (int)hipGetLastError();
 }
 
 extern "C" int md_launch_lzo_compress(uint32_t n, const uint8_t *in, const uint64_t *in_off, const uint64_t *in_len,
                                       uint8_t *out, const uint64_t *out_off, const uint64_t *out_cap,
-                                      uint64_t *out_len, int32_t *status, uint16_t *ws_dict, hipStream_t stream) {
+                                      uint64_t *out_len, int32_t *status, uint16_t *ws_dict, uint32_t *counter, uint32_t slots,
+                                      hipStream_t stream) {
   if (n == 0) return 0;
-  hipLaunchKernelGGL(md::lzo::lzo_compress_kernel, dim3(md::lzo::xcd_grid(n)), dim3(md::lzo::kWave), 0, stream, n, in, in_off, in_len, out,
-                     out_off, out_cap, out_len, status, ws_dict);
+  hipLaunchKernelGGL(md::lzo::lzo_compress_kernel, dim3(n < slots ? n : slots), dim3(md::lzo::kWave), 0, stream, n, in, in_off, in_len, out,
+                     out_off, out_cap, out_len, status, ws_dict, counter);
   return (int)hipGetLastError();
 }

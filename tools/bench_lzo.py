@@ -23,9 +23,11 @@ def main():
     dev = torch.device("cuda", 0)
     eng = decompress_amd.Engine(0)
     n, nb = args.streams, args.stream_kib * 1024
-    pick = lambda i: workloads.text if (args.kind == 'text' or (args.kind == 'mix' and i % 2 == 0)) else workloads.ascii_uniform
+    pick = lambda i: workloads.text if (args.kind == 'text' or (args.kind in ('mix', 'blocks') and i % 2 == 0)) else workloads.ascii_uniform
     uniq = [pick(i)(0xC5 + i, nb) for i in range(min(args.unique, n))]
     bufs = [uniq[i % len(uniq)] for i in range(n)]
+    if args.kind == 'blocks':  # the mix's streams, all text first
+        bufs = [b for i, b in enumerate(bufs) if i % 2 == 0] + [b for i, b in enumerate(bufs) if i % 2 == 1]
     blob, off, ln = workloads.pack(bufs, align=32)
     cap = np.full(n, lzo.max_compressed_length(nb), dtype=np.int64)
     zoff = np.arange(n, dtype=np.int64) * ((int(cap[0]) + 255) // 256 * 256)
