@@ -68,6 +68,7 @@ extern "C" int md_launch_lzo_compress(uint32_t n, const uint8_t *in, const uint6
                                       uint8_t *out, const uint64_t *out_off, const uint64_t *out_cap,
                                       uint64_t *out_len, int32_t *status, uint16_t *ws_dict, uint32_t *counter, uint32_t slots,
                                       hipStream_t stream);
+extern "C" uint32_t md_lzo_slots(int compress, uint32_t cus);
 
 struct md_ctx {
   int device = 0;
@@ -1688,9 +1689,8 @@ static int lzo_batch_device(md_ctx *ctx, bool compress, size_t n, const uint8_t 
   if (!d_in_off || !d_in_len || !d_out_off || !d_out_cap || !d_out_len || !d_status)
     return fail(ctx, MD_E_INVALID_ARGUMENT, "null descriptor array");
   MD_ON_DEVICE(ctx);
-  // persistent workgroups (lzo_kernels.hip): as many as the chip holds at once - 30 per CU by the decoder's 5 KiB of LDS,
-  // 32 by the compressor's 8 wavefronts per SIMD - drawing streams from a counter
-  const uint32_t slots = (uint32_t)ctx->cus * (compress ? 32u : 30u);
+  // persistent workgroups (lzo_kernels.hip): as many as the chip holds at once, drawing streams from a counter
+  const uint32_t slots = md_lzo_slots(compress ? 1 : 0, (uint32_t)ctx->cus);
   const size_t wgs = n < slots ? n : slots;
   if (compress) {  // Lzo's wrkmem: 16 K u16 entries per workgroup
     const size_t need = wgs * (size_t)(1u << 15);

@@ -131,7 +131,7 @@ __device__ __forceinline__ int count(Dec &d, uint32_t *out) {
 // buffer: the interpreter of rounds 2-5, now the slow path - what the batched decoder below does not take (an instruction
 // near the end of the input, a length that goes on over zero bytes, the end marker, anything that fails) comes here, so
 // the error cases and their order are the reference's by construction.  *end: the end-of-stream instruction.
-__device__ __noinline__ int fiber_step(Dec &d, bool *end) {
+__device__ __forceinline__ int fiber_step(Dec &d, bool *end) {
   LZ_EOI()
   uint32_t chr = d.in.byte(d.i_pos++);
   const int st = d.state & 3;  // -1 land 3 = 3
@@ -325,7 +325,7 @@ __device__ __forceinline__ uint32_t pack_ins(uint32_t b, uint32_t p, uint32_t n)
   return (r.k + r.lit) | ((r.mlen + r.lit) << 10) | ((r.exotic || !inside) ? kExotic : 0u) | (next_zero ? kNextZero : 0u);
 }
 
-__device__ int uncompress_stream(Dec &d, LSmem MD_LDS *sm) {
+__device__ __forceinline__ int uncompress_stream(Dec &d, LSmem MD_LDS *sm) {
   LZ_EOI()
   uint32_t chr = d.in.byte(0);
   if (chr == 16) return MD_LZO_NO_DICTIONARY;
@@ -418,7 +418,23 @@ __device__ int uncompress_stream(Dec &d, LSmem MD_LDS *sm) {
       const bool near = mine && mlen != 0 && !far;
       if (__ballot(mine && mlen != 0 && sabs < o0)) {  // some source byte lies in the output buffer
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // earlier batches' bytes have landed
-        if (far) {
+        // the first 32 bytes of every record with all loads in flight together (a load per 8 bytes, each waited for before
+        // the next was asked for, was a memory round trip per step of the longest record: most of a lone stream's time);
+        // whole 8-byte words: up to 7 bytes past the source, which ends at o0 at the latest
+        if (o0 + 8 <= d.cap) {
+          const uint32_t fl = far ? mlen : 0u;
+          const uint8_t *g = d.dst + (far ? sabs : 0u);
+          const uint64_t v0 = wv::out_ld64(g), v1 = wv::out_ld64(g + (fl > 8 ? 8 : 0)), v2 = wv::out_ld64(g + (fl > 16 ? 16 : 0)),
+                         v3 = wv::out_ld64(g + (fl > 24 ? 24 : 0));
+          if (fl) {
+            lds_u8 *t = stage + sidx;
+            lds_put(t, v0, fl < 8 ? fl : 8);
+            if (fl > 8) lds_put(t + 8, v1, fl < 16 ? fl - 8 : 8);
+            if (fl > 16) lds_put(t + 16, v2, fl < 24 ? fl - 16 : 8);
+            if (fl > 24) lds_put(t + 24, v3, fl < 32 ? fl - 24 : 8);
+            for (uint32_t j = 32; j < fl; j += 8) lds_put(t + j, wv::out_ld64(g + j), fl - j < 8 ? fl - j : 8);
+          }
+        } else if (far) {  // the last bytes of the output buffer: nothing is read beyond it
           for (uint32_t j = 0; j < mlen; j += 8)
             lds_put(stage + sidx + j, out_ld_guard(d.dst, sabs + j, mlen - j, d.cap), mlen - j < 8 ? mlen - j : 8);
         }
@@ -752,7 +768,20 @@ __global__ __launch_bounds__(kWave, 8) void lzo_compress_kernel(
 }  // namespace lzo
 }  // namespace md
 
-// grid: `slots` persistent workgroups (what the chip holds at once; the caller knows the device), never more than streams
+// grid: persistent workgroups, as many as the device holds at once (asked of the runtime: registers and LDS decide),
+// never more than there are streams
+template <class K>
+static uint32_t resident_workgroups(K kernel, uint32_t cus) {
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, md::lzo::kWave, 0) != hipSuccess || per_cu < 1) per_cu = 8;
+  return cus * (uint32_t)per_cu;
+}
+extern "C" uint32_t md_lzo_slots(int compress, uint32_t cus) {
+  static uint32_t per_cu[2] = {0, 0};  // (per CU: the same on every device this library runs on)
+  uint32_t &v = per_cu[compress ? 1 : 0];
+  if (!v) v = compress ? resident_workgroups(md::lzo::lzo_compress_kernel, 1) : resident_workgroups(md::lzo::lzo_uncompress_kernel, 1);
+  return v * cus;
+}
 extern "C" int md_launch_lzo_uncompress(uint32_t n, const uint8_t *in, const uint64_t *in_off, const uint64_t *in_len,
                                         uint8_t *out, const uint64_t *out_off, const uint64_t *out_cap,
                                         uint64_t *out_len, int32_t *status, uint32_t *counter, uint32_t slots, hipStream_t stream) {
