@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 SO = os.environ.get("MD_SO_OUT") or os.path.join(HERE, "libmdeflate.so")  # MD_SO_OUT: measurement builds (tools/dbg)
-SOURCES = ["inflate_wave.hip", "deflate_front.hip", "deflate_kernel.hip", "deflate_ns.hip", "gz_kernels.hip", "lzo_kernels.hip", "capi.cpp", "stream_shim.cpp"]
+SOURCES = ["inflate_wave.hip", "inflate_chunked.hip", "deflate_front.hip", "deflate_kernel.hip", "deflate_ns.hip", "gz_kernels.hip", "lzo_kernels.hip", "capi.cpp", "stream_shim.cpp"]
 
 
 def _hipcc():

@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -69,6 +70,15 @@ extern "C" int md_launch_lzo_compress(uint32_t n, const uint8_t *in, const uint6
                                       uint64_t *out_len, int32_t *status, uint16_t *ws_dict, uint32_t *counter, uint32_t slots,
                                       hipStream_t stream);
 extern "C" uint32_t md_lzo_slots(int compress, uint32_t cus);
+// inflate_chunked.hip
+extern "C" int md_launch_find_blocks(const uint8_t *body, uint64_t nbytes, uint64_t K, uint32_t nchunks_behind_first, uint64_t *cand,
+                                     hipStream_t stream);
+extern "C" int md_launch_fill_windows(uint32_t n, uint8_t *out, const uint64_t *out_off, const uint8_t *variant, hipStream_t stream);
+extern "C" int md_launch_window_chain(uint32_t npieces, const uint8_t *dst, const uint8_t *scratch, const uint64_t *offa,
+                                      const uint64_t *offb, const uint64_t *u, uint8_t *wins, uint32_t *flag, hipStream_t stream);
+extern "C" int md_launch_resolve(uint32_t npieces, uint8_t *dst, const uint8_t *scratch, const uint64_t *offa, const uint64_t *offb,
+                                 const uint64_t *u, const uint64_t *pos, const uint8_t *wins, uint32_t *flag, hipStream_t stream);
+extern "C" int md_launch_adler_segments(const uint8_t *data, uint64_t n, uint32_t seg, uint32_t *sums, hipStream_t stream);
 
 struct md_ctx {
   int device = 0;
@@ -109,6 +119,13 @@ struct md_ctx {
   void *host_in = nullptr, *host_out = nullptr, *host_desc = nullptr;
   size_t host_in_bytes = 0, host_out_bytes = 0, host_desc_bytes = 0;
   hipStream_t s_in = nullptr, s_out = nullptr;
+  // one long stream decoded by the whole chip (inflate_parallel): input, output + the pieces' scratch decodes, windows and
+  // descriptors, grow-only; md_set_option "inflate_parallel_min" (compressed bytes from which a single stream goes this
+  // way, 0 = never) and "inflate_parallel_chunk" (compressed bytes per piece)
+  void *par_in = nullptr, *par_out = nullptr, *par_win = nullptr, *par_desc = nullptr;
+  size_t par_in_bytes = 0, par_out_bytes = 0, par_win_bytes = 0, par_desc_bytes = 0;
+  size_t par_min = (size_t)512 << 10, par_chunk = (size_t)64 << 10;
+  int par_last_pieces = 0, par_last_rounds = 0;  // of the last stream that went this way (md_get_option, tests)
   int host_slices_max = 16;  // md_set_option "host_pipeline_slices": 1 = copy-in / kernels / copy-out one after the other
   std::string err;
 };
@@ -297,6 +314,8 @@ void md_destroy(md_ctx *ctx) {
   if (ctx->gz_tmp) hipFree(ctx->gz_tmp);
   if (ctx->lzo_ws) hipFree(ctx->lzo_ws);
   if (ctx->counters) hipFree(ctx->counters);
+  for (void *q : {ctx->par_in, ctx->par_out, ctx->par_win, ctx->par_desc})
+    if (q) hipFree(q);
   if (ctx->gz_hdr_dev) hipFree(ctx->gz_hdr_dev);
   if (ctx->host_in) hipFree(ctx->host_in);
   if (ctx->host_out) hipFree(ctx->host_out);
@@ -376,10 +395,12 @@ int md_set_option(md_ctx *ctx, const char *key, int value) {
     MD_ON_DEVICE(ctx);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     void **bufs[] = {&ctx->ws, &ctx->fsmall, &ctx->fbig, (void **)&ctx->order, &ctx->cont_in, &ctx->cont_out, &ctx->cont_desc,
-                     &ctx->slice_desc, &ctx->slice_state, &ctx->host_in, &ctx->host_out, &ctx->host_desc};
+                     &ctx->slice_desc, &ctx->slice_state, &ctx->host_in, &ctx->host_out, &ctx->host_desc,
+                     &ctx->par_in, &ctx->par_out, &ctx->par_win, &ctx->par_desc};
     size_t *sizes[] = {&ctx->ws_bytes, &ctx->fsmall_bytes, &ctx->fbig_bytes, &ctx->order_words, &ctx->cont_in_bytes,
                        &ctx->cont_out_bytes, &ctx->cont_desc_bytes, &ctx->slice_desc_bytes, &ctx->slice_state_bytes,
-                       &ctx->host_in_bytes, &ctx->host_out_bytes, &ctx->host_desc_bytes};
+                       &ctx->host_in_bytes, &ctx->host_out_bytes, &ctx->host_desc_bytes,
+                       &ctx->par_in_bytes, &ctx->par_out_bytes, &ctx->par_win_bytes, &ctx->par_desc_bytes};
     for (size_t i = 0; i < sizeof bufs / sizeof bufs[0]; i++) {
       if (*bufs[i]) hipFree(*bufs[i]);
       *bufs[i] = nullptr;
@@ -390,6 +411,19 @@ int md_set_option(md_ctx *ctx, const char *key, int value) {
   if (!strcmp(key, "deflate_test_flags")) {
     ctx->test_flags = value;
     return MD_OK;
+  }
+  if (!strcmp(key, "inflate_parallel_min")) {  // KiB of compressed input from which ONE stream is decoded in pieces by the whole chip; 0 = never
+    if (value < 0) return fail(ctx, MD_E_INVALID_ARGUMENT, "inflate_parallel_min >= 0 (KiB)");
+    ctx->par_min = (size_t)value << 10;
+    return MD_OK;
+  }
+  if (!strcmp(key, "inflate_parallel_chunk")) {  // KiB of compressed input per piece
+    if (value < 4 || value > (1 << 20)) return fail(ctx, MD_E_INVALID_ARGUMENT, "inflate_parallel_chunk is 4 .. 2^20 (KiB)");
+    ctx->par_chunk = (size_t)value << 10;
+    return MD_OK;
+  }
+  if (!strcmp(key, "inflate_parallel_last")) {  // (query, value ignored) pieces of the last stream that went that way | rounds << 24; 0: it did not
+    return ctx->par_last_pieces | (ctx->par_last_rounds << 24);
   }
   if (!strcmp(key, "host_pipeline_slices")) {  // md_*_batch_host: slices of streams in flight (1 = no overlap of copies and kernels)
     if (value < 1 || value > 64) return fail(ctx, MD_E_INVALID_ARGUMENT, "host_pipeline_slices is 1 .. 64");
@@ -1592,10 +1626,354 @@ int md_de_def_run(md_ctx *ctx, int queue_len, const uint32_t *ops, size_t nops, 
   return st;
 }
 
+// ---- one long stream on the whole chip (csrc/inflate_chunked.hip has the scheme and the kernels) --------------------
+// De.Higher.uncompress / Zl.Higher.uncompress / Gz on ONE big input (lib/de.ml:4555-4571, lib/zl.ml:650-666,
+// bin/decompress.ml:77-100).  Returns kNotHandled whenever anything is not exactly as a well-formed stream decoded in
+// pieces should be - the caller then takes the serial path, whose statuses and counts are the reference's; MD_OK means
+// the whole stream is decoded, verified against its checksum, and copied out.
+extern "C++" {
+namespace {
+constexpr int kNotHandled = 1000;
+uint32_t par_gf_mul(uint32_t a, uint32_t b) {
+  uint32_t p = 0;
+  for (int k = 0; k < 32; k++) {
+    p ^= b & (0u - ((a >> 31) & 1));
+    a <<= 1;
+    b = (b >> 1) ^ (0xedb88320u & (0u - (b & 1)));
+  }
+  return p;
+}
+// crc(A || B) from crc(A), crc(B) and |B| (reflected CRC-32: bit 31 = x^0)
+uint32_t par_crc_concat(uint32_t crc_a, uint32_t crc_b, uint64_t len_b) {
+  uint32_t sq = 0x00800000u, r = 0x80000000u;  // x^8, x^0
+  for (uint64_t n = len_b; n; n >>= 1) {
+    if (n & 1) r = par_gf_mul(r, sq);
+    sq = par_gf_mul(sq, sq);
+  }
+  return par_gf_mul(crc_a, r) ^ crc_b;
+}
+struct ParPiece {
+  uint64_t bit;      // first bit of the piece in the body (a block start)
+  uint64_t u = 0;    // bytes it produces
+};
+}  // namespace
+
+static int inflate_parallel(md_ctx *ctx, int format, const uint8_t *src, size_t src_len, uint8_t *dst, size_t dst_cap,
+                            size_t *consumed, size_t *written) {
+  ctx->par_last_pieces = ctx->par_last_rounds = 0;
+  // -- the frame: anything but a plain valid header is the serial path's (it knows the reference's answer)
+  size_t hdr = 0, trailer = 0;
+  if (format == MD_FORMAT_ZLIB) {
+    if (src_len < 6 || (((uint32_t)src[0] << 8) + src[1]) % 31 != 0 || (src[0] & 0xf) != 8) return kNotHandled;
+    hdr = 2;
+    trailer = 4;
+  } else if (format == MD_FORMAT_GZIP) {
+    if (src_len < 18 || src[0] != 0x1f || src[1] != 0x8b || (src[3] & 2)) return kNotHandled;  // (a header CRC: serial path)
+    size_t p = 10;
+    const uint32_t flg = src[3];
+    if (flg & 4) {  // FEXTRA, big-endian length as the reference reads it (lib/gz.ml:455)
+      if (src_len - p < 2) return kNotHandled;
+      const size_t xl = ((size_t)src[p] << 8) | src[p + 1];
+      p += 2;
+      if (src_len - p < xl) return kNotHandled;
+      p += xl;
+    }
+    for (int which = 0; which < 2; which++) {
+      if (!(flg & (which == 0 ? 8u : 16u))) continue;
+      while (p < src_len && src[p] != 0) p++;
+      if (p >= src_len) return kNotHandled;
+      p++;
+    }
+    hdr = p;
+    trailer = 8;
+  } else if (format != MD_FORMAT_DEFLATE) return kNotHandled;
+  if (src_len < hdr + trailer) return kNotHandled;
+  const uint8_t *body = src + hdr;
+  const uint64_t body_len = src_len - hdr;  // (the trailer's bytes included: where the stream ends is the decoder's to say)
+  const uint64_t K = ctx->par_chunk;
+  if (body_len < 4 * K || body_len > ((uint64_t)1 << 31) || dst_cap > MD_MAX_STREAM) return kNotHandled;
+  const uint32_t nchunks = (uint32_t)((body_len + K - 1) / K);
+  hipStream_t st = ctx->stream;
+  // -- the body on the device, candidate block starts
+  int rc = grow(ctx, &ctx->par_in, &ctx->par_in_bytes, body_len + 64, "hipMalloc(parallel inflate input)");
+  if (rc != MD_OK) return rc;
+  const size_t desc_bytes = (size_t)nchunks * 2 * 160 + 4096;
+  rc = grow(ctx, &ctx->par_desc, &ctx->par_desc_bytes, desc_bytes, "hipMalloc(parallel inflate descriptors)");
+  if (rc != MD_OK) return rc;
+  uint8_t *d_body = (uint8_t *)ctx->par_in;
+  HIP_TRY(ctx, hipMemcpyAsync(d_body, body, body_len, hipMemcpyHostToDevice, st));
+  uint64_t *d_cand = (uint64_t *)ctx->par_desc;
+  int e = md_launch_find_blocks(d_body, body_len, K, nchunks - 1, d_cand, st);
+  if (e != 0) return fail(ctx, MD_E_HIP, "find_blocks launch", (hipError_t)e);
+  std::vector<uint64_t> cand(nchunks - 1);
+  HIP_TRY(ctx, hipMemcpyAsync(cand.data(), d_cand, (nchunks - 1) * 8, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  std::vector<ParPiece> pc;
+  pc.push_back(ParPiece{0});
+  for (uint64_t c : cand)
+    if (c != ~0ull && c > pc.back().bit) pc.push_back(ParPiece{c});
+  if (pc.size() < 3) return kNotHandled;  // nothing to gain
+  // -- decode, verify the chain of pieces, decode again without a candidate that proved false or with more room
+  uint32_t capmul = 6;
+  uint64_t total = 0, used_body = 0;
+  std::vector<uint64_t> offa, offb;
+  for (int round = 1;; round++) {
+    if (round > 8) return kNotHandled;
+    ctx->par_last_rounds = round;
+    const size_t np = pc.size(), n = 2 * np - 1;  // piece 0 once (its window is real), the others with window A and window B
+    // out blob: [the final output: dst_cap][scratch of piece 1 A, 1 B, 2 A, ...]: 32 KiB of window + room, 64-byte aligned
+    std::vector<uint64_t> in_off(n), in_len(n), out_off(n), out_cap(n);
+    std::vector<uint32_t> start_bit(n), hist(n), adler_in(n, 1);
+    std::vector<uint8_t> variant(n);
+    offa.assign(np, 0);
+    offb.assign(np, 0);
+    uint64_t at = ((uint64_t)dst_cap + 63) & ~(uint64_t)63;
+    for (size_t p = 0; p < np; p++) {
+      const uint64_t b0 = pc[p].bit >> 3, b1 = p + 1 < np ? (pc[p + 1].bit + 7) >> 3 : body_len;
+      for (int v = 0; v < (p ? 2 : 1); v++) {
+        const size_t i = p ? 2 * p - 1 + v : 0;
+        in_off[i] = b0;
+        in_len[i] = b1 - b0;
+        start_bit[i] = (uint32_t)(pc[p].bit & 7);
+        if (p == 0) {
+          out_off[i] = 0;
+          out_cap[i] = dst_cap;
+          hist[i] = 0;
+          variant[i] = 0;
+        } else {
+          const uint64_t room = (uint64_t)capmul * (b1 - b0) + 65536;
+          out_off[i] = at;
+          out_cap[i] = 32768 + room;
+          hist[i] = 32768;
+          variant[i] = (uint8_t)(1 + v);
+          (v ? offb : offa)[p] = at + 32768;
+          at += (32768 + room + 64 + 63) & ~(uint64_t)63;
+        }
+      }
+    }
+    if (at > ((uint64_t)64 << 30)) return kNotHandled;
+    rc = grow(ctx, &ctx->par_out, &ctx->par_out_bytes, at + 64, "hipMalloc(parallel inflate output)");
+    if (rc != MD_OK) return rc;
+    // descriptors: u64 x n: in_off in_len out_off out_cap out_len consumed resume_bits resume_out; u32 x n: start_bit hist
+    // adler_in status checksum resume_adler resume_last; u8 x n: variant
+    const size_t need = n * (8 * 8 + 7 * 4 + 1) + 256;
+    rc = grow(ctx, &ctx->par_desc, &ctx->par_desc_bytes, need, "hipMalloc(parallel inflate descriptors)");
+    if (rc != MD_OK) return rc;
+    uint64_t *d64 = (uint64_t *)ctx->par_desc;
+    uint32_t *d32 = (uint32_t *)(d64 + 8 * n);
+    uint8_t *d8 = (uint8_t *)(d32 + 7 * n);
+    uint8_t *d_out = (uint8_t *)ctx->par_out;
+    HIP_TRY(ctx, hipMemcpyAsync(d64 + 0 * n, in_off.data(), n * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(d64 + 1 * n, in_len.data(), n * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(d64 + 2 * n, out_off.data(), n * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(d64 + 3 * n, out_cap.data(), n * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(d32 + 0 * n, start_bit.data(), n * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(d32 + 1 * n, hist.data(), n * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(d32 + 2 * n, adler_in.data(), n * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(d8, variant.data(), n, hipMemcpyHostToDevice, st));
+    e = md_launch_fill_windows((uint32_t)n, d_out, d64 + 2 * n, d8, st);
+    if (e != 0) return fail(ctx, MD_E_HIP, "fill_windows launch", (hipError_t)e);
+    rc = md_inflate_continue_batch_device(ctx, n, d_body, d64 + 0 * n, d64 + 1 * n, d_out, d64 + 2 * n, d64 + 3 * n, d32 + 0 * n,
+                                          d32 + 1 * n, d32 + 2 * n, d64 + 4 * n, d64 + 5 * n, (int32_t *)(d32 + 3 * n), d32 + 4 * n,
+                                          d64 + 6 * n, d64 + 7 * n, d32 + 5 * n, d32 + 6 * n);
+    if (rc != MD_OK) return rc;
+    std::vector<uint64_t> r_used(n), r_bits(n), r_out(n);
+    std::vector<int32_t> r_st(n);
+    std::vector<uint32_t> r_last(n);
+    HIP_TRY(ctx, hipMemcpyAsync(r_used.data(), d64 + 5 * n, n * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(r_bits.data(), d64 + 6 * n, n * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(r_out.data(), d64 + 7 * n, n * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(r_st.data(), d32 + 3 * n, n * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(r_last.data(), d32 + 6 * n, n * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    // The pieces in order: piece p must end - its last complete block - exactly where piece p + 1 starts ("links").  From
+    // piece 0, the true start of the stream, an unbroken chain of links IS the stream's chain of blocks.  A candidate its
+    // predecessor does not link to goes (all of them in one round: behind a false candidate the verdicts say little, and a
+    // true block start dropped by mistake only costs a split), and everything is decoded again.
+    bool again = false, chain = true;
+    size_t last = np;  // index of the piece that holds the stream's final block
+    std::vector<std::pair<uint64_t, uint64_t>> kill;  // candidates at bits (lo, hi] go
+    std::vector<uint64_t> add;                        // block starts found by hopping over stored blocks
+    // piece p ended its last complete block at bit e, in front of the next candidate: that candidate is no block start.  If
+    // the block at e is STORED, so are all candidates inside it and the stored blocks behind it (compressed data inside the
+    // plaintext - a tar of .gz files - is stored, and full of real block headers that are not this stream's): hop over
+    // them on the host, a read per block, and the block start behind the run is a candidate the finder could not see.
+    auto unlinked = [&](size_t p, uint64_t e) {
+      uint64_t hi = p + 1 < np ? pc[p + 1].bit : ~0ull, pos = e;
+      for (int hops = 0; hops < (1 << 20); hops++) {
+        const uint64_t by = pos >> 3;
+        if (by + 5 > body_len) break;
+        const uint32_t h = ((uint32_t)body[by] | ((uint32_t)body[by + 1] << 8)) >> (pos & 7);
+        if ((h & 6) != 0 || (h & 1)) break;  // not stored, or the final block
+        const uint64_t at = (pos + 3 + 7) >> 3;
+        if (at + 4 > body_len) break;
+        const uint32_t len = body[at] | ((uint32_t)body[at + 1] << 8), nlen = body[at + 2] | ((uint32_t)body[at + 3] << 8);
+        if ((len ^ nlen) != 0xffffu || at + 4 + len > body_len) break;
+        pos = (at + 4 + len) * 8;
+      }
+      if (pos > e) {
+        if (pos > hi) hi = pos;
+        if (pos < body_len * 8) add.push_back(pos);
+      }
+      kill.push_back({pc[p].bit, hi == ~0ull ? pc[p].bit : hi});
+    };
+    total = 0;
+    for (size_t p = 0; p < np; p++) {
+      const size_t i = p ? 2 * p - 1 : 0;
+      const uint64_t base_bits = (pc[p].bit >> 3) * 8;
+      if (p && (r_st[i] != r_st[i + 1] || r_out[i] != r_out[i + 1] || r_bits[i] != r_bits[i + 1])) {
+        if (chain) return kNotHandled;  // (the two decodes of a piece of the real chain differ in more than the window's bytes)
+        if (p + 1 < np) kill.push_back({pc[p].bit, pc[p + 1].bit});
+        again = true;
+        continue;
+      }
+      const bool linked = r_st[i] == MD_UNEXPECTED_END_OF_INPUT && p + 1 < np && base_bits + r_bits[i] == pc[p + 1].bit && r_last[i] == 0;
+      if (linked) {
+        pc[p].u = r_out[i] - hist[i];
+        total += pc[p].u;
+      } else if (r_st[i] == MD_UNEXPECTED_END_OF_OUTPUT && p) {  // (piece 0 writes into the caller's room: the serial path's error)
+        again = true;
+        if (chain) {  // a piece of the real chain needs more room (the candidate behind it stays)
+          capmul *= 6;
+          if (capmul > 1300) return kNotHandled;
+        } else if (p + 1 < np) kill.push_back({pc[p].bit, pc[p + 1].bit});  // (behind a false candidate: garbage that expands)
+        chain = false;
+      } else if (r_st[i] == MD_OK && chain) {  // the final block ended inside this piece: what follows is not the stream's
+        pc[p].u = r_out[i] - hist[i];
+        total += pc[p].u;
+        used_body = (pc[p].bit >> 3) + r_used[i];
+        last = p;
+        break;
+      } else {
+        // on the real chain: a piece that runs over the next candidate makes that candidate false; anything else is an
+        // error of the stream itself (or a stream that ends inside its last block): the serial path's
+        const bool ran_over = r_st[i] == MD_UNEXPECTED_END_OF_INPUT && p + 1 < np && base_bits + r_bits[i] < pc[p + 1].bit;
+        if (chain && !ran_over) return kNotHandled;
+        if (ran_over) unlinked(p, base_bits + r_bits[i]);
+        else if (p + 1 < np) kill.push_back({pc[p].bit, pc[p + 1].bit});
+        again = true;
+        chain = false;
+      }
+    }
+    if (again) {
+      std::vector<ParPiece> keep;
+      for (size_t p = 0; p < np; p++) {
+        bool dead = false;
+        for (const auto &k : kill) dead = dead || (pc[p].bit > k.first && pc[p].bit <= k.second);
+        if (!dead) keep.push_back(pc[p]);
+      }
+      for (uint64_t x : add) {
+        bool dead = false;
+        for (const auto &k : kill) dead = dead || (x > k.first && x < k.second);  // (inside another piece's stored run)
+        if (!dead) keep.push_back(ParPiece{x});
+      }
+      std::sort(keep.begin(), keep.end(), [](const ParPiece &x, const ParPiece &y) { return x.bit < y.bit; });
+      keep.erase(std::unique(keep.begin(), keep.end(), [](const ParPiece &x, const ParPiece &y) { return x.bit == y.bit; }), keep.end());
+      pc.swap(keep);
+      if (pc.size() < 2) return kNotHandled;
+      continue;
+    }
+    if (last == np) return kNotHandled;
+    if (last + 1 < np) pc.resize(last + 1);  // (the scratch of the pieces behind it is simply not looked at)
+    break;
+  }
+  const size_t np = pc.size();
+  if (total > dst_cap || np < 2) return kNotHandled;
+  if (src_len - hdr - used_body < trailer) return kNotHandled;
+  // -- windows, then every byte
+  {
+    std::vector<uint64_t> u(np), pos(np);
+    uint64_t acc = 0;
+    for (size_t p = 0; p < np; p++) {
+      u[p] = pc[p].u;
+      pos[p] = acc;
+      acc += u[p];
+    }
+    rc = grow(ctx, &ctx->par_win, &ctx->par_win_bytes, np * (size_t)32768 + 64, "hipMalloc(parallel inflate windows)");
+    if (rc != MD_OK) return rc;
+    const size_t nseg = (size_t)((total + 65535) / 65536), ncrc = (size_t)((total + ((1u << 20) - 1)) >> 20);
+    const size_t need = np * 32 + 64 + nseg * 8 + ncrc * 24 + 256;
+    rc = grow(ctx, &ctx->par_desc, &ctx->par_desc_bytes, need, "hipMalloc(parallel inflate descriptors)");
+    if (rc != MD_OK) return rc;
+    uint64_t *d64 = (uint64_t *)ctx->par_desc;  // offa offb u pos | crc_off crc_len | flag, sums / crcs
+    uint64_t *d_crc_off = d64 + 4 * np, *d_crc_len = d_crc_off + ncrc;
+    uint32_t *d_flag = (uint32_t *)(d_crc_len + ncrc), *d_sums = d_flag + 16;
+    uint8_t *d_out = (uint8_t *)ctx->par_out;
+    HIP_TRY(ctx, hipMemcpyAsync(d64 + 0 * np, offa.data(), np * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(d64 + 1 * np, offb.data(), np * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(d64 + 2 * np, u.data(), np * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(d64 + 3 * np, pos.data(), np * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemsetAsync(d_flag, 0, 64, st));
+    e = md_launch_window_chain((uint32_t)np, d_out, d_out, d64 + 0 * np, d64 + 1 * np, d64 + 2 * np, (uint8_t *)ctx->par_win, d_flag, st);
+    if (e != 0) return fail(ctx, MD_E_HIP, "window_chain launch", (hipError_t)e);
+    e = md_launch_resolve((uint32_t)np, d_out, d_out, d64 + 0 * np, d64 + 1 * np, d64 + 2 * np, d64 + 3 * np,
+                          (const uint8_t *)ctx->par_win, d_flag, st);
+    if (e != 0) return fail(ctx, MD_E_HIP, "resolve launch", (hipError_t)e);
+    // -- the checksum of the final bytes, in segments joined here
+    uint32_t flag = 0;
+    const uint8_t *t = src + hdr + used_body;
+    if (format == MD_FORMAT_ZLIB) {
+      e = md_launch_adler_segments(d_out, total, 65536, d_sums, st);
+      if (e != 0) return fail(ctx, MD_E_HIP, "adler_segments launch", (hipError_t)e);
+      std::vector<uint32_t> sums(2 * nseg);
+      HIP_TRY(ctx, hipMemcpyAsync(sums.data(), d_sums, nseg * 8, hipMemcpyDeviceToHost, st));
+      HIP_TRY(ctx, hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, st));
+      HIP_TRY(ctx, hipStreamSynchronize(st));
+      uint64_t a = 1, b = 0;
+      for (size_t s = 0; s < nseg; s++) {
+        const uint64_t len = s + 1 < nseg ? 65536 : total - (uint64_t)s * 65536;
+        b = (b + (len % 65521) * a + sums[2 * s + 1]) % 65521;
+        a = (a + sums[2 * s]) % 65521;
+      }
+      const uint32_t want = ((uint32_t)t[0] << 24) | ((uint32_t)t[1] << 16) | ((uint32_t)t[2] << 8) | t[3];
+      if (want != (uint32_t)((b << 16) | a)) return kNotHandled;
+    } else if (format == MD_FORMAT_GZIP) {
+      std::vector<uint64_t> co(ncrc), cl(ncrc);
+      for (size_t s = 0; s < ncrc; s++) {
+        co[s] = (uint64_t)s << 20;
+        cl[s] = s + 1 < ncrc ? (uint64_t)1 << 20 : total - co[s];
+      }
+      HIP_TRY(ctx, hipMemcpyAsync(d_crc_off, co.data(), ncrc * 8, hipMemcpyHostToDevice, st));
+      HIP_TRY(ctx, hipMemcpyAsync(d_crc_len, cl.data(), ncrc * 8, hipMemcpyHostToDevice, st));
+      e = md_launch_crc32((uint32_t)ncrc, d_out, d_crc_off, d_crc_len, d_sums, st);
+      if (e != 0) return fail(ctx, MD_E_HIP, "crc32 launch", (hipError_t)e);
+      std::vector<uint32_t> crcs(ncrc);
+      HIP_TRY(ctx, hipMemcpyAsync(crcs.data(), d_sums, ncrc * 4, hipMemcpyDeviceToHost, st));
+      HIP_TRY(ctx, hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, st));
+      HIP_TRY(ctx, hipStreamSynchronize(st));
+      uint32_t crc = 0;
+      for (size_t s = 0; s < ncrc; s++) crc = s ? par_crc_concat(crc, crcs[s], cl[s]) : crcs[0];
+      uint32_t want = 0, isize = 0;
+      for (int k = 0; k < 4; k++) {
+        want |= (uint32_t)t[k] << (8 * k);
+        isize |= (uint32_t)t[4 + k] << (8 * k);
+      }
+      if (want != crc || isize != (uint32_t)total) return kNotHandled;
+    } else {
+      HIP_TRY(ctx, hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, st));
+      HIP_TRY(ctx, hipStreamSynchronize(st));
+    }
+    if (flag) return kNotHandled;  // a reference in front of the stream's start
+    if (total) HIP_TRY(ctx, hipMemcpy(dst, d_out, total, hipMemcpyDeviceToHost));
+  }
+  *consumed = hdr + (size_t)used_body + trailer;
+  *written = (size_t)total;
+  ctx->par_last_pieces = (int)np;
+  return MD_OK;
+}
+}  // extern "C++"
+
 static int inflate_one(md_ctx *ctx, int format, const uint8_t *src, size_t src_len, uint8_t *dst,
                        size_t dst_cap, size_t *consumed, size_t *written) {
   if (!ctx || !consumed || !written || (!src && src_len) || (!dst && dst_cap))
     return MD_E_INVALID_ARGUMENT;
+  ctx->par_last_pieces = ctx->par_last_rounds = 0;
+  if (ctx->par_min && src_len >= ctx->par_min) {  // one long stream: in pieces, by the whole chip
+    MD_ON_DEVICE(ctx);
+    const int prc = inflate_parallel(ctx, format, src, src_len, dst, dst_cap, consumed, written);
+    if (prc != kNotHandled) return prc;
+    ctx->par_last_pieces = 0;
+  }
   uint64_t in_off = 0, in_len = src_len, out_off = 0, out_cap = dst_cap, out_len = 0, used = 0;
   int32_t status = 0;
   int rc = md_inflate_batch_host(ctx, format, 1, src, src_len, &in_off, &in_len, dst, dst_cap,

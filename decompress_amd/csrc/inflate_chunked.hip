@@ -1,0 +1,409 @@
+// inflate_chunked.hip — ONE long DEFLATE stream on the whole chip (round 6; VERDICT r5 "missing" 1).
+//
+// De.Higher.uncompress / Zl.Higher.uncompress / Gz on one big input (lib/de.ml:4555-4571, lib/zl.ml:650-666) is one
+// serial chain of blocks for the reference, and was one pair of wavefronts here (126-160 MiB/s whatever the chip).  A
+// DEFLATE stream can be decoded from any BLOCK START if the 32 KiB of output in front of it are known - and where they are
+// not, the decode can still run with a PLACEHOLDER window and be corrected afterwards, because every output byte is either a
+// literal of the stream or a copy (of a copy ...) of exactly one window byte.  So (capi.cpp `inflate_parallel` drives this):
+//
+//   1. find_blocks_kernel   the compressed body is cut into chunks of K bytes; for every chunk but the first, the first
+//      bit position at or behind the chunk's start where a non-final dynamic block header parses completely (HLIT / HDIST /
+//      HCLEN, a complete code-length code, lengths that decode without overrun, a complete literal/length code with an
+//      end-of-block code, a complete or single-code distance code - De.Inf's own rules, lib/de.ml:1733-1793, :523-638,
+//      made a little stricter) is a CANDIDATE block start; so is the byte behind an empty stored block (a flush marker).
+//   2. the batch kernel (inflate_wave.hip, unchanged) decodes every piece [candidate c, candidate c + 1) as a stream of its
+//      own (md_inflate_continue_batch_device: starting bit, 32 KiB of history in front of the output) - the first piece
+//      with the real (empty) window straight into the output buffer, every other piece TWICE into scratch buffers, once
+//      with each of two placeholder windows A and B (fill_window_kernel) built so that A[j] != B[j] for every window
+//      position j and (A[j], B[j]) names j.  A piece must end - last complete block - exactly on the next candidate: the
+//      chain of pieces from the true start of the stream is then the stream's own chain of blocks, and a false candidate
+//      shows up as a piece that runs past it (the host drops it and decodes again).
+//   3. window_chain_kernel  one workgroup walks the pieces in order and resolves the LAST 32 KiB of each: the window of
+//      the piece behind it.  resolve_kernel then rewrites every piece in parallel: where the two decodes agree the byte is
+//      a literal (or a copy of one), where they differ it is window byte j = A-byte | (B-byte >> 1) << 8.
+//   4. adler_segments_kernel / the CRC-32 kernel give the checksum of the final bytes in segments that the host joins.
+// Anything unexpected - a status the pieces should not give, a reference in front of the stream's start, a checksum that
+// does not match - sends the caller back to the serial path, whose statuses and counts are the reference's: this path only
+// ever returns a finished, verified stream.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mdeflate.h"
+
+namespace md {
+namespace chunked {
+
+constexpr uint32_t kWin = 32768;
+
+// placeholder windows: A[j] = j & 255; B[j] = (j >> 8) << 1 | f with f chosen so that B[j] != A[j]
+__host__ __device__ __forceinline__ uint32_t pat_a(uint32_t j) { return j & 255u; }
+__host__ __device__ __forceinline__ uint32_t pat_b(uint32_t j) {
+  const uint32_t a = j & 255u, h = (j >> 8) << 1;
+  return h == (a & 0xfeu) ? h | (~a & 1u) : h;
+}
+// the decodes with window A and window B produced bytes a and b at some position: *j = the window byte it copies
+__device__ __forceinline__ bool is_marker(uint32_t a, uint32_t b, uint32_t *j) {
+  *j = a | ((b >> 1) << 8);
+  return a != b;
+}
+
+// ---- 1. candidate block starts -----------------------------------------------------------------------------------------
+struct BitRd {  // LSB-first bit reader over body[0, n), zeros beyond the end (`over` says so)
+  const uint8_t *p;
+  uint64_t n, byte;  // next byte to load
+  uint64_t buf;
+  uint32_t cnt;
+  bool over;
+  __device__ __forceinline__ void init(const uint8_t *body, uint64_t nbytes, uint64_t bit) {
+    p = body;
+    n = nbytes;
+    byte = bit >> 3;
+    buf = 0;
+    cnt = 0;
+    over = false;
+    fill();
+    drop((uint32_t)(bit & 7));
+  }
+  __device__ __forceinline__ void fill() {
+    while (cnt <= 56) {
+      uint64_t b = 0;
+      if (byte < n) b = p[byte];
+      buf |= b << cnt;
+      byte++;
+      cnt += 8;
+    }
+  }
+  __device__ __forceinline__ uint32_t peek(uint32_t k) const { return (uint32_t)(buf & ((1ull << k) - 1)); }
+  __device__ __forceinline__ void drop(uint32_t k) {
+    buf >>= k;
+    cnt -= k;
+  }
+  __device__ __forceinline__ uint32_t take(uint32_t k) {
+    if (cnt < k) fill();
+    const uint32_t v = peek(k);
+    drop(k);
+    return v;
+  }
+  // bits consumed so far lie inside the input
+  __device__ __forceinline__ bool inside() const { return byte * 8 - cnt <= n * 8; }
+};
+
+// a complete dynamic block header at bit q of the body?  (called for the few positions whose first 17 + 3 HCLEN bits pass)
+__device__ __noinline__ bool header_parses(const uint8_t *body, uint64_t nbytes, uint64_t q) {
+  BitRd r;
+  r.init(body, nbytes, q);
+  r.take(3);
+  const uint32_t hlit = r.take(5) + 257, hdist = r.take(5) + 1, hclen = r.take(4) + 4;
+  const uint8_t zig[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+  uint8_t cl[19];
+  for (int i = 0; i < 19; i++) cl[i] = 0;
+  for (uint32_t i = 0; i < hclen; i++) cl[zig[i]] = (uint8_t)r.take(3);
+  // canonical code of the code-length alphabet: counts, first codes, symbols sorted by (length, symbol)
+  uint32_t cnt[8], first[8], offs[8];
+  for (int l = 0; l < 8; l++) cnt[l] = 0;
+  for (int s = 0; s < 19; s++) cnt[cl[s]]++;
+  cnt[0] = 0;
+  uint8_t sorted[19];
+  {
+    uint32_t code = 0, o = 0;
+    for (int l = 1; l < 8; l++) {
+      code = (code + cnt[l - 1]) << 1;
+      first[l] = code;
+      offs[l] = o;
+      o += cnt[l];
+    }
+    uint32_t at[8];
+    for (int l = 1; l < 8; l++) at[l] = offs[l];
+    for (int s = 0; s < 19; s++)
+      if (cl[s]) sorted[at[cl[s]]++] = (uint8_t)s;
+  }
+  // the lengths of both alphabets, run-length coded (lib/de.ml:1291-1345): Kraft sums and the end-of-block code on the way
+  uint32_t lsum = 0, dsum = 0, dcodes = 0, d1 = 0, prev = 0, i = 0;
+  bool eob = false;
+  const uint32_t total = hlit + hdist;
+  while (i < total) {
+    if (r.cnt < 16) r.fill();
+    uint32_t code = 0, len = 0, sym = 0xff;
+    for (len = 1; len < 8; len++) {
+      code = (code << 1) | r.take(1);
+      if (code - first[len] < cnt[len]) {
+        sym = sorted[offs[len] + code - first[len]];
+        break;
+      }
+    }
+    if (sym == 0xff) return false;
+    uint32_t rep = 1, val = sym;
+    if (sym == 16) {
+      if (i == 0) return false;
+      rep = 3 + r.take(2);
+      val = prev;
+    } else if (sym == 17) {
+      rep = 3 + r.take(3);
+      val = 0;
+    } else if (sym == 18) {
+      rep = 11 + r.take(7);
+      val = 0;
+    }
+    if (i + rep > total) return false;
+    for (uint32_t k = 0; k < rep; k++, i++) {
+      if (!val) continue;
+      if (i < hlit) {
+        lsum += 32768u >> val;
+        if (i == 256) eob = true;
+      } else {
+        dsum += 32768u >> val;
+        dcodes++;
+        if (val == 1) d1++;
+      }
+    }
+    prev = val;
+  }
+  if (!r.inside()) return false;
+  if (!eob || lsum != 32768u) return false;
+  return dsum == 32768u || dcodes == 0 || (dcodes == 1 && d1 == 1);
+}
+
+// chunk c of the grid covers body bytes [(c + 1) K, (c + 2) K): cand[c] = the first candidate bit in it, ~0 if none
+__global__ __launch_bounds__(256) void find_blocks_kernel(const uint8_t *__restrict__ body, uint64_t nbytes, uint64_t K,
+                                                          uint64_t *__restrict__ cand) {
+  __shared__ uint32_t found;
+  const uint64_t c = blockIdx.x;
+  const uint64_t b0 = (c + 1) * K * 8, b1x = (c + 2) * K * 8, nbits = nbytes * 8, b1 = b1x < nbits ? b1x : nbits;
+  if (threadIdx.x == 0) found = 0xffffffffu;
+  __syncthreads();
+  for (uint64_t t0 = b0; t0 < b1; t0 += 256) {
+    const uint64_t q = t0 + threadIdx.x;
+    bool ok = q + 3 + 14 + 12 <= b1;
+    if (ok) {
+      // 96 bits from q on: the header's fixed part and the (at most 19 x 3 bits of) code-length code lengths
+      const uint64_t by = q >> 3;
+      uint64_t lo = 0, hi = 0;
+      if (by + 16 <= nbytes) {
+        __builtin_memcpy(&lo, body + by, 8);
+        __builtin_memcpy(&hi, body + by + 8, 8);
+      } else {
+        for (uint32_t k = 0; k < 16 && by + k < nbytes; k++) {
+          if (k < 8) lo |= (uint64_t)body[by + k] << (8 * k);
+          else hi |= (uint64_t)body[by + k] << (8 * (k - 8));
+        }
+      }
+      const uint32_t s = (uint32_t)(q & 7);
+      const uint64_t v0 = s ? (lo >> s) | (hi << (64 - s)) : lo, v1 = hi >> s;
+      ok = (v0 & 7) == 4;  // BFINAL = 0, BTYPE = 2
+      const uint32_t hlit = (uint32_t)(v0 >> 3) & 31, hdist = (uint32_t)(v0 >> 8) & 31, hclen = ((uint32_t)(v0 >> 13) & 15) + 4;
+      ok = ok && hlit <= 29 && hdist <= 29;
+      if (ok) {  // the code-length code is complete (kind CODES, lib/de.ml:549-550)
+        uint32_t kraft = 0;
+        for (uint32_t i = 0; i < hclen; i++) {
+          const uint32_t at = 17 + 3 * i;  // 17 .. 71
+          const uint32_t l = (uint32_t)(at < 64 ? (v0 >> at) | (v1 << (64 - at)) : v1 >> (at - 64)) & 7;
+          kraft += l ? 128u >> l : 0u;
+        }
+        ok = kraft == 128u;
+      }
+      if (ok) ok = header_parses(body, nbytes, q);
+    }
+    // ... or the byte behind an EMPTY STORED BLOCK (00 00 ff ff: what Z_SYNC_FLUSH / Z_FULL_FLUSH leave, pigz between its
+    // blocks), whose three header bits and padding lie in the byte in front: the block behind it starts here, byte-aligned
+    if (!ok && (q & 7) == 0 && q + 8 <= b1) {
+      const uint64_t by = q >> 3;
+      ok = by >= 5 && body[by - 4] == 0 && body[by - 3] == 0 && body[by - 2] == 0xff && body[by - 1] == 0xff && (body[by - 5] >> 5) == 0;
+    }
+    if (ok) atomicMin(&found, (uint32_t)(q - b0));
+    __syncthreads();
+    if (found != 0xffffffffu) break;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) cand[c] = found == 0xffffffffu ? ~0ull : b0 + found;
+}
+
+// ---- 2. placeholder windows in front of the pieces' scratch outputs -------------------------------------------------
+// variant[i]: 0 = leave alone (the first piece: its window is real), 1 = window A, 2 = window B
+__global__ __launch_bounds__(256) void fill_window_kernel(uint32_t n, uint8_t *__restrict__ out, const uint64_t *__restrict__ out_off,
+                                                          const uint8_t *__restrict__ variant) {
+  const uint32_t i = blockIdx.y;
+  if (i >= n || variant[i] == 0) return;
+  uint8_t *o = out + out_off[i];
+  const bool b = variant[i] == 2;
+  for (uint32_t j = (blockIdx.x * 256 + threadIdx.x) * 4; j < kWin; j += gridDim.x * 256 * 4) {
+    uint32_t w = 0;
+    for (uint32_t k = 0; k < 4; k++) w |= (b ? pat_b(j + k) : pat_a(j + k)) << (8 * k);
+    __builtin_memcpy(o + j, &w, 4);
+  }
+}
+
+// ---- 3. windows, then every byte ------------------------------------------------------------------------------------------
+// Piece p (p >= 1): decoded bytes A at scratch + offa[p], B at scratch + offb[p], u[p] of them, final place dst + pos[p].
+// Piece 0 is final already: dst[0, u[0]).  wins[p] = the 32 KiB in front of piece p (right-aligned: wins[p][kWin - 1] is the
+// byte just before it), valid[p] of them real.  flag[0] != 0: a reference in front of the stream's start (the serial path
+// reports Invalid_distance for it).
+__global__ __launch_bounds__(1024) void window_chain_kernel(uint32_t npieces, const uint8_t *__restrict__ dst, const uint8_t *__restrict__ scratch,
+                                                            const uint64_t *__restrict__ offa, const uint64_t *__restrict__ offb,
+                                                            const uint64_t *__restrict__ u, uint8_t *__restrict__ wins,
+                                                            uint32_t *__restrict__ flag) {
+  __shared__ __attribute__((aligned(16))) uint8_t w[2][kWin];
+  const uint32_t t = threadIdx.x;
+  uint32_t cur = 0;
+  uint64_t valid = u[0] < kWin ? u[0] : kWin;
+  for (uint32_t j = t; j < kWin; j += 1024) w[0][j] = j >= kWin - valid ? dst[u[0] - (kWin - j)] : 0;
+  __syncthreads();
+  bool bad = false;
+  for (uint32_t p = 1; p < npieces; p++) {
+    for (uint32_t j = t * 16; j < kWin; j += 1024 * 16)
+      *reinterpret_cast<uint4 *>(wins + (uint64_t)p * kWin + j) = *reinterpret_cast<const uint4 *>(&w[cur][j]);
+    const uint64_t up = u[p];
+    const uint8_t *a = scratch + offa[p], *b = scratch + offb[p];
+    const uint64_t take = up < kWin ? up : kWin;  // the piece's last `take` bytes end the next window
+    for (uint32_t j = t; j < kWin; j += 1024) {
+      uint32_t byte;
+      if (j < kWin - take) byte = w[cur][j + take];  // (a piece shorter than the window: the old one slides)
+      else {
+        const uint64_t i = up - (kWin - j);
+        uint32_t k;
+        byte = a[i];
+        if (is_marker(byte, b[i], &k)) {
+          if (k < kWin - valid) bad = true;
+          byte = w[cur][k];
+        }
+      }
+      w[cur ^ 1][j] = (uint8_t)byte;
+    }
+    valid = valid + up < kWin ? valid + up : kWin;
+    cur ^= 1;
+    __syncthreads();
+  }
+  if (bad) atomicOr(flag, 1u);
+}
+
+// grid.y = piece - 1, grid.x strides over the piece in steps of 4 KiB per workgroup
+__global__ __launch_bounds__(256) void resolve_kernel(uint8_t *__restrict__ dst, const uint8_t *__restrict__ scratch,
+                                                      const uint64_t *__restrict__ offa, const uint64_t *__restrict__ offb,
+                                                      const uint64_t *__restrict__ u, const uint64_t *__restrict__ pos,
+                                                      const uint8_t *__restrict__ wins, uint32_t *__restrict__ flag) {
+  const uint32_t p = blockIdx.y + 1;
+  const uint64_t up = u[p];
+  const uint8_t *a = scratch + offa[p], *b = scratch + offb[p], *w = wins + (uint64_t)p * kWin;
+  uint8_t *o = dst + pos[p];
+  const uint64_t lim = pos[p] < kWin ? kWin - pos[p] : 0;  // window positions below this lie in front of the stream
+  bool bad = false;
+  for (uint64_t i0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 16; i0 < up; i0 += (uint64_t)gridDim.x * 256 * 16) {
+    if (i0 + 16 <= up) {
+      uint4 va, vb;
+      __builtin_memcpy(&va, a + i0, 16);
+      __builtin_memcpy(&vb, b + i0, 16);
+      uint32_t wa[4] = {va.x, va.y, va.z, va.w}, wb[4] = {vb.x, vb.y, vb.z, vb.w};
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        if (wa[q] == wb[q]) continue;
+        uint32_t r = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          uint32_t x = (wa[q] >> (8 * k)) & 255, j;
+          if (is_marker(x, (wb[q] >> (8 * k)) & 255, &j)) {
+            bad = bad || j < lim;
+            x = w[j];
+          }
+          r |= x << (8 * k);
+        }
+        wa[q] = r;
+      }
+      const uint4 vo = make_uint4(wa[0], wa[1], wa[2], wa[3]);
+      __builtin_memcpy(o + i0, &vo, 16);
+    } else {
+      for (uint64_t i = i0; i < up; i++) {
+        uint32_t x = a[i], j;
+        if (is_marker(x, b[i], &j)) {
+          bad = bad || j < lim;
+          x = w[j];
+        }
+        o[i] = (uint8_t)x;
+      }
+    }
+  }
+  if (bad) atomicOr(flag, 1u);
+}
+
+// ---- 4. Adler-32 in segments ----------------------------------------------------------------------------------------------
+// segment s = data[s * seg, min((s + 1) * seg, n)): sums[2 s] = sum of its bytes, sums[2 s + 1] = sum of (len - i) * byte i,
+// both mod 65521 (the host joins them: b += len * a + S2, a += S1; lib/de.ml:453-455's update over the whole output)
+__global__ __launch_bounds__(256) void adler_segments_kernel(const uint8_t *__restrict__ data, uint64_t n, uint32_t seg,
+                                                             uint32_t *__restrict__ sums) {
+  __shared__ uint32_t sh1[256], sh2[256];
+  const uint64_t s0 = (uint64_t)blockIdx.x * seg, s1 = s0 + seg < n ? s0 + seg : n;
+  const uint32_t len = (uint32_t)(s1 - s0);
+  // thread t takes the contiguous slice [t * per, (t + 1) * per) of the segment, per a multiple of 16
+  const uint32_t per = ((len + 255) / 256 + 15) & ~15u;
+  const uint32_t a0 = threadIdx.x * per, a1 = a0 + per < len ? a0 + per : len;
+  uint32_t t1 = 0, t2 = 0;  // of the slice: sum d, sum (slice_len - i) d_i
+  if (a0 < len) {
+    const uint8_t *p = data + s0;
+    const uint32_t sl = a1 - a0;
+    uint32_t i = a0;
+    for (; i + 16 <= a1; i += 16) {
+      uint4 v;
+      __builtin_memcpy(&v, p + i, 16);
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+      uint32_t c1 = 0, ck = 0;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        c1 = __builtin_amdgcn_udot4(w[q], 0x01010101u, c1, false);
+        ck = __builtin_amdgcn_udot4(w[q], 0x03020100u + 0x04040404u * q, ck, false);
+      }
+      t1 += c1;
+      t2 = (t2 + (sl - (i - a0)) * c1 - ck) % 65521u;  // (<= 16 x 255 x 2^20 per step: no overflow before the reduction)
+    }
+    for (; i < a1; i++) {
+      const uint32_t d = p[i];
+      t1 += d;
+      t2 = (t2 + (sl - (i - a0)) * d) % 65521u;
+    }
+    // the slice seen from the segment: every byte counts (len - a1) more times
+    t2 = (t2 + (uint64_t)(len - a1) % 65521u * (t1 % 65521u)) % 65521u;
+    t1 %= 65521u;
+  }
+  sh1[threadIdx.x] = t1;
+  sh2[threadIdx.x] = t2;
+  __syncthreads();
+  for (uint32_t o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      sh1[threadIdx.x] = (sh1[threadIdx.x] + sh1[threadIdx.x + o]) % 65521u;
+      sh2[threadIdx.x] = (sh2[threadIdx.x] + sh2[threadIdx.x + o]) % 65521u;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    sums[2 * blockIdx.x] = sh1[0];
+    sums[2 * blockIdx.x + 1] = sh2[0];
+  }
+}
+
+}  // namespace chunked
+}  // namespace md
+
+extern "C" int md_launch_find_blocks(const uint8_t *body, uint64_t nbytes, uint64_t K, uint32_t nchunks_behind_first, uint64_t *cand,
+                                     hipStream_t stream) {
+  if (nchunks_behind_first == 0) return 0;
+  hipLaunchKernelGGL(md::chunked::find_blocks_kernel, dim3(nchunks_behind_first), dim3(256), 0, stream, body, nbytes, K, cand);
+  return (int)hipGetLastError();
+}
+extern "C" int md_launch_fill_windows(uint32_t n, uint8_t *out, const uint64_t *out_off, const uint8_t *variant, hipStream_t stream) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(md::chunked::fill_window_kernel, dim3(4, n), dim3(256), 0, stream, n, out, out_off, variant);
+  return (int)hipGetLastError();
+}
+extern "C" int md_launch_window_chain(uint32_t npieces, const uint8_t *dst, const uint8_t *scratch, const uint64_t *offa,
+                                      const uint64_t *offb, const uint64_t *u, uint8_t *wins, uint32_t *flag, hipStream_t stream) {
+  hipLaunchKernelGGL(md::chunked::window_chain_kernel, dim3(1), dim3(1024), 0, stream, npieces, dst, scratch, offa, offb, u, wins, flag);
+  return (int)hipGetLastError();
+}
+extern "C" int md_launch_resolve(uint32_t npieces, uint8_t *dst, const uint8_t *scratch, const uint64_t *offa, const uint64_t *offb,
+                                 const uint64_t *u, const uint64_t *pos, const uint8_t *wins, uint32_t *flag, hipStream_t stream) {
+  if (npieces < 2) return 0;
+  hipLaunchKernelGGL(md::chunked::resolve_kernel, dim3(32, npieces - 1), dim3(256), 0, stream, dst, scratch, offa, offb, u, pos, wins, flag);
+  return (int)hipGetLastError();
+}
+extern "C" int md_launch_adler_segments(const uint8_t *data, uint64_t n, uint32_t seg, uint32_t *sums, hipStream_t stream) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(md::chunked::adler_segments_kernel, dim3((uint32_t)((n + seg - 1) / seg)), dim3(256), 0, stream, data, n, seg, sums);
+  return (int)hipGetLastError();
+}
