@@ -131,13 +131,27 @@ def parse(argv=None):
     return ap.parse_args(argv)
 
 
+def share_device():
+    """MD_BENCH_SHARE_DEVICE=1: every rank works on device 0 and the exchange goes over gloo with CPU tensors - the N > 1
+    code path (sharding by bytes, weak-scaling seeds, gather of sizes and payload, max-over-ranks timing) on a box with ONE
+    GPU (tests/test_gpu_multirank.py).  The numbers of such a run mean nothing; under a real launch (one device per rank,
+    backend nccl = RCCL) only the backend, the device index and the device of the exchanged tensors differ."""
+    return os.environ.get("MD_BENCH_SHARE_DEVICE", "") == "1"
+
+
+def _xdev(dev):
+    """the device of the tensors that cross ranks"""
+    import torch
+    return torch.device("cpu") if share_device() else dev
+
+
 def respawn_command(args, argv, device_count):
     """`python bench.py --gpus N` without a launcher: the command that runs N ranks of this script under
     torch.distributed.run (None when this process is already a rank, or N <= 1).  Fails loudly when the box has
     fewer gfx950 devices than asked for."""
     if args.gpus <= 1 or "RANK" in os.environ:
         return None
-    if device_count < args.gpus:
+    if device_count < args.gpus and not share_device():
         raise SystemExit("bench: --gpus %d but only %d gfx950 device(s) are visible" % (args.gpus, device_count))
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -352,7 +366,7 @@ def deflate_leg(args, eng, dev, rank, world, dist, fence):
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=_xdev(dev))
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     out_len, status, adler = res
@@ -382,7 +396,7 @@ def deflate_leg(args, eng, dev, rank, world, dist, fence):
             ok = ok and (int(adler[k].item()) & 0xffffffff) == zlib.adler32(plain)
             sample.append(plain)
     if world > 1:
-        t = torch.tensor([int(ok), comp_bytes], dtype=torch.int64, device=dev)
+        t = torch.tensor([int(ok), comp_bytes], dtype=torch.int64, device=_xdev(dev))
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         ok, comp_all = int(t[0].item()) == world, int(t[1].item())
     else:
@@ -458,7 +472,7 @@ def gzip_leg(args, eng, dev, rank, world, dist):
     def tmax(ms):
         if world == 1:
             return ms
-        tt = torch.tensor([ms], dtype=torch.float64, device=dev)
+        tt = torch.tensor([ms], dtype=torch.float64, device=_xdev(dev))
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt.item())
 
@@ -489,8 +503,8 @@ def gzip_leg(args, eng, dev, rank, world, dist):
     del idx
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    all_zl = torch.cat(shard.gather_varlen(dist, zl, world))
-    parts, sizes = shard.gather_payload(dist, payload, world, rank, dst=0)
+    all_zl = torch.cat(shard.gather_varlen(dist, zl.to(_xdev(dev)), world))
+    parts, sizes = shard.gather_payload(dist, payload.to(_xdev(dev)), world, rank, dst=0)
     torch.cuda.synchronize(dev)
     gather_ms = tmax((time.perf_counter() - t0) * 1e3)
     if rank == 0 and not args.no_verify:
@@ -504,7 +518,7 @@ def gzip_leg(args, eng, dev, rank, world, dist):
         for k in list(range(0, len(uniq), 4)) + [n_total - 1, n_total // 2]:  # members from every part of the gathered blob
             m = got_all[int(starts[k]):int(starts[k]) + int(lens_all[k])].cpu().numpy().tobytes()
             ok = ok and m == orc.gz_deflate(uniq[k % len(uniq)], level=4) and _gz.decompress(m) == uniq[k % len(uniq)]
-    flags = shard.gather_results(dist, torch.tensor([int(ok), total, int(zl.sum().item())], dtype=torch.int64, device=dev), world)
+    flags = shard.gather_results(dist, torch.tensor([int(ok), total, int(zl.sum().item())], dtype=torch.int64, device=_xdev(dev)), world)
     if rank != 0:
         return None
     ok = all(int(f[0].item()) for f in flags)
@@ -634,24 +648,28 @@ def main():
     import torch
     import torch.distributed as dist
 
+    dev_index = 0 if share_device() else local_rank
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
+        torch.cuda.set_device(dev_index)
+        if share_device():
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+    dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
 
     import decompress_amd
     from decompress_amd import shard, workloads
 
-    eng = decompress_amd.Engine(local_rank)
+    eng = decompress_amd.Engine(dev_index)
     if args.inflate_waves != 2:
         eng.set_option("inflate_waves", args.inflate_waves)
     if args.deflate_cap_mib is not None:
         eng.set_option("deflate_workspace_cap_mib", args.deflate_cap_mib)
     ranks_seen = 1
     if world > 1:
-        t = torch.ones(1, dtype=torch.int64, device=dev)
+        t = torch.ones(1, dtype=torch.int64, device=_xdev(dev))
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         ranks_seen = int(t.item())
 
@@ -705,7 +723,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=_xdev(dev))
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -727,9 +745,9 @@ def main():
         del plains
     # the path's only exchange: every rank's per-stream results (sizes, Adler-32 from the kernel), RCCL all_gather
     sums = checksum.to(torch.int64).bitwise_and(0xffffffff)
-    all_len = torch.cat(shard.gather_varlen(dist, out_len, world))
-    all_sum = torch.cat(shard.gather_varlen(dist, sums, world))
-    flags = shard.gather_results(dist, torch.tensor([int(ok)], dtype=torch.int64, device=dev), world)
+    all_len = torch.cat(shard.gather_varlen(dist, out_len.to(_xdev(dev)), world))
+    all_sum = torch.cat(shard.gather_varlen(dist, sums.to(_xdev(dev)), world))
+    flags = shard.gather_results(dist, torch.tensor([int(ok)], dtype=torch.int64, device=_xdev(dev)), world)
     ok = all(int(x.item()) for x in flags)
     ok = ok and all_len.numel() == world * n and bool((all_len == nbytes).all().item())
     digest = int(all_sum.sum().item()) & 0xffffffffffff
