@@ -17,7 +17,7 @@ Prints ONE JSON line (rank 0).
                 read + uncompressed bytes written per launch, over the launch duration
                 measured with HIP events on the stream the kernel runs on; peak = 8 TB/s HBM3E
                 (MI355X_MICROARCH.md).  `traffic` = FETCH_SIZE + WRITE_SIZE of that kernel per launch from the
-                committed rocprofv3 --pmc passes of this same command (profiles/r04_final/pmc_summary.json,
+                committed rocprofv3 --pmc passes of this same command (PMC_DIR below: profiles/<round>_final/pmc_summary.json,
                 gfx950 correction of the guide applied; `traffic_source` names the file and the commit it was
                 collected at), null when the configuration differs.
   cpu_baseline  the repo's C restatement of lib/de.ml (oracle/, kind "port") on the host cores of this box,

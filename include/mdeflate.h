@@ -160,6 +160,15 @@ int md_synchronize(md_ctx *ctx);
  *   "host_pipeline_slices"       1 .. 64 (default 16): most slices of streams a md_*_batch_host call cuts a batch into so that
  *                                its copies overlap with its kernels (1: copy-in, kernels, copy-out one after the other).
  *   "inflate_waves"              1 or 2 (default): wavefronts per stream of the inflate kernel (2 = decoder + copier).
+ *   "inflate_parallel_min"       KiB (default 512; 0 = never): a SINGLE stream handed to md_*_inf_ns_inflate /
+ *                                md_*_higher_uncompress with at least this much compressed input is decoded in pieces by the
+ *                                whole device (csrc/inflate_chunked.hip: candidate block starts, every piece decoded twice
+ *                                with placeholder windows by the batch kernel, windows resolved afterwards, checksum verified)
+ *                                instead of by one pair of wavefronts.  Results are the same by construction: whatever is not
+ *                                a well-formed stream that fits its buffer falls back to the serial path and gets its status.
+ *   "inflate_parallel_chunk"     KiB of compressed input per piece (default 64, 4 .. 2^20).
+ *   "inflate_parallel_last"      a QUERY (value ignored; the return value is the answer, not a status): pieces of the last
+ *                                single stream that went that way | decode rounds << 24; 0 = it took the serial path.
  *   "debug_inflate_lds_pad", "debug_known_bounds"   measurement aids of tools/dbg (occupancy curve, known-boundaries floor).
  *   "profile"                    0 / 1: in-kernel phase profile of stream 0 (md_get_profile, a debugging aid).
  * Unknown keys and values out of range: MD_E_INVALID_ARGUMENT. */

@@ -90,6 +90,27 @@ def test_round_trip_on_gpu(eng):
         assert st == 0 and out == b and adler == zlib.adler32(b)
 
 
+def test_corpus_by_level_matrix(eng, oracle):
+    """the reference's own deflate test shape, test/test_deflate.ml:19-120: every file of test/corpus at every level 0 .. 9
+    through the Zl driver - bytes = the oracle's, Adler-32 = libz's, and the streams inflate back on the GPU (and in libz)"""
+    from concurrent.futures import ThreadPoolExecutor
+    import decompress_amd
+    from decompress_amd import workloads
+    files = list(workloads.corpus().items())
+    assert len(files) == 15
+    bufs = [b for _, b in files]
+    with ThreadPoolExecutor(16) as ex:  # (ctypes releases the GIL)
+        want = {lvl: list(ex.map(lambda b, lvl=lvl: oracle.zl_deflate(b, lvl, 4096, True), bufs)) for lvl in range(10)}
+    for lvl in range(10):
+        res = eng.deflate_many(bufs, fmt=decompress_amd.FORMAT_ZLIB, level=lvl)
+        for (name, b), (st, out, adler), w in zip(files, res, want[lvl]):
+            assert st == 0 and out == w, (name, lvl, len(out), len(w))
+            assert adler == zlib.adler32(b) and zlib.decompress(out) == b
+        back = eng.inflate_many([r[1] for r in res], [len(b) for b in bufs], decompress_amd.FORMAT_ZLIB)
+        for (name, b), (st, used, out, adler), r in zip(files, back, res):
+            assert (st, used, adler) == (0, len(r[1]), zlib.adler32(b)) and out == b, (name, lvl)
+
+
 def test_equal_hashes_inside_a_step(eng, oracle):
     """the link kernel sorts out positions that share a hash inside one 64-position step (and across the steps of a
     group, and across the wavefronts' groups) by ballots: inputs made of short periods and runs put dozens of equal
