@@ -666,6 +666,8 @@ static int host_pipeline(md_ctx *ctx, const std::vector<HostSlice> &sl, const ui
 }
 }  // extern "C++"
 
+static int inflate_parallel(md_ctx *ctx, int format, const uint8_t *src, size_t src_len, uint8_t *dst, size_t dst_cap,
+                            size_t *consumed, size_t *written, uint32_t *checksum);
 int md_inflate_batch_host(md_ctx *ctx, int format, size_t n, const uint8_t *h_in, size_t in_bytes,
                           const uint64_t *in_off, const uint64_t *in_len, uint8_t *h_out,
                           size_t out_bytes, const uint64_t *out_off, const uint64_t *out_cap,
@@ -683,6 +685,22 @@ int md_inflate_batch_host(md_ctx *ctx, int format, size_t n, const uint8_t *h_in
       return fail(ctx, MD_E_INVALID_ARGUMENT, "output range out of bounds");
   }
   MD_ON_DEVICE(ctx);
+  ctx->par_last_pieces = ctx->par_last_rounds = 0;
+  if (n == 1 && ctx->par_min && in_len[0] >= ctx->par_min) {  // ONE long stream: in pieces, by the whole chip (inflate_parallel)
+    size_t used = 0, wrote = 0;
+    uint32_t sum = 0;
+    const int prc = inflate_parallel(ctx, format, h_in + in_off[0], (size_t)in_len[0], h_out + out_off[0], (size_t)out_cap[0], &used, &wrote,
+                                     checksum ? &sum : nullptr);
+    if (prc != 1000 /* kNotHandled: the serial path below decides */) {
+      if (prc != MD_OK) return prc;
+      out_len[0] = wrote;
+      consumed[0] = used;
+      status[0] = MD_OK;
+      if (checksum) checksum[0] = sum;
+      return MD_OK;
+    }
+    ctx->par_last_pieces = 0;
+  }
   const size_t desc_words = 6 * n;  // in_off in_len out_off out_cap out_len consumed
   int grc_ = grow(ctx, &ctx->host_in, &ctx->host_in_bytes, in_bytes + 64, "hipMalloc(host path input)");
   if (grc_ == MD_OK) grc_ = grow(ctx, &ctx->host_out, &ctx->host_out_bytes, out_bytes + 64, "hipMalloc(host path output)");
@@ -743,6 +761,10 @@ int md_inflate_continue_batch_device(md_ctx *ctx, size_t n, const uint8_t *d_in,
 // One piece of a raw DEFLATE stream that is decoded as it arrives (mdeflate.h): the inflate kernel on one stream with
 // a starting bit, the window in front of the output buffer and the checksum state handed in, and the last block
 // boundary inside the piece handed back.
+static int continue_parallel(md_ctx *ctx, const uint8_t *src, size_t src_len, unsigned start_bit, uint8_t *dst, size_t hist_len,
+                             size_t dst_cap, uint32_t adler_in, unsigned flags, size_t *dst_len, int *status, md_inf_resume *resume);
+static int continue_serial(md_ctx *ctx, const uint8_t *src, size_t src_len, unsigned start_bit, uint8_t *dst, size_t hist_len,
+                           size_t dst_cap, uint32_t adler_in, unsigned flags, size_t *dst_len, int *status, md_inf_resume *resume);
 int md_de_inf_continue_host(md_ctx *ctx, const uint8_t *src, size_t src_len, unsigned start_bit, uint8_t *dst, size_t hist_len,
                             size_t dst_cap, uint32_t adler_in, unsigned flags, size_t *dst_len, int *status,
                             md_inf_resume *resume) {
@@ -750,6 +772,16 @@ int md_de_inf_continue_host(md_ctx *ctx, const uint8_t *src, size_t src_len, uns
   if (start_bit > 7 || hist_len > 32768 || hist_len > dst_cap || dst_cap > MD_MAX_STREAM || src_len > MD_MAX_INFLATE_IN)
     return fail(ctx, MD_E_INVALID_ARGUMENT, "md_de_inf_continue_host: start_bit <= 7, hist_len <= 32768 and <= dst_cap");
   MD_ON_DEVICE(ctx);
+  ctx->par_last_pieces = ctx->par_last_rounds = 0;
+  if (ctx->par_min && src_len >= ctx->par_min) {  // a long piece: its complete blocks by the whole chip, the rest as before
+    const int prc = continue_parallel(ctx, src, src_len, start_bit, dst, hist_len, dst_cap, adler_in, flags, dst_len, status, resume);
+    if (prc != 1000 /* kNotHandled */) return prc;
+    ctx->par_last_pieces = 0;
+  }
+  return continue_serial(ctx, src, src_len, start_bit, dst, hist_len, dst_cap, adler_in, flags, dst_len, status, resume);
+}
+static int continue_serial(md_ctx *ctx, const uint8_t *src, size_t src_len, unsigned start_bit, uint8_t *dst, size_t hist_len,
+                           size_t dst_cap, uint32_t adler_in, unsigned flags, size_t *dst_len, int *status, md_inf_resume *resume) {
   // the context's scratch, grow-only: a long stream comes in many pieces, and three hipMalloc / hipFree per piece
   // cost more than a short piece's kernel
   // descriptors: in_off in_len out_off out_cap out_len consumed resume_bits resume_out (u64); status, checksum,
@@ -1658,40 +1690,31 @@ struct ParPiece {
 };
 }  // namespace
 
-static int inflate_parallel(md_ctx *ctx, int format, const uint8_t *src, size_t src_len, uint8_t *dst, size_t dst_cap,
-                            size_t *consumed, size_t *written) {
+// What par_decode works on: a raw DEFLATE body in host memory that starts start_bit bits into body[0], the (at most 32 KiB
+// of) output in front of it, room for dst_cap new bytes.  partial_ok: the body may end inside a block (a piece of a stream
+// that is still arriving) - the complete blocks are decoded, the rest is the caller's.
+struct ParIn {
+  const uint8_t *body;
+  uint64_t body_len;
+  uint32_t start_bit;
+  const uint8_t *hist;
+  uint32_t hist_len;
+  uint64_t dst_cap;
+  bool partial_ok;
+};
+struct ParOut {
+  int status;            // MD_OK: the final block ended; MD_UNEXPECTED_END_OF_INPUT (partial_ok): the body ended inside a block
+  uint64_t total;        // new bytes, final, at ctx->par_out + hist_len
+  uint64_t used_body;    // MD_OK: bytes of the body the stream used
+  uint64_t resume_bits;  // bit of the body behind the last complete block
+};
+static int par_decode(md_ctx *ctx, const ParIn &in, ParOut *out) {
   ctx->par_last_pieces = ctx->par_last_rounds = 0;
-  // -- the frame: anything but a plain valid header is the serial path's (it knows the reference's answer)
-  size_t hdr = 0, trailer = 0;
-  if (format == MD_FORMAT_ZLIB) {
-    if (src_len < 6 || (((uint32_t)src[0] << 8) + src[1]) % 31 != 0 || (src[0] & 0xf) != 8) return kNotHandled;
-    hdr = 2;
-    trailer = 4;
-  } else if (format == MD_FORMAT_GZIP) {
-    if (src_len < 18 || src[0] != 0x1f || src[1] != 0x8b || (src[3] & 2)) return kNotHandled;  // (a header CRC: serial path)
-    size_t p = 10;
-    const uint32_t flg = src[3];
-    if (flg & 4) {  // FEXTRA, big-endian length as the reference reads it (lib/gz.ml:455)
-      if (src_len - p < 2) return kNotHandled;
-      const size_t xl = ((size_t)src[p] << 8) | src[p + 1];
-      p += 2;
-      if (src_len - p < xl) return kNotHandled;
-      p += xl;
-    }
-    for (int which = 0; which < 2; which++) {
-      if (!(flg & (which == 0 ? 8u : 16u))) continue;
-      while (p < src_len && src[p] != 0) p++;
-      if (p >= src_len) return kNotHandled;
-      p++;
-    }
-    hdr = p;
-    trailer = 8;
-  } else if (format != MD_FORMAT_DEFLATE) return kNotHandled;
-  if (src_len < hdr + trailer) return kNotHandled;
-  const uint8_t *body = src + hdr;
-  const uint64_t body_len = src_len - hdr;  // (the trailer's bytes included: where the stream ends is the decoder's to say)
+  const uint8_t *body = in.body;
+  const uint64_t body_len = in.body_len, dst_cap = in.dst_cap;
+  const uint32_t hl = in.hist_len;
   const uint64_t K = ctx->par_chunk;
-  if (body_len < 4 * K || body_len > ((uint64_t)1 << 31) || dst_cap > MD_MAX_STREAM) return kNotHandled;
+  if (body_len < 4 * K || body_len > ((uint64_t)1 << 31) || hl + dst_cap > MD_MAX_STREAM) return kNotHandled;
   const uint32_t nchunks = (uint32_t)((body_len + K - 1) / K);
   hipStream_t st = ctx->stream;
   // -- the body on the device, candidate block starts
@@ -1709,13 +1732,15 @@ static int inflate_parallel(md_ctx *ctx, int format, const uint8_t *src, size_t 
   HIP_TRY(ctx, hipMemcpyAsync(cand.data(), d_cand, (nchunks - 1) * 8, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
   std::vector<ParPiece> pc;
-  pc.push_back(ParPiece{0});
+  pc.push_back(ParPiece{in.start_bit});
   for (uint64_t c : cand)
     if (c != ~0ull && c > pc.back().bit) pc.push_back(ParPiece{c});
   if (pc.size() < 3) return kNotHandled;  // nothing to gain
   // -- decode, verify the chain of pieces, decode again without a candidate that proved false or with more room
   uint32_t capmul = 6;
   uint64_t total = 0, used_body = 0;
+  out->status = MD_OK;
+  out->resume_bits = 0;
   std::vector<uint64_t> offa, offb;
   for (int round = 1;; round++) {
     if (round > 8) return kNotHandled;
@@ -1727,7 +1752,7 @@ static int inflate_parallel(md_ctx *ctx, int format, const uint8_t *src, size_t 
     std::vector<uint8_t> variant(n);
     offa.assign(np, 0);
     offb.assign(np, 0);
-    uint64_t at = ((uint64_t)dst_cap + 63) & ~(uint64_t)63;
+    uint64_t at = ((uint64_t)hl + dst_cap + 63) & ~(uint64_t)63;
     for (size_t p = 0; p < np; p++) {
       const uint64_t b0 = pc[p].bit >> 3, b1 = p + 1 < np ? (pc[p + 1].bit + 7) >> 3 : body_len;
       for (int v = 0; v < (p ? 2 : 1); v++) {
@@ -1737,8 +1762,8 @@ static int inflate_parallel(md_ctx *ctx, int format, const uint8_t *src, size_t 
         start_bit[i] = (uint32_t)(pc[p].bit & 7);
         if (p == 0) {
           out_off[i] = 0;
-          out_cap[i] = dst_cap;
-          hist[i] = 0;
+          out_cap[i] = hl + dst_cap;
+          hist[i] = hl;  // (the caller's window lies in front of the output)
           variant[i] = 0;
         } else {
           const uint64_t room = (uint64_t)capmul * (b1 - b0) + 65536;
@@ -1763,6 +1788,7 @@ static int inflate_parallel(md_ctx *ctx, int format, const uint8_t *src, size_t 
     uint32_t *d32 = (uint32_t *)(d64 + 8 * n);
     uint8_t *d8 = (uint8_t *)(d32 + 7 * n);
     uint8_t *d_out = (uint8_t *)ctx->par_out;
+    if (hl) HIP_TRY(ctx, hipMemcpyAsync(d_out, in.hist, hl, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(d64 + 0 * n, in_off.data(), n * 8, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(d64 + 1 * n, in_len.data(), n * 8, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(d64 + 2 * n, out_off.data(), n * 8, hipMemcpyHostToDevice, st));
@@ -1842,6 +1868,16 @@ static int inflate_parallel(md_ctx *ctx, int format, const uint8_t *src, size_t 
         pc[p].u = r_out[i] - hist[i];
         total += pc[p].u;
         used_body = (pc[p].bit >> 3) + r_used[i];
+        out->resume_bits = base_bits + r_bits[i];
+        out->status = MD_OK;
+        last = p;
+        break;
+      } else if (chain && in.partial_ok && p + 1 == np && r_st[i] == MD_UNEXPECTED_END_OF_INPUT) {
+        // the input ends inside the last piece: its complete blocks count, the caller goes on from the last block boundary
+        pc[p].u = r_out[i] - hist[i];
+        total += pc[p].u;
+        out->resume_bits = base_bits + r_bits[i];
+        out->status = MD_UNEXPECTED_END_OF_INPUT;
         last = p;
         break;
       } else {
@@ -1879,25 +1915,22 @@ static int inflate_parallel(md_ctx *ctx, int format, const uint8_t *src, size_t 
   }
   const size_t np = pc.size();
   if (total > dst_cap || np < 2) return kNotHandled;
-  if (src_len - hdr - used_body < trailer) return kNotHandled;
   // -- windows, then every byte
   {
     std::vector<uint64_t> u(np), pos(np);
     uint64_t acc = 0;
-    for (size_t p = 0; p < np; p++) {
-      u[p] = pc[p].u;
+    for (size_t p = 0; p < np; p++) {  // (the window the caller handed in counts as output in front of piece 0)
+      u[p] = pc[p].u + (p ? 0 : hl);
       pos[p] = acc;
       acc += u[p];
     }
     rc = grow(ctx, &ctx->par_win, &ctx->par_win_bytes, np * (size_t)32768 + 64, "hipMalloc(parallel inflate windows)");
     if (rc != MD_OK) return rc;
-    const size_t nseg = (size_t)((total + 65535) / 65536), ncrc = (size_t)((total + ((1u << 20) - 1)) >> 20);
-    const size_t need = np * 32 + 64 + nseg * 8 + ncrc * 24 + 256;
+    const size_t need = np * 32 + 256;
     rc = grow(ctx, &ctx->par_desc, &ctx->par_desc_bytes, need, "hipMalloc(parallel inflate descriptors)");
     if (rc != MD_OK) return rc;
-    uint64_t *d64 = (uint64_t *)ctx->par_desc;  // offa offb u pos | crc_off crc_len | flag, sums / crcs
-    uint64_t *d_crc_off = d64 + 4 * np, *d_crc_len = d_crc_off + ncrc;
-    uint32_t *d_flag = (uint32_t *)(d_crc_len + ncrc), *d_sums = d_flag + 16;
+    uint64_t *d64 = (uint64_t *)ctx->par_desc;  // offa offb u pos | flag
+    uint32_t *d_flag = (uint32_t *)(d64 + 4 * np);
     uint8_t *d_out = (uint8_t *)ctx->par_out;
     HIP_TRY(ctx, hipMemcpyAsync(d64 + 0 * np, offa.data(), np * 8, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(d64 + 1 * np, offb.data(), np * 8, hipMemcpyHostToDevice, st));
@@ -1909,56 +1942,191 @@ static int inflate_parallel(md_ctx *ctx, int format, const uint8_t *src, size_t 
     e = md_launch_resolve((uint32_t)np, d_out, d_out, d64 + 0 * np, d64 + 1 * np, d64 + 2 * np, d64 + 3 * np,
                           (const uint8_t *)ctx->par_win, d_flag, st);
     if (e != 0) return fail(ctx, MD_E_HIP, "resolve launch", (hipError_t)e);
-    // -- the checksum of the final bytes, in segments joined here
+    // (the flag is read by the caller together with what it needs next)
     uint32_t flag = 0;
-    const uint8_t *t = src + hdr + used_body;
-    if (format == MD_FORMAT_ZLIB) {
-      e = md_launch_adler_segments(d_out, total, 65536, d_sums, st);
-      if (e != 0) return fail(ctx, MD_E_HIP, "adler_segments launch", (hipError_t)e);
-      std::vector<uint32_t> sums(2 * nseg);
-      HIP_TRY(ctx, hipMemcpyAsync(sums.data(), d_sums, nseg * 8, hipMemcpyDeviceToHost, st));
-      HIP_TRY(ctx, hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, st));
-      HIP_TRY(ctx, hipStreamSynchronize(st));
-      uint64_t a = 1, b = 0;
-      for (size_t s = 0; s < nseg; s++) {
-        const uint64_t len = s + 1 < nseg ? 65536 : total - (uint64_t)s * 65536;
-        b = (b + (len % 65521) * a + sums[2 * s + 1]) % 65521;
-        a = (a + sums[2 * s]) % 65521;
-      }
-      const uint32_t want = ((uint32_t)t[0] << 24) | ((uint32_t)t[1] << 16) | ((uint32_t)t[2] << 8) | t[3];
-      if (want != (uint32_t)((b << 16) | a)) return kNotHandled;
-    } else if (format == MD_FORMAT_GZIP) {
-      std::vector<uint64_t> co(ncrc), cl(ncrc);
-      for (size_t s = 0; s < ncrc; s++) {
-        co[s] = (uint64_t)s << 20;
-        cl[s] = s + 1 < ncrc ? (uint64_t)1 << 20 : total - co[s];
-      }
-      HIP_TRY(ctx, hipMemcpyAsync(d_crc_off, co.data(), ncrc * 8, hipMemcpyHostToDevice, st));
-      HIP_TRY(ctx, hipMemcpyAsync(d_crc_len, cl.data(), ncrc * 8, hipMemcpyHostToDevice, st));
-      e = md_launch_crc32((uint32_t)ncrc, d_out, d_crc_off, d_crc_len, d_sums, st);
-      if (e != 0) return fail(ctx, MD_E_HIP, "crc32 launch", (hipError_t)e);
-      std::vector<uint32_t> crcs(ncrc);
-      HIP_TRY(ctx, hipMemcpyAsync(crcs.data(), d_sums, ncrc * 4, hipMemcpyDeviceToHost, st));
-      HIP_TRY(ctx, hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, st));
-      HIP_TRY(ctx, hipStreamSynchronize(st));
-      uint32_t crc = 0;
-      for (size_t s = 0; s < ncrc; s++) crc = s ? par_crc_concat(crc, crcs[s], cl[s]) : crcs[0];
-      uint32_t want = 0, isize = 0;
-      for (int k = 0; k < 4; k++) {
-        want |= (uint32_t)t[k] << (8 * k);
-        isize |= (uint32_t)t[4 + k] << (8 * k);
-      }
-      if (want != crc || isize != (uint32_t)total) return kNotHandled;
-    } else {
-      HIP_TRY(ctx, hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, st));
-      HIP_TRY(ctx, hipStreamSynchronize(st));
-    }
+    HIP_TRY(ctx, hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
     if (flag) return kNotHandled;  // a reference in front of the stream's start
-    if (total) HIP_TRY(ctx, hipMemcpy(dst, d_out, total, hipMemcpyDeviceToHost));
   }
+  out->total = total;
+  out->used_body = used_body;
+  ctx->par_last_pieces = (int)np;
+  return MD_OK;
+}
+
+// Adler-32 of n bytes at d (device) going on from `adler`; CRC-32 of the same bytes (complete value)
+static int par_adler(md_ctx *ctx, const uint8_t *d, uint64_t n, uint32_t adler, uint32_t *res) {
+  *res = adler;
+  if (n == 0) return MD_OK;
+  const size_t nseg = (size_t)((n + 65535) / 65536);
+  int rc = grow(ctx, &ctx->par_desc, &ctx->par_desc_bytes, nseg * 8 + 64, "hipMalloc(parallel inflate descriptors)");
+  if (rc != MD_OK) return rc;
+  uint32_t *d_sums = (uint32_t *)ctx->par_desc;
+  int e = md_launch_adler_segments(d, n, 65536, d_sums, ctx->stream);
+  if (e != 0) return fail(ctx, MD_E_HIP, "adler_segments launch", (hipError_t)e);
+  std::vector<uint32_t> sums(2 * nseg);
+  HIP_TRY(ctx, hipMemcpyAsync(sums.data(), d_sums, nseg * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  uint64_t a = adler & 0xffffu, b = adler >> 16;
+  for (size_t s = 0; s < nseg; s++) {
+    const uint64_t len = s + 1 < nseg ? 65536 : n - (uint64_t)s * 65536;
+    b = (b + (len % 65521) * a + sums[2 * s + 1]) % 65521;
+    a = (a + sums[2 * s]) % 65521;
+  }
+  *res = (uint32_t)((b << 16) | a);
+  return MD_OK;
+}
+static int par_crc(md_ctx *ctx, const uint8_t *d_base, uint64_t off, uint64_t n, uint32_t *res) {
+  *res = 0;
+  if (n == 0) return MD_OK;
+  const size_t ncrc = (size_t)((n + ((1u << 20) - 1)) >> 20);
+  int rc = grow(ctx, &ctx->par_desc, &ctx->par_desc_bytes, ncrc * 24 + 64, "hipMalloc(parallel inflate descriptors)");
+  if (rc != MD_OK) return rc;
+  uint64_t *d_off = (uint64_t *)ctx->par_desc, *d_len = d_off + ncrc;
+  uint32_t *d_crc = (uint32_t *)(d_len + ncrc);
+  std::vector<uint64_t> co(ncrc), cl(ncrc);
+  for (size_t s = 0; s < ncrc; s++) {
+    co[s] = off + ((uint64_t)s << 20);
+    cl[s] = s + 1 < ncrc ? (uint64_t)1 << 20 : n - ((uint64_t)s << 20);
+  }
+  HIP_TRY(ctx, hipMemcpyAsync(d_off, co.data(), ncrc * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d_len, cl.data(), ncrc * 8, hipMemcpyHostToDevice, ctx->stream));
+  int e = md_launch_crc32((uint32_t)ncrc, d_base, d_off, d_len, d_crc, ctx->stream);
+  if (e != 0) return fail(ctx, MD_E_HIP, "crc32 launch", (hipError_t)e);
+  std::vector<uint32_t> crcs(ncrc);
+  HIP_TRY(ctx, hipMemcpyAsync(crcs.data(), d_crc, ncrc * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  uint32_t crc = crcs[0];
+  for (size_t s = 1; s < ncrc; s++) crc = par_crc_concat(crc, crcs[s], cl[s]);
+  *res = crc;
+  return MD_OK;
+}
+
+// md_de_inf_continue_host on a long piece: the blocks that are complete in it by par_decode; if the piece ends inside a
+// block, that tail goes through the serial path from the block boundary on (window = the bytes just decoded), so what the
+// caller sees - status, the output reached inside the incomplete block, the resume point, the checksums there - is what
+// the serial path alone would have said.
+static int continue_parallel(md_ctx *ctx, const uint8_t *src, size_t src_len, unsigned start_bit, uint8_t *dst, size_t hist_len,
+                             size_t dst_cap, uint32_t adler_in, unsigned flags, size_t *dst_len, int *status, md_inf_resume *resume) {
+  ParIn in{src, src_len, start_bit, dst, (uint32_t)hist_len, dst_cap - hist_len, true};
+  ParOut po;
+  int rc = par_decode(ctx, in, &po);
+  if (rc != MD_OK) return rc;
+  const uint8_t *d_out = (const uint8_t *)ctx->par_out;
+  const int pieces = ctx->par_last_pieces, rounds = ctx->par_last_rounds;
+  uint32_t adler = adler_in, crc = 0;
+  rc = par_adler(ctx, d_out + hist_len, po.total, adler_in, &adler);
+  if (rc == MD_OK && (flags & MD_CONT_CRC32)) rc = par_crc(ctx, d_out, hist_len, po.total, &crc);
+  if (rc != MD_OK) return rc;
+  if (po.total) HIP_TRY(ctx, hipMemcpy(dst + hist_len, d_out + hist_len, po.total, hipMemcpyDeviceToHost));
+  const uint64_t O = hist_len + po.total;  // output position behind the last complete block
+  if (po.status == MD_OK) {
+    *dst_len = (size_t)O;
+    *status = MD_OK;
+    resume->bits = po.resume_bits;
+    resume->out = O;
+    resume->adler = adler;
+    resume->last = 1;
+    resume->consumed = po.used_body;
+    resume->checksum = adler;
+    resume->crc_out = resume->crc_end = crc;
+    return MD_OK;
+  }
+  // the tail, serially: from bit B on, with the last 32 KiB in front of it as its window - in place
+  const uint64_t B = po.resume_bits, hl2 = O < 32768 ? O : 32768, shift = O - hl2;
+  size_t t_len = 0;
+  int t_st = 0;
+  md_inf_resume t;
+  rc = continue_serial(ctx, src + (B >> 3), src_len - (size_t)(B >> 3), (unsigned)(B & 7), dst + shift, (size_t)hl2, dst_cap - (size_t)shift, adler,
+                       flags, &t_len, &t_st, &t);
+  if (rc != MD_OK) return rc;
+  *dst_len = (size_t)shift + t_len;
+  *status = t_st;
+  resume->bits = (B >> 3) * 8 + t.bits;
+  resume->out = shift + t.out;
+  resume->adler = t.adler;
+  resume->last = t.last;
+  resume->consumed = (B >> 3) + t.consumed;
+  resume->checksum = t.checksum;
+  if (flags & MD_CONT_CRC32) {
+    const uint64_t n_out = t.out - hl2, n_end = t_len - hl2;
+    resume->crc_out = po.total ? (n_out ? par_crc_concat(crc, t.crc_out, n_out) : crc) : t.crc_out;
+    resume->crc_end = po.total ? (n_end ? par_crc_concat(crc, t.crc_end, n_end) : crc) : t.crc_end;
+  } else resume->crc_out = resume->crc_end = 0;
+  ctx->par_last_pieces = pieces;
+  ctx->par_last_rounds = rounds;
+  return MD_OK;
+}
+
+static int inflate_parallel(md_ctx *ctx, int format, const uint8_t *src, size_t src_len, uint8_t *dst, size_t dst_cap,
+                            size_t *consumed, size_t *written, uint32_t *checksum) {
+  // -- the frame: anything but a plain valid header is the serial path's (it knows the reference's answer)
+  size_t hdr = 0, trailer = 0;
+  if (format == MD_FORMAT_ZLIB) {
+    if (src_len < 6 || (((uint32_t)src[0] << 8) + src[1]) % 31 != 0 || (src[0] & 0xf) != 8) return kNotHandled;
+    hdr = 2;
+    trailer = 4;
+  } else if (format == MD_FORMAT_GZIP) {
+    if (src_len < 18 || src[0] != 0x1f || src[1] != 0x8b || (src[3] & 2)) return kNotHandled;  // (a header CRC: serial path)
+    size_t p = 10;
+    const uint32_t flg = src[3];
+    if (flg & 4) {  // FEXTRA, big-endian length as the reference reads it (lib/gz.ml:455)
+      if (src_len - p < 2) return kNotHandled;
+      const size_t xl = ((size_t)src[p] << 8) | src[p + 1];
+      p += 2;
+      if (src_len - p < xl) return kNotHandled;
+      p += xl;
+    }
+    for (int which = 0; which < 2; which++) {
+      if (!(flg & (which == 0 ? 8u : 16u))) continue;
+      while (p < src_len && src[p] != 0) p++;
+      if (p >= src_len) return kNotHandled;
+      p++;
+    }
+    hdr = p;
+    trailer = 8;
+  } else if (format != MD_FORMAT_DEFLATE) return kNotHandled;
+  if (src_len < hdr + trailer) return kNotHandled;
+  ParIn in{src + hdr, src_len - hdr, 0, nullptr, 0, dst_cap, false};  // (the trailer's bytes included: where the stream ends is the decoder's to say)
+  ParOut po;
+  int rc = par_decode(ctx, in, &po);
+  if (rc != MD_OK) return rc;
+  const uint64_t total = po.total, used_body = po.used_body;
+  if (src_len - hdr - used_body < trailer) {
+    ctx->par_last_pieces = 0;
+    return kNotHandled;
+  }
+  const uint8_t *d_out = (const uint8_t *)ctx->par_out;
+  const uint8_t *t = src + hdr + used_body;
+  bool good = true;
+  if (format == MD_FORMAT_ZLIB || (format == MD_FORMAT_DEFLATE && checksum)) {
+    uint32_t adler = 1;
+    rc = par_adler(ctx, d_out, total, 1u, &adler);
+    if (rc != MD_OK) return rc;
+    if (format == MD_FORMAT_ZLIB) {
+      const uint32_t want = ((uint32_t)t[0] << 24) | ((uint32_t)t[1] << 16) | ((uint32_t)t[2] << 8) | t[3];
+      good = want == adler;
+    }
+    if (checksum) *checksum = adler;
+  } else if (format == MD_FORMAT_GZIP) {
+    uint32_t crc = 0;
+    rc = par_crc(ctx, d_out, 0, total, &crc);
+    if (rc != MD_OK) return rc;
+    uint32_t want = 0, isize = 0;
+    for (int k = 0; k < 4; k++) {
+      want |= (uint32_t)t[k] << (8 * k);
+      isize |= (uint32_t)t[4 + k] << (8 * k);
+    }
+    good = want == crc && isize == (uint32_t)total;
+    if (checksum) *checksum = crc;
+  }
+  if (!good) {  // the serial path reports it
+    ctx->par_last_pieces = 0;
+    return kNotHandled;
+  }
+  if (total) HIP_TRY(ctx, hipMemcpy(dst, d_out, total, hipMemcpyDeviceToHost));
   *consumed = hdr + (size_t)used_body + trailer;
   *written = (size_t)total;
-  ctx->par_last_pieces = (int)np;
   return MD_OK;
 }
 }  // extern "C++"
@@ -1967,13 +2135,6 @@ static int inflate_one(md_ctx *ctx, int format, const uint8_t *src, size_t src_l
                        size_t dst_cap, size_t *consumed, size_t *written) {
   if (!ctx || !consumed || !written || (!src && src_len) || (!dst && dst_cap))
     return MD_E_INVALID_ARGUMENT;
-  ctx->par_last_pieces = ctx->par_last_rounds = 0;
-  if (ctx->par_min && src_len >= ctx->par_min) {  // one long stream: in pieces, by the whole chip
-    MD_ON_DEVICE(ctx);
-    const int prc = inflate_parallel(ctx, format, src, src_len, dst, dst_cap, consumed, written);
-    if (prc != kNotHandled) return prc;
-    ctx->par_last_pieces = 0;
-  }
   uint64_t in_off = 0, in_len = src_len, out_off = 0, out_cap = dst_cap, out_len = 0, used = 0;
   int32_t status = 0;
   int rc = md_inflate_batch_host(ctx, format, 1, src, src_len, &in_off, &in_len, dst, dst_cap,

@@ -5,7 +5,7 @@
 // (lib/zl.ml:509-555, lib/de.mli:300-412) hand a few KiB to the codec per call; a kernel launch per 64 KiB step
 // cannot pay for itself, so the shim keeps the reference's calling protocol on the HOST — it collects the chunks
 // the caller supplies through src and runs the HIP path on them in large pieces: a stream that ends before a piece
-// (md_inf_chunk_bytes, 1 MiB) is full is ONE batch-of-one launch when the caller signals the end of input (src with
+// (md_inf_chunk_bytes, 8 MiB) is full is ONE batch-of-one launch when the caller signals the end of input (src with
 // length 0, as in the reference); a longer stream is decoded piece by piece up to the last block
 // boundary inside each piece (md_de_inf_continue_host: starting bit, 32 KiB window and checksum state go in, the
 // boundary comes back), so that output is handed out through `Flush steps while input is still arriving and only the
@@ -73,7 +73,7 @@ md_inf_stream *md_inf_decoder(md_ctx *ctx, int format, uint8_t *o, size_t o_len)
   s->format = format;
   s->o = o;
   s->o_len = o_len;
-  s->chunk = (size_t)1 << 20;
+  s->chunk = (size_t)8 << 20;  // (pieces this long are decoded by the whole chip: capi.cpp continue_parallel)
   inf_clear(s);
   return s;
 }

@@ -106,7 +106,7 @@ class Inf:
     def decode_chunks(chunks, o_len=65536, fmt=_engine.FORMAT_DEFLATE, device=0, chunk_bytes=None):
         """the streaming protocol of lib/de.mli:82-144 — decoder / src / decode / flush / dst_rem — driven the way
         De.Higher.uncompress drives it: -> ("Ok" | "Malformed", bytes, [signals]).  chunk_bytes: how much input the decoder
-        buffers before it decodes a piece (md_inf_chunk_bytes; default 1 MiB)"""
+        buffers before it decodes a piece (md_inf_chunk_bytes; default 8 MiB)"""
         eng = _engine.default_engine(device)
         lib = eng.lib
         o = ctypes.create_string_buffer(o_len)

@@ -405,7 +405,7 @@ int md_de_inf_continue_host(md_ctx *ctx, const uint8_t *src, size_t src_len, uns
  * one md_def_src call takes at most 1 GiB, and so does what md_def_src calls have handed over since the last md_def_encode
  * (MD_E_INVALID_ARGUMENT beyond that: call md_def_encode between sources - it launches what has arrived).  The bytes are those of the reference handed the input in the same pieces
  * (fill_window's slide depends on how much each fill finds; for whole streams and for pieces the oracle agrees).  The decoder
- * (DEFLATE, ZLIB, GZip) works in pieces: once md_inf_chunk_bytes (default 1 MiB) of input are buffered
+ * (DEFLATE, ZLIB, GZip) works in pieces: once md_inf_chunk_bytes (default 8 MiB; a piece of at least "inflate_parallel_min" is decoded by the whole device) of input are buffered
  * it decodes up to the last block boundary inside them (md_de_inf_continue_host), hands that output out through
  * `Flush steps while input is still arriving, and keeps only the undecoded tail and the 32 KiB window; a stream that
  * ends before a piece is full is decoded in one launch as before.

@@ -333,6 +333,43 @@ def test_one_long_stream_by_the_whole_chip(eng):
     assert got[3][2] == data and got[3][1] == len(z)
 
 
+def test_long_pieces_of_the_decode_protocol(eng):
+    """De.Inf.decode on a long stream (lib/de.ml:1427-1474, the tool's loop bin/decompress.ml:77-100): a piece of the
+    protocol that is long enough is decoded by the whole chip up to its last block boundary, the incomplete block behind
+    it by the serial path (capi.cpp continue_parallel) - same bytes, same signals at the end, Adler-32 and CRC-32 carried
+    across the pieces; a stream cut inside a block still ends in the serial path's `Malformed"""
+    import decompress_amd
+    from decompress_amd import de, engine, workloads
+    eng = engine.default_engine(0)  # (the context de.Inf drives)
+    plain = workloads.text(0x52, 24 << 20)
+    z = zlib.compress(plain, 6)
+    co = zlib.compressobj(6, zlib.DEFLATED, 31)
+    gz = co.compress(plain) + co.flush()
+    for fmt, src in ((decompress_amd.FORMAT_ZLIB, z), (decompress_amd.FORMAT_GZIP, gz), (decompress_amd.FORMAT_DEFLATE, z[2:-4])):
+        for chunk, step in ((3 << 20, 700001), (8 << 20, len(src))):
+            verdict, out, sigs = de.Inf.decode_chunks((src[i:i + step] for i in range(0, len(src), step)), o_len=1 << 20, fmt=fmt,
+                                                      chunk_bytes=chunk)
+            assert verdict == "Ok" and out == plain, (fmt, chunk)
+            assert _par_last(eng)[0] > 0 or chunk < (8 << 20)
+    # the whole input at once: every block but the last few by the pieces
+    verdict, out, _ = de.Inf.decode_chunks([z], o_len=65536, fmt=decompress_amd.FORMAT_ZLIB)
+    assert verdict == "Ok" and out == plain and _par_last(eng)[0] > 50
+    # cut inside a block, a damaged trailer - at once and in pieces: what the serial path says, with everything decoded before
+    # the error handed out
+    feeds = {"cut": z[:len(z) // 2], "bad": z[:-1] + bytes([z[-1] ^ 1])}
+    steps = lambda src: [src[i:i + (1 << 20)] for i in range(0, len(src), 1 << 20)]
+    eng.set_option("inflate_parallel_min", 0)
+    try:
+        want = {k: (de.Inf.decode_chunks([v], o_len=65536, fmt=decompress_amd.FORMAT_ZLIB)[:2],
+                    de.Inf.decode_chunks(steps(v), o_len=65536, fmt=decompress_amd.FORMAT_ZLIB, chunk_bytes=3 << 20)[:2]) for k, v in feeds.items()}
+    finally:
+        eng.set_option("inflate_parallel_min", 512)
+    for k, v in feeds.items():
+        got = (de.Inf.decode_chunks([v], o_len=65536, fmt=decompress_amd.FORMAT_ZLIB)[:2],
+               de.Inf.decode_chunks(steps(v), o_len=65536, fmt=decompress_amd.FORMAT_ZLIB, chunk_bytes=3 << 20)[:2])
+        assert got == want[k] and got[0][0] != "Ok" and got[0][0] == got[1][0], k
+
+
 def test_long_stream_kinds_and_false_candidates(eng):
     """other data through the pieces: flush markers (pigz-like), levels, incompressible stretches in stored blocks, and a
     stream whose stored blocks CONTAIN valid block headers (compressed data inside the plaintext): candidates that are
