@@ -7,6 +7,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -1155,10 +1157,19 @@ static uint64_t slice_positions(const uint64_t *len, size_t n, uint64_t S) {  //
   return (first > second ? first : second) + kSlotPad * n;
 }
 
+// md_deflate_batch_host feeds the slices from host memory and takes finished output away under them: before_slice(k) is
+// called in front of the launches of slice k (it makes the context's stream wait for that slice's input and starts the
+// copy of the next one), after_slice(k, fin) behind them, once the stream has been waited for, with fin[i] = the output
+// bytes of stream i that are final
+struct SliceHooks {
+  std::function<int(uint64_t)> before_slice;  // in front of the launches of slice k
+  std::function<int(uint64_t)> launched;      // right behind them: the place to enqueue copies that should run under them
+  std::function<int(uint64_t, const std::vector<uint64_t> &)> after_slice;
+};
 static int deflate_in_slices(md_ctx *ctx, int format, const md_deflate_params &q, size_t n, uint64_t S, const uint8_t *d_in,
                              const uint64_t *h_in_off, const uint64_t *h_in_len, uint8_t *d_out, const uint64_t *h_out_off,
                              const uint64_t *h_out_cap, uint64_t *h_out_len, int32_t *h_status, uint32_t *h_checksum,
-                             const uint32_t *h_crc) {
+                             const uint32_t *h_crc, const SliceHooks *hooks = nullptr) {
   // state slots for the streams that do not end in the first slice
   std::vector<uint64_t> slot(n, 0), used(n, 0);
   std::vector<uint8_t> done(n, 0);
@@ -1216,12 +1227,20 @@ static int deflate_in_slices(md_ctx *ctx, int format, const md_deflate_params &q
       sums[2 * i + 1] = (uint32_t)len;
       total += front_len[i];
     }
+    if (hooks) {
+      rc = hooks->before_slice(k);
+      if (rc != MD_OK) return rc;
+    }
     HIP_TRY(ctx, hipMemcpyAsync(d64, h64, desc_bytes, hipMemcpyHostToDevice, ctx->stream));
     // (every stream of a later slice stopped less than 262 + 64 short of the slice before's end)
     PieceArgs pa{d64 + n, ctx->ws, {d32 + 2 * n, ctx->slice_state, d64 + 6 * n, d32 + 3 * n}, k == 0 ? 0u : (uint32_t)kSliceKeep - 512u};
     rc = deflate_launch(ctx, format, q.level, q.queue_len, q.driver, q.dynamic, q.matcher, q.gz_header, n, d_in, d64, d64 + 2 * n,
                         d_out, d64 + 3 * n, d64 + 4 * n, d64 + 5 * n, (int32_t *)d32, d32 + n, nullptr, total ? total : 1, &pa);
     if (rc != MD_OK) return rc;
+    if (hooks) {  // (in front of the read-backs: a copy to pageable memory keeps the calling thread until the kernels are done)
+      rc = hooks->launched(k);
+      if (rc != MD_OK) return rc;
+    }
     HIP_TRY(ctx, hipMemcpyAsync(out_len, d64 + 5 * n, n * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(st, d32, 2 * n * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1235,6 +1254,12 @@ static int deflate_in_slices(md_ctx *ctx, int format, const md_deflate_params &q
       h_status[i] = (int32_t)st[i];
       h_checksum[i] = sum_out[i];
       h_out_len[i] = (int32_t)st[i] == MD_OK ? used[i] + out_len[i] : 0;
+    }
+    if (hooks) {
+      std::vector<uint64_t> fin(n);
+      for (size_t i = 0; i < n; i++) fin[i] = done[i] ? h_out_len[i] : used[i];
+      rc = hooks->after_slice(k, fin);
+      if (rc != MD_OK) return rc;
     }
   }
   for (size_t i = 0; i < n; i++)
@@ -1502,6 +1527,137 @@ int md_i_piece_out(md_ctx *ctx, const md_piece *p, size_t off, uint8_t *host, si
   return MD_OK;
 }
 
+// md_deflate_batch_host for a batch of LONG streams laid out at equal distances (what a caller with n equal buffers has; C3):
+// cutting it into slices of streams would leave the sequential kernel short of streams (it wants 4 096), so it is cut into
+// slices of positions (deflate_in_slices: the kernels go on from the state the slice before left, same bytes out) and the
+// copies ride along - the columns [k S, (k + 1) S) of every stream's input as ONE strided copy under the kernels of slice
+// k - 1, and every output column that is final for all streams as one strided copy under the kernels of the next slice.
+// Returns 1000 when the batch is not of that kind (GZip: the CRC-32 of a whole stream comes first; level 0; short or
+// irregular streams): the caller then pipelines slices of streams as before.
+extern "C++" {
+static int deflate_host_positions(md_ctx *ctx, int format, const md_deflate_params *params, size_t n, const uint8_t *h_in, size_t in_bytes,
+                                  const uint64_t *in_off, const uint64_t *in_len, uint8_t *h_out, size_t out_bytes, const uint64_t *out_off,
+                                  const uint64_t *out_cap, uint64_t *out_len, int32_t *status, uint32_t *checksum, uint8_t *din, uint8_t *dout) {
+  if (format == MD_FORMAT_GZIP || n < 2 || ctx->host_slices_max < 2) return 1000;
+  md_deflate_params q;
+  if (check_params(ctx, format, params, &q) != MD_OK) return 1000;  // (the usual path reports it)
+  uint32_t max_chain = 0, nice = 0;
+  md_deflate_level_params(q.driver, q.matcher, q.level, &max_chain, &nice);
+  if (max_chain == 0) return 1000;
+  const uint64_t ip = in_off[1] - in_off[0], op = out_off[1] - out_off[0];
+  uint64_t longest = 0, cap_max = 0;
+  for (size_t i = 0; i < n; i++) {
+    if (in_off[i] != in_off[0] + i * ip || out_off[i] != out_off[0] + i * op || in_len[i] > ip || out_cap[i] > op) return 1000;
+    longest = in_len[i] > longest ? in_len[i] : longest;
+    cap_max = out_cap[i] > cap_max ? out_cap[i] : cap_max;
+  }
+  if (in_off[1] <= in_off[0] || out_off[1] <= out_off[0] || longest < 4 * kSliceMin || longest > MD_MAX_STREAM) return 1000;
+  // four slices (more if the workspace cap asks for smaller ones), S a multiple of 32 KiB
+  uint64_t S = ((longest + 3) / 4 + 32767) / 32768 * 32768;
+  while (S > kSliceMin && ctx->front_cap_bytes && md_front_big_bytes(slice_positions(in_len, n, S)) > ctx->front_cap_bytes) S -= 32768;
+  if (ctx->front_cap_bytes && md_front_big_bytes(slice_positions(in_len, n, S)) > ctx->front_cap_bytes) return 1000;
+  const uint64_t nslices = (longest + S - 1) / S;
+  if (!ctx->s_in && hipStreamCreateWithFlags(&ctx->s_in, hipStreamNonBlocking) != hipSuccess) return fail(ctx, MD_E_HIP, "hipStreamCreate");
+  if (!ctx->s_out && hipStreamCreateWithFlags(&ctx->s_out, hipStreamNonBlocking) != hipSuccess) return fail(ctx, MD_E_HIP, "hipStreamCreate");
+  EventList evs;
+  std::vector<hipEvent_t> e_in(nslices + 1, nullptr);
+  for (auto &e : e_in)
+    if (!(e = evs.make())) return fail(ctx, MD_E_HIP, "hipEventCreate");
+  hipError_t herr = hipSuccess;
+  // columns [c0, c1) of every row of a blob laid out at `pitch`: rows 0 .. n - 2 as one strided copy, the last row by itself
+  // (it may end where the blob ends)
+  auto band = [&](bool to_device, uint64_t c0, uint64_t c1, hipStream_t cs) {
+    if (c1 <= c0 || herr != hipSuccess) return;
+    const uint64_t pitch = to_device ? ip : op, off0 = to_device ? in_off[0] : out_off[0], bytes = to_device ? in_bytes : out_bytes;
+    uint8_t *d = (to_device ? din : dout) + off0 + c0;
+    const uint8_t *hs = h_in + off0 + c0;
+    uint8_t *hd = h_out + off0 + c0;
+    const hipMemcpyKind kind = to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost;
+    const uint64_t w = c1 - c0;
+    if (n > 1) herr = to_device ? hipMemcpy2DAsync(d, pitch, hs, pitch, w, n - 1, kind, cs) : hipMemcpy2DAsync(hd, pitch, d, pitch, w, n - 1, kind, cs);
+    const uint64_t last = off0 + (n - 1) * pitch + c0;
+    uint64_t wl = w;
+    if (last >= bytes) wl = 0;
+    else if (last + wl > bytes) wl = bytes - last;
+    if (wl && herr == hipSuccess)
+      herr = to_device ? hipMemcpyAsync(d + (n - 1) * pitch, hs + (n - 1) * pitch, wl, kind, cs) : hipMemcpyAsync(hd + (n - 1) * pitch, d + (n - 1) * pitch, wl, kind, cs);
+  };
+  auto columns = [&](uint64_t k) { return std::make_pair(k * S < longest ? k * S : longest, (k + 1) * S < longest ? (k + 1) * S : longest); };
+  // (the strided copies are enqueued right BEHIND a slice's kernel launches: should the runtime keep the calling thread
+  // until such a copy is done, the kernels it is meant to run under are on the device already)
+  uint64_t c_done = 0, c_ready = 0;  // output columns [0, c_done) are on their way to the host, [c_done, c_ready) are final
+  const bool dbg_t = getenv("MD_DEBUG_HOSTPATH") != nullptr;
+  const auto t_start = std::chrono::steady_clock::now();
+  auto stamp = [&](const char *what, uint64_t k) {
+    if (dbg_t) fprintf(stderr, "[hostpath] %-14s slice %llu at %.2f ms\n", what, (unsigned long long)k,
+                       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
+  };
+  SliceHooks hooks;
+  hooks.before_slice = [&](uint64_t k) -> int {
+    if (k == 0) {
+      hipEvent_t e0 = evs.make();  // (what the caller queued on the context's stream comes first)
+      if (!e0) return fail(ctx, MD_E_HIP, "hipEventCreate");
+      if (hipEventRecord(e0, ctx->stream) != hipSuccess || hipStreamWaitEvent(ctx->s_in, e0, 0) != hipSuccess) return fail(ctx, MD_E_HIP, "hipEventRecord");
+      const auto c = columns(0);
+      band(true, c.first, c.second, ctx->s_in);
+      if (herr == hipSuccess) herr = hipEventRecord(e_in[0], ctx->s_in);
+    }
+    if (herr == hipSuccess) herr = hipStreamWaitEvent(ctx->stream, e_in[k], 0);
+    stamp("before", k);
+    return herr == hipSuccess ? MD_OK : fail(ctx, MD_E_HIP, "deflate host path: copy-in", herr);
+  };
+  hooks.launched = [&](uint64_t k) -> int {
+    stamp("launched", k);
+    if (k + 1 < nslices) {  // the next slice's input under this slice's kernels
+      const auto c = columns(k + 1);
+      band(true, c.first, c.second, ctx->s_in);
+      if (herr == hipSuccess) herr = hipEventRecord(e_in[k + 1], ctx->s_in);
+    }
+    stamp("h2d queued", k);
+    if (c_ready > c_done) {  // what the slices before made final leaves under them too
+      if (dbg_t) fprintf(stderr, "[hostpath] d2h columns [%llu, %llu)\n", (unsigned long long)c_done, (unsigned long long)c_ready);
+      band(false, c_done, c_ready, ctx->s_out);
+      c_done = c_ready;
+    }
+    stamp("copies queued", k);
+    return herr == hipSuccess ? MD_OK : fail(ctx, MD_E_HIP, "deflate host path: copies", herr);
+  };
+  hooks.after_slice = [&](uint64_t k, const std::vector<uint64_t> &fin) -> int {
+    // (the context's stream has been waited for: what the slice wrote is there)
+    stamp("kernels done", k);
+    uint64_t lo = ~0ull, hi = 0;
+    for (uint64_t f : fin) {
+      lo = f < lo ? f : lo;
+      hi = f > hi ? f : hi;
+    }
+    // (bands begin and end on 4 KiB columns: a strided copy of odd offsets and widths ran at a quarter of the link's rate;
+    // behind the longest output the rows hold nothing anybody reads, up to the distance between two of them)
+    c_ready = k + 1 == nslices ? ((hi + 4095) & ~(uint64_t)4095) : (lo & ~(uint64_t)4095);  // at the end: everything, ragged rows included
+    if (c_ready > op) c_ready = op;
+    if (c_ready < c_done) c_ready = c_done;
+    if (k + 1 == nslices && c_ready > c_done) {
+      band(false, c_done, c_ready, ctx->s_out);
+      c_done = c_ready;
+    }
+    return herr == hipSuccess ? MD_OK : fail(ctx, MD_E_HIP, "deflate host path: copy-out", herr);
+  };
+  std::vector<int32_t> r_st(n);
+  std::vector<uint32_t> r_sum(n);
+  int rc = deflate_in_slices(ctx, format, q, n, S, din, in_off, in_len, dout, out_off, out_cap, out_len, r_st.data(), r_sum.data(), nullptr, &hooks);
+  // everything in flight ends before the call returns, whatever happened (the buffers are the caller's)
+  const hipError_t a = hipStreamSynchronize(ctx->s_in), b2 = hipStreamSynchronize(ctx->stream), c = hipStreamSynchronize(ctx->s_out);
+  stamp("all done", nslices);
+  if (rc != MD_OK) return rc;
+  if (a != hipSuccess || b2 != hipSuccess || c != hipSuccess) return fail(ctx, MD_E_HIP, "deflate host path", a != hipSuccess ? a : b2 != hipSuccess ? b2 : c);
+  for (size_t i = 0; i < n; i++) {
+    status[i] = r_st[i];
+    if (checksum) checksum[i] = r_sum[i];
+  }
+  (void)cap_max;
+  return MD_OK;
+}
+}  // extern "C++"
+
 int md_deflate_batch_host(md_ctx *ctx, int format, const md_deflate_params *params,
                           size_t n, const uint8_t *h_in, size_t in_bytes, const uint64_t *in_off,
                           const uint64_t *in_len, uint8_t *h_out, size_t out_bytes,
@@ -1532,6 +1688,11 @@ int md_deflate_batch_host(md_ctx *ctx, int format, const md_deflate_params *para
   HIP_TRY(ctx, hipMemcpyAsync(d64 + 1 * n, in_len, n * 8, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(d64 + 2 * n, out_off, n * 8, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(d64 + 3 * n, out_cap, n * 8, hipMemcpyHostToDevice, st));
+  {  // long streams in a regular layout: slices of POSITIONS, input arriving and output leaving under the kernels
+    const int prc = deflate_host_positions(ctx, format, params, n, h_in, in_bytes, in_off, in_len, h_out, out_bytes, out_off, out_cap,
+                                           out_len, status, checksum, din, dout);
+    if (prc != 1000 /* not this kind of batch: slices of streams below */) return prc;
+  }
   // the sequential kernel holds 16 streams per CU: a slice of fewer than 4 096 streams leaves the chip part empty for as
   // long as a stream takes, so a batch is only cut where every slice still has that many
   const std::vector<HostSlice> sl = host_slices(n, in_off, in_len, out_off, out_cap, 4096, (size_t)ctx->host_slices_max, in_bytes, out_bytes);

@@ -916,3 +916,45 @@ def test_host_entry_points_in_slices(eng, pinned):
                 z = dres[16][1][i * cap:i * cap + int(dres[16][0][0][i])].tobytes()
                 assert zlib.decompress(z) == pl[i] and z == orc.zl_deflate(pl[i], 4, queue=1024), i
     eng.set_option("release_workspace", 0)
+
+
+@pytest.mark.parametrize("pinned", [True, False], ids=["pinned", "pageable"])
+def test_deflate_host_entry_point_in_slices_of_positions(eng, oracle, pinned):
+    """md_deflate_batch_host on LONG buffers at equal distances (C3's shape): the batch goes through the kernels in slices
+    of positions with its input arriving and its finished output leaving as strided copies under them (capi.cpp
+    deflate_host_positions) - bytes, lengths, statuses and Adler-32 equal the one-after-the-other form's and the oracle's;
+    ragged lengths, an empty buffer, one buffer too small for its output"""
+    import decompress_amd
+    from decompress_amd import workloads
+    pitch, cap = 700032, 760000
+    lens = [700000, 650001, 300000, 100, 0, 699999, 262144, 262145, 524288, 1, 33000, 700032]
+    bufs = [(workloads.text(300 + i, n) if i % 3 else workloads.ascii_uniform(300 + i, n)) for i, n in enumerate(lens)]
+    n = len(bufs)
+    mk = eng.host_buffer if pinned else (lambda m: np.zeros(m, dtype=np.uint8))
+    h_in, h_out = mk(n * pitch), mk(n * cap)
+    for i, b in enumerate(bufs):
+        h_in[i * pitch:i * pitch + len(b)] = np.frombuffer(b, dtype=np.uint8)
+    in_off, in_len = np.arange(n, dtype=np.uint64) * pitch, np.array(lens, dtype=np.uint64)
+    out_off, out_cap = np.arange(n, dtype=np.uint64) * cap, np.full(n, cap, dtype=np.uint64)
+    out_cap[5] = 1000  # no room: its status, nobody else's
+    for fmt, level in ((decompress_amd.FORMAT_ZLIB, 6), (decompress_amd.FORMAT_DEFLATE, 1), (decompress_amd.FORMAT_ZLIB, 9)):
+        got = {}
+        for slices in (16, 1):
+            eng.set_option("host_pipeline_slices", slices)
+            h_out[:] = 0
+            r = eng.deflate_batch_host(fmt, h_in, in_off, in_len, h_out, out_off, out_cap, level=level)
+            got[slices] = ([a.copy() for a in r], [h_out[i * cap:i * cap + int(r[0][i])].tobytes() for i in range(n)])
+        eng.set_option("host_pipeline_slices", 16)
+        good = got[1][0][1] == 0
+        for a, b in zip(got[16][0], got[1][0]):  # (the checksum of a stream that failed is nobody's business)
+            assert (a[good] == b[good]).all(), (fmt, level)
+        assert (got[16][0][1] == got[1][0][1]).all() and got[16][1] == got[1][1], (fmt, level)
+        out_len, status, adler = got[16][0]
+        assert status[5] != 0 and (np.delete(status, 5) == 0).all()
+        for i, b in enumerate(bufs):
+            if i == 5:
+                continue
+            want = oracle.zl_deflate(b, level) if fmt == decompress_amd.FORMAT_ZLIB else oracle.deflate_raw(b, level)[0]
+            assert got[16][1][i] == want, (fmt, level, i)
+            assert (int(adler[i]) & 0xffffffff) == zlib.adler32(b)
+    eng.set_option("release_workspace", 0)
