@@ -591,7 +591,9 @@ std::vector<HostSlice> host_slices(size_t n, const uint64_t *in_off, const uint6
     i0 = i1;
   }
   // a layout whose slices span much more than the blobs hold (streams scattered across the blob): one slice, whole blobs
-  if (v.size() <= 1 || span > in_bytes + out_bytes + (in_bytes + out_bytes) / 4) {
+  // (a batch that is one slice anyway copies the span of its streams like any other slice: the caller's blobs may hold
+  // more than this batch - md_inflate_batch_host picks streams out of one)
+  if (v.empty() || (v.size() > 1 && span > in_bytes + out_bytes + (in_bytes + out_bytes) / 4)) {
     v.clear();
     v.push_back(HostSlice{0, n, 0, in_bytes, 0, out_bytes});
   }
@@ -688,20 +690,68 @@ int md_inflate_batch_host(md_ctx *ctx, int format, size_t n, const uint8_t *h_in
   }
   MD_ON_DEVICE(ctx);
   ctx->par_last_pieces = ctx->par_last_rounds = 0;
-  if (n == 1 && ctx->par_min && in_len[0] >= ctx->par_min) {  // ONE long stream: in pieces, by the whole chip (inflate_parallel)
-    size_t used = 0, wrote = 0;
-    uint32_t sum = 0;
-    const int prc = inflate_parallel(ctx, format, h_in + in_off[0], (size_t)in_len[0], h_out + out_off[0], (size_t)out_cap[0], &used, &wrote,
-                                     checksum ? &sum : nullptr);
-    if (prc != 1000 /* kNotHandled: the serial path below decides */) {
-      if (prc != MD_OK) return prc;
-      out_len[0] = wrote;
-      consumed[0] = used;
-      status[0] = MD_OK;
-      if (checksum) checksum[0] = sum;
+  // A FEW LONG streams (a handful of big files): each of them in pieces, by the whole chip (inflate_parallel) - as streams
+  // of a batch they would get one pair of wavefronts each.  What that path does not take, and the short streams beside
+  // them, go through the batch as before.
+  if (ctx->par_min && n <= 64) {
+    std::vector<size_t> shorts, longs;
+    for (size_t i = 0; i < n; i++) (in_len[i] >= ctx->par_min ? longs : shorts).push_back(i);
+    if (!longs.empty()) {
+      const size_t keep = ctx->par_min;
+      // a batch of picked streams through this same entry point, the long-stream path switched off
+      auto sub = [&](const std::vector<size_t> &pick) -> int {
+        const size_t m = pick.size();
+        std::vector<uint64_t> io(m), il(m), oo(m), oc(m), ol(m), cs(m);
+        std::vector<int32_t> st(m);
+        std::vector<uint32_t> ck(m);
+        for (size_t k = 0; k < m; k++) {
+          io[k] = in_off[pick[k]];
+          il[k] = in_len[pick[k]];
+          oo[k] = out_off[pick[k]];
+          oc[k] = out_cap[pick[k]];
+        }
+        ctx->par_min = 0;
+        const int rc = md_inflate_batch_host(ctx, format, m, h_in, in_bytes, io.data(), il.data(), h_out, out_bytes, oo.data(), oc.data(), ol.data(),
+                                             cs.data(), st.data(), checksum ? ck.data() : nullptr);
+        ctx->par_min = keep;
+        if (rc != MD_OK) return rc;
+        for (size_t k = 0; k < m; k++) {
+          out_len[pick[k]] = ol[k];
+          consumed[pick[k]] = cs[k];
+          status[pick[k]] = st[k];
+          if (checksum) checksum[pick[k]] = ck[k];
+        }
+        return MD_OK;
+      };
+      // the short ones first, as one batch (its copies take the span of the caller's blobs its streams lie in: what the long
+      // streams' places receive from that is overwritten below)
+      if (!shorts.empty()) {
+        const int rc = sub(shorts);
+        if (rc != MD_OK) return rc;
+      }
+      int pieces = 0, rounds = 0;
+      for (size_t i : longs) {
+        size_t used = 0, wrote = 0;
+        uint32_t sum = 0;
+        const int prc = inflate_parallel(ctx, format, h_in + in_off[i], (size_t)in_len[i], h_out + out_off[i], (size_t)out_cap[i], &used, &wrote,
+                                         checksum ? &sum : nullptr);
+        if (prc == 1000 /* kNotHandled: not a well-formed stream that fits - the batch path says what it is */) {
+          const int rc = sub(std::vector<size_t>{i});
+          if (rc != MD_OK) return rc;
+          continue;
+        }
+        if (prc != MD_OK) return prc;
+        out_len[i] = wrote;
+        consumed[i] = used;
+        status[i] = MD_OK;
+        if (checksum) checksum[i] = sum;
+        pieces += ctx->par_last_pieces;
+        rounds = ctx->par_last_rounds > rounds ? ctx->par_last_rounds : rounds;
+      }
+      ctx->par_last_pieces = pieces;
+      ctx->par_last_rounds = rounds;
       return MD_OK;
     }
-    ctx->par_last_pieces = 0;
   }
   const size_t desc_words = 6 * n;  // in_off in_len out_off out_cap out_len consumed
   int grc_ = grow(ctx, &ctx->host_in, &ctx->host_in_bytes, in_bytes + 64, "hipMalloc(host path input)");

@@ -631,8 +631,11 @@ static void lz_eoi(lz_t *s) {
 /* The caller's answer to `Await: the next piece of the input (De.Lz77.src, lib/de.ml:4181-4188; `Manual refill :4200-4201), or the end of it.
  * orc_set_src_piece(p) makes the drivers below hand the input over p bytes at a time (0: all of it at once), which is
  * what decides how much fill_window finds each time it runs. */
-static size_t g_src_piece = 0;
+static size_t g_src_piece = 0, g_src_first = 0;
 void orc_set_src_piece(size_t piece) { g_src_piece = piece; }
+/* ... with a FIRST piece of another size (0: like the others): what decides how far the window is written when
+ * fill_window first slides it (lib/de.ml:4294-4312) - H7's door, tests/test_gpu_deflate.py::test_h7_window_written_short */
+void orc_set_src_first_piece(size_t first) { g_src_first = first; }
 static void lz_await(lz_t *s) {
   if (s->i_len + 1 < s->n_total) {
     long e = s->i_len + (long)s->piece;
@@ -821,7 +824,7 @@ static lz_t *lz_new(int level, queue_t *q, const uint8_t *src, size_t n, int mat
   s->i_pos = 0;
   s->n_total = (long)n;
   s->piece = g_src_piece && g_src_piece < n ? (long)g_src_piece : (long)n;
-  s->i_len = s->piece - 1;
+  s->i_len = (g_src_piece && g_src_first && g_src_first < n ? (long)g_src_first : s->piece) - 1;
   if (n == 0) lz_eoi(s);
   s->lits[256] = 1; /* make_literals, lib/de.ml:2333-2336 */
   s->q = q;

@@ -106,6 +106,7 @@ uint8_t *orc_gz_deflate(const uint8_t *src, size_t n, int level, int queue_len, 
 void orc_free(void *p);
 /* the drivers above hand the input to De.Lz77 `piece` bytes per `Await (0, the default: all at once); not thread-safe */
 void orc_set_src_piece(size_t piece);
+void orc_set_src_first_piece(size_t first); /* the first piece of another size (0: like the others) */
 /* De.Def.Ns.deflate / compress_bound (lib/de.ml:3040-4010) and Zl.Def.Ns.deflate (lib/zl.ml:596-629), oracle/de_def_ns.c:
  * ORC_OK with *out_len = the `Ok n` (0 for the stub levels 5..12), ORC_UNEXPECTED_END_OF_OUTPUT, -1 = `Invalid_compression_level */
 int orc_de_def_ns_deflate(const uint8_t *src, size_t n, uint8_t *dst, size_t dst_cap, int level, size_t *out_len);

@@ -193,6 +193,18 @@ class Oracle:
         finally:
             self.lib.orc_set_src_piece(0)
 
+    @contextlib.contextmanager
+    def src_pieces(self, first, piece):
+        """as src_piece, with a first piece of `first` bytes"""
+        self.lib.orc_set_src_first_piece.argtypes = [ctypes.c_size_t]
+        self.lib.orc_set_src_first_piece.restype = None
+        self.lib.orc_set_src_first_piece(first)
+        try:
+            with self.src_piece(piece):
+                yield
+        finally:
+            self.lib.orc_set_src_first_piece(0)
+
     def deflate_raw(self, data, level=6, queue=4096, driver=0, dynamic=True, matcher=0):
         """De.Lz77 (matcher 0) or lib/lz.ml's Lz (matcher 1) + De.Def under one of the reference's
         drivers -> (raw DEFLATE, adler32 of input)"""

@@ -370,6 +370,44 @@ def test_long_pieces_of_the_decode_protocol(eng):
         assert got == want[k] and got[0][0] != "Ok" and got[0][0] == got[1][0], k
 
 
+def test_a_few_long_streams_in_one_host_batch(eng, oracle):
+    """md_inflate_batch_host with a handful of big streams: each long one is decoded by the whole chip, the short and the
+    broken ones beside them through the batch kernel - every result as the one-pair-of-wavefronts path gives it"""
+    import decompress_amd
+    from decompress_amd import workloads
+    plains = [workloads.text(700 + i, (6 + i) << 20) for i in range(3)] + [workloads.text(9, 5000), workloads.markov_text(3, 3 << 20)]
+    streams = [zlib.compress(p, 6) for p in plains]
+    streams.append(streams[0][:len(streams[0]) // 2])          # cut: Unexpected end of input
+    streams.append(streams[1][:-3] + b"\x00\x00\x00")           # a wrong checksum
+    caps = [len(p) for p in plains] + [len(plains[0]), len(plains[1])]
+    n = len(streams)
+    in_len = np.array([len(z) for z in streams], dtype=np.uint64)
+    in_off = np.zeros(n, dtype=np.uint64)
+    in_off[1:] = np.cumsum((in_len + 15) // 16 * 16)[:-1]
+    cap = np.array(caps, dtype=np.uint64)
+    out_off = np.zeros(n, dtype=np.uint64)
+    out_off[1:] = np.cumsum((cap + 255) // 256 * 256)[:-1]
+    h_in, h_out = eng.host_buffer(int(in_off[-1] + in_len[-1]) + 64), eng.host_buffer(int(out_off[-1] + cap[-1]) + 64)
+    for z, o in zip(streams, in_off):
+        h_in[int(o):int(o) + len(z)] = np.frombuffer(z, dtype=np.uint8)
+    got = {}
+    for par in (512, 0):
+        eng.set_option("inflate_parallel_min", par)
+        h_out[:] = 0
+        r = eng.inflate_batch_host(decompress_amd.FORMAT_ZLIB, h_in, in_off, in_len, h_out, out_off, cap)
+        got[par] = ([a.copy() for a in r], [h_out[int(out_off[i]):int(out_off[i]) + int(r[0][i])].tobytes() for i in range(n)], _par_last(eng)[0])
+    eng.set_option("inflate_parallel_min", 512)
+    assert got[512][2] > 100 and got[0][2] == 0
+    out_len, consumed, status, checksum = got[512][0]
+    assert list(status) == list(got[0][0][2]) == [0, 0, 0, 0, 0, 1, 9]
+    for i in range(5):
+        assert got[512][1][i] == plains[i] and consumed[i] == len(streams[i]) and checksum[i] == zlib.adler32(plains[i])
+    ok = got[0][0][2] == 0
+    for a, b in zip(got[512][0][:2], got[0][0][:2]):
+        assert (a[ok] == b[ok]).all()
+    assert got[512][1][5] == got[0][1][5] and got[512][1][6] == got[0][1][6]  # what was decoded in front of the error
+
+
 def test_long_stream_kinds_and_false_candidates(eng):
     """other data through the pieces: flush markers (pigz-like), levels, incompressible stretches in stored blocks, and a
     stream whose stored blocks CONTAIN valid block headers (compressed data inside the plaintext): candidates that are
