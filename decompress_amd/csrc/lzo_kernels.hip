@@ -621,7 +621,7 @@ __device__ __forceinline__ void record_trailer(Cmp &c, uint32_t off, uint32_t le
 // the step with the same hash or else the LDS entry, and the first lane whose 4 bytes agree with its
 // reference is where the serial loop finds its match; the lanes up to it enter the dictionary in
 // order.  After a match the next probe is the match end itself (`goto next`).
-__device__ uint32_t compress_chunk(Cmp &c, uint16_t *dict, uint32_t in_pos, uint32_t in_len, uint32_t t) {
+__device__ __forceinline__ uint32_t compress_chunk(Cmp &c, uint16_t *dict, uint32_t in_pos, uint32_t in_len, uint32_t t) {
   const uint32_t idx_end = in_len > 20 ? in_len - 20 : 0, lane = c.lane;
   uint32_t idx1 = in_pos;
   uint32_t first = in_pos + (t < 4 ? 4 - t : 0);
