@@ -53,7 +53,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
-PMC_DIR = os.path.join(ROOT, "profiles", "r05_final")
+PMC_DIR = os.path.join(ROOT, "profiles", "r06_final")
 
 
 def _csrc_digest():

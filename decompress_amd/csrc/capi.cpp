@@ -1921,6 +1921,11 @@ struct ParOut {
 };
 static int par_decode(md_ctx *ctx, const ParIn &in, ParOut *out) {
   ctx->par_last_pieces = ctx->par_last_rounds = 0;
+  const bool dbg_t = getenv("MD_DEBUG_HOSTPATH") != nullptr;
+  const auto t_start = std::chrono::steady_clock::now();
+  auto stamp = [&](const char *what) {
+    if (dbg_t) fprintf(stderr, "[par_decode] %-22s at %.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
+  };
   const uint8_t *body = in.body;
   const uint64_t body_len = in.body_len, dst_cap = in.dst_cap;
   const uint32_t hl = in.hist_len;
@@ -1937,15 +1942,53 @@ static int par_decode(md_ctx *ctx, const ParIn &in, ParOut *out) {
   uint8_t *d_body = (uint8_t *)ctx->par_in;
   HIP_TRY(ctx, hipMemcpyAsync(d_body, body, body_len, hipMemcpyHostToDevice, st));
   uint64_t *d_cand = (uint64_t *)ctx->par_desc;
+  if (dbg_t) {
+    hipStreamSynchronize(st);
+    stamp("body on the device");
+  }
   int e = md_launch_find_blocks(d_body, body_len, K, nchunks - 1, d_cand, st);
   if (e != 0) return fail(ctx, MD_E_HIP, "find_blocks launch", (hipError_t)e);
   std::vector<uint64_t> cand(nchunks - 1);
   HIP_TRY(ctx, hipMemcpyAsync(cand.data(), d_cand, (nchunks - 1) * 8, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
+  stamp("candidates found");
+  // A run of STORED blocks from bit `pos` on is followed on the host, a read per block (lib/de.ml:1613-1627: header, padding,
+  // LEN, NLEN): -> the bit behind the run (`pos` itself when the block there is not a stored, non-final one); *mid receives
+  // block starts inside the run at least K bytes apart - stored data is the one kind whose block starts need no decoding to
+  // be found, and a long run of it (incompressible input, level 0, compressed files inside a tar) should not be one piece.
+  auto hop_stored = [&](uint64_t pos, std::vector<uint64_t> *mid) -> uint64_t {
+    uint64_t last_mid = pos;
+    for (int hops = 0; hops < (1 << 22); hops++) {
+      const uint64_t by = pos >> 3;
+      if (by + 5 > body_len) break;
+      const uint32_t h = ((uint32_t)body[by] | ((uint32_t)body[by + 1] << 8)) >> (pos & 7);
+      if ((h & 6) != 0 || (h & 1)) break;  // not stored, or the final block
+      const uint64_t at = (pos + 3 + 7) >> 3;
+      if (at + 4 > body_len) break;
+      const uint32_t len = body[at] | ((uint32_t)body[at + 1] << 8), nlen = body[at + 2] | ((uint32_t)body[at + 3] << 8);
+      if ((len ^ nlen) != 0xffffu || at + 4 + len > body_len) break;
+      if (mid && pos >= last_mid + K * 8) {
+        mid->push_back(pos);
+        last_mid = pos;
+      }
+      pos = (at + 4 + len) * 8;
+    }
+    return pos;
+  };
   std::vector<ParPiece> pc;
   pc.push_back(ParPiece{in.start_bit});
-  for (uint64_t c : cand)
-    if (c != ~0ull && c > pc.back().bit) pc.push_back(ParPiece{c});
+  {  // a stream that BEGINS with stored blocks: their starts are candidates the finder cannot see
+    std::vector<uint64_t> mid;
+    const uint64_t x = hop_stored(in.start_bit, &mid);
+    if (x > in.start_bit && x < body_len * 8) mid.push_back(x);
+    for (uint64_t c : mid)
+      if (c > pc.back().bit) pc.push_back(ParPiece{c});
+  }
+  {
+    const uint64_t seeded = pc.back().bit;
+    for (uint64_t c : cand)
+      if (c != ~0ull && c > seeded && c > pc.back().bit) pc.push_back(ParPiece{c});
+  }
   if (pc.size() < 3) return kNotHandled;  // nothing to gain
   // -- decode, verify the chain of pieces, decode again without a candidate that proved false or with more room
   uint32_t capmul = 6;
@@ -2023,6 +2066,7 @@ static int par_decode(md_ctx *ctx, const ParIn &in, ParOut *out) {
     HIP_TRY(ctx, hipMemcpyAsync(r_st.data(), d32 + 3 * n, n * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipMemcpyAsync(r_last.data(), d32 + 6 * n, n * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
+    stamp("pieces decoded");
     // The pieces in order: piece p must end - its last complete block - exactly where piece p + 1 starts ("links").  From
     // piece 0, the true start of the stream, an unbroken chain of links IS the stream's chain of blocks.  A candidate its
     // predecessor does not link to goes (all of them in one round: behind a false candidate the verdicts say little, and a
@@ -2036,20 +2080,13 @@ static int par_decode(md_ctx *ctx, const ParIn &in, ParOut *out) {
     // plaintext - a tar of .gz files - is stored, and full of real block headers that are not this stream's): hop over
     // them on the host, a read per block, and the block start behind the run is a candidate the finder could not see.
     auto unlinked = [&](size_t p, uint64_t e) {
-      uint64_t hi = p + 1 < np ? pc[p + 1].bit : ~0ull, pos = e;
-      for (int hops = 0; hops < (1 << 20); hops++) {
-        const uint64_t by = pos >> 3;
-        if (by + 5 > body_len) break;
-        const uint32_t h = ((uint32_t)body[by] | ((uint32_t)body[by + 1] << 8)) >> (pos & 7);
-        if ((h & 6) != 0 || (h & 1)) break;  // not stored, or the final block
-        const uint64_t at = (pos + 3 + 7) >> 3;
-        if (at + 4 > body_len) break;
-        const uint32_t len = body[at] | ((uint32_t)body[at + 1] << 8), nlen = body[at + 2] | ((uint32_t)body[at + 3] << 8);
-        if ((len ^ nlen) != 0xffffu || at + 4 + len > body_len) break;
-        pos = (at + 4 + len) * 8;
-      }
+      uint64_t hi = p + 1 < np ? pc[p + 1].bit : ~0ull;
+      std::vector<uint64_t> mid;
+      const uint64_t pos = hop_stored(e, &mid);
       if (pos > e) {
         if (pos > hi) hi = pos;
+        for (uint64_t c : mid)
+          if (c > pc[p].bit) add.push_back(c);
         if (pos < body_len * 8) add.push_back(pos);
       }
       kill.push_back({pc[p].bit, hi == ~0ull ? pc[p].bit : hi});
@@ -2109,11 +2146,7 @@ static int par_decode(md_ctx *ctx, const ParIn &in, ParOut *out) {
         for (const auto &k : kill) dead = dead || (pc[p].bit > k.first && pc[p].bit <= k.second);
         if (!dead) keep.push_back(pc[p]);
       }
-      for (uint64_t x : add) {
-        bool dead = false;
-        for (const auto &k : kill) dead = dead || (x > k.first && x < k.second);  // (inside another piece's stored run)
-        if (!dead) keep.push_back(ParPiece{x});
-      }
+      for (uint64_t x : add) keep.push_back(ParPiece{x});  // (block starts read off the stream itself)
       std::sort(keep.begin(), keep.end(), [](const ParPiece &x, const ParPiece &y) { return x.bit < y.bit; });
       keep.erase(std::unique(keep.begin(), keep.end(), [](const ParPiece &x, const ParPiece &y) { return x.bit == y.bit; }), keep.end());
       pc.swap(keep);
@@ -2157,6 +2190,7 @@ static int par_decode(md_ctx *ctx, const ParIn &in, ParOut *out) {
     uint32_t flag = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
+    stamp("windows + resolve");
     if (flag) return kNotHandled;  // a reference in front of the stream's start
   }
   out->total = total;

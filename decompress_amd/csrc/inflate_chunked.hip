@@ -65,6 +65,15 @@ struct BitRd {  // LSB-first bit reader over body[0, n), zeros beyond the end (`
     drop((uint32_t)(bit & 7));
   }
   __device__ __forceinline__ void fill() {
+    if (cnt <= 56 && byte + 8 <= n) {  // as many whole bytes as fit, from ONE unaligned load
+      uint64_t w;
+      __builtin_memcpy(&w, p + byte, 8);
+      const uint32_t take = (64 - cnt) >> 3;  // 1 .. 8 bytes
+      buf |= (take == 8 ? w : w & ((1ull << (8 * take)) - 1)) << cnt;
+      byte += take;
+      cnt += 8 * take;
+      return;
+    }
     while (cnt <= 56) {
       uint64_t b = 0;
       if (byte < n) b = p[byte];
@@ -89,33 +98,49 @@ struct BitRd {  // LSB-first bit reader over body[0, n), zeros beyond the end (`
 };
 
 // a complete dynamic block header at bit q of the body?  (called for the few positions whose first 17 + 3 HCLEN bits pass)
+// Everything the code-length code needs lives in packed 64-bit registers - lengths 3 bits a symbol, counts / first codes /
+// offsets 8 bits a length, the symbols sorted by (length, symbol) 5 bits each: as arrays indexed at run time they were
+// scratch memory, a round trip per access, and the finder took longer than the decode it prepares (8 MiB of stored text:
+// 33 ms of 34).
 __device__ __noinline__ bool header_parses(const uint8_t *body, uint64_t nbytes, uint64_t q) {
   BitRd r;
   r.init(body, nbytes, q);
   r.take(3);
   const uint32_t hlit = r.take(5) + 257, hdist = r.take(5) + 1, hclen = r.take(4) + 4;
-  const uint8_t zig[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-  uint8_t cl[19];
-  for (int i = 0; i < 19; i++) cl[i] = 0;
-  for (uint32_t i = 0; i < hclen; i++) cl[zig[i]] = (uint8_t)r.take(3);
-  // canonical code of the code-length alphabet: counts, first codes, symbols sorted by (length, symbol)
-  uint32_t cnt[8], first[8], offs[8];
-  for (int l = 0; l < 8; l++) cnt[l] = 0;
-  for (int s = 0; s < 19; s++) cnt[cl[s]]++;
-  cnt[0] = 0;
-  uint8_t sorted[19];
+  constexpr uint64_t kZigA = 16ull | 17ull << 5 | 18ull << 10 | 0ull << 15 | 8ull << 20 | 7ull << 25 | 9ull << 30 | 6ull << 35 | 10ull << 40 |
+                             5ull << 45 | 11ull << 50 | 4ull << 55;
+  constexpr uint64_t kZigB = 12ull | 3ull << 5 | 13ull << 10 | 2ull << 15 | 14ull << 20 | 1ull << 25 | 15ull << 30;
+  uint64_t cl = 0;  // 3 bits per symbol
+  for (uint32_t i = 0; i < hclen; i++) {
+    const uint32_t sym = (uint32_t)((i < 12 ? kZigA >> (5 * i) : kZigB >> (5 * (i - 12))) & 31);
+    cl |= (uint64_t)r.take(3) << (3 * sym);
+  }
+  uint64_t cnt = 0;  // 8 bits per length
+  for (uint32_t sy = 0; sy < 19; sy++) {
+    const uint32_t l = (uint32_t)(cl >> (3 * sy)) & 7;
+    if (l) cnt += 1ull << (8 * l);
+  }
+  uint64_t first = 0, offs = 0;  // 8 bits per length: first canonical code, rank of the first symbol
   {
     uint32_t code = 0, o = 0;
-    for (int l = 1; l < 8; l++) {
-      code = (code + cnt[l - 1]) << 1;
-      first[l] = code;
-      offs[l] = o;
-      o += cnt[l];
+    for (uint32_t l = 1; l < 8; l++) {
+      code = (code + (uint32_t)((cnt >> (8 * (l - 1))) & 255)) << 1;
+      first |= (uint64_t)(code & 255) << (8 * l);
+      offs |= (uint64_t)o << (8 * l);
+      o += (uint32_t)(cnt >> (8 * l)) & 255;
     }
-    uint32_t at[8];
-    for (int l = 1; l < 8; l++) at[l] = offs[l];
-    for (int s = 0; s < 19; s++)
-      if (cl[s]) sorted[at[cl[s]]++] = (uint8_t)s;
+  }
+  uint64_t sortA = 0, sortB = 0;  // 5 bits per rank: ranks 0..11, 12..18
+  {
+    uint64_t at = offs;
+    for (uint32_t sy = 0; sy < 19; sy++) {
+      const uint32_t l = (uint32_t)(cl >> (3 * sy)) & 7;
+      if (!l) continue;
+      const uint32_t rank = (uint32_t)(at >> (8 * l)) & 255;
+      at += 1ull << (8 * l);
+      if (rank < 12) sortA |= (uint64_t)sy << (5 * rank);
+      else sortB |= (uint64_t)sy << (5 * (rank - 12));
+    }
   }
   // the lengths of both alphabets, run-length coded (lib/de.ml:1291-1345): Kraft sums and the end-of-block code on the way
   uint32_t lsum = 0, dsum = 0, dcodes = 0, d1 = 0, prev = 0, i = 0;
@@ -123,11 +148,13 @@ __device__ __noinline__ bool header_parses(const uint8_t *body, uint64_t nbytes,
   const uint32_t total = hlit + hdist;
   while (i < total) {
     if (r.cnt < 16) r.fill();
-    uint32_t code = 0, len = 0, sym = 0xff;
-    for (len = 1; len < 8; len++) {
+    uint32_t code = 0, sym = 0xff;
+    for (uint32_t len = 1; len < 8; len++) {
       code = (code << 1) | r.take(1);
-      if (code - first[len] < cnt[len]) {
-        sym = sorted[offs[len] + code - first[len]];
+      const uint32_t f = (uint32_t)(first >> (8 * len)) & 255, c = (uint32_t)(cnt >> (8 * len)) & 255;
+      if (code - f < c) {
+        const uint32_t rank = ((uint32_t)(offs >> (8 * len)) & 255) + code - f;
+        sym = (uint32_t)((rank < 12 ? sortA >> (5 * rank) : sortB >> (5 * (rank - 12))) & 31);
         break;
       }
     }
@@ -145,17 +172,16 @@ __device__ __noinline__ bool header_parses(const uint8_t *body, uint64_t nbytes,
       val = 0;
     }
     if (i + rep > total) return false;
-    for (uint32_t k = 0; k < rep; k++, i++) {
-      if (!val) continue;
-      if (i < hlit) {
-        lsum += 32768u >> val;
-        if (i == 256) eob = true;
-      } else {
-        dsum += 32768u >> val;
-        dcodes++;
-        if (val == 1) d1++;
-      }
+    if (val) {  // rep symbols of length val from symbol i on: how many fall into each alphabet
+      const uint32_t nl = i < hlit ? (i + rep <= hlit ? rep : hlit - i) : 0u, nd = rep - nl;
+      lsum += nl * (32768u >> val);
+      dsum += nd * (32768u >> val);
+      dcodes += nd;
+      if (val == 1) d1 += nd;
+      if (i <= 256 && 256 < i + rep) eob = true;
+      if (lsum > 32768u || dsum > 32768u) return false;  // over-subscribed already
     }
+    i += rep;
     prev = val;
   }
   if (!r.inside()) return false;
@@ -163,58 +189,89 @@ __device__ __noinline__ bool header_parses(const uint8_t *body, uint64_t nbytes,
   return dsum == 32768u || dcodes == 0 || (dcodes == 1 && d1 == 1);
 }
 
-// chunk c of the grid covers body bytes [(c + 1) K, (c + 2) K): cand[c] = the first candidate bit in it, ~0 if none
+// chunk c of the grid covers body bytes [(c + 1) K, (c + 2) K): cand[c] = the first candidate bit in it, ~0 if none.
+// A round takes kRoundTiles x 256 bit positions: every thread runs the cheap filter (header bits, a complete code-length
+// code) over its positions and appends what passes to a list in LDS; then the list is VALIDATED with one position per
+// thread.  (Validating inside the filter loop kept 63 lanes waiting for the one that had something to validate - one
+// position in ~900 passes the filter, a validation is thousands of instructions: 4 ms for 3 MB of input, four times the
+// decode it prepares.)  The first valid position of the first round that has one is the chunk's candidate.
+constexpr uint32_t kRoundTiles = 64, kListCap = 1024, kSubRanges = 4;
+// the filter at bit q: 1 = a dynamic header that deserves validation, 2 = the byte behind an EMPTY STORED BLOCK (00 00 ff ff:
+// what Z_SYNC_FLUSH / Z_FULL_FLUSH leave, pigz between its blocks; its three header bits and padding lie in the byte in
+// front: the block behind it starts here, byte-aligned - needs no second look), 0 = neither
+__device__ __forceinline__ uint32_t header_filter(const uint8_t *__restrict__ body, uint64_t nbytes, uint64_t q) {
+  // the 8 bytes in front of q's byte and 96 bits from q on (the header's fixed part and the at most 19 x 3 bits of
+  // code-length code lengths): three 8-byte loads
+  const uint64_t by = q >> 3;
+  uint64_t pre = 0, lo = 0, hi = 0;
+  if (by >= 8 && by + 16 <= nbytes) {
+    __builtin_memcpy(&pre, body + by - 8, 8);
+    __builtin_memcpy(&lo, body + by, 8);
+    __builtin_memcpy(&hi, body + by + 8, 8);
+  } else {
+    for (uint32_t k = 0; k < 8 && k < by; k++) pre |= (uint64_t)body[by - 1 - k] << (8 * (7 - k));
+    for (uint32_t k = 0; k < 16 && by + k < nbytes; k++) {
+      if (k < 8) lo |= (uint64_t)body[by + k] << (8 * k);
+      else hi |= (uint64_t)body[by + k] << (8 * (k - 8));
+    }
+  }
+  // pre holds bytes by - 8 .. by - 1 (byte by - 1 on top): 00 00 ff ff in front, and the top three bits of the byte before zero
+  if ((q & 7) == 0 && by >= 5 && (pre >> 32) == 0xffff0000ull && ((pre >> 24) & 0xe0) == 0) return 2;
+  const uint32_t s = (uint32_t)(q & 7);
+  const uint64_t v0 = s ? (lo >> s) | (hi << (64 - s)) : lo, v1 = hi >> s;
+  if ((v0 & 7) != 4) return 0;  // BFINAL = 0, BTYPE = 2
+  const uint32_t hlit = (uint32_t)(v0 >> 3) & 31, hdist = (uint32_t)(v0 >> 8) & 31, hclen = ((uint32_t)(v0 >> 13) & 15) + 4;
+  if (hlit > 29 || hdist > 29) return 0;
+  uint32_t kraft = 0;  // the code-length code is complete (kind CODES, lib/de.ml:549-550)
+  for (uint32_t i = 0; i < hclen; i++) {
+    const uint32_t at = 17 + 3 * i;  // 17 .. 71
+    const uint32_t l = (uint32_t)(at < 64 ? (v0 >> at) | (v1 << (64 - at)) : v1 >> (at - 64)) & 7;
+    kraft += l ? 128u >> l : 0u;
+  }
+  return kraft == 128u ? 1u : 0u;
+}
+// grid = (kSubRanges, chunks behind the first): workgroup (s, c) searches the s-th part of chunk c's bits and lowers cand[c]
+// (set to ~0 before the launch) to its first candidate - the parts of a chunk run side by side, a small input has few chunks
 __global__ __launch_bounds__(256) void find_blocks_kernel(const uint8_t *__restrict__ body, uint64_t nbytes, uint64_t K,
-                                                          uint64_t *__restrict__ cand) {
-  __shared__ uint32_t found;
-  const uint64_t c = blockIdx.x;
-  const uint64_t b0 = (c + 1) * K * 8, b1x = (c + 2) * K * 8, nbits = nbytes * 8, b1 = b1x < nbits ? b1x : nbits;
-  if (threadIdx.x == 0) found = 0xffffffffu;
+                                                          unsigned long long *__restrict__ cand) {
+  __shared__ uint32_t found, nlist;
+  __shared__ uint32_t list[kListCap];
+  const uint64_t c = blockIdx.y;
+  const uint64_t part = ((K * 8 / kSubRanges) + 255) & ~(uint64_t)255;
+  const uint64_t c0 = (c + 1) * K * 8, c1x = (c + 2) * K * 8, nbits = nbytes * 8, c1 = c1x < nbits ? c1x : nbits;
+  const uint64_t b0 = c0 + blockIdx.x * part, b1y = blockIdx.x + 1 == kSubRanges ? c1 : b0 + part, b1 = b1y < c1 ? b1y : c1;
+  if (b0 >= b1) return;
+  if (threadIdx.x == 0) {
+    found = 0xffffffffu;
+    nlist = 0;
+  }
   __syncthreads();
-  for (uint64_t t0 = b0; t0 < b1; t0 += 256) {
-    const uint64_t q = t0 + threadIdx.x;
-    bool ok = q + 3 + 14 + 12 <= b1;
-    if (ok) {
-      // 96 bits from q on: the header's fixed part and the (at most 19 x 3 bits of) code-length code lengths
-      const uint64_t by = q >> 3;
-      uint64_t lo = 0, hi = 0;
-      if (by + 16 <= nbytes) {
-        __builtin_memcpy(&lo, body + by, 8);
-        __builtin_memcpy(&hi, body + by + 8, 8);
-      } else {
-        for (uint32_t k = 0; k < 16 && by + k < nbytes; k++) {
-          if (k < 8) lo |= (uint64_t)body[by + k] << (8 * k);
-          else hi |= (uint64_t)body[by + k] << (8 * (k - 8));
-        }
+  for (uint64_t r0 = b0; r0 < b1; r0 += (uint64_t)kRoundTiles * 256) {
+    if (blockIdx.x && r0 > b0 && __hip_atomic_load(&cand[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < b0) break;  // an earlier part has one
+    for (uint32_t j = 0; j < kRoundTiles; j++) {
+      const uint64_t q = r0 + (uint64_t)j * 256 + threadIdx.x;
+      const uint32_t f = q + 3 + 14 + 12 <= c1 && q < b1 ? header_filter(body, nbytes, q) : 0u;
+      if (f == 2) atomicMin(&found, (uint32_t)(q - b0));
+      if (f == 1) {
+        const uint32_t at = atomicAdd(&nlist, 1u);
+        if (at < kListCap) list[at] = (uint32_t)(q - b0);
+        else atomicMin(&found, 0xfffffffeu);  // (cannot be: a list of a thousand in 16 K positions; the part has no candidate then)
       }
-      const uint32_t s = (uint32_t)(q & 7);
-      const uint64_t v0 = s ? (lo >> s) | (hi << (64 - s)) : lo, v1 = hi >> s;
-      ok = (v0 & 7) == 4;  // BFINAL = 0, BTYPE = 2
-      const uint32_t hlit = (uint32_t)(v0 >> 3) & 31, hdist = (uint32_t)(v0 >> 8) & 31, hclen = ((uint32_t)(v0 >> 13) & 15) + 4;
-      ok = ok && hlit <= 29 && hdist <= 29;
-      if (ok) {  // the code-length code is complete (kind CODES, lib/de.ml:549-550)
-        uint32_t kraft = 0;
-        for (uint32_t i = 0; i < hclen; i++) {
-          const uint32_t at = 17 + 3 * i;  // 17 .. 71
-          const uint32_t l = (uint32_t)(at < 64 ? (v0 >> at) | (v1 << (64 - at)) : v1 >> (at - 64)) & 7;
-          kraft += l ? 128u >> l : 0u;
-        }
-        ok = kraft == 128u;
-      }
-      if (ok) ok = header_parses(body, nbytes, q);
     }
-    // ... or the byte behind an EMPTY STORED BLOCK (00 00 ff ff: what Z_SYNC_FLUSH / Z_FULL_FLUSH leave, pigz between its
-    // blocks), whose three header bits and padding lie in the byte in front: the block behind it starts here, byte-aligned
-    if (!ok && (q & 7) == 0 && q + 8 <= b1) {
-      const uint64_t by = q >> 3;
-      ok = by >= 5 && body[by - 4] == 0 && body[by - 3] == 0 && body[by - 2] == 0xff && body[by - 1] == 0xff && (body[by - 5] >> 5) == 0;
-    }
-    if (ok) atomicMin(&found, (uint32_t)(q - b0));
     __syncthreads();
-    if (found != 0xffffffffu) break;
+    const uint32_t n = nlist < kListCap ? nlist : kListCap;
+    for (uint32_t k = threadIdx.x; k < n; k += 256) {
+      const uint32_t rel = list[k];
+      if (rel < found && header_parses(body, nbytes, b0 + rel)) atomicMin(&found, rel);
+    }
+    __syncthreads();
+    const uint32_t f = found;
+    __syncthreads();
+    if (threadIdx.x == 0) nlist = 0;
+    if (f != 0xffffffffu) break;
     __syncthreads();
   }
-  if (threadIdx.x == 0) cand[c] = found == 0xffffffffu ? ~0ull : b0 + found;
+  if (threadIdx.x == 0 && found < 0xfffffffeu) atomicMin(&cand[c], (unsigned long long)(b0 + found));
 }
 
 // ---- 2. placeholder windows in front of the pieces' scratch outputs -------------------------------------------------
@@ -383,7 +440,9 @@ __global__ __launch_bounds__(256) void adler_segments_kernel(const uint8_t *__re
 extern "C" int md_launch_find_blocks(const uint8_t *body, uint64_t nbytes, uint64_t K, uint32_t nchunks_behind_first, uint64_t *cand,
                                      hipStream_t stream) {
   if (nchunks_behind_first == 0) return 0;
-  hipLaunchKernelGGL(md::chunked::find_blocks_kernel, dim3(nchunks_behind_first), dim3(256), 0, stream, body, nbytes, K, cand);
+  if (hipMemsetAsync(cand, 0xff, (size_t)nchunks_behind_first * 8, stream) != hipSuccess) return (int)hipGetLastError();
+  hipLaunchKernelGGL(md::chunked::find_blocks_kernel, dim3(md::chunked::kSubRanges, nchunks_behind_first), dim3(256), 0, stream, body, nbytes, K,
+                     (unsigned long long *)cand);
   return (int)hipGetLastError();
 }
 extern "C" int md_launch_fill_windows(uint32_t n, uint8_t *out, const uint64_t *out_off, const uint8_t *variant, hipStream_t stream) {

@@ -426,6 +426,12 @@ def test_long_stream_kinds_and_false_candidates(eng):
             z = zlib.compress(t, lvl)
             st, _, out = _higher(eng, "zl", z, len(t))
             assert st == 0 and out == t and _par_last(eng)[0] > 20
+        # stored blocks need no finder: their starts are read off the stream (level 0; noise, which zlib stores)
+        noise = np.random.default_rng(4).integers(0, 256, size=5 << 20, dtype=np.uint8).tobytes()
+        for data, lvl in ((t, 0), (noise, 6), (t[:1 << 20] + noise + t[1 << 20:], 6)):
+            z = zlib.compress(data, lvl)
+            st, _, out = _higher(eng, "zl", z, len(data))
+            assert st == 0 and out == data and _par_last(eng)[0] > 50, (lvl, _par_last(eng))
         co = zlib.compressobj(6)
         parts = []
         for i in range(0, len(t), 30011):
