@@ -33,6 +33,8 @@ Prints ONE JSON line (rank 0).
                 exact-size send/recv) — `results_gathered`, `gather_ms`.
   lzo           BASELINE.json config[4] (N = 1 only): 8192 x 128 KiB buffers through Lzo.compress then
                 Lzo.uncompress — MiB/s, ms and HBM fraction per direction, round trip and oracle bytes checked.
+  long_stream   ONE zlib stream of 64 MiB through Zl.Higher.uncompress (N = 1 only): decoded in pieces by the whole device
+                (DESIGN 3b), host to host, beside the one-pair-of-wavefronts path the call took before round 6.
   def_ns        SURVEY 8(f) row 4 (N = 1 only): De.Def.Ns.deflate level 4 over 1024 x 256 KiB buffers, inflated back,
                 oracle bytes checked on a sample.
   ranks_seen    an all_reduce over the process group: how many ranks really took part.
@@ -586,6 +588,47 @@ def def_ns_leg(args, eng, dev):
             "parity_ok": ok}
 
 
+def long_stream_leg(args, eng):
+    """ONE long stream (N = 1 only): Zl.Higher.uncompress on 64 MiB of seeded word text (lib/zl.ml:650-666; the reference's
+    tool on one big file) - decoded in pieces by the whole device, host to host from pinned buffers; beside it
+    the one-pair-of-wavefronts path the same call took before round 6 (on the first 8 MiB of the same text)."""
+    import ctypes
+    from decompress_amd import workloads
+    n = 64 << 20
+    plain = workloads.text(0x51, n)
+    z = zlib.compress(plain, 6)
+    h_in, h_out = eng.host_buffer(len(z)), eng.host_buffer(n)
+    h_in[:] = np.frombuffer(z, dtype=np.uint8)
+    wrote = ctypes.c_size_t()
+
+    def run(src_ptr, src_len, cap):
+        t0 = time.perf_counter()
+        st = eng.lib.md_zl_higher_uncompress(eng.ctx, ctypes.c_void_p(src_ptr), src_len, ctypes.c_void_p(h_out.ctypes.data), cap, ctypes.byref(wrote))
+        return st, (time.perf_counter() - t0) * 1e3
+
+    best = None
+    for _ in range(4):
+        st, ms = run(h_in.ctypes.data, len(z), n)
+        best = ms if best is None or ms < best else best
+    v = eng.lib.md_set_option(eng.ctx, b"inflate_parallel_last", 0)
+    ok = st == 0 and wrote.value == n and h_out.tobytes() == plain
+    # the serial path on a shorter stream of the same text (it runs at ~0.15 GiB/s: 8 MiB take 50 ms)
+    m = 8 << 20
+    z8 = zlib.compress(plain[:m], 6)
+    h_in[:len(z8)] = np.frombuffer(z8, dtype=np.uint8)
+    eng.set_option("inflate_parallel_min", 0)
+    try:
+        st8, ms8 = run(h_in.ctypes.data, len(z8), m)
+    finally:
+        eng.set_option("inflate_parallel_min", 512)
+    ok = ok and st8 == 0 and h_out[:m].tobytes() == plain[:m]
+    return {"workload": "Zl.Higher.uncompress on ONE zlib stream of 64 MiB of seeded word text (level 6, %d bytes), pinned host buffers in and out" % len(z),
+            "ms": round(best, 3), "mib_per_s": round(n / 2**20 / (best * 1e-3), 1), "pieces": v & 0xffffff, "decode_rounds": v >> 24,
+            "serial_path": {"what": "the same call with the pieces switched off (one pair of wavefronts), first 8 MiB of the text", "ms": round(ms8, 3),
+                            "mib_per_s": round(m / 2**20 / (ms8 * 1e-3), 1)},
+            "parity_ok": bool(ok)}
+
+
 def lzo_leg(args, eng, dev):
     """BASELINE config 5: 8192 x 128 KiB buffers (half word text, half printable-ASCII noise; 128 distinct),
     Lzo.compress then Lzo.uncompress; bytes checked against the oracle on a sample."""
@@ -832,12 +875,15 @@ def main():
         lz = lzo_leg(args, eng, dev) if world == 1 else None
         torch.cuda.empty_cache()
         dn = def_ns_leg(args, eng, dev) if world == 1 else None
+        ls = long_stream_leg(args, eng) if world == 1 else None
         if rank == 0:
             line["gzip"] = leg
             if lz:
                 line["lzo"] = lz
             if dn:
                 line["def_ns"] = dn
+            if ls:
+                line["long_stream"] = ls
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -2,7 +2,7 @@
 # Run ON THE GPU BOX: the round's profile set (kernel trace + HBM counters of bench.py, instruction mix of the deflate kernels,
 # kernel trace of the gzip / LZO legs)
 cd "$(dirname "$0")/.." && REPO=$PWD
-TAG=${TAG:-r05_final}
+TAG=${TAG:-r06_final}
 bash tools/profile_gpu.sh $TAG
 bash tools/dbg/pmc_deflate.sh > /dev/null 2>&1
 cp gpurun_out/pmc_deflate/summary.txt gpurun_out/prof_$TAG/pmc_insts_deflate.txt
