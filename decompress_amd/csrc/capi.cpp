@@ -2183,6 +2183,10 @@ static int par_decode(md_ctx *ctx, const ParIn &in, ParOut *out) {
     HIP_TRY(ctx, hipMemsetAsync(d_flag, 0, 64, st));
     e = md_launch_window_chain((uint32_t)np, d_out, d_out, d64 + 0 * np, d64 + 1 * np, d64 + 2 * np, (uint8_t *)ctx->par_win, d_flag, st);
     if (e != 0) return fail(ctx, MD_E_HIP, "window_chain launch", (hipError_t)e);
+    if (dbg_t) {
+      hipStreamSynchronize(st);
+      stamp("window chain");
+    }
     e = md_launch_resolve((uint32_t)np, d_out, d_out, d64 + 0 * np, d64 + 1 * np, d64 + 2 * np, d64 + 3 * np,
                           (const uint8_t *)ctx->par_win, d_flag, st);
     if (e != 0) return fail(ctx, MD_E_HIP, "resolve launch", (hipError_t)e);

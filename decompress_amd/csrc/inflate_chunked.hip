@@ -102,7 +102,7 @@ struct BitRd {  // LSB-first bit reader over body[0, n), zeros beyond the end (`
 // offsets 8 bits a length, the symbols sorted by (length, symbol) 5 bits each: as arrays indexed at run time they were
 // scratch memory, a round trip per access, and the finder took longer than the decode it prepares (8 MiB of stored text:
 // 33 ms of 34).
-__device__ __noinline__ bool header_parses(const uint8_t *body, uint64_t nbytes, uint64_t q) {
+__device__ __noinline__ bool header_parses(const uint8_t *body, uint64_t nbytes, uint64_t q, uint8_t *lut /* [128][256], this thread's column */) {
   BitRd r;
   r.init(body, nbytes, q);
   r.take(3);
@@ -120,26 +120,22 @@ __device__ __noinline__ bool header_parses(const uint8_t *body, uint64_t nbytes,
     const uint32_t l = (uint32_t)(cl >> (3 * sy)) & 7;
     if (l) cnt += 1ull << (8 * l);
   }
-  uint64_t first = 0, offs = 0;  // 8 bits per length: first canonical code, rank of the first symbol
+  // a 7-bit look-up table of the code-length code in LDS (entry = symbol | length << 5; column of this thread, the rows
+  // 256 bytes apart: conflict-free): a symbol of the 300 that follow is one look-up instead of up to seven compare steps
   {
-    uint32_t code = 0, o = 0;
+    uint64_t next = 0;  // next canonical code per length, 8 bits each
+    uint32_t code = 0;
     for (uint32_t l = 1; l < 8; l++) {
       code = (code + (uint32_t)((cnt >> (8 * (l - 1))) & 255)) << 1;
-      first |= (uint64_t)(code & 255) << (8 * l);
-      offs |= (uint64_t)o << (8 * l);
-      o += (uint32_t)(cnt >> (8 * l)) & 255;
+      next |= (uint64_t)(code & 255) << (8 * l);
     }
-  }
-  uint64_t sortA = 0, sortB = 0;  // 5 bits per rank: ranks 0..11, 12..18
-  {
-    uint64_t at = offs;
     for (uint32_t sy = 0; sy < 19; sy++) {
       const uint32_t l = (uint32_t)(cl >> (3 * sy)) & 7;
       if (!l) continue;
-      const uint32_t rank = (uint32_t)(at >> (8 * l)) & 255;
-      at += 1ull << (8 * l);
-      if (rank < 12) sortA |= (uint64_t)sy << (5 * rank);
-      else sortB |= (uint64_t)sy << (5 * (rank - 12));
+      const uint32_t c = (uint32_t)(next >> (8 * l)) & 255;
+      next += 1ull << (8 * l);
+      const uint32_t rev = __builtin_bitreverse32(c) >> (32 - l);  // the stream carries a code most significant bit first
+      for (uint32_t k = rev; k < 128; k += 1u << l) lut[k * 256] = (uint8_t)(sy | (l << 5));
     }
   }
   // the lengths of both alphabets, run-length coded (lib/de.ml:1291-1345): Kraft sums and the end-of-block code on the way
@@ -148,17 +144,9 @@ __device__ __noinline__ bool header_parses(const uint8_t *body, uint64_t nbytes,
   const uint32_t total = hlit + hdist;
   while (i < total) {
     if (r.cnt < 16) r.fill();
-    uint32_t code = 0, sym = 0xff;
-    for (uint32_t len = 1; len < 8; len++) {
-      code = (code << 1) | r.take(1);
-      const uint32_t f = (uint32_t)(first >> (8 * len)) & 255, c = (uint32_t)(cnt >> (8 * len)) & 255;
-      if (code - f < c) {
-        const uint32_t rank = ((uint32_t)(offs >> (8 * len)) & 255) + code - f;
-        sym = (uint32_t)((rank < 12 ? sortA >> (5 * rank) : sortB >> (5 * (rank - 12))) & 31);
-        break;
-      }
-    }
-    if (sym == 0xff) return false;
+    const uint32_t ent = lut[r.peek(7) * 256];
+    const uint32_t sym = ent & 31;
+    r.drop(ent >> 5);
     uint32_t rep = 1, val = sym;
     if (sym == 16) {
       if (i == 0) return false;
@@ -195,30 +183,33 @@ __device__ __noinline__ bool header_parses(const uint8_t *body, uint64_t nbytes,
 // thread.  (Validating inside the filter loop kept 63 lanes waiting for the one that had something to validate - one
 // position in ~900 passes the filter, a validation is thousands of instructions: 4 ms for 3 MB of input, four times the
 // decode it prepares.)  The first valid position of the first round that has one is the chunk's candidate.
-constexpr uint32_t kRoundTiles = 64, kListCap = 1024, kSubRanges = 4;
+constexpr uint32_t kRoundTiles = 64, kListCap = 1024;
 // the filter at bit q: 1 = a dynamic header that deserves validation, 2 = the byte behind an EMPTY STORED BLOCK (00 00 ff ff:
 // what Z_SYNC_FLUSH / Z_FULL_FLUSH leave, pigz between its blocks; its three header bits and padding lie in the byte in
 // front: the block behind it starts here, byte-aligned - needs no second look), 0 = neither
-__device__ __forceinline__ uint32_t header_filter(const uint8_t *__restrict__ body, uint64_t nbytes, uint64_t q) {
-  // the 8 bytes in front of q's byte and 96 bits from q on (the header's fixed part and the at most 19 x 3 bits of
-  // code-length code lengths): three 8-byte loads
-  const uint64_t by = q >> 3;
-  uint64_t pre = 0, lo = 0, hi = 0;
+struct Bits24 {  // the 8 bytes in front of byte `by` and the 16 from it on
+  uint64_t pre, lo, hi;
+};
+__device__ __forceinline__ Bits24 header_bytes(const uint8_t *__restrict__ body, uint64_t nbytes, uint64_t by) {
+  Bits24 v{0, 0, 0};
   if (by >= 8 && by + 16 <= nbytes) {
-    __builtin_memcpy(&pre, body + by - 8, 8);
-    __builtin_memcpy(&lo, body + by, 8);
-    __builtin_memcpy(&hi, body + by + 8, 8);
+    __builtin_memcpy(&v.pre, body + by - 8, 8);
+    __builtin_memcpy(&v.lo, body + by, 8);
+    __builtin_memcpy(&v.hi, body + by + 8, 8);
   } else {
-    for (uint32_t k = 0; k < 8 && k < by; k++) pre |= (uint64_t)body[by - 1 - k] << (8 * (7 - k));
+    for (uint32_t k = 0; k < 8 && k < by; k++) v.pre |= (uint64_t)body[by - 1 - k] << (8 * (7 - k));
     for (uint32_t k = 0; k < 16 && by + k < nbytes; k++) {
-      if (k < 8) lo |= (uint64_t)body[by + k] << (8 * k);
-      else hi |= (uint64_t)body[by + k] << (8 * (k - 8));
+      if (k < 8) v.lo |= (uint64_t)body[by + k] << (8 * k);
+      else v.hi |= (uint64_t)body[by + k] << (8 * (k - 8));
     }
   }
+  return v;
+}
+// bit s (0 .. 7) of the byte the words were loaded for
+__device__ __forceinline__ uint32_t header_filter(const Bits24 &w, uint64_t by, uint32_t s) {
   // pre holds bytes by - 8 .. by - 1 (byte by - 1 on top): 00 00 ff ff in front, and the top three bits of the byte before zero
-  if ((q & 7) == 0 && by >= 5 && (pre >> 32) == 0xffff0000ull && ((pre >> 24) & 0xe0) == 0) return 2;
-  const uint32_t s = (uint32_t)(q & 7);
-  const uint64_t v0 = s ? (lo >> s) | (hi << (64 - s)) : lo, v1 = hi >> s;
+  if (s == 0 && by >= 5 && (w.pre >> 32) == 0xffff0000ull && ((w.pre >> 24) & 0xe0) == 0) return 2;
+  const uint64_t v0 = s ? (w.lo >> s) | (w.hi << (64 - s)) : w.lo, v1 = w.hi >> s;
   if ((v0 & 7) != 4) return 0;  // BFINAL = 0, BTYPE = 2
   const uint32_t hlit = (uint32_t)(v0 >> 3) & 31, hdist = (uint32_t)(v0 >> 8) & 31, hclen = ((uint32_t)(v0 >> 13) & 15) + 4;
   if (hlit > 29 || hdist > 29) return 0;
@@ -230,13 +221,15 @@ __device__ __forceinline__ uint32_t header_filter(const uint8_t *__restrict__ bo
   }
   return kraft == 128u ? 1u : 0u;
 }
-// grid = (kSubRanges, chunks behind the first): workgroup (s, c) searches the s-th part of chunk c's bits and lowers cand[c]
+// grid = (parts, chunks behind the first): workgroup (s, c) searches the s-th part of chunk c's bits and lowers cand[c]
 // (set to ~0 before the launch) to its first candidate - the parts of a chunk run side by side, a small input has few chunks
 __global__ __launch_bounds__(256) void find_blocks_kernel(const uint8_t *__restrict__ body, uint64_t nbytes, uint64_t K,
                                                           unsigned long long *__restrict__ cand) {
   __shared__ uint32_t found, nlist;
   __shared__ uint32_t list[kListCap];
+  __shared__ uint8_t cl_lut[128 * 256];
   const uint64_t c = blockIdx.y;
+  const uint32_t kSubRanges = gridDim.x;  // parts of a chunk side by side: only while the chunks alone would leave the chip empty
   const uint64_t part = ((K * 8 / kSubRanges) + 255) & ~(uint64_t)255;
   const uint64_t c0 = (c + 1) * K * 8, c1x = (c + 2) * K * 8, nbits = nbytes * 8, c1 = c1x < nbits ? c1x : nbits;
   const uint64_t b0 = c0 + blockIdx.x * part, b1y = blockIdx.x + 1 == kSubRanges ? c1 : b0 + part, b1 = b1y < c1 ? b1y : c1;
@@ -248,21 +241,30 @@ __global__ __launch_bounds__(256) void find_blocks_kernel(const uint8_t *__restr
   __syncthreads();
   for (uint64_t r0 = b0; r0 < b1; r0 += (uint64_t)kRoundTiles * 256) {
     if (blockIdx.x && r0 > b0 && __hip_atomic_load(&cand[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < b0) break;  // an earlier part has one
-    for (uint32_t j = 0; j < kRoundTiles; j++) {
-      const uint64_t q = r0 + (uint64_t)j * 256 + threadIdx.x;
-      const uint32_t f = q + 3 + 14 + 12 <= c1 && q < b1 ? header_filter(body, nbytes, q) : 0u;
-      if (f == 2) atomicMin(&found, (uint32_t)(q - b0));
-      if (f == 1) {
-        const uint32_t at = atomicAdd(&nlist, 1u);
-        if (at < kListCap) list[at] = (uint32_t)(q - b0);
-        else atomicMin(&found, 0xfffffffeu);  // (cannot be: a list of a thousand in 16 K positions; the part has no candidate then)
+    // a thread takes the eight bit positions of ONE byte from one set of loads (a load per position was a memory round trip
+    // per 256 positions: 3 ms for 25 MB), the loads of the next byte column on their way meanwhile
+    Bits24 nx = header_bytes(body, nbytes, (r0 >> 3) + threadIdx.x);
+    for (uint32_t j = 0; j < kRoundTiles / 8; j++) {
+      const uint64_t by = (r0 >> 3) + (uint64_t)j * 256 + threadIdx.x;
+      const Bits24 w = nx;
+      if (j + 1 < kRoundTiles / 8) nx = header_bytes(body, nbytes, by + 256);
+#pragma unroll 1
+      for (uint32_t sb = 0; sb < 8; sb++) {
+        const uint64_t q = by * 8 + sb;
+        const uint32_t f = q + 3 + 14 + 12 <= c1 && q < b1 ? header_filter(w, by, sb) : 0u;
+        if (f == 2) atomicMin(&found, (uint32_t)(q - b0));
+        if (f == 1) {
+          const uint32_t at = atomicAdd(&nlist, 1u);
+          if (at < kListCap) list[at] = (uint32_t)(q - b0);
+          else atomicMin(&found, 0xfffffffeu);  // (cannot be: a list of a thousand in 16 K positions; the part has no candidate then)
+        }
       }
     }
     __syncthreads();
     const uint32_t n = nlist < kListCap ? nlist : kListCap;
     for (uint32_t k = threadIdx.x; k < n; k += 256) {
       const uint32_t rel = list[k];
-      if (rel < found && header_parses(body, nbytes, b0 + rel)) atomicMin(&found, rel);
+      if (rel < found && header_parses(body, nbytes, b0 + rel, cl_lut + threadIdx.x)) atomicMin(&found, rel);
     }
     __syncthreads();
     const uint32_t f = found;
@@ -294,37 +296,102 @@ __global__ __launch_bounds__(256) void fill_window_kernel(uint32_t n, uint8_t *_
 // Piece 0 is final already: dst[0, u[0]).  wins[p] = the 32 KiB in front of piece p (right-aligned: wins[p][kWin - 1] is the
 // byte just before it), valid[p] of them real.  flag[0] != 0: a reference in front of the stream's start (the serial path
 // reports Invalid_distance for it).
+// Thread t owns window bytes [32 t, 32 t + 32).  The pieces are a serial chain, but only through the window in LDS: the
+// tails of piece p + 1's two decodes are loaded (two 16-byte loads each) while piece p is resolved - the first version read
+// them byte by byte when it got there, a memory round trip per piece and byte column: 13 us a piece, 5 ms of the 11 a
+// 64 MiB stream took.
+struct TailRegs {
+  uint32_t a[8], b[8];
+  uint64_t up;
+};
+struct PieceDesc {
+  uint64_t offa, offb, up;
+};
+__device__ __forceinline__ PieceDesc desc_load(uint32_t p, uint32_t npieces, const uint64_t *__restrict__ offa, const uint64_t *__restrict__ offb,
+                                               const uint64_t *__restrict__ u) {
+  PieceDesc d{0, 0, 0};
+  if (p < npieces) {
+    d.offa = offa[p];
+    d.offb = offb[p];
+    d.up = u[p];
+  }
+  return d;
+}
+__device__ __forceinline__ void tail_load(TailRegs &r, const PieceDesc &d, const uint8_t *__restrict__ scratch, uint32_t j0) {
+#pragma unroll
+  for (int k = 0; k < 8; k++) r.a[k] = r.b[k] = 0;
+  r.up = d.up;
+  const uint8_t *a = scratch + d.offa, *b = scratch + d.offb;
+  const uint64_t take = r.up < kWin ? r.up : kWin;
+  // window byte j (>= kWin - take) is piece byte up - (kWin - j)
+  if (j0 >= kWin - take) {  // all 32 bytes come from the piece
+    const uint64_t i = r.up - (kWin - j0);
+    __builtin_memcpy(r.a, a + i, 32);
+    __builtin_memcpy(r.b, b + i, 32);
+  } else if (j0 + 32 > kWin - take) {  // the piece begins inside this thread's bytes
+    const uint32_t k0 = (uint32_t)(kWin - take) - j0;
+#pragma unroll
+    for (uint32_t k = 0; k < 32; k++) {  // (unrolled: the registers are indexed by constants - at run time they were scratch memory)
+      if (k < k0) continue;
+      const uint64_t i = r.up - (kWin - (j0 + k));
+      r.a[k >> 2] |= (uint32_t)a[i] << (8 * (k & 3));
+      r.b[k >> 2] |= (uint32_t)b[i] << (8 * (k & 3));
+    }
+  }
+}
 __global__ __launch_bounds__(1024) void window_chain_kernel(uint32_t npieces, const uint8_t *__restrict__ dst, const uint8_t *__restrict__ scratch,
                                                             const uint64_t *__restrict__ offa, const uint64_t *__restrict__ offb,
                                                             const uint64_t *__restrict__ u, uint8_t *__restrict__ wins,
                                                             uint32_t *__restrict__ flag) {
   __shared__ __attribute__((aligned(16))) uint8_t w[2][kWin];
-  const uint32_t t = threadIdx.x;
+  const uint32_t t = threadIdx.x, j0 = 32 * t;
   uint32_t cur = 0;
   uint64_t valid = u[0] < kWin ? u[0] : kWin;
   for (uint32_t j = t; j < kWin; j += 1024) w[0][j] = j >= kWin - valid ? dst[u[0] - (kWin - j)] : 0;
+  TailRegs r;
+  tail_load(r, desc_load(1, npieces, offa, offb, u), scratch, j0);
+  PieceDesc dn = desc_load(2, npieces, offa, offb, u);  // (descriptors two pieces ahead, tails one: no dependent round trips in the loop)
   __syncthreads();
   bool bad = false;
   for (uint32_t p = 1; p < npieces; p++) {
-    for (uint32_t j = t * 16; j < kWin; j += 1024 * 16)
-      *reinterpret_cast<uint4 *>(wins + (uint64_t)p * kWin + j) = *reinterpret_cast<const uint4 *>(&w[cur][j]);
-    const uint64_t up = u[p];
-    const uint8_t *a = scratch + offa[p], *b = scratch + offb[p];
-    const uint64_t take = up < kWin ? up : kWin;  // the piece's last `take` bytes end the next window
-    for (uint32_t j = t; j < kWin; j += 1024) {
-      uint32_t byte;
-      if (j < kWin - take) byte = w[cur][j + take];  // (a piece shorter than the window: the old one slides)
-      else {
-        const uint64_t i = up - (kWin - j);
-        uint32_t k;
-        byte = a[i];
-        if (is_marker(byte, b[i], &k)) {
-          if (k < kWin - valid) bad = true;
-          byte = w[cur][k];
-        }
-      }
-      w[cur ^ 1][j] = (uint8_t)byte;
+    const TailRegs now = r;
+    tail_load(r, dn, scratch, j0);  // (piece p + 1: on its way while this piece is resolved)
+    dn = desc_load(p + 2, npieces, offa, offb, u);
+    {  // the window in front of piece p, for resolve_kernel (behind the loads: waiting for them must not wait for this)
+      const uint4 *src = reinterpret_cast<const uint4 *>(&w[cur][j0]);
+      uint4 *d = reinterpret_cast<uint4 *>(wins + (uint64_t)p * kWin + j0);
+      d[0] = src[0];
+      d[1] = src[1];
     }
+    const uint64_t up = now.up, take = up < kWin ? up : kWin;
+    uint32_t out[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      if (j0 + 4 * q >= kWin - take && now.a[q] == now.b[q]) {  // four bytes of the piece, none of them from the window: the usual case
+        out[q] = now.a[q];
+        continue;
+      }
+      uint32_t word = 0;
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) {
+        const uint32_t k = 4 * q + kk, j = j0 + k;
+        uint32_t byte;
+        if (j < kWin - take) byte = w[cur][j + take];  // (a piece shorter than the window: the old one slides)
+        else {
+          uint32_t idx;
+          byte = (now.a[q] >> (8 * kk)) & 255;
+          if (is_marker(byte, (now.b[q] >> (8 * kk)) & 255, &idx)) {
+            if (idx < kWin - valid) bad = true;
+            byte = w[cur][idx];
+          }
+        }
+        word |= byte << (8 * kk);
+      }
+      out[q] = word;
+    }
+    uint4 *o = reinterpret_cast<uint4 *>(&w[cur ^ 1][j0]);
+    o[0] = make_uint4(out[0], out[1], out[2], out[3]);
+    o[1] = make_uint4(out[4], out[5], out[6], out[7]);
     valid = valid + up < kWin ? valid + up : kWin;
     cur ^= 1;
     __syncthreads();
@@ -441,7 +508,8 @@ extern "C" int md_launch_find_blocks(const uint8_t *body, uint64_t nbytes, uint6
                                      hipStream_t stream) {
   if (nchunks_behind_first == 0) return 0;
   if (hipMemsetAsync(cand, 0xff, (size_t)nchunks_behind_first * 8, stream) != hipSuccess) return (int)hipGetLastError();
-  hipLaunchKernelGGL(md::chunked::find_blocks_kernel, dim3(md::chunked::kSubRanges, nchunks_behind_first), dim3(256), 0, stream, body, nbytes, K,
+  const uint32_t parts = nchunks_behind_first >= 1024 ? 1u : nchunks_behind_first >= 512 ? 2u : 4u;
+  hipLaunchKernelGGL(md::chunked::find_blocks_kernel, dim3(parts, nchunks_behind_first), dim3(256), 0, stream, body, nbytes, K,
                      (unsigned long long *)cand);
   return (int)hipGetLastError();
 }
