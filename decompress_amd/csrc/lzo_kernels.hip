@@ -221,6 +221,7 @@ constexpr uint32_t kInRing = 2048, kInBlk = 1024;  // input window: a ring of tw
 constexpr uint32_t kStage = 3072;                  // staging: one batch of output, 16-byte aligned with the output buffer
 constexpr uint32_t kBatchMax = kStage - 16;        // bytes a batch may produce
 constexpr uint32_t kExotic = 1u << 20, kNextZero = 1u << 21;
+constexpr int kWindows = 4;                       // windows of 64 input bytes per batch
 struct LSmem {
   alignas(16) uint8_t in[kInRing + 32];  // (+ the ring's first bytes again: an access may run over the end)
   alignas(16) uint8_t stage[kStage + 32];
@@ -352,106 +353,147 @@ __device__ __forceinline__ int uncompress_stream(Dec &d, LSmem MD_LDS *sm) {
       slow = false;
       continue;
     }
-    // ---- decode: the 64 instructions that would start at base .. base + 63
-    const uint32_t base = d.i_pos, n = d.in.n;
-    ir.ensure(base);
-    const uint32_t p = base + lane;
-    const uint32_t b = *reinterpret_cast<const MD_LDS wv::u32_u *>(ir.at(p));
-    const uint32_t wz = pack_ins<true>(b, p, n), wn = pack_ins<false>(b, p, n);
-    // ---- walk (wave-uniform)
-    uint32_t cur = 0, zero = (d.state & 3) == 0 ? 1u : 0u, osum = 0;
-    uint64_t taken = 0, zmask = 0;
-    while (cur < 64) {
-      const uint32_t w = zero ? rdl(wz, cur) : rdl(wn, cur);
-      if (w & kExotic) {
-        slow = true;
-        break;
-      }
-      const uint32_t ob = (w >> 10) & 1023;
-      if (osum + ob > kBatchMax) break;
-      taken |= 1ull << cur;
-      zmask |= (uint64_t)zero << cur;
-      osum += ob;
-      cur += w & 1023;
-      zero = (w >> 21) & 1;
-    }
-    // ---- the marked lanes: their instruction, their place in the output
-    bool mine = (taken >> lane) & 1;
-    const bool mz = (zmask >> lane) & 1;
-    const Ins rz = decode_ins<true>(b), rn = decode_ins<false>(b);
-    const uint32_t k = mz ? rz.k : rn.k, off = mz ? rz.off : rn.off, mlen = mz ? rz.mlen : rn.mlen, lit = mz ? rz.lit : rn.lit;
-    const uint32_t o0 = d.o_pos, rb = o0 & ~15u;
-    const uint32_t orel = wv::wave_excl_scan(mine ? mlen + lit : 0u, lane);
-    const uint32_t oabs = o0 + orel;
-    {  // what does not fit the output is the slow path's (it fails there, with the reference's error)
-      const uint64_t bad = __ballot(mine && ((mlen != 0 && off > oabs) || mlen + lit > d.cap - oabs || oabs > d.cap));
-      if (bad) {
-        const uint32_t fb = (uint32_t)__builtin_ctzll(bad);
-        taken &= (1ull << fb) - 1;
-        mine = (taken >> lane) & 1;
-        osum = rdl(orel, fb);
-        cur = fb;
-        zero = (uint32_t)((zmask >> fb) & 1);
-        slow = true;
-      }
-    }
-    if (taken) {
-      const uint32_t sidx = oabs - rb;  // staging index of this lane's first byte
-      // literals: input window -> staging
-      {
-        const uint32_t lsrc = p + k, ldst = sidx + mlen;
-        const bool shortl = mine && lit != 0 && lit <= 16;
-        if (shortl) {
-          const uint64_t v0 = lds_ld64(ir.at(lsrc));
-          lds_put(stage + ldst, v0, lit < 8 ? lit : 8);
-          if (lit > 8) lds_put(stage + ldst + 8, lds_ld64(ir.at(lsrc + 8)), lit - 8);
+    // ---- a batch: up to kWindows windows of 64 input bytes, one after the other: decode, walk, places, literals - then the
+    // matches of all of them and ONE write-out (the fence, the far loads' round trip and the flush are per batch, not per
+    // 64 bytes of input: a lone stream spent most of its time on them)
+    const uint32_t o0 = d.o_pos, rb = o0 & ~15u, n = d.in.n;
+    uint32_t osum = 0;             // bytes of the batch so far
+    uint32_t rec_m[kWindows], rec_p[kWindows];  // per window and lane: off | mlen << 16 ; staging index (0xffffffff: no match)
+#pragma unroll
+    for (int w = 0; w < kWindows; w++) rec_m[w] = 0, rec_p[w] = 0xffffffffu;
+    bool more = true;
+#pragma unroll
+    for (int w = 0; w < kWindows; w++) {
+      if (more) {
+        // decode: the 64 instructions that would start at base .. base + 63
+        const uint32_t base = d.i_pos;
+        ir.ensure(base);
+        const uint32_t p = base + lane;
+        const uint32_t b = *reinterpret_cast<const MD_LDS wv::u32_u *>(ir.at(p));
+        const uint32_t wz = pack_ins<true>(b, p, n), wn = pack_ins<false>(b, p, n);
+        // walk (wave-uniform)
+        uint32_t cur = 0, zero = (d.state & 3) == 0 ? 1u : 0u, wsum = 0;
+        uint64_t taken = 0, zmask = 0;
+        while (cur < 64) {
+          const uint32_t wd = zero ? rdl(wz, cur) : rdl(wn, cur);
+          if (wd & kExotic) {
+            slow = true;
+            break;
+          }
+          const uint32_t ob = (wd >> 10) & 1023;
+          if (osum + wsum + ob > kBatchMax) {
+            more = false;  // the batch is full: the next one starts here
+            break;
+          }
+          taken |= 1ull << cur;
+          zmask |= (uint64_t)zero << cur;
+          wsum += ob;
+          cur += wd & 1023;
+          zero = (wd >> 21) & 1;
         }
-        for (uint64_t lm = __ballot(mine && lit > 16); lm; lm &= lm - 1) {  // a long run: by the whole wave (<= 273 bytes)
-          const uint32_t l = (uint32_t)__builtin_ctzll(lm);
-          const uint32_t s = rdl(lsrc, l), t = rdl(ldst, l), c = rdl(lit, l), j = lane * 8;
-          if (j < c) lds_put(stage + t + j, lds_ld64(ir.at(s + j)), c - j < 8 ? c - j : 8);
+        // the marked lanes: their instruction, their place in the output
+        bool mine = (taken >> lane) & 1;
+        const bool mz = (zmask >> lane) & 1;
+        const Ins rz = decode_ins<true>(b), rn = decode_ins<false>(b);
+        const uint32_t k = mz ? rz.k : rn.k, off = mz ? rz.off : rn.off, mlen = mz ? rz.mlen : rn.mlen, lit = mz ? rz.lit : rn.lit;
+        const uint32_t orel = osum + wv::wave_excl_scan(mine ? mlen + lit : 0u, lane);
+        const uint32_t oabs = o0 + orel;
+        {  // what does not fit the output is the slow path's (it fails there, with the reference's error)
+          const uint64_t bad = __ballot(mine && ((mlen != 0 && off > oabs) || mlen + lit > d.cap - oabs || oabs > d.cap));
+          if (bad) {
+            const uint32_t fb = (uint32_t)__builtin_ctzll(bad);
+            taken &= (1ull << fb) - 1;
+            mine = (taken >> lane) & 1;
+            wsum = rdl(orel, fb) - osum;
+            cur = fb;
+            zero = (uint32_t)((zmask >> fb) & 1);
+            slow = true;
+          }
         }
+        const uint32_t sidx = oabs - rb;  // staging index of this lane's first byte
+        if (taken) {  // literals: input window -> staging
+          const uint32_t lsrc = p + k, ldst = sidx + mlen;
+          if (mine && lit != 0 && lit <= 16) {
+            const uint64_t v0 = lds_ld64(ir.at(lsrc));
+            lds_put(stage + ldst, v0, lit < 8 ? lit : 8);
+            if (lit > 8) lds_put(stage + ldst + 8, lds_ld64(ir.at(lsrc + 8)), lit - 8);
+          }
+          for (uint64_t lm = __ballot(mine && lit > 16); lm; lm &= lm - 1) {  // a long run: by the whole wave (<= 273 bytes)
+            const uint32_t l = (uint32_t)__builtin_ctzll(lm);
+            const uint32_t sp = rdl(lsrc, l), t = rdl(ldst, l), c = rdl(lit, l), j = lane * 8;
+            if (j < c) lds_put(stage + t + j, lds_ld64(ir.at(sp + j)), c - j < 8 ? c - j : 8);
+          }
+          if (mine && mlen != 0) {
+            rec_m[w] = off | (mlen << 16);
+            rec_p[w] = sidx;
+          }
+        }
+        osum += wsum;
+        d.i_pos = base + cur;
+        d.state = zero ? 0 : 1;
+        if (slow || taken == 0) more = false;
       }
-      // matches
-      const uint32_t sabs = oabs - off;  // (mlen != 0)
-      const bool far = mine && mlen != 0 && sabs + mlen <= o0;
-      const bool near = mine && mlen != 0 && !far;
-      if (__ballot(mine && mlen != 0 && sabs < o0)) {  // some source byte lies in the output buffer
+    }
+    if (osum) {
+      // ---- matches.  Older than the batch: from the output buffer, every lane its own, the first 16 bytes of all windows'
+      // records in flight together; into the batch: in stream order by the whole wave, byte j = source byte j mod off
+      bool anyfar = false;
+#pragma unroll
+      for (int w = 0; w < kWindows; w++) {
+        const uint32_t mlen = rec_m[w] >> 16, off = rec_m[w] & 0xffffu;
+        anyfar = anyfar || (rec_p[w] != 0xffffffffu && rb + rec_p[w] - off < o0);
+      }
+      if (__ballot(anyfar)) {  // some source byte lies in the output buffer
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // earlier batches' bytes have landed
-        // the first 32 bytes of every record with all loads in flight together (a load per 8 bytes, each waited for before
-        // the next was asked for, was a memory round trip per step of the longest record: most of a lone stream's time);
-        // whole 8-byte words: up to 7 bytes past the source, which ends at o0 at the latest
-        if (o0 + 8 <= d.cap) {
-          const uint32_t fl = far ? mlen : 0u;
-          const uint8_t *g = d.dst + (far ? sabs : 0u);
-          const uint64_t v0 = wv::out_ld64(g), v1 = wv::out_ld64(g + (fl > 8 ? 8 : 0)), v2 = wv::out_ld64(g + (fl > 16 ? 16 : 0)),
-                         v3 = wv::out_ld64(g + (fl > 24 ? 24 : 0));
-          if (fl) {
-            lds_u8 *t = stage + sidx;
-            lds_put(t, v0, fl < 8 ? fl : 8);
-            if (fl > 8) lds_put(t + 8, v1, fl < 16 ? fl - 8 : 8);
-            if (fl > 16) lds_put(t + 16, v2, fl < 24 ? fl - 16 : 8);
-            if (fl > 24) lds_put(t + 24, v3, fl < 32 ? fl - 24 : 8);
-            for (uint32_t j = 32; j < fl; j += 8) lds_put(t + j, wv::out_ld64(g + j), fl - j < 8 ? fl - j : 8);
+        if (o0 + 8 <= d.cap) {  // whole 8-byte words: up to 7 bytes past a source, which ends at o0 at the latest
+          uint64_t v0[kWindows], v1[kWindows];
+#pragma unroll
+          for (int w = 0; w < kWindows; w++) {
+            const uint32_t mlen = rec_m[w] >> 16, off = rec_m[w] & 0xffffu, sabs = rb + rec_p[w] - off;
+            const bool far = rec_p[w] != 0xffffffffu && sabs + mlen <= o0;
+            const uint8_t *g = d.dst + (far ? sabs : 0u);
+            v0[w] = wv::out_ld64(g);
+            v1[w] = wv::out_ld64(g + (far && mlen > 8 ? 8 : 0));
           }
-        } else if (far) {  // the last bytes of the output buffer: nothing is read beyond it
-          for (uint32_t j = 0; j < mlen; j += 8)
-            lds_put(stage + sidx + j, out_ld_guard(d.dst, sabs + j, mlen - j, d.cap), mlen - j < 8 ? mlen - j : 8);
+#pragma unroll
+          for (int w = 0; w < kWindows; w++) {
+            const uint32_t mlen = rec_m[w] >> 16, off = rec_m[w] & 0xffffu, sabs = rb + rec_p[w] - off;
+            const bool far = rec_p[w] != 0xffffffffu && sabs + mlen <= o0;
+            if (far) {
+              lds_u8 *t = stage + rec_p[w];
+              lds_put(t, v0[w], mlen < 8 ? mlen : 8);
+              if (mlen > 8) lds_put(t + 8, v1[w], mlen < 16 ? mlen - 8 : 8);
+              for (uint32_t j = 16; j < mlen; j += 8) lds_put(t + j, wv::out_ld64(d.dst + sabs + j), mlen - j < 8 ? mlen - j : 8);
+            }
+          }
+        } else {  // the last bytes of the output buffer: nothing is read beyond it
+#pragma unroll
+          for (int w = 0; w < kWindows; w++) {
+            const uint32_t mlen = rec_m[w] >> 16, off = rec_m[w] & 0xffffu, sabs = rb + rec_p[w] - off;
+            if (rec_p[w] != 0xffffffffu && sabs + mlen <= o0)
+              for (uint32_t j = 0; j < mlen; j += 8)
+                lds_put(stage + rec_p[w] + j, out_ld_guard(d.dst, sabs + j, mlen - j, d.cap), mlen - j < 8 ? mlen - j : 8);
+          }
         }
       }
-      for (uint64_t nm = __ballot(near); nm; nm &= nm - 1) {  // in stream order; byte j = source byte j mod off
-        const uint32_t l = (uint32_t)__builtin_ctzll(nm);
-        const uint32_t s = rdl(sabs, l), t = rdl(sidx, l), c = rdl(mlen, l), f = rdl(off, l);
-        const float inv = 1.0f / (float)f;
-        for (uint32_t j = lane; j < c; j += kWave) {
-          uint32_t r = j;
-          if (f < c) {
-            r = j - (uint32_t)((float)j * inv) * f;  // j mod f, the quotient may be one off either way
-            r = (int32_t)r < 0 ? r + f : r;
-            r = r >= f ? r - f : r;
+#pragma unroll
+      for (int w = 0; w < kWindows; w++) {
+        const uint32_t mlen = rec_m[w] >> 16, off = rec_m[w] & 0xffffu, sidx = rec_p[w], sabs = rb + sidx - off;
+        const bool near = sidx != 0xffffffffu && sabs + mlen > o0;
+        for (uint64_t nm = __ballot(near); nm; nm &= nm - 1) {
+          const uint32_t l = (uint32_t)__builtin_ctzll(nm);
+          const uint32_t sp = rdl(sabs, l), t = rdl(sidx, l), c = rdl(mlen, l), f = rdl(off, l);
+          const float inv = 1.0f / (float)f;
+          for (uint32_t j = lane; j < c; j += kWave) {
+            uint32_t r = j;
+            if (f < c) {
+              r = j - (uint32_t)((float)j * inv) * f;  // j mod f, the quotient may be one off either way
+              r = (int32_t)r < 0 ? r + f : r;
+              r = r >= f ? r - f : r;
+            }
+            const uint32_t x = sp + r;
+            stage[t + j] = x >= o0 ? stage[x - rb] : (uint8_t)out_ld8(d.dst + x);
           }
-          const uint32_t x = s + r;
-          stage[t + j] = x >= o0 ? stage[x - rb] : (uint8_t)out_ld8(d.dst + x);
         }
       }
       // the batch leaves: whole 16-byte chunks one per lane, the bytes in front of the first and behind the last one by one
@@ -471,8 +513,6 @@ __device__ __forceinline__ int uncompress_stream(Dec &d, LSmem MD_LDS *sm) {
         d.o_pos = endp;
       }
     }
-    d.i_pos = base + cur;
-    d.state = zero ? 0 : 1;
   }
 }
 
