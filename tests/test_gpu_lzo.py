@@ -93,3 +93,30 @@ def test_c_abi_single_buffer(eng):
     from decompress_amd import lzo
     d = b"Salut les copains!"  # test/test.ml:2067-2079
     assert lzo.uncompress(lzo.compress(d), 128) == ("Ok", d)
+
+
+def test_corpus_files(eng, oracle):
+    """the reference's test/corpus through Lzo.compress / uncompress (test/test.ml:2067-2097's shape on real files): compressed
+    bytes = the oracle's, minilzo reads them, and both minilzo's and our streams come back through the batched decoder - whole
+    files (21 KB .. 769 KB: the decoder's windows, long literal runs, long matches, the slow path at the ends)"""
+    from decompress_amd import lzo, workloads
+    files = list(workloads.corpus().items())
+    bufs = [b for _, b in files]
+    res = eng.lzo_many(True, bufs, [lzo.max_compressed_length(len(b)) for b in bufs])
+    zs = []
+    for (name, b), (st, z) in zip(files, res):
+        assert (st, z) == oracle.lzo_compress(b), name
+        zs.append(z)
+    m = oracle_lib.load_minilzo()
+    srcs = zs + ([m.compress(b) for b in bufs] if m is not None else [])
+    want = bufs + (bufs if m is not None else [])
+    for k, (b, (st, out)) in enumerate(zip(want, eng.lzo_many(False, srcs, [len(b) for b in want]))):
+        assert (st, out) == (0, b), k
+    if m is not None:
+        for b, z in zip(bufs, zs):
+            assert m.decompress(z, len(b)) == (0, b)
+    # exact room, one byte short, a cut stream: the oracle's answers
+    for b, z in list(zip(bufs, zs))[:4]:
+        cases = [(z, len(b) - 1), (z[:len(z) * 2 // 3], len(b)), (z[:-1], len(b))]
+        for (src, cap), (st, out) in zip(cases, eng.lzo_many(False, [c[0] for c in cases], [c[1] for c in cases])):
+            assert (st, out) == oracle.lzo_uncompress(src, cap)
