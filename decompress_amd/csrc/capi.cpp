@@ -78,6 +78,10 @@ extern "C" int md_launch_find_blocks(const uint8_t *body, uint64_t nbytes, uint6
 extern "C" int md_launch_fill_windows(uint32_t n, uint8_t *out, const uint64_t *out_off, const uint8_t *variant, hipStream_t stream);
 extern "C" int md_launch_window_chain(uint32_t npieces, const uint8_t *dst, const uint8_t *scratch, const uint64_t *offa,
                                       const uint64_t *offb, const uint64_t *u, uint8_t *wins, uint32_t *flag, hipStream_t stream);
+extern "C" size_t md_windows_work_bytes(uint32_t npieces, uint32_t group);
+extern "C" int md_launch_windows_parallel(uint32_t npieces, uint32_t group, const uint8_t *dst, uint64_t u0, const uint8_t *scratch, const uint64_t *offa,
+                                          const uint64_t *offb, const uint64_t *u, const uint64_t *pos, uint8_t *wins, uint32_t *work, uint32_t *flag,
+                                          hipStream_t stream);
 extern "C" int md_launch_resolve(uint32_t npieces, uint8_t *dst, const uint8_t *scratch, const uint64_t *offa, const uint64_t *offb,
                                  const uint64_t *u, const uint64_t *pos, const uint8_t *wins, uint32_t *flag, hipStream_t stream);
 extern "C" int md_launch_adler_segments(const uint8_t *data, uint64_t n, uint32_t seg, uint32_t *sums, hipStream_t stream);
@@ -2168,7 +2172,13 @@ static int par_decode(md_ctx *ctx, const ParIn &in, ParOut *out) {
       pos[p] = acc;
       acc += u[p];
     }
-    rc = grow(ctx, &ctx->par_win, &ctx->par_win_bytes, np * (size_t)32768 + 64, "hipMalloc(parallel inflate windows)");
+    // the windows: by pointer jumping over the whole chip (a table of 128 KiB per piece, twice, in groups of 1 023 pieces), or -
+    // a handful of pieces - by the one-workgroup chain
+    const uint32_t kGroup = 1023;
+    const bool jumping = np >= 24;
+    const size_t win_bytes = ((np * (size_t)32768 + 255) & ~(size_t)255);
+    rc = grow(ctx, &ctx->par_win, &ctx->par_win_bytes, win_bytes + (jumping ? md_windows_work_bytes((uint32_t)np, kGroup) : 0) + 64,
+              "hipMalloc(parallel inflate windows)");
     if (rc != MD_OK) return rc;
     const size_t need = np * 32 + 256;
     rc = grow(ctx, &ctx->par_desc, &ctx->par_desc_bytes, need, "hipMalloc(parallel inflate descriptors)");
@@ -2181,7 +2191,10 @@ static int par_decode(md_ctx *ctx, const ParIn &in, ParOut *out) {
     HIP_TRY(ctx, hipMemcpyAsync(d64 + 2 * np, u.data(), np * 8, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(d64 + 3 * np, pos.data(), np * 8, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemsetAsync(d_flag, 0, 64, st));
-    e = md_launch_window_chain((uint32_t)np, d_out, d_out, d64 + 0 * np, d64 + 1 * np, d64 + 2 * np, (uint8_t *)ctx->par_win, d_flag, st);
+    if (jumping)
+      e = md_launch_windows_parallel((uint32_t)np, kGroup, d_out, u[0], d_out, d64 + 0 * np, d64 + 1 * np, d64 + 2 * np, d64 + 3 * np,
+                                     (uint8_t *)ctx->par_win, (uint32_t *)((uint8_t *)ctx->par_win + win_bytes), d_flag, st);
+    else e = md_launch_window_chain((uint32_t)np, d_out, d_out, d64 + 0 * np, d64 + 1 * np, d64 + 2 * np, (uint8_t *)ctx->par_win, d_flag, st);
     if (e != 0) return fail(ctx, MD_E_HIP, "window_chain launch", (hipError_t)e);
     if (dbg_t) {
       hipStreamSynchronize(st);

@@ -322,79 +322,168 @@ __device__ __forceinline__ void tail_load(TailRegs &r, const PieceDesc &d, const
   for (int k = 0; k < 8; k++) r.a[k] = r.b[k] = 0;
   r.up = d.up;
   const uint8_t *a = scratch + d.offa, *b = scratch + d.offb;
-  const uint64_t take = r.up < kWin ? r.up : kWin;
-  // window byte j (>= kWin - take) is piece byte up - (kWin - j)
-  if (j0 >= kWin - take) {  // all 32 bytes come from the piece
+  // window byte j is piece byte up - (kWin - j); a piece shorter than the window is not fetched ahead (the loop takes it
+  // byte by byte: rare, and its registers would be indexed at run time)
+  if (r.up >= kWin) {
     const uint64_t i = r.up - (kWin - j0);
     __builtin_memcpy(r.a, a + i, 32);
     __builtin_memcpy(r.b, b + i, 32);
-  } else if (j0 + 32 > kWin - take) {  // the piece begins inside this thread's bytes
-    const uint32_t k0 = (uint32_t)(kWin - take) - j0;
-#pragma unroll
-    for (uint32_t k = 0; k < 32; k++) {  // (unrolled: the registers are indexed by constants - at run time they were scratch memory)
-      if (k < k0) continue;
-      const uint64_t i = r.up - (kWin - (j0 + k));
-      r.a[k >> 2] |= (uint32_t)a[i] << (8 * (k & 3));
-      r.b[k >> 2] |= (uint32_t)b[i] << (8 * (k & 3));
-    }
   }
 }
-__global__ __launch_bounds__(1024) void window_chain_kernel(uint32_t npieces, const uint8_t *__restrict__ dst, const uint8_t *__restrict__ scratch,
-                                                            const uint64_t *__restrict__ offa, const uint64_t *__restrict__ offb,
-                                                            const uint64_t *__restrict__ u, uint8_t *__restrict__ wins,
-                                                            uint32_t *__restrict__ flag) {
+// 512 threads, two 32-byte segments of the window each (bytes 32 t .. and 16 K + 32 t ..); the tails of the pieces are
+// loaded kAhead pieces ahead - a load issued one piece ahead still left 6 us a piece, the memory's latency, not the work
+constexpr int kAhead = 3, kSegs = 2;
+constexpr uint32_t kChainThreads = 512;
+__global__ __launch_bounds__(kChainThreads) void window_chain_kernel(uint32_t npieces, const uint8_t *__restrict__ dst, const uint8_t *__restrict__ scratch,
+                                                                     const uint64_t *__restrict__ offa, const uint64_t *__restrict__ offb,
+                                                                     const uint64_t *__restrict__ u, uint8_t *__restrict__ wins,
+                                                                     uint32_t *__restrict__ flag) {
   __shared__ __attribute__((aligned(16))) uint8_t w[2][kWin];
-  const uint32_t t = threadIdx.x, j0 = 32 * t;
+  const uint32_t t = threadIdx.x;
   uint32_t cur = 0;
   uint64_t valid = u[0] < kWin ? u[0] : kWin;
-  for (uint32_t j = t; j < kWin; j += 1024) w[0][j] = j >= kWin - valid ? dst[u[0] - (kWin - j)] : 0;
-  TailRegs r;
-  tail_load(r, desc_load(1, npieces, offa, offb, u), scratch, j0);
-  PieceDesc dn = desc_load(2, npieces, offa, offb, u);  // (descriptors two pieces ahead, tails one: no dependent round trips in the loop)
+  for (uint32_t j = t; j < kWin; j += kChainThreads) w[0][j] = j >= kWin - valid ? dst[u[0] - (kWin - j)] : 0;
+  TailRegs r[kAhead][kSegs];  // r[0]: the piece at hand, r[1]: the next one, ...
+#pragma unroll
+  for (int a = 0; a < kAhead; a++) {
+    const PieceDesc d = desc_load(1 + a, npieces, offa, offb, u);
+#pragma unroll
+    for (int sg = 0; sg < kSegs; sg++) tail_load(r[a][sg], d, scratch, 32 * t + sg * (kWin / kSegs));
+  }
+  PieceDesc dn = desc_load(1 + kAhead, npieces, offa, offb, u);
   __syncthreads();
   bool bad = false;
   for (uint32_t p = 1; p < npieces; p++) {
-    const TailRegs now = r;
-    tail_load(r, dn, scratch, j0);  // (piece p + 1: on its way while this piece is resolved)
-    dn = desc_load(p + 2, npieces, offa, offb, u);
-    {  // the window in front of piece p, for resolve_kernel (behind the loads: waiting for them must not wait for this)
+    TailRegs now[kSegs];
+#pragma unroll
+    for (int sg = 0; sg < kSegs; sg++) now[sg] = r[0][sg];
+#pragma unroll
+    for (int a = 0; a + 1 < kAhead; a++)
+#pragma unroll
+      for (int sg = 0; sg < kSegs; sg++) r[a][sg] = r[a + 1][sg];
+#pragma unroll
+    for (int sg = 0; sg < kSegs; sg++) tail_load(r[kAhead - 1][sg], dn, scratch, 32 * t + sg * (kWin / kSegs));  // piece p + kAhead
+    dn = desc_load(p + 1 + kAhead, npieces, offa, offb, u);
+    const uint64_t up = now[0].up;
+#pragma unroll
+    for (int sg = 0; sg < kSegs; sg++) {  // the window in front of piece p, for resolve_kernel (behind the loads: waiting for them must not wait for this)
+      const uint32_t j0 = 32 * t + sg * (kWin / kSegs);
       const uint4 *src = reinterpret_cast<const uint4 *>(&w[cur][j0]);
       uint4 *d = reinterpret_cast<uint4 *>(wins + (uint64_t)p * kWin + j0);
       d[0] = src[0];
       d[1] = src[1];
     }
-    const uint64_t up = now.up, take = up < kWin ? up : kWin;
-    uint32_t out[8];
+    if (up >= kWin) {  // (wave-uniform) the piece's last 32 KiB are the next window
 #pragma unroll
-    for (int q = 0; q < 8; q++) {
-      if (j0 + 4 * q >= kWin - take && now.a[q] == now.b[q]) {  // four bytes of the piece, none of them from the window: the usual case
-        out[q] = now.a[q];
-        continue;
+      for (int sg = 0; sg < kSegs; sg++) {
+        const uint32_t j0 = 32 * t + sg * (kWin / kSegs);
+        uint32_t out[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          if (now[sg].a[q] == now[sg].b[q]) {  // four bytes, none of them from the window: the usual case
+            out[q] = now[sg].a[q];
+            continue;
+          }
+          uint32_t word = 0;
+#pragma unroll
+          for (int kk = 0; kk < 4; kk++) {
+            uint32_t idx, byte = (now[sg].a[q] >> (8 * kk)) & 255;
+            if (is_marker(byte, (now[sg].b[q] >> (8 * kk)) & 255, &idx)) {
+              if (idx < kWin - valid) bad = true;
+              byte = w[cur][idx];
+            }
+            word |= byte << (8 * kk);
+          }
+          out[q] = word;
+        }
+        uint4 *o = reinterpret_cast<uint4 *>(&w[cur ^ 1][j0]);
+        o[0] = make_uint4(out[0], out[1], out[2], out[3]);
+        o[1] = make_uint4(out[4], out[5], out[6], out[7]);
       }
-      uint32_t word = 0;
-#pragma unroll
-      for (int kk = 0; kk < 4; kk++) {
-        const uint32_t k = 4 * q + kk, j = j0 + k;
+    } else {  // a piece shorter than the window: the old window slides, the piece's bytes come straight from memory
+      const PieceDesc dd = desc_load(p, npieces, offa, offb, u);
+      const uint8_t *a = scratch + dd.offa, *b = scratch + dd.offb;
+      for (uint32_t j = t; j < kWin; j += kChainThreads) {
         uint32_t byte;
-        if (j < kWin - take) byte = w[cur][j + take];  // (a piece shorter than the window: the old one slides)
+        if (j < kWin - up) byte = w[cur][j + up];
         else {
+          const uint64_t i = up - (kWin - j);
           uint32_t idx;
-          byte = (now.a[q] >> (8 * kk)) & 255;
-          if (is_marker(byte, (now.b[q] >> (8 * kk)) & 255, &idx)) {
+          byte = a[i];
+          if (is_marker(byte, b[i], &idx)) {
             if (idx < kWin - valid) bad = true;
             byte = w[cur][idx];
           }
         }
-        word |= byte << (8 * kk);
+        w[cur ^ 1][j] = (uint8_t)byte;
       }
-      out[q] = word;
     }
-    uint4 *o = reinterpret_cast<uint4 *>(&w[cur ^ 1][j0]);
-    o[0] = make_uint4(out[0], out[1], out[2], out[3]);
-    o[1] = make_uint4(out[4], out[5], out[6], out[7]);
     valid = valid + up < kWin ? valid + up : kWin;
     cur ^= 1;
     __syncthreads();
+  }
+  if (bad) atomicOr(flag, 1u);
+}
+
+// ---- the windows in PARALLEL (pointer jumping) -------------------------------------------------------------------------
+// The chain above is one workgroup: with word text two bytes in five of a piece's last 32 KiB still descend from the window
+// in front of it (a frequent word is a copy of a copy of ... its first occurrence), so a piece is 13 000 dependent LDS
+// look-ups and the chain 6 us a piece whatever is fetched ahead (64 MiB: 2.4 ms of 7.8).  The same thing as a table: T[q][j] =
+// window byte j behind piece g0 + q - 1 (T[0]: the window in front of the group) is either a LITERAL byte or a REFERENCE
+// (t, i) "the same as T[t][i]" with t < q.  One round replaces every reference by what it points at; after ceil(log2(pieces))
+// rounds every entry is a literal - every round one launch over all entries, the whole chip.
+constexpr uint32_t kLit = 0x80000000u, kInvalid = 0x40000000u;
+__global__ __launch_bounds__(256) void win_first_kernel(const uint8_t *__restrict__ dst, uint64_t u0, uint8_t *__restrict__ win1) {
+  const uint64_t valid = u0 < kWin ? u0 : kWin;
+  for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < kWin; j += gridDim.x * 256) win1[j] = j >= kWin - valid ? dst[u0 - (kWin - j)] : 0;
+}
+// grid (x, cnt + 1): row q of the table of the group of pieces g0 .. g0 + cnt - 1
+__global__ __launch_bounds__(256) void jump_init_kernel(uint32_t g0, const uint8_t *__restrict__ scratch, const uint64_t *__restrict__ offa,
+                                                        const uint64_t *__restrict__ offb, const uint64_t *__restrict__ u,
+                                                        const uint64_t *__restrict__ pos, const uint8_t *__restrict__ wins, uint32_t *__restrict__ T) {
+  const uint32_t q = blockIdx.y;
+  uint32_t *row = T + (uint64_t)q * kWin;
+  if (q == 0) {  // the window in front of the group: bytes, of which the stream's first pos[g0] are real
+    const uint64_t valid = pos[g0] < kWin ? pos[g0] : kWin;
+    const uint8_t *w = wins + (uint64_t)g0 * kWin;
+    for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < kWin; j += gridDim.x * 256) row[j] = kLit | (j < kWin - valid ? kInvalid : 0u) | w[j];
+    return;
+  }
+  const uint32_t p = g0 + q - 1;
+  const uint64_t up = u[p], take = up < kWin ? up : kWin;
+  const uint8_t *a = scratch + offa[p], *b = scratch + offb[p];
+  for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < kWin; j += gridDim.x * 256) {
+    uint32_t e;
+    if (j < kWin - take) e = ((q - 1) << 15) | (uint32_t)(j + take);  // (a piece shorter than the window: the old one slides)
+    else {
+      const uint64_t i = up - (kWin - j);
+      uint32_t idx;
+      const uint32_t x = a[i];
+      e = is_marker(x, b[i], &idx) ? ((q - 1) << 15) | idx : kLit | x;
+    }
+    row[j] = e;
+  }
+}
+__global__ __launch_bounds__(256) void jump_round_kernel(uint64_t entries, const uint32_t *__restrict__ Tin, uint32_t *__restrict__ Tout) {
+  for (uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x; k < entries; k += (uint64_t)gridDim.x * 256) {
+    uint32_t e = Tin[k];
+    if (!(e & kLit)) e = Tin[(uint64_t)(e >> 15) * kWin + (e & (kWin - 1))];
+    Tout[k] = e;
+  }
+}
+// rows 1 .. cnt of the table are the windows in front of pieces g0 + 1 .. g0 + cnt (those that exist)
+__global__ __launch_bounds__(256) void jump_final_kernel(uint32_t g0, uint32_t npieces, const uint32_t *__restrict__ T, const uint64_t *__restrict__ pos,
+                                                         uint8_t *__restrict__ wins, uint32_t *__restrict__ flag) {
+  const uint32_t q = blockIdx.y + 1, p1 = g0 + q;  // the window in front of piece p1
+  if (p1 >= npieces) return;
+  const uint32_t *row = T + (uint64_t)q * kWin;
+  const uint64_t valid = pos[p1] < kWin ? pos[p1] : kWin;
+  uint8_t *w = wins + (uint64_t)p1 * kWin;
+  bool bad = false;
+  for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < kWin; j += gridDim.x * 256) {
+    const uint32_t e = row[j];
+    bad = bad || !(e & kLit) || ((e & kInvalid) && j >= kWin - valid);  // a byte of the stream that copies what lies in front of its start
+    w[j] = (uint8_t)e;
   }
   if (bad) atomicOr(flag, 1u);
 }
@@ -520,7 +609,36 @@ extern "C" int md_launch_fill_windows(uint32_t n, uint8_t *out, const uint64_t *
 }
 extern "C" int md_launch_window_chain(uint32_t npieces, const uint8_t *dst, const uint8_t *scratch, const uint64_t *offa,
                                       const uint64_t *offb, const uint64_t *u, uint8_t *wins, uint32_t *flag, hipStream_t stream) {
-  hipLaunchKernelGGL(md::chunked::window_chain_kernel, dim3(1), dim3(1024), 0, stream, npieces, dst, scratch, offa, offb, u, wins, flag);
+  hipLaunchKernelGGL(md::chunked::window_chain_kernel, dim3(1), dim3(md::chunked::kChainThreads), 0, stream, npieces, dst, scratch, offa, offb, u, wins, flag);
+  return (int)hipGetLastError();
+}
+// the same windows by pointer jumping, in groups of at most `group` pieces (work: 2 x (group + 1) x 32 Ki 32-bit entries);
+// u0 = u[0] (the host knows it), pos = the pieces' places in the output
+extern "C" size_t md_windows_work_bytes(uint32_t npieces, uint32_t group) {
+  const size_t g = npieces - 1 < group ? npieces - 1 : group;
+  return 2 * (g + 1) * (size_t)md::chunked::kWin * 4;
+}
+extern "C" int md_launch_windows_parallel(uint32_t npieces, uint32_t group, const uint8_t *dst, uint64_t u0, const uint8_t *scratch, const uint64_t *offa,
+                                          const uint64_t *offb, const uint64_t *u, const uint64_t *pos, uint8_t *wins, uint32_t *work, uint32_t *flag,
+                                          hipStream_t stream) {
+  using namespace md::chunked;
+  if (npieces < 2) return 0;
+  hipLaunchKernelGGL(win_first_kernel, dim3(16), dim3(256), 0, stream, dst, u0, wins + kWin);
+  const size_t gmax = npieces - 1 < group ? npieces - 1 : group;
+  uint32_t *T0 = work, *T1 = work + (gmax + 1) * (size_t)kWin;
+  for (uint32_t g0 = 1; g0 < npieces; g0 += group) {
+    const uint32_t cnt = npieces - g0 < group ? npieces - g0 : group;  // pieces g0 .. g0 + cnt - 1
+    hipLaunchKernelGGL(jump_init_kernel, dim3(8, cnt + 1), dim3(256), 0, stream, g0, scratch, offa, offb, u, pos, wins, T0);
+    uint32_t *in = T0, *out = T1;
+    const uint64_t entries = (uint64_t)(cnt + 1) * kWin;
+    for (uint32_t span = 1; span < cnt + 1; span *= 2) {
+      hipLaunchKernelGGL(jump_round_kernel, dim3((uint32_t)((entries + 256 * 8 - 1) / (256 * 8))), dim3(256), 0, stream, entries, in, out);
+      uint32_t *t = in;
+      in = out;
+      out = t;
+    }
+    hipLaunchKernelGGL(jump_final_kernel, dim3(8, cnt), dim3(256), 0, stream, g0, npieces, in, pos, wins, flag);
+  }
   return (int)hipGetLastError();
 }
 extern "C" int md_launch_resolve(uint32_t npieces, uint8_t *dst, const uint8_t *scratch, const uint64_t *offa, const uint64_t *offb,
