@@ -620,7 +620,7 @@ def long_stream_leg(args, eng):
     try:
         st8, ms8 = run(h_in.ctypes.data, len(z8), m)
     finally:
-        eng.set_option("inflate_parallel_min", 512)
+        eng.set_option("inflate_parallel_min", 96)
     ok = ok and st8 == 0 and h_out[:m].tobytes() == plain[:m]
     return {"workload": "Zl.Higher.uncompress on ONE zlib stream of 64 MiB of seeded word text (level 6, %d bytes), pinned host buffers in and out" % len(z),
             "ms": round(best, 3), "mib_per_s": round(n / 2**20 / (best * 1e-3), 1), "pieces": v & 0xffffff, "decode_rounds": v >> 24,

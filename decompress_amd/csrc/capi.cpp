@@ -130,7 +130,7 @@ struct md_ctx {
   // way, 0 = never) and "inflate_parallel_chunk" (compressed bytes per piece)
   void *par_in = nullptr, *par_out = nullptr, *par_win = nullptr, *par_desc = nullptr;
   size_t par_in_bytes = 0, par_out_bytes = 0, par_win_bytes = 0, par_desc_bytes = 0;
-  size_t par_min = (size_t)512 << 10, par_chunk = (size_t)64 << 10;
+  size_t par_min = (size_t)96 << 10, par_chunk = (size_t)64 << 10;  // (measured: the pieces pay from ~100 KB of input, ~1 ms flat up to 4 MiB of text)
   int par_last_pieces = 0, par_last_rounds = 0;  // of the last stream that went this way (md_get_option, tests)
   int host_slices_max = 16;  // md_set_option "host_pipeline_slices": 1 = copy-in / kernels / copy-out one after the other
   std::string err;
@@ -699,7 +699,10 @@ int md_inflate_batch_host(md_ctx *ctx, int format, size_t n, const uint8_t *h_in
   // them, go through the batch as before.
   if (ctx->par_min && n <= 64) {
     std::vector<size_t> shorts, longs;
-    for (size_t i = 0; i < n; i++) (in_len[i] >= ctx->par_min ? longs : shorts).push_back(i);
+    // (each long stream is a call of ~1 ms at least, one after the other, where the batch kernel takes all n at once at ~0.2
+    // GiB/s each: worth it from ~128 KiB of input per stream of the batch)
+    const uint64_t long_from = ctx->par_min > n * ((uint64_t)128 << 10) ? ctx->par_min : n * ((uint64_t)128 << 10);
+    for (size_t i = 0; i < n; i++) (in_len[i] >= long_from ? longs : shorts).push_back(i);
     if (!longs.empty()) {
       const size_t keep = ctx->par_min;
       // a batch of picked streams through this same entry point, the long-stream path switched off
@@ -1933,7 +1936,11 @@ static int par_decode(md_ctx *ctx, const ParIn &in, ParOut *out) {
   const uint8_t *body = in.body;
   const uint64_t body_len = in.body_len, dst_cap = in.dst_cap;
   const uint32_t hl = in.hist_len;
-  const uint64_t K = ctx->par_chunk;
+  // pieces of "inflate_parallel_chunk" (64 KiB) of input - smaller ones for a smaller stream, so that it still comes in a few
+  // hundred pieces (a piece is a serial decode: 880 KB of 40-byte flush units in 14 pieces took 36 ms), never under 4 KiB
+  uint64_t K = ctx->par_chunk;
+  if (in.body_len / 256 < K) K = (in.body_len / 256 + 4095) & ~(uint64_t)4095;
+  if (K < 4096) K = 4096;
   if (body_len < 4 * K || body_len > ((uint64_t)1 << 31) || hl + dst_cap > MD_MAX_STREAM) return kNotHandled;
   const uint32_t nchunks = (uint32_t)((body_len + K - 1) / K);
   hipStream_t st = ctx->stream;

@@ -60,6 +60,7 @@ class Engine:
         if not torch.cuda.is_available():
             raise Error("decompress_amd needs a HIP device (no CPU fallback)")
         self.device = torch.device("cuda", device)
+        self.own_stream = bool(own_stream)
         if own_stream:
             handle = None
         else:
@@ -274,8 +275,10 @@ class Engine:
         d_in = torch.from_numpy(blob).to(dev)
         d_out = torch.zeros(int(out_off[-1] + cap[-1]) + 16, dtype=torch.uint8, device=dev)
         t = lambda a: torch.from_numpy(a).to(dev)
-        out_len, consumed, status, checksum = self.inflate_batch(
-            fmt, d_in, t(in_off), t(in_len), d_out, t(out_off), t(cap))
+        args = (fmt, d_in, t(in_off), t(in_len), d_out, t(out_off), t(cap))
+        if self.own_stream:  # torch's fills and copies above ran on ITS stream: they come first (the caller synchronises, i.e. we)
+            torch.cuda.synchronize(dev)
+        out_len, consumed, status, checksum = self.inflate_batch(*args)
         torch.cuda.synchronize(dev)
         out = d_out.cpu().numpy()
         out_len, consumed, status = out_len.cpu().numpy(), consumed.cpu().numpy(), status.cpu().numpy()
@@ -328,7 +331,10 @@ class Engine:
         d_in = torch.from_numpy(blob).to(dev)
         d_out = torch.zeros(int(out_off[-1] + cap[-1]) + 16, dtype=torch.uint8, device=dev)
         t = lambda a: torch.from_numpy(a).to(dev)
-        out_len, status, checksum = self.deflate_batch(fmt, d_in, t(in_off), t(in_len), d_out, t(out_off), t(cap),
+        d_off, d_len, d_ooff, d_cap = t(in_off), t(in_len), t(out_off), t(cap)
+        if self.own_stream:
+            torch.cuda.synchronize(dev)
+        out_len, status, checksum = self.deflate_batch(fmt, d_in, d_off, d_len, d_out, d_ooff, d_cap,
                                                        level, queue, driver, dynamic, matcher=matcher, header=header,
                                                        total_in=max(1, int(in_len.sum())))
         torch.cuda.synchronize(dev)

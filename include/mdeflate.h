@@ -160,7 +160,7 @@ int md_synchronize(md_ctx *ctx);
  *   "host_pipeline_slices"       1 .. 64 (default 16): most slices of streams a md_*_batch_host call cuts a batch into so that
  *                                its copies overlap with its kernels (1: copy-in, kernels, copy-out one after the other).
  *   "inflate_waves"              1 or 2 (default): wavefronts per stream of the inflate kernel (2 = decoder + copier).
- *   "inflate_parallel_min"       KiB (default 512; 0 = never): a SINGLE stream handed to md_*_inf_ns_inflate /
+ *   "inflate_parallel_min"       KiB (default 96; 0 = never): a SINGLE stream handed to md_*_inf_ns_inflate /
  *                                md_*_higher_uncompress with at least this much compressed input is decoded in pieces by the
  *                                whole device (csrc/inflate_chunked.hip: candidate block starts, every piece decoded twice
  *                                with placeholder windows by the batch kernel, windows resolved afterwards, checksum verified)

@@ -328,7 +328,7 @@ def test_one_long_stream_by_the_whole_chip(eng):
         want = [_higher(eng, "zlns", c, cap) for c, cap in cases]
         assert _par_last(eng)[0] == 0
     finally:
-        eng.set_option("inflate_parallel_min", 512)
+        eng.set_option("inflate_parallel_min", 96)
     assert [g[:2] for g in got] == [w[:2] for w in want] and [g[0] for g in got] == [9, 1, 2, 0]
     assert got[3][2] == data and got[3][1] == len(z)
 
@@ -363,7 +363,7 @@ def test_long_pieces_of_the_decode_protocol(eng):
         want = {k: (de.Inf.decode_chunks([v], o_len=65536, fmt=decompress_amd.FORMAT_ZLIB)[:2],
                     de.Inf.decode_chunks(steps(v), o_len=65536, fmt=decompress_amd.FORMAT_ZLIB, chunk_bytes=3 << 20)[:2]) for k, v in feeds.items()}
     finally:
-        eng.set_option("inflate_parallel_min", 512)
+        eng.set_option("inflate_parallel_min", 96)
     for k, v in feeds.items():
         got = (de.Inf.decode_chunks([v], o_len=65536, fmt=decompress_amd.FORMAT_ZLIB)[:2],
                de.Inf.decode_chunks(steps(v), o_len=65536, fmt=decompress_amd.FORMAT_ZLIB, chunk_bytes=3 << 20)[:2])
@@ -396,7 +396,7 @@ def test_a_few_long_streams_in_one_host_batch(eng, oracle):
         h_out[:] = 0
         r = eng.inflate_batch_host(decompress_amd.FORMAT_ZLIB, h_in, in_off, in_len, h_out, out_off, cap)
         got[par] = ([a.copy() for a in r], [h_out[int(out_off[i]):int(out_off[i]) + int(r[0][i])].tobytes() for i in range(n)], _par_last(eng)[0])
-    eng.set_option("inflate_parallel_min", 512)
+    eng.set_option("inflate_parallel_min", 96)
     assert got[512][2] > 100 and got[0][2] == 0
     out_len, consumed, status, checksum = got[512][0]
     assert list(status) == list(got[0][0][2]) == [0, 0, 0, 0, 0, 1, 9]

@@ -43,7 +43,7 @@ z = zlib.compress(data, 6)
 print("text %d MiB -> %d bytes" % (mib, len(z)))
 eng.set_option("inflate_parallel_min", 0)
 run("zl serial (one pair of waves)", "zl", z[:len(z)], data) if mib <= 16 else None
-eng.set_option("inflate_parallel_min", 512)
+eng.set_option("inflate_parallel_min", 96)
 run("zl parallel", "zl", z, data)
 run("zl.ns parallel", "zlns", z, data)
 co = zlib.compressobj(6, zlib.DEFLATED, -15)
