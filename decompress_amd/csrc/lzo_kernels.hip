@@ -565,18 +565,39 @@ struct Cmp {
   // the byte at op - 2 when it is the second-to-last byte of the latest match (record_literals /
   // record_trailer OR the literal count into its two low bits, lib/lzo.ml:509, :548)
   uint32_t patch;
+  // The last bytes of the latest match (its offset bytes, and its marker when that is one byte) wait HERE until the run
+  // of literals behind it is known: the count of a short run goes into the second-to-last of them, and then they leave
+  // with one store (lane k takes byte k) instead of a byte store each and another one for the count.  `op` has them
+  // counted already.
+  uint32_t pend, pend_n, pend_pos;
 };
 __device__ __forceinline__ void c_set(Cmp &c, uint32_t pos, uint32_t b) {  // wave-uniform byte store
   if (pos >= c.cap) c.oob = true;
   else if (c.lane == 0) c.dst[pos] = (uint8_t)b;
 }
+__device__ __forceinline__ void flush_pending(Cmp &c) {
+  if (c.pend_n == 0) return;
+  if (c.pend_pos + c.pend_n > c.cap) c.oob = true;
+  if (c.lane < c.pend_n && c.pend_pos + c.lane < c.cap) c.dst[c.pend_pos + c.lane] = (uint8_t)(c.pend >> (8 * c.lane));
+  c.pend_n = 0;
+}
+// the count of a run of 1..3 literals goes into the latest match (lib/lzo.ml:509, :548)
+__device__ __forceinline__ void patch_pending(Cmp &c, uint32_t len) {
+  if (c.pend_n) c.pend |= len << (8 * (c.pend_n - 2));
+  else if (c.op < 2) c.oob = true;
+  else c_set(c, c.op - 2, c.patch | len);
+}
 // blit in_data off out_data op len (lib/lzo.ml:81-89) — `room` bytes must fit both buffers, `len`
 // of them are kept (the reference copies 4 / 16 bytes for short runs and overwrites the excess)
-__device__ __forceinline__ void c_blit(Cmp &c, uint32_t off, uint32_t len, uint32_t room) {
+__device__ __forceinline__ bool blit_fits(Cmp &c, uint32_t off, uint32_t room) {
   if (off > c.n || room > c.n - off || c.op > c.cap || room > c.cap - c.op) {
     c.oob = true;
-    return;
+    return false;
   }
+  return true;
+}
+__device__ __forceinline__ void c_blit(Cmp &c, uint32_t off, uint32_t len, uint32_t room) {
+  if (!blit_fits(c, off, room)) return;
   for (uint32_t k = c.lane; k < len; k += kWave) c.dst[c.op + k] = c.src[off + k];
 }
 __device__ __forceinline__ void long_run(Cmp &c, uint32_t len) {  // 19+ literals: 0, 0..., rest
@@ -592,13 +613,15 @@ __device__ __forceinline__ void long_run(Cmp &c, uint32_t len) {  // 19+ literal
 __device__ __forceinline__ void record_literals(Cmp &c, uint32_t off, uint32_t len) {
   if (len == 0) return;
   if (len <= 3) {
-    if (c.op < 2) c.oob = true;
-    else c_set(c, c.op - 2, c.patch | len);
+    patch_pending(c, len);
+    flush_pending(c);
     c_blit(c, off, len, 4);
   } else if (len <= 16) {
+    flush_pending(c);
     c_set(c, c.op++, len - 3);
     c_blit(c, off, len, 16);
   } else {
+    flush_pending(c);
     if (len <= 18) c_set(c, c.op++, len - 3);
     else long_run(c, len);
     c_blit(c, off, len, len);
@@ -607,11 +630,14 @@ __device__ __forceinline__ void record_literals(Cmp &c, uint32_t off, uint32_t l
 }
 // record_match, lib/lzo.ml:443-500
 __device__ __forceinline__ void record_match(Cmp &c, uint32_t off, uint32_t len) {
+  flush_pending(c);
   if (len <= 8 && off <= 0x0800) {
     off -= 1;
     c.patch = ((len - 1) << 5) | ((off & 7) << 2);
-    c_set(c, c.op++, c.patch);
-    c_set(c, c.op++, off >> 3);
+    c.pend = c.patch | ((off >> 3) << 8);
+    c.pend_n = 2;
+    c.pend_pos = c.op;
+    c.op += 2;
     return;
   }
   uint32_t marker, maxl;
@@ -624,8 +650,11 @@ __device__ __forceinline__ void record_match(Cmp &c, uint32_t off, uint32_t len)
     marker = 16 | ((off >> 11) & 8);
     maxl = 9;
   }
-  if (len <= maxl) c_set(c, c.op++, marker | (len - 2));
-  else {
+  uint32_t head = 0, head_n = 0;
+  if (len <= maxl) {
+    head = marker | (len - 2);
+    head_n = 1;
+  } else {
     uint32_t l = len - maxl;
     c_set(c, c.op++, marker);
     while (l > 255) {
@@ -635,24 +664,140 @@ __device__ __forceinline__ void record_match(Cmp &c, uint32_t off, uint32_t len)
     c_set(c, c.op++, l);
   }
   c.patch = (off << 2) & 0xff;
-  c_set(c, c.op++, c.patch);
-  c_set(c, c.op++, (off >> 6) & 0xff);
+  c.pend = head | (((off << 2) & 0xff) << (8 * head_n)) | (((off >> 6) & 0xff) << (8 * head_n + 8));
+  c.pend_n = head_n + 2;
+  c.pend_pos = c.op;
+  c.op += head_n + 2;
 }
 // record_trailer, lib/lzo.ml:540-576
 __device__ __forceinline__ void record_trailer(Cmp &c, uint32_t off, uint32_t len) {
   if (len > 0) {
     if (c.op == 0 && len < 238) c_set(c, c.op++, 17 + len);
-    else if (len <= 3) {
-      if (c.op < 2) c.oob = true;
-      else c_set(c, c.op - 2, c.patch | len);
-    } else if (len <= 18) c_set(c, c.op++, len - 3);
-    else long_run(c, len);
+    else if (len <= 3) patch_pending(c, len);
+    else {
+      flush_pending(c);
+      if (len <= 18) c_set(c, c.op++, len - 3);
+      else long_run(c, len);
+    }
+    flush_pending(c);
     c_blit(c, off, len, len);
   }
+  flush_pending(c);
   c.op += len;
   c_set(c, c.op++, 16 | 1);
   c_set(c, c.op++, 0);
   c_set(c, c.op++, 0);
+}
+
+struct CSmem {
+  alignas(16) uint8_t in[kInRing + 32];  // the input around the probe position (InRing)
+  uint8_t tbl[1024];                     // which lane probed a dictionary slot in this step
+};
+constexpr uint32_t kFirstProbes = 8;  // probes taken in the step right behind a match
+
+// The step right behind a match (`next:` of lib/lzo.ml:596-640 with idx0 = idx1).  In text the next match starts a few
+// bytes on (C5's text: 2.6 literals between matches, matches of 6.7 bytes), so this step decides the kernel.  It takes
+// kFirstProbes positions and keeps every dependent memory round trip off the chain that it can:
+//   * the bytes at the probe positions, and the 8 behind them, come from the input ring in LDS;
+//   * a lane reads 12 bytes at its reference, not 4: a match shorter than 12 needs no second look at memory;
+//   * the literals between two matches are the low bytes of the lanes in front of the hit;
+//   * two lanes on one dictionary slot (then the later one's reference is the earlier lane, not the dictionary's entry)
+//     are looked for with one byte store and load per lane in a small table in LDS; if there are any in front of the hit
+//     - or a false alarm of the table - the step is the general one's.
+// Returns 0: done, go on at `first`; 1: the chunk ends (*ret); 2: nothing done, take the general step.
+__device__ __forceinline__ int first_step(Cmp &c, InRing &ring, lds_u8 *tbl, uint16_t *dict, uint32_t in_pos, uint32_t in_len,
+                                          uint32_t idx_end, uint32_t &first, uint32_t &idx1, uint32_t *ret) {
+  const uint32_t lane = c.lane;
+  const uint32_t room = first - in_pos < idx_end ? idx_end - (first - in_pos) : 0u;
+  const uint32_t nvalid = room < kFirstProbes ? room : kFirstProbes;
+  if (nvalid == 0) {
+    *ret = in_len - (idx1 - in_pos);
+    return 1;
+  }
+  ring.ensure(first);
+  const bool valid = lane < nvalid;
+  const uint32_t mine = first + lane;
+  uint32_t w0 = 0, w1 = 0, w2 = 0, r0 = 0, r1 = 0, r2 = 0, ref = 0, index = 0, back = lane;
+  if (valid) {
+    const lds_u8 *q = ring.at(mine);
+    w0 = *reinterpret_cast<const MD_LDS wv::u32_u *>(q);
+    w1 = *reinterpret_cast<const MD_LDS wv::u32_u *>(q + 4);
+    w2 = *reinterpret_cast<const MD_LDS wv::u32_u *>(q + 8);
+    index = ((uint32_t)(0x1824429du * w0) >> 18) & 0x3fff;
+    ref = (uint32_t)__builtin_nontemporal_load(dict + index) + in_pos;
+    volatile lds_u8 *slot = tbl + (index & 1023u);  // (volatile: what comes back is the LAST lane's, not this one's)
+    *slot = (uint8_t)lane;
+    // (a reference lies in front of its probe, and a probe 20 bytes in front of the chunk's end: 12 bytes are there)
+    uint32_t r[3];
+    __builtin_memcpy(r, c.src + ref, 12);
+    r0 = r[0], r1 = r[1], r2 = r[2];
+    back = *slot;
+  }
+  const uint64_t hit = __ballot(valid && r0 == w0);
+  const uint64_t dup = __ballot(back != lane);
+  const uint32_t stop = hit ? (uint32_t)__builtin_ctzll(hit) : nvalid - 1;
+  if (dup & ((2ull << stop) - 1)) return 2;
+  if (valid && lane <= stop) dict[index] = (uint16_t)(mine - in_pos);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (!hit) {
+    first += nvalid;
+    return 0;
+  }
+  // ---- stop literals (record_literals, lib/lzo.ml:502-538), with the waiting bytes of the match in front of them
+  if (stop != 0) {
+    bool fits;
+    if (stop <= 3) {
+      patch_pending(c, stop);
+      fits = blit_fits(c, idx1, 4);
+    } else {
+      if (c.pend_n) {
+        c.pend |= (stop - 3) << (8 * c.pend_n);
+        c.pend_n++;
+      } else {
+        c.pend = stop - 3, c.pend_n = 1, c.pend_pos = c.op;
+      }
+      c.op++;
+      fits = blit_fits(c, idx1, 16);
+    }
+    flush_pending(c);
+    if (fits && lane < stop) c.dst[c.op + lane] = (uint8_t)w0;
+    c.op += stop;
+  }
+  // ---- the match: 4 bytes are known to agree, the next 8 are in the registers of lane `stop`
+  const uint64_t x = (((uint64_t)w2 << 32) | w1) ^ (((uint64_t)r2 << 32) | r1);
+  const bool more = x == 0 && mine + 4 - in_pos < idx_end;
+  const uint32_t short_len = 4 + (x ? (uint32_t)__builtin_ctzll(x) >> 3 : 0u);
+  const uint32_t idx0 = first + stop;
+  const uint32_t mref = rdl(ref, stop);
+  uint32_t len = rdl(short_len, stop);
+  if (rdl(more ? 1u : 0u, stop)) {
+    len = 12;
+    for (;;) {  // 8 bytes per lane; the loop of lib/lzo.ml:616-621 stops at the first lane that fails
+      const uint32_t o = len + 8 * lane;
+      const bool inb = idx0 + o + 8 <= c.n;
+      uint64_t a = 0, b = 0;
+      if (inb) {
+        __builtin_memcpy(&a, c.src + idx0 + o, 8);
+        __builtin_memcpy(&b, c.src + mref + o, 8);
+      }
+      const bool go = idx0 + o - in_pos < idx_end && inb && a == b;
+      const uint64_t fm = __ballot(!go);
+      if (fm == 0) {
+        len += 8 * kWave;
+        continue;
+      }
+      const uint32_t L = (uint32_t)__builtin_ctzll(fm);
+      len += 8 * L;
+      const uint64_t y = a ^ b;
+      const uint32_t extra = (inb && y) ? (uint32_t)__builtin_ctzll(y) >> 3 : 0u;
+      if (idx0 + len - in_pos < in_len) len += (uint32_t)__shfl((int)extra, (int)L);
+      break;
+    }
+  }
+  record_match(c, idx0 - mref, len);
+  first = idx0 + len;
+  idx1 = first;
+  return 0;
 }
 
 // One 48 KiB chunk (lib/lzo.ml:578-640).  The probe positions of a literal run are known in advance
@@ -661,12 +806,19 @@ __device__ __forceinline__ void record_trailer(Cmp &c, uint32_t off, uint32_t le
 // the step with the same hash or else the LDS entry, and the first lane whose 4 bytes agree with its
 // reference is where the serial loop finds its match; the lanes up to it enter the dictionary in
 // order.  After a match the next probe is the match end itself (`goto next`).
-__device__ __forceinline__ uint32_t compress_chunk(Cmp &c, uint16_t *dict, uint32_t in_pos, uint32_t in_len, uint32_t t) {
+__device__ __forceinline__ uint32_t compress_chunk(Cmp &c, InRing &ring, lds_u8 *tbl, uint16_t *dict, uint32_t in_pos, uint32_t in_len,
+                                                uint32_t t) {
   const uint32_t idx_end = in_len > 20 ? in_len - 20 : 0, lane = c.lane;
   uint32_t idx1 = in_pos;
   uint32_t first = in_pos + (t < 4 ? 4 - t : 0);
   first += 1 + ((first - idx1) >> 5);
   for (;;) {
+    if (first == idx1) {  // right behind a match (t is 0 then)
+      uint32_t ret = 0;
+      const int how = first_step(c, ring, tbl, dict, in_pos, in_len, idx_end, first, idx1, &ret);
+      if (how == 0) continue;
+      if (how == 1) return ret;
+    }
     // ---- the next probe positions of this run (wave-uniform recurrence, lane j keeps p_j)
     uint32_t p = first, mine = 0, nvalid = 0;
     if (first - idx1 < 24u) {
@@ -756,12 +908,14 @@ __device__ __forceinline__ uint32_t compress_chunk(Cmp &c, uint16_t *dict, uint3
   }
 }
 
-__global__ __launch_bounds__(kWave, 8) void lzo_compress_kernel(
+__global__ __launch_bounds__(kWave, 6) void lzo_compress_kernel(
     uint32_t n, const uint8_t *__restrict__ in, const uint64_t *__restrict__ in_off,
     const uint64_t *__restrict__ in_len, uint8_t *__restrict__ out, const uint64_t *__restrict__ out_off,
     const uint64_t *__restrict__ out_cap, uint64_t *__restrict__ out_len, int32_t *__restrict__ status,
     uint16_t *__restrict__ ws_dict, uint32_t *counter) {
   const uint32_t lane = threadIdx.x;
+  __shared__ CSmem smem;
+  CSmem MD_LDS *sm = (CSmem MD_LDS *)&smem;
   // make_wrkmem (lib/lzo.ml:645-646): 16 K u16 entries per (persistent) workgroup in an HBM workspace — in LDS the
   // 32 KiB would hold residency to 5 wavefronts per CU, and the probe loop lives on occupancy
   uint16_t *dict = ws_dict + (size_t)blockIdx.x * (1u << 14);
@@ -785,6 +939,14 @@ __global__ __launch_bounds__(kWave, 8) void lzo_compress_kernel(
     c.op = 0;
     c.oob = false;
     c.patch = 0;
+    c.pend = 0, c.pend_n = 0, c.pend_pos = 0;
+    InRing ring;
+    ring.ring = sm->in;
+    ring.src = c.src;
+    ring.n = c.n;
+    ring.lane = lane;
+    ring.lo = 0xfffffff0u;
+    ring.ahead = make_uint4(0, 0, 0, 0);
     // Lzo.compress, lib/lzo.ml:648-660
     uint32_t idx = 0, len = c.n, t = 0;
     while (len > 20) {
@@ -792,7 +954,7 @@ __global__ __launch_bounds__(kWave, 8) void lzo_compress_kernel(
       if (((t + ll) >> 5) == 0) break;
       for (uint32_t i = lane; i < (1u << 11); i += kWave) reinterpret_cast<uint4 *>(dict)[i] = make_uint4(0, 0, 0, 0);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      t = compress_chunk(c, dict, idx, ll, t);
+      t = compress_chunk(c, ring, sm->tbl, dict, idx, ll, t);
       idx += ll;
       len -= ll;
     }
