@@ -590,7 +590,9 @@ __device__ __forceinline__ void patch_pending(Cmp &c, uint32_t len) {
 // blit in_data off out_data op len (lib/lzo.ml:81-89) — `room` bytes must fit both buffers, `len`
 // of them are kept (the reference copies 4 / 16 bytes for short runs and overwrites the excess)
 __device__ __forceinline__ bool blit_fits(Cmp &c, uint32_t off, uint32_t room) {
-  if (off > c.n || room > c.n - off || c.op > c.cap || room > c.cap - c.op) {
+  // (room >= 1 at every call; written without a borrow so that it stays on the scalar unit)
+  const uint32_t in_left = c.n > off ? c.n - off : 0u, out_left = c.cap > c.op ? c.cap - c.op : 0u;
+  if (room > in_left || room > out_left) {
     c.oob = true;
     return false;
   }
@@ -598,6 +600,7 @@ __device__ __forceinline__ bool blit_fits(Cmp &c, uint32_t off, uint32_t room) {
 }
 __device__ __forceinline__ void c_blit(Cmp &c, uint32_t off, uint32_t len, uint32_t room) {
   if (!blit_fits(c, off, room)) return;
+#pragma clang loop vectorize(disable) unroll(disable)
   for (uint32_t k = c.lane; k < len; k += kWave) c.dst[c.op + k] = c.src[off + k];
 }
 __device__ __forceinline__ void long_run(Cmp &c, uint32_t len) {  // 19+ literals: 0, 0..., rest
@@ -693,44 +696,53 @@ struct CSmem {
   alignas(16) uint8_t in[kInRing + 32];  // the input around the probe position (InRing)
   uint8_t tbl[1024];                     // which lane probed a dictionary slot in this step
 };
-constexpr uint32_t kFirstProbes = 8;  // probes taken in the step right behind a match
+#ifndef MD_LZO_FIRST
+#define MD_LZO_FIRST 8
+#endif
+#ifndef MD_LZO_C_WAVES
+#define MD_LZO_C_WAVES 6
+#endif
+constexpr uint32_t kFirstProbes = MD_LZO_FIRST;  // probes taken in the step right behind a match
 
-// The step right behind a match (`next:` of lib/lzo.ml:596-640 with idx0 = idx1).  In text the next match starts a few
-// bytes on (C5's text: 2.6 literals between matches, matches of 6.7 bytes), so this step decides the kernel.  It takes
-// kFirstProbes positions and keeps every dependent memory round trip off the chain that it can:
-//   * the bytes at the probe positions, and the 8 behind them, come from the input ring in LDS;
-//   * a lane reads 12 bytes at its reference, not 4: a match shorter than 12 needs no second look at memory;
-//   * the literals between two matches are the low bytes of the lanes in front of the hit;
+// The steps right behind a match (`next:` / `literal:` of lib/lzo.ml:596-640 while the stride is still 1, that is up to 32
+// bytes behind the match).  In text the next match starts a few bytes on (C5's text: 48 % of the matches at once, 89 %
+// within 8 bytes, 98 % within 16; 2.6 literals between matches, matches of 6.7 bytes), so this step decides the kernel.  It
+// takes kFirstProbes positions and keeps every dependent memory round trip off the chain that it can:
+//   * the bytes at the probe positions, and the 12 behind them, come from the input ring in LDS;
+//   * a lane reads 16 bytes at its reference, not 4: a match shorter than 16 (99 %) needs no second look at memory;
+//   * right behind a match the literals up to the next one are the low bytes of the lanes in front of the hit;
 //   * two lanes on one dictionary slot (then the later one's reference is the earlier lane, not the dictionary's entry)
 //     are looked for with one byte store and load per lane in a small table in LDS; if there are any in front of the hit
 //     - or a false alarm of the table - the step is the general one's.
 // Returns 0: done, go on at `first`; 1: the chunk ends (*ret); 2: nothing done, take the general step.
-__device__ __forceinline__ int first_step(Cmp &c, InRing &ring, lds_u8 *tbl, uint16_t *dict, uint32_t in_pos, uint32_t in_len,
-                                          uint32_t idx_end, uint32_t &first, uint32_t &idx1, uint32_t *ret) {
+__device__ __forceinline__ int near_step(Cmp &c, InRing &ring, lds_u8 *tbl, uint16_t *dict, uint32_t in_pos, uint32_t in_len,
+                                         uint32_t idx_end, uint32_t &first, uint32_t &idx1, uint32_t &t, uint32_t *ret) {
   const uint32_t lane = c.lane;
   const uint32_t room = first - in_pos < idx_end ? idx_end - (first - in_pos) : 0u;
   const uint32_t nvalid = room < kFirstProbes ? room : kFirstProbes;
   if (nvalid == 0) {
+    idx1 -= t;
     *ret = in_len - (idx1 - in_pos);
     return 1;
   }
   ring.ensure(first);
   const bool valid = lane < nvalid;
   const uint32_t mine = first + lane;
-  uint32_t w0 = 0, w1 = 0, w2 = 0, r0 = 0, r1 = 0, r2 = 0, ref = 0, index = 0, back = lane;
+  uint32_t w0 = 0, x1 = 0, x2 = 0, x3 = 0, r0 = 0, ref = 0, index = 0, back = lane;
   if (valid) {
     const lds_u8 *q = ring.at(mine);
     w0 = *reinterpret_cast<const MD_LDS wv::u32_u *>(q);
-    w1 = *reinterpret_cast<const MD_LDS wv::u32_u *>(q + 4);
-    w2 = *reinterpret_cast<const MD_LDS wv::u32_u *>(q + 8);
     index = ((uint32_t)(0x1824429du * w0) >> 18) & 0x3fff;
     ref = (uint32_t)__builtin_nontemporal_load(dict + index) + in_pos;
     volatile lds_u8 *slot = tbl + (index & 1023u);  // (volatile: what comes back is the LAST lane's, not this one's)
     *slot = (uint8_t)lane;
-    // (a reference lies in front of its probe, and a probe 20 bytes in front of the chunk's end: 12 bytes are there)
-    uint32_t r[3];
-    __builtin_memcpy(r, c.src + ref, 12);
-    r0 = r[0], r1 = r[1], r2 = r[2];
+    // (a reference lies in front of its probe, and a probe 20 bytes in front of the chunk's end: 16 bytes are there)
+    uint32_t r[4];
+    __builtin_memcpy(r, c.src + ref, 16);
+    r0 = r[0];
+    x1 = r[1] ^ *reinterpret_cast<const MD_LDS wv::u32_u *>(q + 4);
+    x2 = r[2] ^ *reinterpret_cast<const MD_LDS wv::u32_u *>(q + 8);
+    x3 = r[3] ^ *reinterpret_cast<const MD_LDS wv::u32_u *>(q + 12);
     back = *slot;
   }
   const uint64_t hit = __ballot(valid && r0 == w0);
@@ -743,8 +755,13 @@ __device__ __forceinline__ int first_step(Cmp &c, InRing &ring, lds_u8 *tbl, uin
     first += nvalid;
     return 0;
   }
-  // ---- stop literals (record_literals, lib/lzo.ml:502-538), with the waiting bytes of the match in front of them
-  if (stop != 0) {
+  const uint32_t idx0 = first + stop;
+  if (first != idx1 || t != 0) {
+    idx1 -= t;
+    t = 0;
+    record_literals(c, idx1, idx0 - idx1);
+  } else if (stop != 0) {
+    // ---- stop literals (record_literals, lib/lzo.ml:502-538) with the waiting bytes of the match in front of them
     bool fits;
     if (stop <= 3) {
       patch_pending(c, stop);
@@ -763,16 +780,20 @@ __device__ __forceinline__ int first_step(Cmp &c, InRing &ring, lds_u8 *tbl, uin
     if (fits && lane < stop) c.dst[c.op + lane] = (uint8_t)w0;
     c.op += stop;
   }
-  // ---- the match: 4 bytes are known to agree, the next 8 are in the registers of lane `stop`
-  const uint64_t x = (((uint64_t)w2 << 32) | w1) ^ (((uint64_t)r2 << 32) | r1);
-  const bool more = x == 0 && mine + 4 - in_pos < idx_end;
-  const uint32_t short_len = 4 + (x ? (uint32_t)__builtin_ctzll(x) >> 3 : 0u);
-  const uint32_t idx0 = first + stop;
+  // ---- the match: 4 bytes are known to agree, the next 12 are compared in lane `stop` (the loop of lib/lzo.ml:616-631
+  // goes 8 bytes at a time while the probe is in front of idx_end, then counts the bytes of the next 8 that still agree)
+  const uint64_t x = ((uint64_t)x2 << 32) | x1;
+  const bool in_front = mine + 4 - in_pos < idx_end;
+  uint32_t mlen;  // bit 31: go on from 12 with memory
+  if (x) mlen = 4 + ((uint32_t)__builtin_ctzll(x) >> 3);
+  else if (!in_front) mlen = 4;
+  else if (x3) mlen = 12 + ((uint32_t)__builtin_ctz(x3) >> 3);
+  else mlen = 0x80000000u;
   const uint32_t mref = rdl(ref, stop);
-  uint32_t len = rdl(short_len, stop);
-  if (rdl(more ? 1u : 0u, stop)) {
+  uint32_t len = rdl(mlen, stop);
+  if (len >> 31) {
     len = 12;
-    for (;;) {  // 8 bytes per lane; the loop of lib/lzo.ml:616-621 stops at the first lane that fails
+    for (;;) {  // 8 bytes per lane, stops at the first lane that fails
       const uint32_t o = len + 8 * lane;
       const bool inb = idx0 + o + 8 <= c.n;
       uint64_t a = 0, b = 0;
@@ -790,7 +811,7 @@ __device__ __forceinline__ int first_step(Cmp &c, InRing &ring, lds_u8 *tbl, uin
       len += 8 * L;
       const uint64_t y = a ^ b;
       const uint32_t extra = (inb && y) ? (uint32_t)__builtin_ctzll(y) >> 3 : 0u;
-      if (idx0 + len - in_pos < in_len) len += (uint32_t)__shfl((int)extra, (int)L);
+      if (idx0 + len - in_pos < in_len) len += rdl(extra, L);
       break;
     }
   }
@@ -813,9 +834,9 @@ __device__ __forceinline__ uint32_t compress_chunk(Cmp &c, InRing &ring, lds_u8 
   uint32_t first = in_pos + (t < 4 ? 4 - t : 0);
   first += 1 + ((first - idx1) >> 5);
   for (;;) {
-    if (first == idx1) {  // right behind a match (t is 0 then)
+    if (first - idx1 <= 32u - kFirstProbes) {  // behind a match (or the chunk's start), stride 1
       uint32_t ret = 0;
-      const int how = first_step(c, ring, tbl, dict, in_pos, in_len, idx_end, first, idx1, &ret);
+      const int how = near_step(c, ring, tbl, dict, in_pos, in_len, idx_end, first, idx1, t, &ret);
       if (how == 0) continue;
       if (how == 1) return ret;
     }
@@ -874,8 +895,8 @@ __device__ __forceinline__ uint32_t compress_chunk(Cmp &c, InRing &ring, lds_u8 
       continue;
     }
     // ---- the match at lane `stop`
-    const uint32_t idx0 = (uint32_t)__shfl((int)mine, (int)stop);
-    const uint32_t mref = (uint32_t)__shfl((int)ref, (int)stop);
+    const uint32_t idx0 = rdl(mine, stop);  // (readlane: the compiler knows the result is the same in all lanes)
+    const uint32_t mref = rdl(ref, stop);
     idx1 -= t;
     t = 0;
     record_literals(c, idx1, idx0 - idx1);
@@ -899,7 +920,7 @@ __device__ __forceinline__ uint32_t compress_chunk(Cmp &c, InRing &ring, lds_u8 
       // then the bytes of the next 8 that still agree (lib/lzo.ml:624-631; ctz 0 = 0)
       const uint64_t x = a ^ b;
       const uint32_t extra = (inb && x) ? (uint32_t)__builtin_ctzll(x) >> 3 : 0u;
-      if (idx0 + len - in_pos < in_len) len += (uint32_t)__shfl((int)extra, (int)L);
+      if (idx0 + len - in_pos < in_len) len += rdl(extra, L);
       break;
     }
     record_match(c, idx0 - mref, len);
@@ -908,7 +929,7 @@ __device__ __forceinline__ uint32_t compress_chunk(Cmp &c, InRing &ring, lds_u8 
   }
 }
 
-__global__ __launch_bounds__(kWave, 6) void lzo_compress_kernel(
+__global__ __launch_bounds__(kWave, MD_LZO_C_WAVES) void lzo_compress_kernel(
     uint32_t n, const uint8_t *__restrict__ in, const uint64_t *__restrict__ in_off,
     const uint64_t *__restrict__ in_len, uint8_t *__restrict__ out, const uint64_t *__restrict__ out_off,
     const uint64_t *__restrict__ out_cap, uint64_t *__restrict__ out_len, int32_t *__restrict__ status,

@@ -38,6 +38,12 @@ def run(batches, seed, verbose=True):
                 k = rng.randrange(len(src)); src = src[:k] + bytes([rng.getrandbits(8)]) + src[k + 1:]
             cap = len(d) + rng.choice((0, 0, 0, 1, 3, 70, 5000)) if rng.random() < 0.8 else max(0, len(d) - rng.choice((1, 2, 3, 30, 1000)))
             srcs.append(src); caps.append(cap)
+        # the compressor again into room that is (mostly) too small: status and bytes = the oracle's
+        small = [max(0, len(z) - rng.choice((0, 1, 2, 3, 4, 17, 300))) if rng.random() < 0.7 else rng.randrange(0, len(z) + 1) for _, z in zs]
+        for d, cap, got in zip(datas, small, eng.lzo_many(True, datas, small)):
+            if got != orc.lzo_compress(d, cap=cap):
+                bad += 1
+                print("COMPRESS (short room) MISMATCH batch %d len %d cap %d" % (b, len(d), cap), flush=True)
         res = eng.lzo_many(False, srcs, caps)
         for src, cap, (st, out) in zip(srcs, caps, res):
             ost, oout = orc.lzo_uncompress(src, cap)
