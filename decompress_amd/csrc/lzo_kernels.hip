@@ -600,8 +600,25 @@ __device__ __forceinline__ bool blit_fits(Cmp &c, uint32_t off, uint32_t room) {
 }
 __device__ __forceinline__ void c_blit(Cmp &c, uint32_t off, uint32_t len, uint32_t room) {
   if (!blit_fits(c, off, room)) return;
+  const uint8_t *s = c.src + off;
+  uint8_t *o = c.dst + c.op;
+  if (len < 256) {
 #pragma clang loop vectorize(disable) unroll(disable)
-  for (uint32_t k = c.lane; k < len; k += kWave) c.dst[c.op + k] = c.src[off + k];
+    for (uint32_t k = c.lane; k < len; k += kWave) o[k] = s[k];
+    return;
+  }
+  // a long run (incompressible input is one run per chunk): 16 bytes per lane and step, stores on the output's alignment
+  const uint32_t head = (16u - (uint32_t)((uintptr_t)o & 15)) & 15u;
+  const uint32_t body = (len - head) & ~15u;
+  if (c.lane < head) o[c.lane] = s[c.lane];
+#pragma clang loop vectorize(disable) unroll(disable)
+  for (uint32_t k = head + c.lane * 16; k < head + body; k += kWave * 16) {
+    uint4 v;
+    __builtin_memcpy(&v, s + k, 16);
+    *reinterpret_cast<uint4 *>(o + k) = v;
+  }
+  const uint32_t k = head + body + c.lane;
+  if (k < len) o[k] = s[k];
 }
 __device__ __forceinline__ void long_run(Cmp &c, uint32_t len) {  // 19+ literals: 0, 0..., rest
   uint32_t l = len - 18;
@@ -692,6 +709,11 @@ __device__ __forceinline__ void record_trailer(Cmp &c, uint32_t off, uint32_t le
   c_set(c, c.op++, 0);
 }
 
+// A dictionary entry as it is in L2 (the wavefront's own stores are there, in order).  As a non-temporal load - the way
+// past a stale line in the CU's cache until now - the entries were also the first to leave L2: with the dictionaries of
+// 16 and more streams per CU at four times the L2 of their XCD, 63 % of all L2 requests missed (4 096 text streams: 31.1
+// ms; like this: 25.7).
+__device__ __forceinline__ uint16_t dict_ld(const uint16_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 struct CSmem {
   alignas(16) uint8_t in[kInRing + 32];  // the input around the probe position (InRing)
   uint8_t tbl[1024];                     // which lane probed a dictionary slot in this step
@@ -733,7 +755,7 @@ __device__ __forceinline__ int near_step(Cmp &c, InRing &ring, lds_u8 *tbl, uint
     const lds_u8 *q = ring.at(mine);
     w0 = *reinterpret_cast<const MD_LDS wv::u32_u *>(q);
     index = ((uint32_t)(0x1824429du * w0) >> 18) & 0x3fff;
-    ref = (uint32_t)__builtin_nontemporal_load(dict + index) + in_pos;
+    ref = (uint32_t)dict_ld(dict + index) + in_pos;
     volatile lds_u8 *slot = tbl + (index & 1023u);  // (volatile: what comes back is the LAST lane's, not this one's)
     *slot = (uint8_t)lane;
     // (a reference lies in front of its probe, and a probe 20 bytes in front of the chunk's end: 16 bytes are there)
@@ -879,7 +901,7 @@ __device__ __forceinline__ uint32_t compress_chunk(Cmp &c, InRing &ring, lds_u8 
     const uint32_t pred = (uint32_t)__shfl((int)mine, below ? 63 - (int)__builtin_clzll(below) : 0);
     uint32_t ref = 0, rv = 0;
     if (valid) {
-      ref = below ? pred : (uint32_t)__builtin_nontemporal_load(dict + index) + in_pos;
+      ref = below ? pred : (uint32_t)dict_ld(dict + index) + in_pos;
       __builtin_memcpy(&rv, c.src + ref, 4);
     }
     const uint64_t hit = __ballot(valid && rv == v);
@@ -1003,6 +1025,11 @@ extern "C" uint32_t md_lzo_slots(int compress, uint32_t cus) {
   static uint32_t per_cu[2] = {0, 0};  // (per CU: the same on every device this library runs on)
   uint32_t &v = per_cu[compress ? 1 : 0];
   if (!v) v = compress ? resident_workgroups(md::lzo::lzo_compress_kernel, 1) : resident_workgroups(md::lzo::lzo_uncompress_kernel, 1);
+  // The compressor is a chain of dependent memory round trips per stream: beyond four wavefronts per SIMD a CU gains
+  // little (32 streams per CU: +12 % over 16) and a batch loses more at its end - the last streams run alone at the
+  // slow rate, and in a mixed batch the CUs end up with unequal numbers of the expensive streams (C5: 14 to 20 text
+  // streams per CU with 28 slots, 16 each with 16: 32.0 -> 26.8 ms).
+  if (compress && v > 16) v = 16;
   return v * cus;
 }
 extern "C" int md_launch_lzo_uncompress(uint32_t n, const uint8_t *in, const uint64_t *in_off, const uint64_t *in_len,
