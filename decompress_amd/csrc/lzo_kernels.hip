@@ -11,9 +11,11 @@
 //   lzo_compress_kernel     lzo1x-1 (lib/lzo.ml:578-660): the probe loop is serial by construction
 //       (what is inserted in the dictionary depends on where the previous match ended), so it runs
 //       wave-uniformly with the 16 K-entry u16 dictionary of the current 48 KiB chunk in an HBM
-//       workspace (L2-resident; in LDS it would cap residency at 5 wavefronts per CU); match
-//       extension compares 8 bytes per lane (512 per step), literal runs and the trailer are
-//       coalesced copies.
+//       workspace (in LDS it would cap residency at 5 wavefronts per CU); match extension
+//       compares 8 bytes per lane (512 per step), literal runs and the trailer are coalesced
+//       copies.  Within 32 bytes of a match - where text spends its time - the step is near_step:
+//       8 probes from an input ring in LDS, 16 bytes at the reference, the match's last bytes
+//       held back for the count of the literals behind it.
 // Semantics, error cases and quirks are those of the reference as restated in oracle/lzo.c
 // (the decoder state after a literal run behaves as 3, the EOI guard on every instruction, the
 // `< 238` first-byte form, the match extension that stops 20 bytes before the end of a chunk).
