@@ -325,7 +325,9 @@ __device__ __forceinline__ uint32_t pack_ins(uint32_t b, uint32_t p, uint32_t n)
   const bool inside = p < n && p + r.k < n && p + r.k + r.lit <= n;
   // a run of literals leaves the state -1 (not zero), a match the number of its literals (lib/lzo.ml:283-288, :322-336)
   const bool next_zero = r.mlen != 0 && r.lit == 0;
-  return (r.k + r.lit) | ((r.mlen + r.lit) << 10) | ((r.exotic || !inside) ? kExotic : 0u) | (next_zero ? kNextZero : 0u);
+  // (not for the fast path: it "advances" out of the window, so that the walk needs no test of its own for it)
+  if (r.exotic || !inside) return 64u | kExotic;
+  return (r.k + r.lit) | ((r.mlen + r.lit) << 10) | (next_zero ? kNextZero : 0u);
 }
 
 __device__ __forceinline__ int uncompress_stream(Dec &d, LSmem MD_LDS *sm) {
@@ -373,25 +375,27 @@ __device__ __forceinline__ int uncompress_stream(Dec &d, LSmem MD_LDS *sm) {
         const uint32_t p = base + lane;
         const uint32_t b = *reinterpret_cast<const MD_LDS wv::u32_u *>(ir.at(p));
         const uint32_t wz = pack_ins<true>(b, p, n), wn = pack_ins<false>(b, p, n);
-        // walk (wave-uniform)
-        uint32_t cur = 0, zero = (d.state & 3) == 0 ? 1u : 0u, wsum = 0;
+        // walk (wave-uniform): a dozen scalar instructions per instruction - the two ways out of the fast path are not
+        // tested here: an instruction that is not for the fast path leaves the window by itself (pack_ins) and is looked
+        // at after the loop, a batch that is full is cut where the places are known (the walk is the stream's own chain:
+        // with both tests, and what the compiler made of the three exits, it was 30)
+        uint32_t cur = 0, zero = (d.state & 3) == 0 ? 1u : 0u, last = 0, zlast = zero, wd = 0;
         uint64_t taken = 0, zmask = 0;
-        while (cur < 64) {
-          const uint32_t wd = zero ? rdl(wz, cur) : rdl(wn, cur);
-          if (wd & kExotic) {
-            slow = true;
-            break;
-          }
-          const uint32_t ob = (wd >> 10) & 1023;
-          if (osum + wsum + ob > kBatchMax) {
-            more = false;  // the batch is full: the next one starts here
-            break;
-          }
+        do {
+          const uint32_t a = rdl(wz, cur), c = rdl(wn, cur);
+          wd = zero ? a : c;
           taken |= 1ull << cur;
           zmask |= (uint64_t)zero << cur;
-          wsum += ob;
+          last = cur;
+          zlast = zero;
           cur += wd & 1023;
           zero = (wd >> 21) & 1;
+        } while (cur < 64);
+        if (wd & kExotic) {  // the slow path's: the batch ends in front of it
+          taken &= ~(1ull << last);
+          cur = last;
+          zero = zlast;
+          slow = true;
         }
         // the marked lanes: their instruction, their place in the output
         bool mine = (taken >> lane) & 1;
@@ -400,17 +404,24 @@ __device__ __forceinline__ int uncompress_stream(Dec &d, LSmem MD_LDS *sm) {
         const uint32_t k = mz ? rz.k : rn.k, off = mz ? rz.off : rn.off, mlen = mz ? rz.mlen : rn.mlen, lit = mz ? rz.lit : rn.lit;
         const uint32_t orel = osum + wv::wave_excl_scan(mine ? mlen + lit : 0u, lane);
         const uint32_t oabs = o0 + orel;
-        {  // what does not fit the output is the slow path's (it fails there, with the reference's error)
+        {  // the batch is full: the next one starts at that instruction.  What does not fit the output is the slow path's
+           // (it fails there, with the reference's error).  Whichever comes first.
+          const uint64_t full = __ballot(mine && orel + mlen + lit > kBatchMax);
           const uint64_t bad = __ballot(mine && ((mlen != 0 && off > oabs) || mlen + lit > d.cap - oabs || oabs > d.cap));
-          if (bad) {
-            const uint32_t fb = (uint32_t)__builtin_ctzll(bad);
+          if (full | bad) {
+            const uint32_t fb = (uint32_t)__builtin_ctzll(full | bad);
             taken &= (1ull << fb) - 1;
             mine = (taken >> lane) & 1;
-            wsum = rdl(orel, fb) - osum;
             cur = fb;
             zero = (uint32_t)((zmask >> fb) & 1);
-            slow = true;
+            slow = ((bad >> fb) & 1) && !((full >> fb) & 1);
+            if (!slow) more = false;
           }
+        }
+        uint32_t wsum = 0;
+        if (taken) {
+          const uint32_t lt = 63u - (uint32_t)__builtin_clzll(taken);
+          wsum = rdl(orel + mlen + lit, lt) - osum;
         }
         const uint32_t sidx = oabs - rb;  // staging index of this lane's first byte
         if (taken) {  // literals: input window -> staging
