@@ -70,6 +70,10 @@ struct Dec {
   uint8_t *dst;
   uint32_t cap, i_pos, o_pos, lane;
   int state;
+#ifdef MD_LZO_PROF
+  uint32_t prof[4];
+  uint64_t prof_t;
+#endif
 };
 
 // transmit (lib/lzo.ml:188-192) with blit's bounds (:81-89).  Long runs (incompressible input is ONE literal run) go 16
@@ -277,59 +281,69 @@ struct InRing {
 
 __device__ __forceinline__ uint32_t rdl(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
 
-// the instruction that would start with the bytes b (b0 = opcode) in state zero (ZERO) / not zero
-struct Ins {
-  uint32_t k, off, mlen, lit;  // opcode bytes, offset, match bytes (0: none), literals that follow
-  bool exotic;
+// The instruction that would start with the bytes b (b0 = opcode): opcodes from 16 on are the same in both states of the
+// decoder, below 16 a run of literals in state zero and a two-byte match otherwise (lib/lzo.ml:322-369).  Straight-line
+// selects: as four branchy decodes per window (two states, before and after the walk) this was 40 divergent branches
+// and a third of the decoder's time.
+struct InsAll {
+  uint32_t kc, offc, mlenc, litc;  // opcode >= 16: opcode bytes, offset, match bytes, literals that follow
+  uint32_t kz, litz;               // opcode < 16, state zero: a run of literals (no match)
+  uint32_t offn, litn;             // opcode < 16, state not zero: 2 opcode bytes, a match of 2
+  bool low, exc, exz;              // opcode < 16; not for the fast path (a length that goes on over zero bytes, the end marker)
 };
-template <bool ZERO>
-__device__ __forceinline__ Ins decode_ins(uint32_t b) {
+__device__ __forceinline__ InsAll decode_all(uint32_t b) {
   const uint32_t chr = b & 0xff, b1 = (b >> 8) & 0xff;
-  Ins r;
-  r.exotic = false;
-  if (chr >= 64) {
-    r.k = 2;
-    r.off = (b1 << 3) + ((chr >> 2) & 7) + 1;
-    r.mlen = (chr >> 5) + 1;
-    r.lit = chr & 3;
-  } else if (chr >= 16) {
-    const bool m3 = chr >= 32;
-    uint32_t L = m3 ? chr & 31 : chr & 7;
-    const bool ext = L == 0;
-    r.exotic = ext && b1 == 0;  // the length goes on over zero bytes
-    if (ext) L = (m3 ? 31u : 7u) + b1;
-    const uint32_t s = ext ? b >> 16 : (b >> 8) & 0xffff;
-    r.k = ext ? 4 : 3;
-    r.off = m3 ? (s >> 2) + 1 : 16384 + ((chr & 8) << 11) + (s >> 2);
-    r.exotic = r.exotic || r.off == 16384;  // the end marker
-    r.mlen = L + 2;
-    r.lit = s & 3;
-  } else if (ZERO) {
-    const bool ext = chr == 0;
-    r.exotic = ext && b1 == 0;
-    r.k = ext ? 2 : 1;
-    r.off = 0;
-    r.mlen = 0;
-    r.lit = ext ? 18 + b1 : chr + 3;
-  } else {
-    r.k = 2;
-    r.off = (b1 << 2) + (chr >> 2) + 1;
-    r.mlen = 2;
-    r.lit = chr & 3;
-  }
+  InsAll r;
+  r.low = chr < 16;
+  const bool m2 = chr >= 64, m3 = chr >= 32;
+  uint32_t L = m3 ? chr & 31 : chr & 7;
+  const bool ext = L == 0;
+  L = ext ? (m3 ? 31u : 7u) + b1 : L;
+  const uint32_t s = ext ? b >> 16 : (b >> 8) & 0xffff;
+  const uint32_t off34 = m3 ? (s >> 2) + 1 : 16384 + ((chr & 8) << 11) + (s >> 2);
+  r.kc = m2 ? 2u : ext ? 4u : 3u;
+  r.offc = m2 ? (b1 << 3) + ((chr >> 2) & 7) + 1 : off34;
+  r.mlenc = m2 ? (chr >> 5) + 1 : L + 2;
+  r.litc = m2 ? chr & 3 : s & 3;
+  r.exc = !m2 && ((ext && b1 == 0) || off34 == 16384);
+  const bool extz = chr == 0;
+  r.kz = extz ? 2u : 1u;
+  r.litz = extz ? 18 + b1 : chr + 3;
+  r.exz = extz && b1 == 0;
+  r.offn = (b1 << 2) + (chr >> 2) + 1;
+  r.litn = chr & 3;
   return r;
 }
-template <bool ZERO>
-__device__ __forceinline__ uint32_t pack_ins(uint32_t b, uint32_t p, uint32_t n) {
-  const Ins r = decode_ins<ZERO>(b);
-  const bool inside = p < n && p + r.k < n && p + r.k + r.lit <= n;
+// the walk's word of an instruction at input position p: bytes to advance | the state it leaves; what is not for the fast
+// path "advances" out of the window, so that the walk needs no test of its own for it
+__device__ __forceinline__ uint32_t walk_word(uint32_t k, uint32_t lit, bool match, bool exotic, uint32_t p, uint32_t n) {
+  const bool inside = p < n && p + k < n && p + k + lit <= n;
   // a run of literals leaves the state -1 (not zero), a match the number of its literals (lib/lzo.ml:283-288, :322-336)
-  const bool next_zero = r.mlen != 0 && r.lit == 0;
-  // (not for the fast path: it "advances" out of the window, so that the walk needs no test of its own for it)
-  if (r.exotic || !inside) return 64u | kExotic;
-  return (r.k + r.lit) | ((r.mlen + r.lit) << 10) | (next_zero ? kNextZero : 0u);
+  const uint32_t fast = (k + lit) | ((match && lit == 0) ? kNextZero : 0u);
+  return (exotic || !inside) ? (64u | kExotic) : fast;
+}
+// exclusive prefix sum over the wavefront on the DPP network (row shifts, then the row broadcasts of gfx9)
+__device__ __forceinline__ uint32_t wave_excl_scan_dpp(uint32_t x) {
+  uint32_t v = x;
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+  return v - x;
 }
 
+#ifdef MD_LZO_PROF  // measurement build (tools/dbg/lzo_phases.py): cycles per phase of the decoder, left in out_len
+#define LZ_PROF_MARK(k)                                   \
+  {                                                       \
+    const uint64_t now_ = __builtin_readcyclecounter();   \
+    d.prof[k] += (uint32_t)(now_ - d.prof_t);             \
+    d.prof_t = now_;                                      \
+  }
+#else
+#define LZ_PROF_MARK(k)
+#endif
 __device__ __forceinline__ int uncompress_stream(Dec &d, LSmem MD_LDS *sm) {
   LZ_EOI()
   uint32_t chr = d.in.byte(0);
@@ -361,6 +375,7 @@ __device__ __forceinline__ int uncompress_stream(Dec &d, LSmem MD_LDS *sm) {
     // matches of all of them and ONE write-out (the fence, the far loads' round trip and the flush are per batch, not per
     // 64 bytes of input: a lone stream spent most of its time on them)
     const uint32_t o0 = d.o_pos, rb = o0 & ~15u, n = d.in.n;
+    LZ_PROF_MARK(3)
     uint32_t osum = 0;             // bytes of the batch so far
     uint32_t rec_m[kWindows], rec_p[kWindows];  // per window and lane: off | mlen << 16 ; staging index (0xffffffff: no match)
 #pragma unroll
@@ -374,7 +389,9 @@ __device__ __forceinline__ int uncompress_stream(Dec &d, LSmem MD_LDS *sm) {
         ir.ensure(base);
         const uint32_t p = base + lane;
         const uint32_t b = *reinterpret_cast<const MD_LDS wv::u32_u *>(ir.at(p));
-        const uint32_t wz = pack_ins<true>(b, p, n), wn = pack_ins<false>(b, p, n);
+        const InsAll ia = decode_all(b);
+        const uint32_t wz = walk_word(ia.low ? ia.kz : ia.kc, ia.low ? ia.litz : ia.litc, !ia.low, ia.low ? ia.exz : ia.exc, p, n);
+        const uint32_t wn = walk_word(ia.low ? 2u : ia.kc, ia.low ? ia.litn : ia.litc, true, !ia.low && ia.exc, p, n);
         // walk (wave-uniform): a dozen scalar instructions per instruction - the two ways out of the fast path are not
         // tested here: an instruction that is not for the fast path leaves the window by itself (pack_ins) and is looked
         // at after the loop, a batch that is full is cut where the places are known (the walk is the stream's own chain:
@@ -400,9 +417,9 @@ __device__ __forceinline__ int uncompress_stream(Dec &d, LSmem MD_LDS *sm) {
         // the marked lanes: their instruction, their place in the output
         bool mine = (taken >> lane) & 1;
         const bool mz = (zmask >> lane) & 1;
-        const Ins rz = decode_ins<true>(b), rn = decode_ins<false>(b);
-        const uint32_t k = mz ? rz.k : rn.k, off = mz ? rz.off : rn.off, mlen = mz ? rz.mlen : rn.mlen, lit = mz ? rz.lit : rn.lit;
-        const uint32_t orel = osum + wv::wave_excl_scan(mine ? mlen + lit : 0u, lane);
+        const uint32_t k = ia.low ? (mz ? ia.kz : 2u) : ia.kc, off = ia.low ? (mz ? 0u : ia.offn) : ia.offc;
+        const uint32_t mlen = ia.low ? (mz ? 0u : 2u) : ia.mlenc, lit = ia.low ? (mz ? ia.litz : ia.litn) : ia.litc;
+        const uint32_t orel = osum + wave_excl_scan_dpp(mine ? mlen + lit : 0u);
         const uint32_t oabs = o0 + orel;
         {  // the batch is full: the next one starts at that instruction.  What does not fit the output is the slow path's
            // (it fails there, with the reference's error).  Whichever comes first.
@@ -447,6 +464,7 @@ __device__ __forceinline__ int uncompress_stream(Dec &d, LSmem MD_LDS *sm) {
         if (slow || taken == 0) more = false;
       }
     }
+    LZ_PROF_MARK(0)
     if (osum) {
       // ---- matches.  Older than the batch: from the output buffer, every lane its own, the first 16 bytes of all windows'
       // records in flight together; into the batch: in stream order by the whole wave, byte j = source byte j mod off
@@ -489,6 +507,7 @@ __device__ __forceinline__ int uncompress_stream(Dec &d, LSmem MD_LDS *sm) {
           }
         }
       }
+      LZ_PROF_MARK(1)
 #pragma unroll
       for (int w = 0; w < kWindows; w++) {
         const uint32_t mlen = rec_m[w] >> 16, off = rec_m[w] & 0xffffu, sidx = rec_p[w], sabs = rb + sidx - off;
@@ -509,6 +528,7 @@ __device__ __forceinline__ int uncompress_stream(Dec &d, LSmem MD_LDS *sm) {
           }
         }
       }
+      LZ_PROF_MARK(2)
       // the batch leaves: whole 16-byte chunks one per lane, the bytes in front of the first and behind the last one by one
       {
         const uint32_t endp = o0 + osum;
@@ -556,10 +576,18 @@ __global__ __launch_bounds__(kWave) void lzo_uncompress_kernel(
     d.i_pos = d.o_pos = 0;
     d.lane = lane;
     d.state = 0;
+#ifdef MD_LZO_PROF
+    d.prof[0] = d.prof[1] = d.prof[2] = d.prof[3] = 0;
+    d.prof_t = __builtin_readcyclecounter();
+#endif
     const int st = uncompress_stream(d, (LSmem MD_LDS *)&smem);
     if (lane == 0) {
       status[sid] = st;
       out_len[sid] = st == MD_OK ? d.o_pos : 0;
+#ifdef MD_LZO_PROF  // windows (decode, walk, literals) | far matches | near matches | write-out + slow path: 1024 cycles each
+      out_len[sid] = (uint64_t)(d.prof[0] >> 10) | ((uint64_t)(d.prof[1] >> 10) << 16) | ((uint64_t)(d.prof[2] >> 10) << 32) |
+                     ((uint64_t)(d.prof[3] >> 10) << 48);
+#endif
     }
   }
 }
