@@ -226,7 +226,7 @@ __device__ __forceinline__ int fiber_step(Dec &d, bool *end) {
 constexpr uint32_t kInRing = 2048, kInBlk = 1024;  // input window: a ring of two 1 KiB blocks, the next one on its way
 constexpr uint32_t kStage = 3072;                  // staging: one batch of output, 16-byte aligned with the output buffer
 constexpr uint32_t kBatchMax = kStage - 16;        // bytes a batch may produce
-constexpr uint32_t kExotic = 1u << 20, kNextZero = 1u << 21;
+constexpr uint32_t kNextZeroBit = 14, kExotic = 1u << 15, kNextZero = 1u << kNextZeroBit;  // (a walk word is 16 bits: advance | flags)
 constexpr int kWindows = 4;                       // windows of 64 input bytes per batch
 struct LSmem {
   alignas(16) uint8_t in[kInRing + 32];  // (+ the ring's first bytes again: an access may run over the end)
@@ -396,22 +396,21 @@ __device__ __forceinline__ int uncompress_stream(Dec &d, LSmem MD_LDS *sm) {
         // tested here: an instruction that is not for the fast path leaves the window by itself (pack_ins) and is looked
         // at after the loop, a batch that is full is cut where the places are known (the walk is the stream's own chain:
         // with both tests, and what the compiler made of the three exits, it was 30)
-        uint32_t cur = 0, zero = (d.state & 3) == 0 ? 1u : 0u, last = 0, zlast = zero, wd = 0;
+        uint32_t cur = 0, zero = (d.state & 3) == 0 ? 1u : 0u, wd = 0;
         uint64_t taken = 0, zmask = 0;
+        const uint32_t wboth = wn | (wz << 16);  // (one lane read per instruction: the word of the state is picked by a shift)
         do {
-          const uint32_t a = rdl(wz, cur), c = rdl(wn, cur);
-          wd = zero ? a : c;
+          wd = rdl(wboth, cur) >> (zero << 4);
           taken |= 1ull << cur;
           zmask |= (uint64_t)zero << cur;
-          last = cur;
-          zlast = zero;
           cur += wd & 1023;
-          zero = (wd >> 21) & 1;
+          zero = (wd >> kNextZeroBit) & 1;
         } while (cur < 64);
         if (wd & kExotic) {  // the slow path's: the batch ends in front of it
+          const uint32_t last = 63u - (uint32_t)__builtin_clzll(taken);
           taken &= ~(1ull << last);
           cur = last;
-          zero = zlast;
+          zero = (uint32_t)((zmask >> last) & 1);
           slow = true;
         }
         // the marked lanes: their instruction, their place in the output
