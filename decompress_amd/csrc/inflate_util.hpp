@@ -63,20 +63,24 @@ struct Prof<false> {
 };
 
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+// Sums over the wavefront on the DPP network (row shifts, then gfx9's row broadcasts): no LDS round trips - as six
+// ds_bpermute steps each of them was ~700 cycles of nothing else on its wavefront's chain.
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
+  uint32_t v = x;
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
   return v;
 }
-__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t lane) {
-  uint32_t x = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    uint32_t t = __shfl_up(x, o);
-    if (lane >= (uint32_t)o) x += t;
-  }
-  return x - v;
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {  // (a lane read: the compiler knows it is the same in all lanes)
+  return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(v), 63);
 }
+__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t) { return wave_incl_scan(v) - v; }
+// the value of the lane below (lane 0: 0)
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false); }
 __device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) {
   return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(l));
 }

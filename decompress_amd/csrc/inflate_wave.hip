@@ -1221,7 +1221,7 @@ __device__ __forceinline__ int inflate_block(lds_smem *sm, const uint8_t *__rest
     pf.tick(P_DECODE1);
     const uint32_t passes = zs * PASSES >= PASS_BITS ? PASSES : PASS_BITS / zs > PASSES_MAX ? PASSES_MAX : PASS_BITS / zs;
     for (uint32_t it = 0; it < passes; it++) {
-      const uint32_t pe = __shfl_up(end, 1), ps = __shfl_up(stop, 1);
+      const uint32_t pe = wave_shr1(end), ps = wave_shr1(stop);
       const bool redo = lane == 0 ? !counted : (ps == 0 && (pe != start || !counted));
       if (__ballot(redo) == 0) break;
       if (redo && lane > 0) start = pe;
@@ -1237,7 +1237,7 @@ __device__ __forceinline__ int inflate_block(lds_smem *sm, const uint8_t *__rest
     pf.tick(P_DECODE2);
     uint32_t nvalid;
     {
-      const uint32_t pe = __shfl_up(end, 1), ps = __shfl_up(stop, 1);
+      const uint32_t pe = wave_shr1(end), ps = wave_shr1(stop);
       const uint64_t bad = __ballot(!counted || (lane > 0 && (ps != 0 || pe != start)));
       nvalid = bad ? (uint32_t)__builtin_ctzll(bad) : 64;  // lane 0 is always counted: nvalid >= 1
     }

@@ -322,18 +322,6 @@ __device__ __forceinline__ uint32_t walk_word(uint32_t k, uint32_t lit, bool mat
   const uint32_t fast = (k + lit) | ((match && lit == 0) ? kNextZero : 0u);
   return (exotic || !inside) ? (64u | kExotic) : fast;
 }
-// exclusive prefix sum over the wavefront on the DPP network (row shifts, then the row broadcasts of gfx9)
-__device__ __forceinline__ uint32_t wave_excl_scan_dpp(uint32_t x) {
-  uint32_t v = x;
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
-  return v - x;
-}
-
 #ifdef MD_LZO_PROF  // measurement build (tools/dbg/lzo_phases.py): cycles per phase of the decoder, left in out_len
 #define LZ_PROF_MARK(k)                                   \
   {                                                       \
@@ -418,7 +406,7 @@ __device__ __forceinline__ int uncompress_stream(Dec &d, LSmem MD_LDS *sm) {
         const bool mz = (zmask >> lane) & 1;
         const uint32_t k = ia.low ? (mz ? ia.kz : 2u) : ia.kc, off = ia.low ? (mz ? 0u : ia.offn) : ia.offc;
         const uint32_t mlen = ia.low ? (mz ? 0u : 2u) : ia.mlenc, lit = ia.low ? (mz ? ia.litz : ia.litn) : ia.litc;
-        const uint32_t orel = osum + wave_excl_scan_dpp(mine ? mlen + lit : 0u);
+        const uint32_t orel = osum + wv::wave_excl_scan(mine ? mlen + lit : 0u, lane);
         const uint32_t oabs = o0 + orel;
         {  // the batch is full: the next one starts at that instruction.  What does not fit the output is the slow path's
            // (it fails there, with the reference's error).  Whichever comes first.
