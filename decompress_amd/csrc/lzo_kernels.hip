@@ -71,7 +71,7 @@ struct Dec {
   uint32_t cap, i_pos, o_pos, lane;
   int state;
 #ifdef MD_LZO_PROF
-  uint32_t prof[4];
+  uint32_t prof[8];
   uint64_t prof_t;
 #endif
 };
@@ -227,7 +227,7 @@ constexpr uint32_t kInRing = 2048, kInBlk = 1024;  // input window: a ring of tw
 constexpr uint32_t kStage = 3072;                  // staging: one batch of output, 16-byte aligned with the output buffer
 constexpr uint32_t kBatchMax = kStage - 16;        // bytes a batch may produce
 constexpr uint32_t kNextZeroBit = 14, kExotic = 1u << 15, kNextZero = 1u << kNextZeroBit;  // (a walk word is 16 bits: advance | flags)
-constexpr int kWindows = 4;                       // windows of 64 input bytes per batch
+constexpr int kWindows = 4;                       // windows of 64 input bytes per batch (6: the same, 8: registers for 3 wavefronts per SIMD, slower)
 struct LSmem {
   alignas(16) uint8_t in[kInRing + 32];  // (+ the ring's first bytes again: an access may run over the end)
   alignas(16) uint8_t stage[kStage + 32];
@@ -316,8 +316,9 @@ __device__ __forceinline__ InsAll decode_all(uint32_t b) {
 }
 // the walk's word of an instruction at input position p: bytes to advance | the state it leaves; what is not for the fast
 // path "advances" out of the window, so that the walk needs no test of its own for it
+template <bool CHECK>
 __device__ __forceinline__ uint32_t walk_word(uint32_t k, uint32_t lit, bool match, bool exotic, uint32_t p, uint32_t n) {
-  const bool inside = p < n && p + k < n && p + k + lit <= n;
+  const bool inside = !CHECK || (p < n && p + k < n && p + k + lit <= n);
   // a run of literals leaves the state -1 (not zero), a match the number of its literals (lib/lzo.ml:283-288, :322-336)
   const uint32_t fast = (k + lit) | ((match && lit == 0) ? kNextZero : 0u);
   return (exotic || !inside) ? (64u | kExotic) : fast;
@@ -378,8 +379,16 @@ __device__ __forceinline__ int uncompress_stream(Dec &d, LSmem MD_LDS *sm) {
         const uint32_t p = base + lane;
         const uint32_t b = *reinterpret_cast<const MD_LDS wv::u32_u *>(ir.at(p));
         const InsAll ia = decode_all(b);
-        const uint32_t wz = walk_word(ia.low ? ia.kz : ia.kc, ia.low ? ia.litz : ia.litc, !ia.low, ia.low ? ia.exz : ia.exc, p, n);
-        const uint32_t wn = walk_word(ia.low ? 2u : ia.kc, ia.low ? ia.litn : ia.litc, true, !ia.low && ia.exc, p, n);
+        const uint32_t kzz = ia.low ? ia.kz : ia.kc, lzz = ia.low ? ia.litz : ia.litc, knn = ia.low ? 2u : ia.kc, lnn = ia.low ? ia.litn : ia.litc;
+        const bool ezz = ia.low ? ia.exz : ia.exc, enn = !ia.low && ia.exc;
+        uint32_t wz, wn;
+        if (base + 64u + 4u + 273u + 1u <= n) {  // far from the input's end (an instruction is <= 4 + 273 bytes): nothing to test
+          wz = walk_word<false>(kzz, lzz, !ia.low, ezz, p, n);
+          wn = walk_word<false>(knn, lnn, true, enn, p, n);
+        } else {
+          wz = walk_word<true>(kzz, lzz, !ia.low, ezz, p, n);
+          wn = walk_word<true>(knn, lnn, true, enn, p, n);
+        }
         // walk (wave-uniform): a dozen scalar instructions per instruction - the two ways out of the fast path are not
         // tested here: an instruction that is not for the fast path leaves the window by itself (pack_ins) and is looked
         // at after the loop, a batch that is full is cut where the places are known (the walk is the stream's own chain:
@@ -387,6 +396,7 @@ __device__ __forceinline__ int uncompress_stream(Dec &d, LSmem MD_LDS *sm) {
         uint32_t cur = 0, zero = (d.state & 3) == 0 ? 1u : 0u, wd = 0;
         uint64_t taken = 0, zmask = 0;
         const uint32_t wboth = wn | (wz << 16);  // (one lane read per instruction: the word of the state is picked by a shift)
+        LZ_PROF_MARK(4)  // (measurement build: the window's decode)
         do {
           wd = rdl(wboth, cur) >> (zero << 4);
           taken |= 1ull << cur;
@@ -401,6 +411,7 @@ __device__ __forceinline__ int uncompress_stream(Dec &d, LSmem MD_LDS *sm) {
           zero = (uint32_t)((zmask >> last) & 1);
           slow = true;
         }
+        LZ_PROF_MARK(5)  // (the walk)
         // the marked lanes: their instruction, their place in the output
         bool mine = (taken >> lane) & 1;
         const bool mz = (zmask >> lane) & 1;
@@ -411,7 +422,11 @@ __device__ __forceinline__ int uncompress_stream(Dec &d, LSmem MD_LDS *sm) {
         {  // the batch is full: the next one starts at that instruction.  What does not fit the output is the slow path's
            // (it fails there, with the reference's error).  Whichever comes first.
           const uint64_t full = __ballot(mine && orel + mlen + lit > kBatchMax);
-          const uint64_t bad = __ballot(mine && ((mlen != 0 && off > oabs) || mlen + lit > d.cap - oabs || oabs > d.cap));
+          // (the output has room for a whole batch, and every offset - at most 49 151 - has that much output behind it:
+          // nothing to test)
+          uint64_t bad = 0;
+          if (o0 < 49152u || d.cap - o0 < kStage)
+            bad = __ballot(mine && ((mlen != 0 && off > oabs) || mlen + lit > d.cap - oabs || oabs > d.cap));
           if (full | bad) {
             const uint32_t fb = (uint32_t)__builtin_ctzll(full | bad);
             taken &= (1ull << fb) - 1;
@@ -427,6 +442,7 @@ __device__ __forceinline__ int uncompress_stream(Dec &d, LSmem MD_LDS *sm) {
           const uint32_t lt = 63u - (uint32_t)__builtin_clzll(taken);
           wsum = rdl(orel + mlen + lit, lt) - osum;
         }
+        LZ_PROF_MARK(6)  // (places and cuts)
         const uint32_t sidx = oabs - rb;  // staging index of this lane's first byte
         if (taken) {  // literals: input window -> staging
           const uint32_t lsrc = p + k, ldst = sidx + mlen;
@@ -449,6 +465,7 @@ __device__ __forceinline__ int uncompress_stream(Dec &d, LSmem MD_LDS *sm) {
         d.i_pos = base + cur;
         d.state = zero ? 0 : 1;
         if (slow || taken == 0) more = false;
+        LZ_PROF_MARK(0)  // (literals into staging, records)
       }
     }
     LZ_PROF_MARK(0)
@@ -502,6 +519,10 @@ __device__ __forceinline__ int uncompress_stream(Dec &d, LSmem MD_LDS *sm) {
         for (uint64_t nm = __ballot(near); nm; nm &= nm - 1) {
           const uint32_t l = (uint32_t)__builtin_ctzll(nm);
           const uint32_t sp = rdl(sabs, l), t = rdl(sidx, l), c = rdl(mlen, l), f = rdl(off, l);
+          if (f >= c && sp >= o0 && c <= (uint32_t)kWave) {  // the usual one: inside the batch, no overlap, one step
+            if (lane < c) stage[t + lane] = stage[sp - rb + lane];
+            continue;
+          }
           const float inv = 1.0f / (float)f;
           for (uint32_t j = lane; j < c; j += kWave) {
             uint32_t r = j;
@@ -564,16 +585,21 @@ __global__ __launch_bounds__(kWave) void lzo_uncompress_kernel(
     d.lane = lane;
     d.state = 0;
 #ifdef MD_LZO_PROF
-    d.prof[0] = d.prof[1] = d.prof[2] = d.prof[3] = 0;
+    for (int k_ = 0; k_ < 8; k_++) d.prof[k_] = 0;
     d.prof_t = __builtin_readcyclecounter();
 #endif
     const int st = uncompress_stream(d, (LSmem MD_LDS *)&smem);
     if (lane == 0) {
       status[sid] = st;
       out_len[sid] = st == MD_OK ? d.o_pos : 0;
-#ifdef MD_LZO_PROF  // windows (decode, walk, literals) | far matches | near matches | write-out + slow path: 1024 cycles each
-      out_len[sid] = (uint64_t)(d.prof[0] >> 10) | ((uint64_t)(d.prof[1] >> 10) << 16) | ((uint64_t)(d.prof[2] >> 10) << 32) |
-                     ((uint64_t)(d.prof[3] >> 10) << 48);
+#ifdef MD_LZO_PROF  // 8 x 8 bits: a phase's share of the stream's cycles in 1/255 (tools/dbg/lzo_phases.py names them)
+      {
+        uint64_t tot_ = 0, pk_ = 0;
+        for (int k_ = 0; k_ < 8; k_++) tot_ += d.prof[k_];
+        for (int k_ = 0; k_ < 8; k_++) pk_ |= (uint64_t)((uint64_t)d.prof[k_] * 255 / (tot_ ? tot_ : 1)) << (8 * k_);
+        out_len[sid] = pk_;
+        status[sid] = (int32_t)(tot_ >> 10);
+      }
 #endif
     }
   }

@@ -24,10 +24,10 @@ ocap = np.full(n, nb, dtype=np.int64)
 r = eng.lzo_batch(False, t(blob), t(off), t(ln), d_out, t(ooff), t(ocap))
 torch.cuda.synchronize()
 v = r[0].cpu().numpy().astype(np.uint64)
-names = ("windows (decode, walk, literals)", "far matches (fence, loads)", "near matches", "write-out, slow path")
-tot = 0
+tot = r[1].cpu().numpy().astype(np.float64) * 1024
+names = ("literals into staging, records (rest of the windows)", "far matches (fence, loads)", "near matches", "write-out, slow path",
+         "windows: ring, decode of both states", "windows: the walk", "windows: places, cuts", "-")
+print("cycles per stream: %.0f K" % (tot.mean() / 1e3))
 for k, nm in enumerate(names):
-    c = ((v >> np.uint64(16 * k)) & np.uint64(0xffff)).astype(np.float64) * 1024
-    tot += c.mean()
-    print("%-36s %8.0f K cycles per stream" % (nm, c.mean() / 1e3))
-print("total %.0f K cycles" % (tot / 1e3))
+    c = ((v >> np.uint64(8 * k)) & np.uint64(0xff)).astype(np.float64) / 255
+    print("%-56s %5.1f %%" % (nm, 100 * c.mean()))
