@@ -120,3 +120,62 @@ def test_corpus_files(eng, oracle):
         cases = [(z, len(b) - 1), (z[:len(z) * 2 // 3], len(b)), (z[:-1], len(b))]
         for (src, cap), (st, out) in zip(cases, eng.lzo_many(False, [c[0] for c in cases], [c[1] for c in cases])):
             assert (st, out) == oracle.lzo_uncompress(src, cap)
+
+
+def _planted(rng, n, plants):
+    """n bytes without repeats of 4 bytes (a counter in base 251 under a permutation), then `plants`: (at, distance, length)
+    copies of earlier bytes - the matches the compressor has to find (or not) where the opcode forms change"""
+    perm = list(range(256))
+    rng.shuffle(perm)
+    d = bytearray()
+    k = 0
+    while len(d) < n:
+        d += bytes((perm[(k // 251 ** j) % 251] for j in range(4)))
+        k += 1
+    d = d[:n]
+    for at, dist, ln in plants:
+        if at - dist >= 0 and at + ln <= n:
+            d[at:at + ln] = d[at - dist:at - dist + ln] if dist >= ln else bytes(d[at - dist + (j % dist)] for j in range(ln))
+    return bytes(d)
+
+
+def test_compressor_step_edge_cases(eng, oracle):
+    """round 6's step behind a match (csrc/lzo_kernels.hip near_step) where its cases change: match lengths around 12 and 16
+    (decided in the hit lane's registers or by the 8-bytes-per-lane loop), 33 / 34 and 9 / 10 (a length that goes on over more
+    bytes), offsets around 2 KiB, 16 KiB and the 48 KiB chunk (M2 / M3 / M4 forms), runs of 0..9, 16, 18, 19 and 300
+    literals between matches (the count in the match, its own byte, the long form), periodic inputs (several probes of a
+    step on one dictionary slot: the byte table in LDS sends the step to the general code), sizes around the chunk.
+    Bytes = the oracle's, the round trip and minilzo's decoder give the input back."""
+    from decompress_amd import lzo
+    rng = random.Random(606)
+    data = []
+    for ln in (4, 5, 8, 9, 10, 11, 12, 13, 15, 16, 17, 19, 20, 27, 28, 33, 34, 35, 264, 265, 523, 524, 525, 600, 2000):
+        for dist in (1, 2, 3, 4, 7, 8, 9, 2047, 2048, 2049, 16383, 16384, 16385, 40000, 49151):
+            n = 60000
+            plants = [(at, dist, ln) for at in range(50000, 50000 + 12 * (ln + 9), ln + 9)]  # runs of 9 literals between them
+            data.append(_planted(rng, n, plants))
+    for gap in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 15, 16, 17, 18, 19, 20, 31, 32, 33, 300):
+        plants, at = [], 20000
+        for _ in range(40):
+            plants.append((at, 5000 + rng.randrange(3), rng.choice((4, 6, 8, 11, 12, 16, 40))))
+            at += plants[-1][2] + gap
+        data.append(_planted(rng, 40000, plants))
+    for period in range(1, 12):
+        for n in (100, 5000, 49152 + 37):
+            unit = bytes(rng.getrandbits(8) for _ in range(period))
+            data.append((unit * (n // period + 1))[:n])
+            data.append((unit * 40 + bytes(rng.getrandbits(8) for _ in range(23))) * (n // (40 * period + 23) + 1))
+    for n in (49152 - 21, 49152 - 20, 49152 - 1, 49152, 49152 + 1, 49152 + 19, 49152 + 20, 49152 + 21, 2 * 49152, 2 * 49152 + 5, 3 * 49152 + 31):
+        data.append(_planted(rng, n, [(n - 30, 9000, 25), (49140, 300, 30), (49150, 20000, 8), (98300, 47000, 12)]))
+        data.append(bytes(n))
+    res = eng.lzo_many(True, data, [lzo.max_compressed_length(len(d)) for d in data])
+    zs = []
+    for k, (d, (st, z)) in enumerate(zip(data, res)):
+        assert (st, z) == oracle.lzo_compress(d), (k, len(d))
+        zs.append(z)
+    for k, (d, (st, out)) in enumerate(zip(data, eng.lzo_many(False, zs, [len(d) for d in data]))):
+        assert (st, out) == (0, d), (k, len(d))
+    m = oracle_lib.load_minilzo()
+    if m is not None:
+        for d, z in zip(data[::7], zs[::7]):
+            assert m.decompress(z, len(d)) == (0, d)
