@@ -669,9 +669,11 @@ struct LaneOut {
 };
 
 // The token at ptok, with every check in the oracle's order (oracle/de_inflate.c ns_inflate_block): called for
-// the lanes the emit pass stopped.  Returns the stop reason; *pend_out = bit after an end-of-block code.
+// the lanes the emit pass stopped.  Returns the stop reason (< 256) | the bit after an end-of-block code << 8 - in ONE
+// value: as an out-parameter of this call the caller's variable lived in scratch memory, a store and a load of every
+// emit pass whether anything had stopped or not.
 __device__ __noinline__ uint32_t slow_token(const lds_u32 *win, const lds_u32 *lut, uint32_t lroot, uint32_t ptok, uint32_t q,
-                                            uint32_t tot, uint32_t cap, uint32_t *pend_out) {
+                                            uint32_t tot, uint32_t cap) {
   uint32_t p = ptok;
   uint32_t w = peek(win, p);
   uint32_t e = lut_step(lut, e_root(lroot), w);
@@ -683,10 +685,7 @@ __device__ __noinline__ uint32_t slow_token(const lds_u32 *win, const lds_u32 *l
   uint32_t n = e_n(e), xb = e_xb(e), ntb = e_tb(e);
   uint32_t pn = p + n;
   if (pn > tot) return MD_UNEXPECTED_END_OF_INPUT;  // D1
-  if (ntb == kStopEobI) {
-    *pend_out = pn;
-    return kStEob;
-  }
+  if (ntb == kStopEobI) return kStEob | (pn << 8);
   if (ntb != kDistB) {  // literal
     if (q >= cap) return MD_UNEXPECTED_END_OF_OUTPUT;
     return kStTrunc;
@@ -770,8 +769,9 @@ __device__ __forceinline__ void emit_pass(const lds_u32 *win, const lds_u32 *lut
   }
   uint32_t stopc = 0, endp = p;
   if (go && stopped) {
-    endp = ptok;
-    stopc = slow_token(win, lut, lroot, ptok, q, tot, cap, &endp);
+    const uint32_t r = slow_token(win, lut, lroot, ptok, q, tot, cap);
+    stopc = r & 0xffu;
+    endp = stopc == kStEob ? r >> 8 : ptok;
   }
   if (go) {
     lo.endp = endp;
