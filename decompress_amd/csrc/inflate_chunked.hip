@@ -102,7 +102,8 @@ struct BitRd {  // LSB-first bit reader over body[0, n), zeros beyond the end (`
 // offsets 8 bits a length, the symbols sorted by (length, symbol) 5 bits each: as arrays indexed at run time they were
 // scratch memory, a round trip per access, and the finder took longer than the decode it prepares (8 MiB of stored text:
 // 33 ms of 34).
-__device__ __noinline__ bool header_parses(const uint8_t *body, uint64_t nbytes, uint64_t q, uint8_t *lut /* [128][256], this thread's column */) {
+constexpr uint32_t kLutCols = 128;  // threads of a workgroup that validate side by side (a column of the look-up table each)
+__device__ __noinline__ bool header_parses(const uint8_t *body, uint64_t nbytes, uint64_t q, uint8_t *lut /* [128][kLutCols], this thread's column */) {
   BitRd r;
   r.init(body, nbytes, q);
   r.take(3);
@@ -135,7 +136,7 @@ __device__ __noinline__ bool header_parses(const uint8_t *body, uint64_t nbytes,
       const uint32_t c = (uint32_t)(next >> (8 * l)) & 255;
       next += 1ull << (8 * l);
       const uint32_t rev = __builtin_bitreverse32(c) >> (32 - l);  // the stream carries a code most significant bit first
-      for (uint32_t k = rev; k < 128; k += 1u << l) lut[k * 256] = (uint8_t)(sy | (l << 5));
+      for (uint32_t k = rev; k < 128; k += 1u << l) lut[k * kLutCols] = (uint8_t)(sy | (l << 5));
     }
   }
   // the lengths of both alphabets, run-length coded (lib/de.ml:1291-1345): Kraft sums and the end-of-block code on the way
@@ -144,7 +145,7 @@ __device__ __noinline__ bool header_parses(const uint8_t *body, uint64_t nbytes,
   const uint32_t total = hlit + hdist;
   while (i < total) {
     if (r.cnt < 16) r.fill();
-    const uint32_t ent = lut[r.peek(7) * 256];
+    const uint32_t ent = lut[r.peek(7) * kLutCols];
     const uint32_t sym = ent & 31;
     r.drop(ent >> 5);
     uint32_t rep = 1, val = sym;
@@ -183,7 +184,7 @@ __device__ __noinline__ bool header_parses(const uint8_t *body, uint64_t nbytes,
 // thread.  (Validating inside the filter loop kept 63 lanes waiting for the one that had something to validate - one
 // position in ~900 passes the filter, a validation is thousands of instructions: 4 ms for 3 MB of input, four times the
 // decode it prepares.)  The first valid position of the first round that has one is the chunk's candidate.
-constexpr uint32_t kRoundTiles = 64, kListCap = 1024;
+constexpr uint32_t kRoundTiles = 64, kListCap = 1024, kPreCap = 8192;
 // the filter at bit q: 1 = a dynamic header that deserves validation, 2 = the byte behind an EMPTY STORED BLOCK (00 00 ff ff:
 // what Z_SYNC_FLUSH / Z_FULL_FLUSH leave, pigz between its blocks; its three header bits and padding lie in the byte in
 // front: the block behind it starts here, byte-aligned - needs no second look), 0 = neither
@@ -205,29 +206,41 @@ __device__ __forceinline__ Bits24 header_bytes(const uint8_t *__restrict__ body,
   }
   return v;
 }
-// bit s (0 .. 7) of the byte the words were loaded for
-__device__ __forceinline__ uint32_t header_filter(const Bits24 &w, uint64_t by, uint32_t s) {
+// bit s (0 .. 7) of the byte the words were loaded for.  The filter in two steps: the header's first 17 bits (one position
+// in nine passes), then the code-length code's completeness - up to 19 three-bit fields, ~250 instructions, which a
+// wavefront paid in full for every column of positions while ONE of its lanes had passed the first step: the survivors go
+// to a list first and the second step takes them one per thread (64 MiB of text: finder 2.2 -> see DESIGN 3b).
+__device__ __forceinline__ uint32_t header_first(const Bits24 &w, uint64_t by, uint32_t s) {
   // pre holds bytes by - 8 .. by - 1 (byte by - 1 on top): 00 00 ff ff in front, and the top three bits of the byte before zero
   if (s == 0 && by >= 5 && (w.pre >> 32) == 0xffff0000ull && ((w.pre >> 24) & 0xe0) == 0) return 2;
+  const uint32_t v = (uint32_t)((s ? (w.lo >> s) | (w.hi << (64 - s)) : w.lo));
+  if ((v & 7) != 4) return 0;  // BFINAL = 0, BTYPE = 2
+  const uint32_t hlit = (v >> 3) & 31, hdist = (v >> 8) & 31;
+  return hlit <= 29 && hdist <= 29 ? 1u : 0u;
+}
+__device__ __forceinline__ bool header_precode_complete(const Bits24 &w, uint32_t s) {
   const uint64_t v0 = s ? (w.lo >> s) | (w.hi << (64 - s)) : w.lo, v1 = w.hi >> s;
-  if ((v0 & 7) != 4) return 0;  // BFINAL = 0, BTYPE = 2
-  const uint32_t hlit = (uint32_t)(v0 >> 3) & 31, hdist = (uint32_t)(v0 >> 8) & 31, hclen = ((uint32_t)(v0 >> 13) & 15) + 4;
-  if (hlit > 29 || hdist > 29) return 0;
+  const uint32_t hclen = ((uint32_t)(v0 >> 13) & 15) + 4;
   uint32_t kraft = 0;  // the code-length code is complete (kind CODES, lib/de.ml:549-550)
   for (uint32_t i = 0; i < hclen; i++) {
     const uint32_t at = 17 + 3 * i;  // 17 .. 71
     const uint32_t l = (uint32_t)(at < 64 ? (v0 >> at) | (v1 << (64 - at)) : v1 >> (at - 64)) & 7;
     kraft += l ? 128u >> l : 0u;
   }
-  return kraft == 128u ? 1u : 0u;
+  return kraft == 128u;
 }
 // grid = (parts, chunks behind the first): workgroup (s, c) searches the s-th part of chunk c's bits and lowers cand[c]
 // (set to ~0 before the launch) to its first candidate - the parts of a chunk run side by side, a small input has few chunks
 __global__ __launch_bounds__(256) void find_blocks_kernel(const uint8_t *__restrict__ body, uint64_t nbytes, uint64_t K,
                                                           unsigned long long *__restrict__ cand) {
-  __shared__ uint32_t found, nlist;
+  __shared__ uint32_t found, nlist, npre;
   __shared__ uint32_t list[kListCap];
-  __shared__ uint8_t cl_lut[128 * 256];
+  __shared__ alignas(16) uint8_t cl_lut[128 * kLutCols];  // (one wavefront validates: the rest of the table was three quarters of the
+                                                           // workgroup's LDS, and LDS is what limits the workgroups per CU here)
+  // positions of the round (relative to its start) that passed the first step: in the validation's table space, which is
+  // not in use while they are
+  uint16_t *pre = reinterpret_cast<uint16_t *>(cl_lut);
+  static_assert(kPreCap * 2 <= 128 * kLutCols, "the list fits the table");
   const uint64_t c = blockIdx.y;
   const uint32_t kSubRanges = gridDim.x;  // parts of a chunk side by side: only while the chunks alone would leave the chip empty
   const uint64_t part = ((K * 8 / kSubRanges) + 255) & ~(uint64_t)255;
@@ -237,8 +250,15 @@ __global__ __launch_bounds__(256) void find_blocks_kernel(const uint8_t *__restr
   if (threadIdx.x == 0) {
     found = 0xffffffffu;
     nlist = 0;
+    npre = 0;
   }
   __syncthreads();
+  // a position that is complete goes on the list of the round's candidates
+  auto to_list = [&](uint64_t q) {
+    const uint32_t at = atomicAdd(&nlist, 1u);
+    if (at < kListCap) list[at] = (uint32_t)(q - b0);
+    else atomicMin(&found, 0xfffffffeu);  // (cannot be: a list of a thousand in 16 K positions; the part has no candidate then)
+  };
   for (uint64_t r0 = b0; r0 < b1; r0 += (uint64_t)kRoundTiles * 256) {
     if (blockIdx.x && r0 > b0 && __hip_atomic_load(&cand[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < b0) break;  // an earlier part has one
     // a thread takes the eight bit positions of ONE byte from one set of loads (a load per position was a memory round trip
@@ -251,21 +271,40 @@ __global__ __launch_bounds__(256) void find_blocks_kernel(const uint8_t *__restr
 #pragma unroll 1
       for (uint32_t sb = 0; sb < 8; sb++) {
         const uint64_t q = by * 8 + sb;
-        const uint32_t f = q + 3 + 14 + 12 <= c1 && q < b1 ? header_filter(w, by, sb) : 0u;
+        const uint32_t f = q + 3 + 14 + 12 <= c1 && q < b1 ? header_first(w, by, sb) : 0u;
         if (f == 2) atomicMin(&found, (uint32_t)(q - b0));
-        if (f == 1) {
-          const uint32_t at = atomicAdd(&nlist, 1u);
-          if (at < kListCap) list[at] = (uint32_t)(q - b0);
-          else atomicMin(&found, 0xfffffffeu);  // (cannot be: a list of a thousand in 16 K positions; the part has no candidate then)
+        {  // survivors of the first step: one LDS atomic per wavefront and column, not one per survivor
+          const uint64_t m = __ballot(f == 1);
+          if (m) {
+            const uint32_t lane = threadIdx.x & 63u, cnt = (uint32_t)__popcll(m);
+            uint32_t base = 0;
+            if (lane == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(&npre, cnt);
+            base = (uint32_t)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(m));
+            if (f == 1) {
+              const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+              if (at < kPreCap) pre[at] = (uint16_t)(q - r0);
+              else if (header_precode_complete(w, sb)) to_list(q);  // (a quarter of the round: checked where it stands)
+            }
+          }
         }
       }
     }
     __syncthreads();
-    const uint32_t n = nlist < kListCap ? nlist : kListCap;
-    for (uint32_t k = threadIdx.x; k < n; k += 256) {
-      const uint32_t rel = list[k];
-      if (rel < found && header_parses(body, nbytes, b0 + rel, cl_lut + threadIdx.x)) atomicMin(&found, rel);
+    {
+      const uint32_t n1 = npre < kPreCap ? npre : kPreCap;
+      for (uint32_t k = threadIdx.x; k < n1; k += 256) {
+        const uint64_t q = r0 + pre[k];
+        if (header_precode_complete(header_bytes(body, nbytes, q >> 3), (uint32_t)(q & 7))) to_list(q);
+      }
     }
+    __syncthreads();
+    if (threadIdx.x == 0) npre = 0;
+    const uint32_t n = nlist < kListCap ? nlist : kListCap;
+    if (threadIdx.x < kLutCols)
+      for (uint32_t k = threadIdx.x; k < n; k += kLutCols) {
+        const uint32_t rel = list[k];
+        if (rel < found && header_parses(body, nbytes, b0 + rel, cl_lut + threadIdx.x)) atomicMin(&found, rel);
+      }
     __syncthreads();
     const uint32_t f = found;
     __syncthreads();
